@@ -1,0 +1,198 @@
+/* vc_cyclegan.h -- C-ABI of libvcgan_hip.so: the MI355X (gfx950) CycleGAN-VC
+ * train-step hot path.
+ *
+ * The reference (leimao/Voice-Converter-CycleGAN) has no FFI: its hot path is a
+ * TensorFlow-1 graph built by module.py and driven by model.CycleGAN.train().
+ * Each entry point below therefore cites the reference *Python/TF call site* it
+ * replaces (file:line relative to the reference tree).  INTEGRATION.md shows the
+ * ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no torch types.
+ *   - Every data pointer is a DEVICE pointer owned by the caller (fp32 unless
+ *     noted).  `stream` is a hipStream_t passed as void*.  Calls enqueue work on
+ *     that stream and return; they never synchronise.  Steady-state calls never
+ *     allocate (small geometry tables are created on first use of a geometry, or
+ *     ahead of time by vc_plan_create).
+ *   - Return value: 0 = ok, <0 = argument error (VC_E_*), >0 = hipError_t.
+ *     vc_last_error() returns a human-readable message for the calling thread.
+ *   - Layout is time-contiguous: 1-D activations [G][B][C][T], 2-D activations
+ *     [G][B][C][H][W] (W = time).  G is the "group" dimension: both generators
+ *     (or both discriminators) run in lock-step inside one launch; a tensor's
+ *     group stride is a signed element count so group 1 may sit before group 0.
+ *   - Conv kernels keep the TensorFlow layout [kh][kw][Cin][Cout] (Cout
+ *     contiguous).  The value and gate convolutions of a gated block
+ *     (module.py:85-98) are stored as ONE kernel with Cout = 2C: filters
+ *     [0,C) are `*_h1_conv`, [C,2C) are `*_h1_gates`; same for bias/gamma/beta.
+ */
+#ifndef VC_CYCLEGAN_H
+#define VC_CYCLEGAN_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VC_E_ARG      (-1)   /* bad argument / unsupported geometry */
+#define VC_E_NOMEM    (-2)   /* workspace too small */
+#define VC_E_STATE    (-3)   /* bad handle */
+
+typedef struct vc_plan vc_plan;   /* opaque: geometry tables + workspace map for one (F, T) */
+
+/* ---- library ------------------------------------------------------------- */
+int         vc_version(void);
+const char* vc_last_error(void);
+/* Opt-in per-launch timing of the implicit-GEMM kernels (bench.py roofline leg).
+ * While enabled every igemm/wgrad launch is bracketed by hipEvents on its stream. */
+int  vc_prof_enable(int on);
+/* Collect: sum of kernel ms, launch count and algorithmic FLOPs since enable/reset,
+ * kind 0 = igemm (conv fwd + dgrad), 1 = wgrad.  Synchronises the recorded events. */
+int  vc_prof_collect(int kind, double* ms, long long* launches, double* flops);
+
+/* ---- parameter layout (replaces tf.get_variable bookkeeping, module.py:154-159,
+ *      194-199; variable names of SURVEY.md section 8a row 13) ------------------ */
+typedef struct {
+    char    name[96];     /* TF variable name below the scope, e.g. "h1_conv/kernel" */
+    int64_t offset;       /* float offset of element [..,0,0] inside one network's block */
+    int32_t ndim;
+    int32_t shape[4];     /* TF shape */
+    int32_t ld;           /* stride (floats) between consecutive rows of the last dim */
+} vc_param_rec;
+/* kind 0 = generator_gatedcnn, 1 = discriminator.  Returns number of records
+ * (writes at most max_recs); *n_floats = padded size of one network's block. */
+int vc_param_layout(int kind, int num_features, vc_param_rec* recs, int max_recs, int64_t* n_floats);
+
+/* ---- operator level (used by the network level; exported for parity tests) ---- */
+
+/* tf.layers.conv1d / tf.layers.conv2d, padding='same' (module.py:32-40, 54-62).
+ * x [G][B][Cin][H][W] -> y [G][B][Cout][OH][OW], 1-D: H = kh = sh = 1.
+ * w [kh][kw][Cin][Cout], bias [Cout] or NULL.  *_gs are signed group strides. */
+int vc_conv2d_fwd(const float* x, int64_t x_gs, const float* w, int64_t w_gs,
+                  const float* bias, int64_t b_gs, float* y, int64_t y_gs,
+                  int G, int B, int Cin, int H, int W, int Cout,
+                  int kh, int kw, int sh, int sw, void* stream);
+/* Conv2DBackpropInput of the same op (autodiff of model.py:107-108).
+ * dy [G][B][Cout][OH][OW] -> dx [G][B][Cin][H][W].  addend (same shape as dx,
+ * may be NULL) is added (residual skip, module.py:81).  accumulate != 0 adds
+ * into the existing contents of dx instead of overwriting. */
+int vc_conv2d_dgrad(const float* dy, int64_t dy_gs, const float* w, int64_t w_gs,
+                    float* dx, int64_t dx_gs, const float* addend, int64_t add_gs, int accumulate,
+                    int G, int B, int Cin, int H, int W, int Cout,
+                    int kh, int kw, int sh, int sw, void* stream);
+/* Conv2DBackpropFilter: dw += sum over batch and pixels (ALWAYS accumulates). */
+int vc_conv2d_wgrad(const float* x, int64_t x_gs, const float* dy, int64_t dy_gs,
+                    float* dw, int64_t dw_gs,
+                    int G, int B, int Cin, int H, int W, int Cout,
+                    int kh, int kw, int sh, int sw, void* stream);
+/* BiasAddGrad: db[c] += sum_{b,l} dy[g][b][c][l]  (dy [G][B][C][L]). */
+int vc_bias_grad(const float* dy, int64_t dy_gs, float* db, int64_t db_gs,
+                 int G, int B, int C, int L, void* stream);
+
+/* instance_norm_layer + gated_linear_layer + pixel_shuffler + residual add
+ * (module.py:3-20, 81, 135-146), fused.
+ *   mode 0: out = IN(y_val) * sigmoid(IN(y_gate))      y [G][B][2*Cy][Ly]
+ *   mode 1: out = y_val * sigmoid(y_gate)   (h1 pair, module.py:161-163, 201-203)
+ *   mode 2: out = res + IN(y)               (residual1d_block tail, module.py:79-81)
+ * ps != 0 applies tf.reshape pixel shuffle (x2) to each branch BEFORE the norm:
+ *   logical row (c, l) of length L = 2*Ly reads conv channel (l&1)*C + c at l>>1.
+ * C = output channels, L = logical row length (T, or H*W).  gamma/beta hold the
+ * value branch in [0,C) and the gate branch in [C,2C).  stats [G][B][nb*C][2]
+ * receives (mean, rstd) for the backward pass (unused in mode 1). */
+int vc_instnorm_glu_fwd(int mode, int ps, const float* y, int64_t y_gs,
+                        const float* res, int64_t res_gs,
+                        const float* gamma, const float* beta, int64_t par_gs,
+                        float* out, int64_t out_gs, float* stats, int64_t st_gs,
+                        int G, int B, int C, int L, void* stream);
+/* Backward of the above.  dout [G][B][C][L]; writes dy in the raw conv layout of y
+ * (out of place), and ACCUMULATES dgamma/dbeta (same layout as gamma/beta; NULL in
+ * mode 1) and dbias (conv bias gradient, [nb*Cy]) with atomics. */
+int vc_instnorm_glu_bwd(int mode, int ps, const float* y, int64_t y_gs,
+                        const float* dout, int64_t do_gs,
+                        const float* gamma, const float* beta, int64_t par_gs,
+                        const float* stats, int64_t st_gs,
+                        float* dy, int64_t dy_gs,
+                        float* dgamma, float* dbeta, int64_t dpar_gs,
+                        float* dbias, int64_t dbias_gs,
+                        int G, int B, int C, int L, void* stream);
+
+/* tf.layers.dense(units=1, activation=sigmoid) on the channel axis (module.py:211).
+ * x [G][B][C][HW] -> o [G][B][HW]. */
+int vc_disc_head_fwd(const float* x, int64_t x_gs, const float* w, const float* b, int64_t par_gs,
+                     float* o, int64_t o_gs, int G, int B, int C, int HW, void* stream);
+/* dout,o [G][B][HW] -> dx [G][B][C][HW] (NULL to skip); dw [C], db [1] accumulate (NULL to skip). */
+int vc_disc_head_bwd(const float* x, int64_t x_gs, const float* w, int64_t par_gs,
+                     const float* o, int64_t o_gs, const float* dout, int64_t do_gs,
+                     float* dx, int64_t dx_gs, float* dw, float* db, int64_t dpar_gs,
+                     int G, int B, int C, int HW, void* stream);
+
+/* tf.train.AdamOptimizer(lr, beta1=0.5).minimize -> ApplyAdam (model.py:107-108):
+ *   m += (g-m)(1-b1); v += (g*g-v)(1-b2); p -= alpha*m/(sqrt(v)+eps)
+ * alpha = lr*sqrt(1-b2^t)/(1-b1^t) is computed by the caller in fp32 (TF keeps
+ * the beta powers as fp32 variables).  grad_scale multiplies g first (1/world
+ * after a summing all-reduce). */
+int vc_adam_tf_update(float* p, float* m, float* v, const float* g, int64_t n,
+                      float alpha, float beta1, float beta2, float eps, float grad_scale, void* stream);
+
+/* ---- network level --------------------------------------------------------- */
+/* Geometry plan for num_features x n_frames inputs (n_frames % 4 == 0). */
+int  vc_plan_create(int num_features, int n_frames, vc_plan** out);
+void vc_plan_destroy(vc_plan* p);
+/* Workspace sizes in floats for batch B per group. */
+int64_t vc_generator_save_floats(const vc_plan* p, int B);       /* activations kept for backward */
+int64_t vc_discriminator_save_floats(const vc_plan* p, int B);
+int64_t vc_scratch_floats(const vc_plan* p, int B);              /* backward scratch (max over G and D) */
+
+/* module.generator_gatedcnn (module.py:148-185) for G networks in lock-step.
+ * params: base of group 0's parameter block, par_gs = signed stride to group 1's.
+ * x [G][B][F][T] (group stride x_gs) -> y [G][B][F][T].  save: vc_generator_save_floats(p,B)*G floats. */
+int vc_generator_forward(const vc_plan* p, const float* params, int64_t par_gs,
+                         const float* x, int64_t x_gs, float* y, int64_t y_gs,
+                         float* save, int G, int B, void* stream);
+/* Backward of the same application.  dy [G][B][F][T]; gradients ACCUMULATE into
+ * dparams (layout == params; NULL skips all weight gradients); dx (NULL to skip)
+ * receives d/dx, added to its contents if dx_accumulate.  scratch: vc_scratch_floats(p,B)*G. */
+int vc_generator_backward(const vc_plan* p, const float* params, int64_t par_gs,
+                          const float* x, int64_t x_gs, const float* dy, int64_t dy_gs,
+                          const float* save, float* dparams, int64_t dpar_gs,
+                          float* dx, int64_t dx_gs, int dx_accumulate,
+                          float* scratch, int G, int B, void* stream);
+/* module.discriminator (module.py:188-213).  x [G][B][F][T] -> o [G][B][H'*W']. */
+int vc_discriminator_out_elems(const vc_plan* p);   /* H'*W' per sample (48 for 24x128) */
+int vc_discriminator_forward(const vc_plan* p, const float* params, int64_t par_gs,
+                             const float* x, int64_t x_gs, float* o, int64_t o_gs,
+                             float* save, int G, int B, void* stream);
+int vc_discriminator_backward(const vc_plan* p, const float* params, int64_t par_gs,
+                              const float* x, int64_t x_gs, const float* dout, int64_t do_gs,
+                              const float* save, float* dparams, int64_t dpar_gs,
+                              float* dx, int64_t dx_gs, int dx_accumulate,
+                              float* scratch, int G, int B, void* stream);
+
+/* ---- step level: model.CycleGAN.train (model.py:110-125) minus the update ---- */
+/* Offsets (floats) of the networks inside the flat parameter / gradient / Adam buffers:
+ * [generator_A2B | generator_B2A | discriminator_A | discriminator_B]. */
+int64_t vc_flat_param_floats(const vc_plan* p);
+int64_t vc_flat_offset(const vc_plan* p, int net /*0..3*/);
+int64_t vc_step_workspace_floats(const vc_plan* p, int B);
+/* One fused forward+backward of the whole CycleGAN graph (model.py:44-90):
+ * inputs A,B [B][F][T]; params/grads flat buffers; grads are ZEROED then filled.
+ * losses[8] (device) = cycle_loss, identity_loss, generator_loss_A2B,
+ * generator_loss_B2A, generator_loss, discriminator_loss_A, discriminator_loss_B,
+ * discriminator_loss (model.py:155-167).  gen_A/gen_B [B][F][T] receive
+ * generation_A / generation_B (model.py:112).  The Adam updates (vc_adam_tf_update)
+ * and, for N>1 ranks, the gradient all-reduce are issued by the caller.
+ * d_first != 0 additionally records (hipEvent) when the discriminator gradients
+ * are complete so the caller can overlap their all-reduce: see vc_step_d_grads_ready. */
+int vc_cyclegan_step_grads(const vc_plan* p, const float* params, float* grads,
+                           const float* A, const float* B, int batch,
+                           float lambda_cycle, float lambda_identity,
+                           float* losses, float* gen_A, float* gen_B,
+                           float* workspace, int64_t workspace_floats, void* stream);
+/* Makes `other_stream` wait until the discriminator half of `grads` from the most recent
+ * vc_cyclegan_step_grads on this plan is final (it is produced before the generator backward). */
+int vc_step_wait_d_grads(const vc_plan* p, void* other_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,251 @@
+"""-m gpu: operator-level parity of the HIP kernels (through the C-ABI) against the
+numpy oracle (oracle/cyclegan_oracle.py), fp32, tolerance 1e-4 relative to the
+tensor's max magnitude (north_star asks 1e-3; exact-fp32 MFMA leaves ~1e-6)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+def _oracle():
+    from oracle import cyclegan_oracle as O
+    return O
+
+
+# (Cin, H, W, Cout, kh, kw, sh, sw, B) -- every conv geometry of both networks plus ragged cases
+CONV_CASES = [
+    (24, 1, 128, 256, 1, 15, 1, 1, 2),     # G.h1 (value+gate)
+    (128, 1, 128, 512, 1, 5, 1, 2, 2),     # G.d1
+    (256, 1, 64, 1024, 1, 5, 1, 2, 2),     # G.d2
+    (512, 1, 32, 2048, 1, 3, 1, 1, 3),     # G.rN.h1
+    (1024, 1, 32, 512, 1, 3, 1, 1, 2),     # G.rN.h2
+    (512, 1, 32, 2048, 1, 5, 1, 1, 1),     # G.u1
+    (512, 1, 64, 1024, 1, 5, 1, 1, 2),     # G.u2
+    (256, 1, 128, 24, 1, 15, 1, 1, 2),     # G.o1
+    (1, 24, 128, 256, 3, 3, 1, 2, 2),      # D.h1
+    (128, 24, 64, 512, 3, 3, 2, 2, 1),     # D.d1
+    (256, 12, 32, 1024, 3, 3, 2, 2, 2),    # D.d2
+    (512, 6, 16, 2048, 6, 3, 1, 2, 2),     # D.d3
+    (36, 1, 20, 64, 1, 15, 1, 1, 3),       # 36-dim MCEP, ragged T
+    (32, 9, 10, 64, 3, 3, 2, 2, 2),        # odd H (TF SAME pads differ by parity)
+    (64, 1, 132, 128, 1, 5, 1, 2, 1),      # T=132
+    (16, 5, 7, 32, 6, 3, 1, 2, 2),         # odd everything
+    (128, 1, 8, 512, 1, 5, 1, 2, 3),       # tiny T (T=8 utterance): W smaller than the kernel
+    (256, 1, 4, 1024, 1, 5, 1, 2, 3),
+    (512, 1, 2, 2048, 1, 3, 1, 1, 3),
+    (512, 1, 2, 2048, 1, 5, 1, 1, 3),
+    (256, 1, 8, 24, 1, 15, 1, 1, 3),
+    (24, 1, 8, 256, 1, 15, 1, 1, 3),
+]
+
+
+def _np_conv(O, x_cl, w, b, kh, sh, sw):
+    if kh == 1 and x_cl.shape[1] == 1:
+        y, cache = O.conv1d_fwd(x_cl[:, 0], w[0], b, sw)
+        return y[:, None], cache, True
+    y, cache = O.conv2d_fwd(x_cl, w, b, (sh, sw))
+    return y, cache, False
+
+
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv_fwd_dgrad_wgrad(built_lib, case):
+    from tests import gpu_util as U
+    O = _oracle()
+    Cin, H, W, Cout, kh, kw, sh, sw, B = case
+    rng = np.random.default_rng(hash(case) % (2 ** 31))
+    G = 2
+    xs = rng.standard_normal((G, B, H, W, Cin)).astype(np.float32)          # channels-last for the oracle
+    ws = (rng.standard_normal((G, kh, kw, Cin, Cout)) / np.sqrt(kh * kw * Cin)).astype(np.float32)
+    bs = rng.uniform(-0.5, 0.5, (G, Cout)).astype(np.float32)
+    ys, dxs, dws, dys = [], [], [], []
+    for g in range(G):
+        y, cache, one_d = _np_conv(O, xs[g], ws[g], bs[g], kh, sh, sw)
+        dy = rng.standard_normal(y.shape).astype(np.float32)
+        if one_d:
+            dx, dw, _ = O.conv1d_bwd(dy[:, 0], ws[g][0], cache)
+            dx, dw = dx[:, None], dw[None]
+        else:
+            dx, dw, _ = O.conv2d_bwd(dy, ws[g], cache)
+        ys.append(y); dxs.append(dx); dws.append(dw); dys.append(dy)
+    to_cf = lambda a: np.ascontiguousarray(np.transpose(np.stack(a), (0, 1, 4, 2, 3)))   # [G,B,C,H,W]
+    x_d, w_d, b_d = U.dev(to_cf(list(xs))), U.dev(ws), U.dev(bs)
+    y_d = U.conv_fwd(x_d, w_d, b_d, kh, kw, sh, sw)
+    e = U.rel_err(y_d.cpu().numpy(), to_cf(ys))
+    assert e < TOL, 'fwd rel err %g' % e
+    dy_d = U.dev(to_cf(dys))
+    dx_d = U.conv_dgrad(dy_d, w_d, H, W, kh, kw, sh, sw)
+    e = U.rel_err(dx_d.cpu().numpy(), to_cf(dxs))
+    assert e < TOL, 'dgrad rel err %g' % e
+    # addend + accumulate semantics
+    add = rng.standard_normal(to_cf(dxs).shape).astype(np.float32)
+    init = rng.standard_normal(to_cf(dxs).shape).astype(np.float32)
+    dx2 = U.conv_dgrad(dy_d, w_d, H, W, kh, kw, sh, sw, addend=U.dev(add), init=U.dev(init))
+    e = U.rel_err(dx2.cpu().numpy(), to_cf(dxs) + add + init)
+    assert e < TOL, 'dgrad(+addend,+accumulate) rel err %g' % e
+    dw_d = U.conv_wgrad(x_d, dy_d, kh, kw, sh, sw)
+    e = U.rel_err(dw_d.cpu().numpy(), np.stack(dws))
+    assert e < TOL, 'wgrad rel err %g' % e
+
+
+def test_conv_group_stride_negative(built_lib):
+    """group 1 placed BEFORE group 0 in memory (signed group strides)."""
+    from tests import gpu_util as U
+    from voice_converter_cyclegan_amd._lib import lib, ptr, check
+    O = _oracle()
+    rng = np.random.default_rng(7)
+    B, Cin, T, Cout, k = 2, 32, 16, 64, 3
+    x = rng.standard_normal((2, B, T, Cin)).astype(np.float32)
+    w = rng.standard_normal((2, 1, k, Cin, Cout)).astype(np.float32) * 0.1
+    b = rng.standard_normal((2, Cout)).astype(np.float32)
+    x_d = U.dev(np.transpose(x, (0, 1, 3, 2))[:, :, :, None, :])
+    w_d, b_d = U.dev(w), U.dev(b)
+    y_d = torch.zeros((2, B, Cout, 1, T), device=U.DEV)
+    n = x_d[0].numel()
+    check(lib.vc_conv2d_fwd(U._lib.vp(x_d.data_ptr() + 4 * n), -n, ptr(w_d), w_d[0].numel(), ptr(b_d), Cout,
+                            ptr(y_d), y_d[0].numel(), 2, B, Cin, 1, T, Cout, 1, k, 1, 1, U.stream()))
+    for g in range(2):   # output group g was computed from input group 1-g with weights g
+        ref, _ = O.conv1d_fwd(x[1 - g], w[g][0], b[g], 1)
+        assert U.rel_err(y_d[g, :, :, 0].cpu().numpy(), np.transpose(ref, (0, 2, 1))) < TOL
+
+
+# (mode, ps, C, L, B)
+NORM_CASES = [
+    (0, 0, 256, 64, 2), (0, 0, 1024, 32, 3), (0, 1, 512, 64, 2), (0, 1, 256, 128, 2),
+    (0, 0, 256, 384, 2), (0, 0, 512, 96, 2), (0, 0, 1024, 48, 3), (0, 0, 16, 1000, 1),
+    (1, 0, 128, 128, 2), (1, 0, 128, 1536, 2), (2, 0, 512, 32, 3), (2, 0, 64, 33, 2), (0, 1, 8, 6, 2),
+    (0, 0, 512, 2, 3), (0, 0, 256, 4, 3), (2, 0, 512, 2, 3), (0, 1, 512, 4, 3), (0, 1, 256, 8, 3), (1, 0, 128, 8, 3),
+]
+
+
+@pytest.mark.parametrize('case', NORM_CASES)
+def test_instnorm_glu(built_lib, case):
+    from tests import gpu_util as U
+    from voice_converter_cyclegan_amd._lib import lib, ptr, check
+    O = _oracle()
+    mode, ps, C, L, B = case
+    rng = np.random.default_rng(hash(case) % (2 ** 31))
+    G = 2
+    nb = 1 if mode == 2 else 2
+    Cy, Ly = (2 * C, L // 2) if ps else (C, L)          # conv channels per branch / conv length
+    y = rng.standard_normal((G, B, nb * Cy, Ly)).astype(np.float32) * 2 + 0.3     # [G,B,C,T] device layout
+    gam = rng.uniform(0.5, 1.5, (G, nb * C)).astype(np.float32)
+    bet = rng.uniform(-0.3, 0.3, (G, nb * C)).astype(np.float32)
+    res = rng.standard_normal((G, B, C, L)).astype(np.float32)
+    dout = rng.standard_normal((G, B, C, L)).astype(np.float32)
+    outs, dys, dgs, dbs, dbias = [], [], [], [], []
+    for g in range(G):
+        br_out, caches = [], []
+        for br in range(nb):
+            h = np.transpose(y[g][:, br * Cy:(br + 1) * Cy], (0, 2, 1))           # [B,T,Cy] channels-last
+            if ps:
+                h = O.pixel_shuffle_fwd(h)
+            if mode != 1:
+                h, cch = O.instance_norm_fwd(h, gam[g][br * C:(br + 1) * C], bet[g][br * C:(br + 1) * C])
+                caches.append(cch)
+            br_out.append(h)
+        do = np.transpose(dout[g], (0, 2, 1))
+        if mode == 2:
+            out = np.transpose(res[g], (0, 2, 1)) + br_out[0]
+            dbr = [do]
+        else:
+            out, gc = O.glu_fwd(br_out[0], br_out[1])
+            dbr = list(O.glu_bwd(do, gc))
+        dyg, dgg, dbg, dbi = [], [], [], []
+        for br in range(nb):
+            d = dbr[br]
+            if mode != 1:
+                d, dga, dbe = O.instance_norm_bwd(d, caches[br])
+                dgg.append(dga); dbg.append(dbe)
+            if ps:
+                d = O.pixel_shuffle_bwd(d)
+            dyg.append(np.transpose(d, (0, 2, 1)))
+            dbi.append(d.sum(axis=(0, 1)))
+        outs.append(np.transpose(out, (0, 2, 1))); dys.append(np.concatenate(dyg, axis=1))
+        dgs.append(np.concatenate(dgg) if dgg else None); dbs.append(np.concatenate(dbg) if dbg else None)
+        dbias.append(np.concatenate(dbi))
+    y_d, gam_d, bet_d, res_d, do_d = map(U.dev, (y, gam, bet, res, dout))
+    out_d = torch.full((G, B, C, L), float('nan'), device=U.DEV)
+    st_d = torch.zeros((G, B, nb * C, 2), device=U.DEV)
+    check(lib.vc_instnorm_glu_fwd(mode, ps, ptr(y_d), y_d[0].numel(), ptr(res_d), res_d[0].numel(),
+                                  ptr(gam_d), ptr(bet_d), nb * C, ptr(out_d), out_d[0].numel(),
+                                  ptr(st_d), st_d[0].numel(), G, B, C, L, U.stream()))
+    e = U.rel_err(out_d.cpu().numpy(), np.stack(outs))
+    assert e < TOL, 'fwd rel err %g' % e
+    dy_d = torch.full_like(y_d, float('nan'))
+    dg_d = torch.zeros_like(gam_d); db_d = torch.zeros_like(bet_d)
+    dbias_d = torch.zeros((G, nb * Cy), device=U.DEV)
+    check(lib.vc_instnorm_glu_bwd(mode, ps, ptr(y_d), y_d[0].numel(), ptr(do_d), do_d[0].numel(),
+                                  ptr(gam_d), ptr(bet_d), nb * C, ptr(st_d), st_d[0].numel(),
+                                  ptr(dy_d), dy_d[0].numel(), ptr(dg_d), ptr(db_d), nb * C,
+                                  ptr(dbias_d), nb * Cy, G, B, C, L, U.stream()))
+    e = U.rel_err(dy_d.cpu().numpy(), np.stack(dys))
+    assert e < TOL, 'dy rel err %g' % e
+    if mode != 1:
+        assert U.rel_err(dg_d.cpu().numpy(), np.stack(dgs)) < TOL
+        assert U.rel_err(db_d.cpu().numpy(), np.stack(dbs)) < TOL
+        if ps:
+            # the norm pools conv channels c and c+C, so each conv bias keeps a real gradient
+            assert U.rel_err(dbias_d.cpu().numpy(), np.stack(dbias)) < TOL
+        else:
+            # conv bias directly under an instance norm: exactly-zero gradient, rounding noise on both sides
+            scale = np.abs(np.stack(dys)).sum(axis=(1, 3)).max()
+            assert np.abs(dbias_d.cpu().numpy()).max() < 2e-4 * scale
+    else:
+        assert U.rel_err(dbias_d.cpu().numpy(), np.stack(dbias)) < TOL
+
+
+@pytest.mark.parametrize('B,C,HW', [(2, 1024, 48), (3, 64, 144), (1, 1024, 70)])
+def test_disc_head(built_lib, B, C, HW):
+    from tests import gpu_util as U
+    from voice_converter_cyclegan_amd._lib import lib, ptr, check
+    O = _oracle()
+    rng = np.random.default_rng(B * 1000 + C + HW)
+    G = 2
+    x = rng.standard_normal((G, B, C, HW)).astype(np.float32)
+    w = (rng.standard_normal((G, C)) / np.sqrt(C)).astype(np.float32)
+    b = rng.standard_normal((G, 1)).astype(np.float32)
+    dout = rng.standard_normal((G, B, HW)).astype(np.float32)
+    par = np.zeros((G, C + 4), np.float32); par[:, :C] = w; par[:, C] = b[:, 0]
+    x_d, par_d, do_d = U.dev(x), U.dev(par), U.dev(dout)
+    o_d = torch.zeros((G, B, HW), device=U.DEV)
+    check(lib.vc_disc_head_fwd(ptr(x_d), x_d[0].numel(), ptr(par_d), U._lib.vp(par_d.data_ptr() + 4 * C), C + 4,
+                               ptr(o_d), B * HW, G, B, C, HW, U.stream()))
+    z = np.einsum('gbcp,gc->gbp', x.astype(np.float64), w.astype(np.float64)) + b[:, :, None]
+    o = O.sigmoid(z)
+    assert U.rel_err(o_d.cpu().numpy(), o) < TOL
+    dx_d = torch.zeros_like(x_d); dpar_d = torch.zeros_like(par_d)
+    check(lib.vc_disc_head_bwd(ptr(x_d), x_d[0].numel(), ptr(par_d), C + 4, ptr(o_d), B * HW, ptr(do_d), B * HW,
+                               ptr(dx_d), dx_d[0].numel(), ptr(dpar_d), U._lib.vp(dpar_d.data_ptr() + 4 * C), C + 4,
+                               G, B, C, HW, U.stream()))
+    dz = dout * o * (1 - o)
+    assert U.rel_err(dx_d.cpu().numpy(), dz[:, :, None, :] * w[:, None, :, None]) < TOL
+    assert U.rel_err(dpar_d.cpu().numpy()[:, :C], np.einsum('gbp,gbcp->gc', dz, x)) < TOL
+    assert U.rel_err(dpar_d.cpu().numpy()[:, C], dz.sum(axis=(1, 2))) < TOL
+
+
+def test_bias_grad_and_adam(built_lib):
+    from tests import gpu_util as U
+    from voice_converter_cyclegan_amd._lib import lib, ptr, check
+    O = _oracle()
+    rng = np.random.default_rng(3)
+    dy = rng.standard_normal((2, 3, 24, 128)).astype(np.float32)
+    dy_d = U.dev(dy); db_d = torch.zeros((2, 24), device=U.DEV)
+    check(lib.vc_bias_grad(ptr(dy_d), dy_d[0].numel(), ptr(db_d), 24, 2, 3, 24, 128, U.stream()))
+    assert U.rel_err(db_d.cpu().numpy(), dy.sum(axis=(1, 3))) < TOL
+    # Adam, TF form, 3 steps, odd length (tail path)
+    n = 4 * 1000 + 3
+    P = {'generator_x': rng.standard_normal(n).astype(np.float32)}
+    opt = O.AdamTF(['generator_x'], P)
+    p_d = U.dev(np.concatenate([P['generator_x'], [0.0]]))
+    m_d = torch.zeros_like(p_d); v_d = torch.zeros_like(p_d)
+    for step in range(3):
+        g = (rng.standard_normal(n) * (10.0 ** rng.integers(-6, 1, n))).astype(np.float32)
+        alpha = float(opt.alpha(2e-4))
+        g_d = U.dev(np.concatenate([g, [0.0]]))
+        check(lib.vc_adam_tf_update(ptr(p_d), ptr(m_d), ptr(v_d), ptr(g_d), n, alpha, 0.5, 0.999, 1e-8, 1.0, U.stream()))
+        opt.apply(P, {'generator_x': g}, 2e-4)
+        got = p_d.cpu().numpy()[:n]
+        assert np.abs(got - P['generator_x']).max() < 2e-7, (step, np.abs(got - P['generator_x']).max())

@@ -1,0 +1,79 @@
+"""ctypes binding of libvcgan_hip.so (include/vc_cyclegan.h).
+
+The product path has NO fallback: if the library is missing or fails to load,
+importing this module raises.  (The build container has no GPU but does have
+libamdhip64, so loading and symbol checks work there; launching does not.)
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'csrc', 'libvcgan_hip.so')
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        'libvcgan_hip.so not built: run `python -c "import __graft_entry__ as g; g.build()"` '
+        '(hipcc --offload-arch=gfx950).  There is no CPU or eager fallback for the hot path.')
+
+lib = C.CDLL(LIB_PATH)
+
+i32, i64, f32, vp = C.c_int, C.c_int64, C.c_float, C.c_void_p
+
+
+class ParamRec(C.Structure):
+    _fields_ = [('name', C.c_char * 96), ('offset', C.c_int64), ('ndim', C.c_int32),
+                ('shape', C.c_int32 * 4), ('ld', C.c_int32)]
+
+
+# (name, restype, argtypes) -- every symbol declared in include/vc_cyclegan.h
+SIGNATURES = [
+    ('vc_version', i32, []),
+    ('vc_last_error', C.c_char_p, []),
+    ('vc_prof_enable', i32, [i32]),
+    ('vc_prof_collect', i32, [i32, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_double)]),
+    ('vc_param_layout', i32, [i32, i32, C.POINTER(ParamRec), i32, C.POINTER(i64)]),
+    ('vc_conv2d_fwd', i32, [vp, i64, vp, i64, vp, i64, vp, i64] + [i32] * 10 + [vp]),
+    ('vc_conv2d_dgrad', i32, [vp, i64, vp, i64, vp, i64, vp, i64, i32] + [i32] * 10 + [vp]),
+    ('vc_conv2d_wgrad', i32, [vp, i64, vp, i64, vp, i64] + [i32] * 10 + [vp]),
+    ('vc_bias_grad', i32, [vp, i64, vp, i64, i32, i32, i32, i32, vp]),
+    ('vc_instnorm_glu_fwd', i32, [i32, i32, vp, i64, vp, i64, vp, vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, vp]),
+    ('vc_instnorm_glu_bwd', i32, [i32, i32, vp, i64, vp, i64, vp, vp, i64, vp, i64, vp, i64, vp, vp, i64, vp, i64,
+                                  i32, i32, i32, i32, vp]),
+    ('vc_disc_head_fwd', i32, [vp, i64, vp, vp, i64, vp, i64, i32, i32, i32, i32, vp]),
+    ('vc_disc_head_bwd', i32, [vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, vp, vp, i64, i32, i32, i32, i32, vp]),
+    ('vc_adam_tf_update', i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp]),
+    ('vc_plan_create', i32, [i32, i32, C.POINTER(vp)]),
+    ('vc_plan_destroy', None, [vp]),
+    ('vc_generator_save_floats', i64, [vp, i32]),
+    ('vc_discriminator_save_floats', i64, [vp, i32]),
+    ('vc_scratch_floats', i64, [vp, i32]),
+    ('vc_generator_forward', i32, [vp, vp, i64, vp, i64, vp, i64, vp, i32, i32, vp]),
+    ('vc_generator_backward', i32, [vp, vp, i64, vp, i64, vp, i64, vp, vp, i64, vp, i64, i32, vp, i32, i32, vp]),
+    ('vc_discriminator_out_elems', i32, [vp]),
+    ('vc_discriminator_forward', i32, [vp, vp, i64, vp, i64, vp, i64, vp, i32, i32, vp]),
+    ('vc_discriminator_backward', i32, [vp, vp, i64, vp, i64, vp, i64, vp, vp, i64, vp, i64, i32, vp, i32, i32, vp]),
+    ('vc_flat_param_floats', i64, [vp]),
+    ('vc_flat_offset', i64, [vp, i32]),
+    ('vc_step_workspace_floats', i64, [vp, i32]),
+    ('vc_cyclegan_step_grads', i32, [vp, vp, vp, vp, vp, i32, f32, f32, vp, vp, vp, vp, i64, vp]),
+    ('vc_step_wait_d_grads', i32, [vp, vp]),
+]
+for _n, _r, _a in SIGNATURES:
+    _f = getattr(lib, _n)          # AttributeError here == header/library mismatch
+    _f.restype = _r
+    _f.argtypes = _a
+
+
+class VcError(RuntimeError):
+    pass
+
+
+def check(rc, what=''):
+    if rc != 0:
+        msg = lib.vc_last_error()
+        raise VcError('%s failed (rc=%d): %s' % (what or 'libvcgan_hip call', rc, msg.decode() if msg else ''))
+
+
+def ptr(t):
+    """device pointer of a torch tensor (or None)"""
+    return None if t is None else C.c_void_p(t.data_ptr())

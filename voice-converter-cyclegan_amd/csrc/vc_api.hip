@@ -1,0 +1,722 @@
+// vc_api.hip -- host side of libvcgan_hip.so: geometry tables, parameter layout, the
+// generator / discriminator forward+backward schedules and the fused CycleGAN step.
+// Everything exported here is declared (with reference citations) in include/vc_cyclegan.h.
+#include "vc_internal.h"
+#include "../../include/vc_cyclegan.h"
+#include <algorithm>
+#include <array>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+// ------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void vc_set_error(const char* fmt, ...) {
+    va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
+}
+extern "C" const char* vc_last_error(void) { return g_err; }
+extern "C" int vc_version(void) { return 100; }
+#define VC_CHECK(x) do { int _r = (x); if (_r != 0) return _r; } while (0)
+#define VC_ARG(cond, ...) do { if (!(cond)) { vc_set_error(__VA_ARGS__); return VC_E_ARG; } } while (0)
+
+// ------------------------------------------------------------------------------------
+// geometry: TF 'SAME' padding (extra pad goes right/bottom)
+// ------------------------------------------------------------------------------------
+struct Geom { int Cin, H, W, Cout, kh, kw, sh, sw, OH, OW, pt, pl; };
+static void same_pad(int n, int k, int s, int* out, int* lo) {
+    *out = (n + s - 1) / s;
+    int total = (*out - 1) * s + k - n; if (total < 0) total = 0;
+    *lo = total / 2;
+}
+static Geom make_geom(int Cin, int H, int W, int Cout, int kh, int kw, int sh, int sw) {
+    Geom g{Cin, H, W, Cout, kh, kw, sh, sw, 0, 0, 0, 0};
+    same_pad(H, kh, sh, &g.OH, &g.pt);
+    same_pad(W, kw, sw, &g.OW, &g.pl);
+    return g;
+}
+
+// ------------------------------------------------------------------------------------
+// K tables (device resident, cached per geometry)
+// ------------------------------------------------------------------------------------
+struct Table { KEntry* dev = nullptr; int rows = 0; int valid = 0; };
+static std::mutex g_tab_mu;
+static std::map<std::array<int, 12>, Table> g_tabs;
+
+static int upload_table(const std::vector<KEntry>& h, int valid, Table* t) {
+    VC_HIP(hipMalloc((void**)&t->dev, h.size() * sizeof(KEntry)));
+    VC_HIP(hipMemcpy(t->dev, h.data(), h.size() * sizeof(KEntry), hipMemcpyHostToDevice));
+    t->rows = (int)h.size(); t->valid = valid;
+    return 0;
+}
+// forward / wgrad table: row kk = ((i*kw + j)*Cin + ci)
+static int get_fwd_table(const Geom& g, Table* out) {
+    std::array<int, 12> key{0, g.Cin, g.Cout, g.kh, g.kw, g.sh, g.sw, g.pt, g.pl, 0, 0, 0};
+    std::lock_guard<std::mutex> l(g_tab_mu);
+    auto it = g_tabs.find(key);
+    if (it != g_tabs.end()) { *out = it->second; return 0; }
+    std::vector<KEntry> h;
+    for (int i = 0; i < g.kh; ++i) for (int j = 0; j < g.kw; ++j) for (int ci = 0; ci < g.Cin; ++ci) {
+        const int kk = (i * g.kw + j) * g.Cin + ci;
+        h.push_back(KEntry{ci, i - g.pt, j - g.pl, kk * g.Cout});
+    }
+    const int valid = (int)h.size();
+    while (h.size() % 64) h.push_back(KEntry{0, 0, 0, -1});
+    Table t; VC_CHECK(upload_table(h, valid, &t));
+    g_tabs[key] = t; *out = t;
+    return 0;
+}
+// input-gradient table of parity class (ph, pw): rows (tap in class, co)
+static int get_dgrad_table(const Geom& g, int ph, int pw, Table* out) {
+    std::array<int, 12> key{1, g.Cin, g.Cout, g.kh, g.kw, g.sh, g.sw, g.pt, g.pl, ph, pw, 0};
+    std::lock_guard<std::mutex> l(g_tab_mu);
+    auto it = g_tabs.find(key);
+    if (it != g_tabs.end()) { *out = it->second; return 0; }
+    std::vector<KEntry> h;
+    for (int i = 0; i < g.kh; ++i) {
+        const int nh = ph + g.pt - i;
+        if (((nh % g.sh) + g.sh) % g.sh) continue;
+        for (int j = 0; j < g.kw; ++j) {
+            const int nw = pw + g.pl - j;
+            if (((nw % g.sw) + g.sw) % g.sw) continue;
+            const int dh = nh / g.sh, dw = nw / g.sw;   // exact
+            for (int co = 0; co < g.Cout; ++co)
+                h.push_back(KEntry{co, dh, dw, ((i * g.kw + j) * g.Cin) * g.Cout + co});
+        }
+    }
+    const int valid = (int)h.size();
+    while (h.size() % 32 || h.empty()) h.push_back(KEntry{0, 0, 0, -1});
+    Table t; VC_CHECK(upload_table(h, valid, &t));
+    g_tabs[key] = t; *out = t;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// conv operators
+// ------------------------------------------------------------------------------------
+static int igemm_run(IgemmArgs& a, bool a_trans, float* y_zero_base, long y_zero_gs, long y_zero_elems,
+                     hipStream_t s, double flops, bool* zeroed) {
+    igemm_config(a);
+    if (a.splitk > 1 && !a.accumulate) {
+        // atomics need a zeroed destination; parity classes of one dgrad share the tensor -> zero once
+        if (!*zeroed) {
+            for (int g = 0; g < a.groups; ++g)
+                VC_HIP(hipMemsetAsync(y_zero_base + (long)g * y_zero_gs, 0, y_zero_elems * sizeof(float), s));
+            *zeroed = true;
+        }
+        a.accumulate = 1;
+    }
+    return launch_igemm(a, a_trans, s, flops);
+}
+
+static int conv_fwd(const float* x, long x_gs, const float* w, long w_gs, const float* bias, long b_gs,
+                    float* y, long y_gs, int G, int B, const Geom& g, hipStream_t s) {
+    Table t; VC_CHECK(get_fwd_table(g, &t));
+    IgemmArgs a{};
+    a.A = w; a.X = x; a.Y = y; a.bias = bias; a.addend = nullptr; a.ktab = t.dev;
+    a.a_gs = w_gs; a.x_gs = x_gs; a.y_gs = y_gs; a.bias_gs = b_gs; a.add_gs = 0;
+    a.x_bs = (long)g.Cin * g.H * g.W; a.y_bs = (long)g.Cout * g.OH * g.OW;
+    a.nchunks = t.rows / 32; a.M = g.Cout; a.a_ms = 1;
+    a.Hl = g.H; a.Wl = g.W; a.xHW = g.H * g.W; a.xW = g.W; a.si = g.sh; a.sj = g.sw;
+    a.NPB = g.OH * g.OW; a.OWc = g.OW; a.Ptot = B * a.NPB;
+    a.yHW = g.OH * g.OW; a.yW = g.OW; a.so_h = 1; a.so_w = 1; a.o_h0 = 0; a.o_w0 = 0;
+    a.accumulate = 0; a.groups = G;
+    bool zeroed = false;
+    const double flops = 2.0 * G * B * a.NPB * (double)g.Cout * t.valid;
+    return igemm_run(a, false, y, y_gs, (long)B * a.y_bs, s, flops, &zeroed);
+}
+
+static int conv_dgrad(const float* dy, long dy_gs, const float* w, long w_gs, float* dx, long dx_gs,
+                      const float* addend, long add_gs, int accumulate, int G, int B, const Geom& g, hipStream_t s) {
+    // one launch per stride-parity class (ph, pw): inside a class the transposed conv is a dense stride-1 gather
+    std::vector<IgemmArgs> cls; std::vector<double> fl;
+    bool any_split = false;
+    for (int ph = 0; ph < g.sh; ++ph) for (int pw = 0; pw < g.sw; ++pw) {
+        const int Hc = (g.H - ph + g.sh - 1) / g.sh, Wc = (g.W - pw + g.sw - 1) / g.sw;
+        if (Hc <= 0 || Wc <= 0) continue;
+        Table t; VC_CHECK(get_dgrad_table(g, ph, pw, &t));
+        IgemmArgs a{};
+        a.A = w; a.X = dy; a.Y = dx; a.bias = nullptr; a.addend = addend; a.ktab = t.dev;
+        a.a_gs = w_gs; a.x_gs = dy_gs; a.y_gs = dx_gs; a.bias_gs = 0; a.add_gs = add_gs;
+        a.x_bs = (long)g.Cout * g.OH * g.OW; a.y_bs = (long)g.Cin * g.H * g.W;
+        a.nchunks = t.rows / 32; a.M = g.Cin; a.a_ms = g.Cout;
+        a.Hl = g.OH; a.Wl = g.OW; a.xHW = g.OH * g.OW; a.xW = g.OW; a.si = 1; a.sj = 1;
+        a.NPB = Hc * Wc; a.OWc = Wc; a.Ptot = B * a.NPB;
+        a.yHW = g.H * g.W; a.yW = g.W; a.so_h = g.sh; a.so_w = g.sw; a.o_h0 = ph; a.o_w0 = pw;
+        a.accumulate = accumulate; a.groups = G;
+        igemm_config(a);
+        any_split = any_split || a.splitk > 1;
+        cls.push_back(a); fl.push_back(2.0 * G * B * a.NPB * (double)g.Cin * t.valid);
+    }
+    // the classes interleave inside dx: if ANY of them needs atomics, zero dx once up front and let all accumulate
+    if (any_split && !accumulate) {
+        for (int gi = 0; gi < G; ++gi)
+            VC_HIP(hipMemsetAsync(dx + (long)gi * dx_gs, 0, (size_t)B * g.Cin * g.H * g.W * sizeof(float), s));
+        for (auto& a : cls) a.accumulate = 1;
+    }
+    for (size_t i = 0; i < cls.size(); ++i) VC_CHECK(launch_igemm(cls[i], true, s, fl[i]));
+    return 0;
+}
+
+static int conv_wgrad(const float* x, long x_gs, const float* dy, long dy_gs, float* dw, long dw_gs,
+                      int G, int B, const Geom& g, hipStream_t s) {
+    Table t; VC_CHECK(get_fwd_table(g, &t));
+    WgradArgs a{};
+    a.X = x; a.dY = dy; a.dW = dw; a.ktab = t.dev;
+    a.x_gs = x_gs; a.dy_gs = dy_gs; a.dw_gs = dw_gs;
+    a.x_bs = (long)g.Cin * g.H * g.W; a.dy_bs = (long)g.Cout * g.OH * g.OW;
+    a.N = g.Cout; a.Hl = g.H; a.Wl = g.W; a.xHW = g.H * g.W; a.xW = g.W; a.si = g.sh; a.sj = g.sw;
+    a.NPB = g.OH * g.OW; a.OWc = g.OW; a.Ptot = B * a.NPB; a.nchunks = (a.Ptot + 31) / 32;
+    a.ktiles = t.rows / 64; a.groups = G;
+    const double flops = 2.0 * G * B * a.NPB * (double)g.Cout * t.valid;
+    return launch_wgrad(a, s, flops);
+}
+
+extern "C" int vc_conv2d_fwd(const float* x, int64_t x_gs, const float* w, int64_t w_gs,
+                             const float* bias, int64_t b_gs, float* y, int64_t y_gs,
+                             int G, int B, int Cin, int H, int W, int Cout,
+                             int kh, int kw, int sh, int sw, void* stream) {
+    VC_ARG(x && w && y && G > 0 && B > 0 && Cin > 0 && H > 0 && W > 0 && Cout > 0, "vc_conv2d_fwd: bad args");
+    VC_ARG(Cout % 4 == 0, "vc_conv2d_fwd: Cout must be a multiple of 4");
+    return conv_fwd(x, x_gs, w, w_gs, bias, b_gs, y, y_gs, G, B, make_geom(Cin, H, W, Cout, kh, kw, sh, sw), (hipStream_t)stream);
+}
+extern "C" int vc_conv2d_dgrad(const float* dy, int64_t dy_gs, const float* w, int64_t w_gs,
+                               float* dx, int64_t dx_gs, const float* addend, int64_t add_gs, int accumulate,
+                               int G, int B, int Cin, int H, int W, int Cout,
+                               int kh, int kw, int sh, int sw, void* stream) {
+    VC_ARG(dy && w && dx && G > 0 && B > 0, "vc_conv2d_dgrad: bad args");
+    return conv_dgrad(dy, dy_gs, w, w_gs, dx, dx_gs, addend, add_gs, accumulate, G, B,
+                      make_geom(Cin, H, W, Cout, kh, kw, sh, sw), (hipStream_t)stream);
+}
+extern "C" int vc_conv2d_wgrad(const float* x, int64_t x_gs, const float* dy, int64_t dy_gs,
+                               float* dw, int64_t dw_gs, int G, int B, int Cin, int H, int W, int Cout,
+                               int kh, int kw, int sh, int sw, void* stream) {
+    VC_ARG(x && dy && dw && G > 0 && B > 0, "vc_conv2d_wgrad: bad args");
+    return conv_wgrad(x, x_gs, dy, dy_gs, dw, dw_gs, G, B, make_geom(Cin, H, W, Cout, kh, kw, sh, sw), (hipStream_t)stream);
+}
+extern "C" int vc_bias_grad(const float* dy, int64_t dy_gs, float* db, int64_t db_gs,
+                            int G, int B, int C, int L, void* stream) {
+    VC_ARG(dy && db, "vc_bias_grad: bad args");
+    return launch_bias_grad(dy, dy_gs, db, db_gs, G, B, C, L, (hipStream_t)stream);
+}
+
+extern "C" int vc_instnorm_glu_fwd(int mode, int ps, const float* y, int64_t y_gs,
+                                   const float* res, int64_t res_gs,
+                                   const float* gamma, const float* beta, int64_t par_gs,
+                                   float* out, int64_t out_gs, float* stats, int64_t st_gs,
+                                   int G, int B, int C, int L, void* stream) {
+    VC_ARG(y && out && G > 0 && B > 0 && C > 0 && L > 0, "vc_instnorm_glu_fwd: bad args");
+    VC_ARG(mode == 1 || (gamma && beta && stats), "vc_instnorm_glu_fwd: gamma/beta/stats required");
+    VC_ARG(mode != 2 || res, "vc_instnorm_glu_fwd: mode 2 needs res");
+    NormArgs a{};
+    a.y = y; a.res = res; a.gamma = gamma; a.beta = beta; a.out = out; a.stats = stats;
+    a.y_gs = y_gs; a.res_gs = res_gs; a.par_gs = par_gs; a.out_gs = out_gs; a.st_gs = st_gs;
+    a.G = G; a.B = B; a.C = C; a.L = L; a.ps = ps;
+    return launch_norm_fwd(mode, a, (hipStream_t)stream);
+}
+extern "C" int vc_instnorm_glu_bwd(int mode, int ps, const float* y, int64_t y_gs,
+                                   const float* dout, int64_t do_gs,
+                                   const float* gamma, const float* beta, int64_t par_gs,
+                                   const float* stats, int64_t st_gs, float* dy, int64_t dy_gs,
+                                   float* dgamma, float* dbeta, int64_t dpar_gs,
+                                   float* dbias, int64_t dbias_gs,
+                                   int G, int B, int C, int L, void* stream) {
+    VC_ARG(y && dout && dy && G > 0 && B > 0 && C > 0 && L > 0, "vc_instnorm_glu_bwd: bad args");
+    VC_ARG(mode == 1 || (gamma && beta && stats), "vc_instnorm_glu_bwd: gamma/beta/stats required");
+    NormArgs a{};
+    a.y = y; a.dout = dout; a.gamma = gamma; a.beta = beta; a.stats_in = stats; a.dy = dy;
+    a.dgamma = dgamma; a.dbeta = dbeta; a.dbias = dbias;
+    a.y_gs = y_gs; a.do_gs = do_gs; a.par_gs = par_gs; a.st_gs = st_gs; a.dy_gs = dy_gs;
+    a.dpar_gs = dpar_gs; a.dbias_gs = dbias_gs;
+    a.G = G; a.B = B; a.C = C; a.L = L; a.ps = ps;
+    return launch_norm_bwd(mode, a, (hipStream_t)stream);
+}
+extern "C" int vc_disc_head_fwd(const float* x, int64_t x_gs, const float* w, const float* b, int64_t par_gs,
+                                float* o, int64_t o_gs, int G, int B, int C, int HW, void* stream) {
+    VC_ARG(x && w && b && o, "vc_disc_head_fwd: bad args");
+    return launch_head_fwd(x, x_gs, w, b, par_gs, o, o_gs, G, B, C, HW, (hipStream_t)stream);
+}
+extern "C" int vc_disc_head_bwd(const float* x, int64_t x_gs, const float* w, int64_t par_gs,
+                                const float* o, int64_t o_gs, const float* dout, int64_t do_gs,
+                                float* dx, int64_t dx_gs, float* dw, float* db, int64_t dpar_gs,
+                                int G, int B, int C, int HW, void* stream) {
+    VC_ARG(x && w && o && dout, "vc_disc_head_bwd: bad args");
+    return launch_head_bwd(x, x_gs, w, par_gs, o, o_gs, dout, do_gs, dx, dx_gs, dw, db, dpar_gs, G, B, C, HW, (hipStream_t)stream);
+}
+extern "C" int vc_adam_tf_update(float* p, float* m, float* v, const float* g, int64_t n,
+                                 float alpha, float beta1, float beta2, float eps, float grad_scale, void* stream) {
+    VC_ARG(p && m && v && g && n > 0, "vc_adam_tf_update: bad args");
+    VC_ARG(((uintptr_t)p % 16 == 0) && ((uintptr_t)m % 16 == 0) && ((uintptr_t)v % 16 == 0) && ((uintptr_t)g % 16 == 0),
+           "vc_adam_tf_update: buffers must be 16-byte aligned");
+    return launch_adam(p, m, v, g, n, alpha, beta1, beta2, eps, grad_scale, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------
+// network descriptions + parameter layout
+// ------------------------------------------------------------------------------------
+enum { M_GATED_IN = 0, M_GATED = 1, M_IN_RES = 2, M_PLAIN = 3 };
+struct Layer {
+    int kh, kw, cin, cout, sh, sw;   // cout = stored conv width (2C for gated pairs)
+    int mode, ps;
+    int C;                           // channels per norm/GLU branch after (optional) shuffle
+    long w, b, gamma, beta;          // float offsets inside one network block
+    std::string n_conv, n_gate;      // TF scope names
+    int in_idx;                      // index of first InstanceNorm scope (creation order)
+};
+struct NetDesc { std::vector<Layer> layers; long head_w = -1, head_b = -1; int head_c = 0; long total = 0; };
+
+static long align4(long x) { return (x + 3) & ~3L; }
+
+static void add_layer(NetDesc& n, int& in_ctr, const char* conv, const char* gate, int kh, int kw, int cin,
+                      int cout, int sh, int sw, int mode, int ps) {
+    Layer L{};
+    L.kh = kh; L.kw = kw; L.cin = cin; L.cout = cout; L.sh = sh; L.sw = sw; L.mode = mode; L.ps = ps;
+    L.n_conv = conv; L.n_gate = gate ? gate : "";
+    L.C = (mode == M_GATED_IN || mode == M_GATED) ? (ps ? cout / 4 : cout / 2) : cout;
+    L.w = n.total; n.total = align4(n.total + (long)kh * kw * cin * cout);
+    L.b = n.total; n.total = align4(n.total + cout);
+    L.gamma = L.beta = -1; L.in_idx = -1;
+    if (mode == M_GATED_IN || mode == M_IN_RES) {
+        const int nb = (mode == M_GATED_IN) ? 2 : 1;
+        L.in_idx = in_ctr; in_ctr += nb;
+        L.gamma = n.total; n.total = align4(n.total + nb * L.C);
+        L.beta = n.total; n.total = align4(n.total + nb * L.C);
+    }
+    n.layers.push_back(L);
+}
+
+static NetDesc make_generator(int F) {   // module.py:161-182
+    NetDesc n; int in = 0; char a[64], b[64];
+    add_layer(n, in, "h1_conv", "h1_conv_gates", 1, 15, F, 256, 1, 1, M_GATED, 0);
+    add_layer(n, in, "downsample1d_block1_h1_conv", "downsample1d_block1_h1_gates", 1, 5, 128, 512, 1, 2, M_GATED_IN, 0);
+    add_layer(n, in, "downsample1d_block2_h1_conv", "downsample1d_block2_h1_gates", 1, 5, 256, 1024, 1, 2, M_GATED_IN, 0);
+    for (int i = 1; i <= 6; ++i) {
+        snprintf(a, sizeof a, "residual1d_block%d_h1_conv", i); snprintf(b, sizeof b, "residual1d_block%d_h1_gates", i);
+        add_layer(n, in, a, b, 1, 3, 512, 2048, 1, 1, M_GATED_IN, 0);
+        snprintf(a, sizeof a, "residual1d_block%d_h2_conv", i);
+        add_layer(n, in, a, nullptr, 1, 3, 1024, 512, 1, 1, M_IN_RES, 0);
+    }
+    add_layer(n, in, "upsample1d_block1_h1_conv", "upsample1d_block1_h1_gates", 1, 5, 512, 2048, 1, 1, M_GATED_IN, 1);
+    add_layer(n, in, "upsample1d_block2_h1_conv", "upsample1d_block2_h1_gates", 1, 5, 512, 1024, 1, 1, M_GATED_IN, 1);
+    add_layer(n, in, "o1_conv", nullptr, 1, 15, 256, F, 1, 1, M_PLAIN, 0);   // module.py:182 (24 == num_features)
+    return n;
+}
+static NetDesc make_discriminator() {    // module.py:201-211
+    NetDesc n; int in = 0;
+    add_layer(n, in, "h1_conv", "h1_conv_gates", 3, 3, 1, 256, 1, 2, M_GATED, 0);
+    add_layer(n, in, "downsample2d_block1_h1_conv", "downsample2d_block1_h1_gates", 3, 3, 128, 512, 2, 2, M_GATED_IN, 0);
+    add_layer(n, in, "downsample2d_block2_h1_conv", "downsample2d_block2_h1_gates", 3, 3, 256, 1024, 2, 2, M_GATED_IN, 0);
+    add_layer(n, in, "downsample2d_block3_h1_conv", "downsample2d_block3_h1_gates", 6, 3, 512, 2048, 1, 2, M_GATED_IN, 0);
+    n.head_c = 1024;
+    n.head_w = n.total; n.total = align4(n.total + 1024);
+    n.head_b = n.total; n.total = align4(n.total + 1);
+    return n;
+}
+
+static void put_rec(std::vector<vc_param_rec>& R, const std::string& name, long off, int nd, const int* shp, int ld) {
+    vc_param_rec r{}; snprintf(r.name, sizeof r.name, "%s", name.c_str());
+    r.offset = off; r.ndim = nd; for (int i = 0; i < nd; ++i) r.shape[i] = shp[i]; r.ld = ld;
+    R.push_back(r);
+}
+static std::string in_name(int idx) { return idx == 0 ? "InstanceNorm" : "InstanceNorm_" + std::to_string(idx); }
+
+extern "C" int vc_param_layout(int kind, int num_features, vc_param_rec* recs, int max_recs, int64_t* n_floats) {
+    VC_ARG(kind == 0 || kind == 1, "vc_param_layout: kind must be 0 or 1");
+    VC_ARG(kind == 1 || (num_features > 0 && num_features % 4 == 0), "vc_param_layout: num_features must be a positive multiple of 4");
+    const NetDesc n = kind == 0 ? make_generator(num_features) : make_discriminator();
+    std::vector<vc_param_rec> R;
+    for (const Layer& L : n.layers) {
+        const bool gated = L.mode == M_GATED || L.mode == M_GATED_IN;
+        const int Cb = gated ? L.cout / 2 : L.cout;            // filters per TF conv
+        int shp[4]; int nd;
+        if (kind == 0) { nd = 3; shp[0] = L.kw; shp[1] = L.cin; shp[2] = Cb; }
+        else { nd = 4; shp[0] = L.kh; shp[1] = L.kw; shp[2] = L.cin; shp[3] = Cb; }
+        int s1[1] = {Cb};
+        put_rec(R, L.n_conv + "/kernel", L.w, nd, shp, L.cout);
+        put_rec(R, L.n_conv + "/bias", L.b, 1, s1, 1);
+        int sc[1] = {L.C};
+        if (L.in_idx >= 0) {
+            put_rec(R, in_name(L.in_idx) + "/beta", L.beta, 1, sc, 1);
+            put_rec(R, in_name(L.in_idx) + "/gamma", L.gamma, 1, sc, 1);
+        }
+        if (gated) {
+            put_rec(R, L.n_gate + "/kernel", L.w + Cb, nd, shp, L.cout);
+            put_rec(R, L.n_gate + "/bias", L.b + Cb, 1, s1, 1);
+            if (L.in_idx >= 0) {
+                put_rec(R, in_name(L.in_idx + 1) + "/beta", L.beta + L.C, 1, sc, 1);
+                put_rec(R, in_name(L.in_idx + 1) + "/gamma", L.gamma + L.C, 1, sc, 1);
+            }
+        }
+    }
+    if (kind == 1) {
+        int s2[2] = {n.head_c, 1}; int s1[1] = {1};
+        put_rec(R, "dense/kernel", n.head_w, 2, s2, 1);
+        put_rec(R, "dense/bias", n.head_b, 1, s1, 1);
+    }
+    if (n_floats) *n_floats = n.total;
+    for (int i = 0; i < (int)R.size() && i < max_recs; ++i) recs[i] = R[i];
+    return (int)R.size();
+}
+
+// ------------------------------------------------------------------------------------
+// plan
+// ------------------------------------------------------------------------------------
+struct LayerGeo { Geom g; int inL; long raw_ps, act_ps; };   // per-sample sizes (floats) of raw conv output / activation
+struct vc_plan {
+    int F, T;
+    NetDesc G, D;
+    std::vector<LayerGeo> gg, dg;
+    int d_hw;                     // discriminator output pixels per sample
+    long g_scr, d_scr;            // per-sample scratch unit
+    hipEvent_t d_ready = nullptr;
+};
+
+static void plan_geos(const NetDesc& n, int C0, int H0, int W0, std::vector<LayerGeo>& out) {
+    int C = C0, H = H0, W = W0;
+    for (const Layer& L : n.layers) {
+        LayerGeo lg{};
+        lg.g = make_geom(C, H, W, L.cout, L.kh, L.kw, L.sh, L.sw);
+        lg.raw_ps = (long)L.cout * lg.g.OH * lg.g.OW;
+        const int nb = (L.mode == M_GATED || L.mode == M_GATED_IN) ? 2 : 1;
+        lg.act_ps = lg.raw_ps / nb;
+        out.push_back(lg);
+        if (L.mode == M_IN_RES) { C = L.cout; }           // residual tail: same shape as block input
+        else if (L.mode == M_PLAIN) { C = L.cout; }
+        else { C = L.C; }
+        H = lg.g.OH; W = lg.g.OW * (L.ps ? 2 : 1);
+    }
+}
+
+extern "C" int vc_plan_create(int num_features, int n_frames, vc_plan** out) {
+    VC_ARG(out, "vc_plan_create: out is NULL");
+    VC_ARG(num_features > 0 && num_features % 4 == 0, "vc_plan_create: num_features must be a positive multiple of 4");
+    VC_ARG(n_frames > 0 && n_frames % 4 == 0, "vc_plan_create: n_frames must be a positive multiple of 4 (preprocess.py:146-156)");
+    vc_plan* p = new vc_plan();
+    p->F = num_features; p->T = n_frames;
+    p->G = make_generator(num_features); p->D = make_discriminator();
+    plan_geos(p->G, num_features, 1, n_frames, p->gg);
+    plan_geos(p->D, 1, num_features, n_frames, p->dg);
+    p->d_hw = p->dg.back().g.OH * p->dg.back().g.OW;
+    long m = 0; for (auto& l : p->gg) m = std::max(m, l.raw_ps); p->g_scr = m;
+    m = 0; for (auto& l : p->dg) m = std::max(m, l.raw_ps); p->d_scr = m;
+    // build every geometry table now so steady-state calls never allocate
+    for (auto* v : {&p->gg, &p->dg}) for (auto& l : *v) {
+        Table t; int r = get_fwd_table(l.g, &t); if (r) { delete p; return r; }
+        for (int ph = 0; ph < l.g.sh; ++ph) for (int pw = 0; pw < l.g.sw; ++pw) { r = get_dgrad_table(l.g, ph, pw, &t); if (r) { delete p; return r; } }
+    }
+    hipError_t e = hipEventCreateWithFlags(&p->d_ready, hipEventDisableTiming);
+    if (e != hipSuccess) { vc_set_error("hipEventCreate failed: %s", hipGetErrorString(e)); delete p; return (int)e; }
+    *out = p;
+    return 0;
+}
+extern "C" void vc_plan_destroy(vc_plan* p) { if (p) { if (p->d_ready) hipEventDestroy(p->d_ready); delete p; } }
+
+static long align64(long x) { return (x + 63) & ~63L; }
+// save map: for every layer raw output, activation, stats -- offsets (floats) inside one group's save area
+struct SaveMap { std::vector<long> raw, act, st; long total; };
+static SaveMap save_map(const NetDesc& n, const std::vector<LayerGeo>& geo, int B, bool has_head) {
+    SaveMap m; long o = 0;
+    for (size_t i = 0; i < n.layers.size(); ++i) {
+        const Layer& L = n.layers[i];
+        const bool last_plain = L.mode == M_PLAIN;
+        m.raw.push_back(o); if (!last_plain) o = align64(o + geo[i].raw_ps * B);
+        m.act.push_back(o); if (!last_plain) o = align64(o + geo[i].act_ps * B);
+        m.st.push_back(o);
+        if (L.mode == M_GATED_IN) o = align64(o + (long)B * 2 * L.C * 2);
+        else if (L.mode == M_IN_RES) o = align64(o + (long)B * L.C * 2);
+    }
+    (void)has_head;
+    m.total = o;
+    return m;
+}
+extern "C" int64_t vc_generator_save_floats(const vc_plan* p, int B) { return p ? save_map(p->G, p->gg, B, false).total : 0; }
+extern "C" int64_t vc_discriminator_save_floats(const vc_plan* p, int B) { return p ? save_map(p->D, p->dg, B, true).total : 0; }
+extern "C" int64_t vc_scratch_floats(const vc_plan* p, int B) {
+    if (!p) return 0;
+    return 3 * align64(std::max(p->g_scr, p->d_scr) * B);
+}
+extern "C" int vc_discriminator_out_elems(const vc_plan* p) { return p ? p->d_hw : 0; }
+
+// ------------------------------------------------------------------------------------
+// forward / backward schedules (shared by generator and discriminator)
+// ------------------------------------------------------------------------------------
+struct NetCtx {
+    const NetDesc* n; const std::vector<LayerGeo>* geo;
+    const float* params; long par_gs;
+    float* dparams; long dpar_gs;          // may be null
+    float* save; long save_gs; SaveMap sm; // layout batch = Bl
+    int G, B, Bl;
+    hipStream_t s;
+};
+
+static int net_forward(NetCtx& c, const float* x, long x_gs, float* y_plain, long y_plain_gs) {
+    const float* in = x; long in_gs = x_gs;
+    const float* blk_in = nullptr; long blk_in_gs = 0;
+    for (size_t i = 0; i < c.n->layers.size(); ++i) {
+        const Layer& L = c.n->layers[i]; const LayerGeo& lg = (*c.geo)[i];
+        float* raw = (L.mode == M_PLAIN) ? y_plain : c.save + c.sm.raw[i];
+        const long raw_gs = (L.mode == M_PLAIN) ? y_plain_gs : c.save_gs;
+        if (L.mode == M_GATED_IN && i + 1 < c.n->layers.size() && c.n->layers[i + 1].mode == M_IN_RES) { blk_in = in; blk_in_gs = in_gs; }
+        VC_CHECK(conv_fwd(in, in_gs, c.params + L.w, c.par_gs, c.params + L.b, c.par_gs, raw, raw_gs, c.G, c.B, lg.g, c.s));
+        if (L.mode == M_PLAIN) break;
+        NormArgs a{};
+        a.y = raw; a.y_gs = raw_gs; a.out = c.save + c.sm.act[i]; a.out_gs = c.save_gs;
+        a.G = c.G; a.B = c.B; a.C = L.C; a.ps = L.ps;
+        a.L = lg.g.OH * lg.g.OW * (L.ps ? 2 : 1);
+        if (L.mode != M_GATED) {
+            a.gamma = c.params + L.gamma; a.beta = c.params + L.beta; a.par_gs = c.par_gs;
+            a.stats = c.save + c.sm.st[i]; a.st_gs = c.save_gs;
+        }
+        if (L.mode == M_IN_RES) { a.res = blk_in; a.res_gs = blk_in_gs; }
+        VC_CHECK(launch_norm_fwd(L.mode, a, c.s));
+        in = a.out; in_gs = c.save_gs;
+    }
+    return 0;
+}
+
+// dtop: gradient w.r.t. the network's last activation (for the generator: d o1 output, i.e. dy of the
+// plain layer; for the discriminator: gradient w.r.t. the last GLU output, produced by the head).
+static int net_backward(NetCtx& c, const float* x, long x_gs, const float* dtop, long dtop_gs,
+                        float* dx, long dx_gs, int dx_acc, float* scratch, long scr_gs, long scr_unit) {
+    float* S[3] = {scratch, scratch + scr_unit, scratch + 2 * scr_unit};
+    const float* dcur = dtop; long dcur_gs = dtop_gs;   // gradient w.r.t. output activation of layer i
+    int cur = -1;                                        // index of S holding dcur (-1: external)
+    const float* skip = nullptr; long skip_gs = 0; int skip_idx = -1;
+    auto pick = [&](int a, int b) { for (int k = 0; k < 3; ++k) if (k != a && k != b) return k; return 0; };
+    for (int i = (int)c.n->layers.size() - 1; i >= 0; --i) {
+        const Layer& L = c.n->layers[i]; const LayerGeo& lg = (*c.geo)[i];
+        const float* in = (i == 0) ? x : c.save + c.sm.act[i - 1];
+        const long in_gs = (i == 0) ? x_gs : c.save_gs;
+        const float* dyp; long dy_gs;
+        int dyi = -1;
+        if (L.mode == M_PLAIN) {
+            dyp = dcur; dy_gs = dcur_gs;
+            if (c.dparams) VC_CHECK(launch_bias_grad(dyp, dy_gs, c.dparams + L.b, c.dpar_gs, c.G, c.B, L.cout, lg.g.OH * lg.g.OW, c.s));
+        } else {
+            if (L.mode == M_IN_RES) { skip = dcur; skip_gs = dcur_gs; skip_idx = cur; }
+            dyi = pick(cur, skip_idx);
+            NormArgs a{};
+            a.y = c.save + c.sm.raw[i]; a.y_gs = c.save_gs; a.dout = dcur; a.do_gs = dcur_gs;
+            a.dy = S[dyi]; a.dy_gs = scr_gs;
+            a.G = c.G; a.B = c.B; a.C = L.C; a.ps = L.ps; a.L = lg.g.OH * lg.g.OW * (L.ps ? 2 : 1);
+            if (L.mode != M_GATED) {
+                a.gamma = c.params + L.gamma; a.beta = c.params + L.beta; a.par_gs = c.par_gs;
+                a.stats_in = c.save + c.sm.st[i]; a.st_gs = c.save_gs;
+                if (c.dparams) { a.dgamma = c.dparams + L.gamma; a.dbeta = c.dparams + L.beta; a.dpar_gs = c.dpar_gs; }
+            }
+            if (c.dparams) { a.dbias = c.dparams + L.b; a.dbias_gs = c.dpar_gs; }
+            VC_CHECK(launch_norm_bwd(L.mode, a, c.s));
+            dyp = S[dyi]; dy_gs = scr_gs;
+        }
+        if (c.dparams) VC_CHECK(conv_wgrad(in, in_gs, dyp, dy_gs, c.dparams + L.w, c.dpar_gs, c.G, c.B, lg.g, c.s));
+        if (i == 0) {
+            if (dx) VC_CHECK(conv_dgrad(dyp, dy_gs, c.params + L.w, c.par_gs, dx, dx_gs, nullptr, 0, dx_acc, c.G, c.B, lg.g, c.s));
+            break;
+        }
+        // gradient w.r.t. this layer's input = output activation of layer i-1
+        const bool block_head = (L.mode == M_GATED_IN && i + 1 < (int)c.n->layers.size() && c.n->layers[i + 1].mode == M_IN_RES);
+        const int outi = pick(dyi, skip_idx);
+        VC_CHECK(conv_dgrad(dyp, dy_gs, c.params + L.w, c.par_gs, S[outi], scr_gs,
+                            block_head ? skip : nullptr, block_head ? skip_gs : 0, 0, c.G, c.B, lg.g, c.s));
+        if (block_head) { skip = nullptr; skip_idx = -1; }
+        dcur = S[outi]; dcur_gs = scr_gs; cur = outi;
+    }
+    return 0;
+}
+
+static NetCtx gen_ctx(const vc_plan* p, const float* params, long par_gs, float* dparams, long dpar_gs,
+                      float* save, int G, int B, int Bl, hipStream_t s) {
+    NetCtx c{};
+    c.n = &p->G; c.geo = &p->gg; c.params = params; c.par_gs = par_gs; c.dparams = dparams; c.dpar_gs = dpar_gs;
+    c.sm = save_map(p->G, p->gg, Bl, false); c.save = save; c.save_gs = c.sm.total; c.G = G; c.B = B; c.Bl = Bl; c.s = s;
+    return c;
+}
+static NetCtx disc_ctx(const vc_plan* p, const float* params, long par_gs, float* dparams, long dpar_gs,
+                       float* save, int G, int B, int Bl, hipStream_t s) {
+    NetCtx c{};
+    c.n = &p->D; c.geo = &p->dg; c.params = params; c.par_gs = par_gs; c.dparams = dparams; c.dpar_gs = dpar_gs;
+    c.sm = save_map(p->D, p->dg, Bl, true); c.save = save; c.save_gs = c.sm.total; c.G = G; c.B = B; c.Bl = Bl; c.s = s;
+    return c;
+}
+
+static int gen_forward(const vc_plan* p, const float* params, long par_gs, const float* x, long x_gs,
+                       float* y, long y_gs, float* save, int G, int B, hipStream_t s) {
+    NetCtx c = gen_ctx(p, params, par_gs, nullptr, 0, save, G, B, B, s);
+    return net_forward(c, x, x_gs, y, y_gs);
+}
+static int gen_backward(const vc_plan* p, const float* params, long par_gs, const float* x, long x_gs,
+                        const float* dy, long dy_gs, float* save, int Bl, float* dparams, long dpar_gs,
+                        float* dx, long dx_gs, int dx_acc, float* scratch, int G, int B, hipStream_t s) {
+    NetCtx c = gen_ctx(p, params, par_gs, dparams, dpar_gs, save, G, B, Bl, s);
+    const long unit = align64(std::max(p->g_scr, p->d_scr) * B);
+    return net_backward(c, x, x_gs, dy, dy_gs, dx, dx_gs, dx_acc, scratch, 3 * unit, unit);
+}
+static int disc_forward(const vc_plan* p, const float* params, long par_gs, const float* x, long x_gs,
+                        float* o, long o_gs, float* save, int G, int B, hipStream_t s) {
+    NetCtx c = disc_ctx(p, params, par_gs, nullptr, 0, save, G, B, B, s);
+    VC_CHECK(net_forward(c, x, x_gs, nullptr, 0));
+    const int last = (int)p->D.layers.size() - 1;
+    return launch_head_fwd(save + c.sm.act[last], c.save_gs, params + p->D.head_w, params + p->D.head_b, par_gs,
+                           o, o_gs, G, B, p->D.head_c, p->d_hw, s);
+}
+// o: the forward outputs [G][Bl][HW] (first B samples are used)
+static int disc_backward(const vc_plan* p, const float* params, long par_gs, const float* x, long x_gs,
+                         const float* o, long o_gs, const float* dout, long do_gs, float* save, int Bl,
+                         float* dparams, long dpar_gs, float* dx, long dx_gs, int dx_acc,
+                         float* scratch, int G, int B, hipStream_t s) {
+    NetCtx c = disc_ctx(p, params, par_gs, dparams, dpar_gs, save, G, B, Bl, s);
+    const long unit = align64(std::max(p->g_scr, p->d_scr) * B);
+    const int last = (int)p->D.layers.size() - 1;
+    float* dtop = scratch + 2 * unit;   // slot 2: the discriminator has no skip links, so the chain only ever
+                                        // picks slots 0/1 while this external gradient is live
+    VC_CHECK(launch_head_bwd(save + c.sm.act[last], c.save_gs, params + p->D.head_w, par_gs, o, o_gs, dout, do_gs,
+                             dtop, 3 * unit, dparams ? dparams + p->D.head_w : nullptr,
+                             dparams ? dparams + p->D.head_b : nullptr, dpar_gs, G, B, p->D.head_c, p->d_hw, s));
+    return net_backward(c, x, x_gs, dtop, 3 * unit, dx, dx_gs, dx_acc, scratch, 3 * unit, unit);
+}
+
+extern "C" int vc_generator_forward(const vc_plan* p, const float* params, int64_t par_gs,
+                                    const float* x, int64_t x_gs, float* y, int64_t y_gs,
+                                    float* save, int G, int B, void* stream) {
+    VC_ARG(p && params && x && y && save && G > 0 && B > 0, "vc_generator_forward: bad args");
+    return gen_forward(p, params, par_gs, x, x_gs, y, y_gs, save, G, B, (hipStream_t)stream);
+}
+extern "C" int vc_generator_backward(const vc_plan* p, const float* params, int64_t par_gs,
+                                     const float* x, int64_t x_gs, const float* dy, int64_t dy_gs,
+                                     const float* save, float* dparams, int64_t dpar_gs,
+                                     float* dx, int64_t dx_gs, int dx_accumulate,
+                                     float* scratch, int G, int B, void* stream) {
+    VC_ARG(p && params && x && dy && save && scratch && G > 0 && B > 0, "vc_generator_backward: bad args");
+    return gen_backward(p, params, par_gs, x, x_gs, dy, dy_gs, const_cast<float*>(save), B, dparams, dpar_gs,
+                        dx, dx_gs, dx_accumulate, scratch, G, B, (hipStream_t)stream);
+}
+extern "C" int vc_discriminator_forward(const vc_plan* p, const float* params, int64_t par_gs,
+                                        const float* x, int64_t x_gs, float* o, int64_t o_gs,
+                                        float* save, int G, int B, void* stream) {
+    VC_ARG(p && params && x && o && save && G > 0 && B > 0, "vc_discriminator_forward: bad args");
+    return disc_forward(p, params, par_gs, x, x_gs, o, o_gs, save, G, B, (hipStream_t)stream);
+}
+extern "C" int vc_discriminator_backward(const vc_plan* p, const float* params, int64_t par_gs,
+                                         const float* x, int64_t x_gs, const float* dout, int64_t do_gs,
+                                         const float* save, float* dparams, int64_t dpar_gs,
+                                         float* dx, int64_t dx_gs, int dx_accumulate,
+                                         float* scratch, int G, int B, void* stream) {
+    VC_ARG(p && params && x && dout && save && scratch && G > 0 && B > 0, "vc_discriminator_backward: bad args");
+    // the sigmoid outputs are recomputed from the saved last activation (cheap) into the tail of scratch
+    hipStream_t s = (hipStream_t)stream;
+    const long unit = align64(std::max(p->g_scr, p->d_scr) * B);
+    SaveMap sm = save_map(p->D, p->dg, B, true);
+    const int last = (int)p->D.layers.size() - 1;
+    // slot 1 is free until the first dgrad writes it; o only has to survive the head kernels (stream-ordered)
+    float* o = scratch + unit;
+    const long o_gs = (long)B * p->d_hw;
+    VC_CHECK(launch_head_fwd(save + sm.act[last], sm.total, params + p->D.head_w, params + p->D.head_b, par_gs,
+                             o, o_gs, G, B, p->D.head_c, p->d_hw, s));
+    return disc_backward(p, params, par_gs, x, x_gs, o, o_gs, dout, do_gs, const_cast<float*>(save), B, dparams, dpar_gs,
+                         dx, dx_gs, dx_accumulate, scratch, G, B, s);
+}
+
+// ------------------------------------------------------------------------------------
+// fused step (model.py:44-90 forward + every gradient; Adam is a separate call)
+// ------------------------------------------------------------------------------------
+extern "C" int64_t vc_flat_param_floats(const vc_plan* p) { return p ? 2 * p->G.total + 2 * p->D.total : 0; }
+extern "C" int64_t vc_flat_offset(const vc_plan* p, int net) {
+    if (!p) return -1;
+    switch (net) { case 0: return 0; case 1: return p->G.total; case 2: return 2 * p->G.total; case 3: return 2 * p->G.total + p->D.total; }
+    return -1;
+}
+struct StepMap { long X1, O1, CY, DX, DO, dO1, dCY, dDO_D, dDO_G, S1, S2, SD, SCR, ACC, total;
+                 long ft2, ft1, hw2, hw1, s1_gs, s2_gs, sd_gs, scr_gs; };
+static StepMap step_map(const vc_plan* p, int B) {
+    StepMap m{}; long o = 0;
+    const long FT = (long)p->F * p->T;
+    m.ft2 = 2 * B * FT; m.ft1 = B * FT; m.hw2 = 2L * B * p->d_hw; m.hw1 = (long)B * p->d_hw;
+    auto take = [&](long n) { long r = o; o = align64(o + 2 * align64(n)); return r; };   // two groups each
+    m.X1 = take(m.ft2); m.O1 = take(m.ft2); m.CY = take(m.ft1); m.DX = take(m.ft2); m.DO = take(m.hw2);
+    m.dO1 = take(m.ft2); m.dCY = take(m.ft1); m.dDO_D = take(m.hw2); m.dDO_G = take(m.hw1);
+    m.s1_gs = vc_generator_save_floats(p, 2 * B); m.S1 = take(m.s1_gs);
+    m.s2_gs = vc_generator_save_floats(p, B);     m.S2 = take(m.s2_gs);
+    m.sd_gs = vc_discriminator_save_floats(p, 2 * B); m.SD = take(m.sd_gs);
+    m.scr_gs = vc_scratch_floats(p, 2 * B); m.SCR = take(m.scr_gs);
+    m.ACC = o; o += 64;
+    m.total = o;
+    return m;
+}
+extern "C" int64_t vc_step_workspace_floats(const vc_plan* p, int B) { return p ? step_map(p, B).total : 0; }
+
+extern "C" int vc_cyclegan_step_grads(const vc_plan* p, const float* params, float* grads,
+                                      const float* A, const float* Bm, int batch,
+                                      float lambda_cycle, float lambda_identity,
+                                      float* losses, float* gen_A, float* gen_B,
+                                      float* ws, int64_t ws_floats, void* stream) {
+    VC_ARG(p && params && grads && A && Bm && losses && ws && batch > 0, "vc_cyclegan_step_grads: bad args");
+    hipStream_t s = (hipStream_t)stream;
+    const int B = batch;
+    const StepMap m = step_map(p, B);
+    if (ws_floats < m.total) { vc_set_error("workspace too small: %lld < %lld floats", (long long)ws_floats, (long long)m.total); return VC_E_NOMEM; }
+    auto gs = [](long n) { return align64(n); };     // group stride of a two-group region
+    const long PG = p->G.total, PD = p->D.total;
+    const long FTb = (long)B * p->F * p->T * sizeof(float);
+    const long ft1 = m.ft1;
+    float *X1 = ws + m.X1, *O1 = ws + m.O1, *CY = ws + m.CY, *DX = ws + m.DX, *DO = ws + m.DO;
+    float *dO1 = ws + m.dO1, *dCY = ws + m.dCY, *dDO_D = ws + m.dDO_D, *dDO_G = ws + m.dDO_G;
+    const long X1g = gs(m.ft2), O1g = gs(m.ft2), CYg = gs(m.ft1), DXg = gs(m.ft2), DOg = gs(m.hw2);
+    const long dO1g = gs(m.ft2), dCYg = gs(m.ft1), dDDg = gs(m.hw2), dDGg = gs(m.hw1);
+    float *S1 = ws + m.S1, *S2 = ws + m.S2, *SD = ws + m.SD, *SCR = ws + m.SCR;
+    // the save/scratch areas were sized with take(): group stride = align64(size)
+    // (save_map totals are already multiples of 64, so align64 is the identity there)
+
+    VC_HIP(hipMemsetAsync(grads, 0, (size_t)vc_flat_param_floats(p) * sizeof(float), s));
+    // 1. first-hop inputs: g0 = A2B on [A;B], g1 = B2A on [B;A]   (model.py:44,51 / 47,50)
+    VC_HIP(hipMemcpyAsync(X1, A, FTb, hipMemcpyDeviceToDevice, s));
+    VC_HIP(hipMemcpyAsync(X1 + ft1, Bm, FTb, hipMemcpyDeviceToDevice, s));
+    VC_HIP(hipMemcpyAsync(X1 + X1g, Bm, FTb, hipMemcpyDeviceToDevice, s));
+    VC_HIP(hipMemcpyAsync(X1 + X1g + ft1, A, FTb, hipMemcpyDeviceToDevice, s));
+    // 2. O1[g0] = [gen_B; id_B], O1[g1] = [gen_A; id_A]
+    VC_CHECK(gen_forward(p, params, PG, X1, X1g, O1, O1g, S1, 2, 2 * B, s));
+    // 3. cycle hop: g0 = A2B(gen_A) = cycle_B, g1 = B2A(gen_B) = cycle_A   (model.py:45,48)
+    VC_CHECK(gen_forward(p, params, PG, O1 + O1g, -O1g, CY, CYg, S2, 2, B, s));
+    // 4. discriminator inputs: g0 = D_A on [gen_A; A], g1 = D_B on [gen_B; B]   (model.py:53-54,75-78)
+    VC_HIP(hipMemcpyAsync(DX, O1 + O1g, FTb, hipMemcpyDeviceToDevice, s));
+    VC_HIP(hipMemcpyAsync(DX + ft1, A, FTb, hipMemcpyDeviceToDevice, s));
+    VC_HIP(hipMemcpyAsync(DX + DXg, O1, FTb, hipMemcpyDeviceToDevice, s));
+    VC_HIP(hipMemcpyAsync(DX + DXg + ft1, Bm, FTb, hipMemcpyDeviceToDevice, s));
+    if (gen_A) VC_HIP(hipMemcpyAsync(gen_A, O1 + O1g, FTb, hipMemcpyDeviceToDevice, s));
+    if (gen_B) VC_HIP(hipMemcpyAsync(gen_B, O1, FTb, hipMemcpyDeviceToDevice, s));
+    // 5. D forward (the fake half doubles as D(fake) of the D sub-step: D weights are unchanged by the G update)
+    VC_CHECK(disc_forward(p, params + 2 * PG, PD, DX, DXg, DO, DOg, SD, 2, 2 * B, s));
+    // 6. losses + seed gradients
+    LossArgs la{};
+    la.A = A; la.Bm = Bm; la.out1 = O1; la.out1_gs = O1g; la.cyc = CY; la.cyc_gs = CYg; la.dout = DO; la.dout_gs = DOg;
+    la.d_out1 = dO1; la.d_out1_gs = dO1g; la.d_cyc = dCY; la.d_cyc_gs = dCYg;
+    la.d_dout_D = dDO_D; la.d_dout_D_gs = dDDg; la.d_dout_G = dDO_G; la.d_dout_G_gs = dDGg;
+    la.acc = ws + m.ACC; la.losses = losses; la.B = B; la.FT = p->F * p->T; la.HW = p->d_hw;
+    la.lambda_cycle = lambda_cycle; la.lambda_identity = lambda_identity;
+    VC_CHECK(launch_loss(la, s));
+    // 7. discriminator_loss backward over [fake; real] -> D gradients (model.py:94,107)
+    VC_CHECK(disc_backward(p, params + 2 * PG, PD, DX, DXg, DO, DOg, dDO_D, dDDg, SD, 2 * B,
+                           grads + 2 * PG, PD, nullptr, 0, 0, SCR, 2, 2 * B, s));
+    VC_HIP(hipEventRecord(p->d_ready, s));
+    // 8. adversarial generator terms: gradient through D's inputs only (var_list = generator_vars, model.py:95,108)
+    //    g0 = D_A -> d gen_A = dO1[g1][0:B]; g1 = D_B -> d gen_B = dO1[g0][0:B]
+    VC_CHECK(disc_backward(p, params + 2 * PG, PD, DX, DXg, DO, DOg, dDO_G, dDGg, SD, 2 * B,
+                           nullptr, 0, dO1 + dO1g, -dO1g, 0, SCR, 2, B, s));
+    // 9. cycle hop backward: g0 = A2B on gen_A -> adds into d gen_A; g1 = B2A on gen_B -> d gen_B
+    VC_CHECK(gen_backward(p, params, PG, O1 + O1g, -O1g, dCY, dCYg, S2, B, grads, PG,
+                          dO1 + dO1g, -dO1g, 1, SCR, 2, B, s));
+    // 10. first-hop backward over [generation; identity]
+    VC_CHECK(gen_backward(p, params, PG, X1, X1g, dO1, dO1g, S1, 2 * B, grads, PG,
+                          nullptr, 0, 0, SCR, 2, 2 * B, s));
+    return 0;
+}
+
+extern "C" int vc_step_wait_d_grads(const vc_plan* p, void* other_stream) {
+    VC_ARG(p, "vc_step_wait_d_grads: bad plan");
+    VC_HIP(hipStreamWaitEvent((hipStream_t)other_stream, p->d_ready, 0));
+    return 0;
+}

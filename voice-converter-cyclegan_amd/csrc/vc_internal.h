@@ -1,0 +1,81 @@
+// Internal launch descriptors shared by vc_kernels.hip (device code + launchers)
+// and vc_api.hip (host orchestration + C-ABI).  gfx950 only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// One entry per GEMM-K row of an implicit-GEMM convolution.
+//   c     : channel of the gathered tensor this K row reads
+//   dh,dw : offset (in gathered-tensor pixels) added to the launch pixel (i*si, j*sj)
+//   a_off : float offset of this K row inside the weight tensor, -1 = padding row
+struct __attribute__((aligned(16))) KEntry { int c, dh, dw, a_off; };
+
+// Y[g][b][m][P(i,j)] (+)= sum_kk A[a_off(kk) + m*a_ms] * X[g][b][c(kk)][i*si+dh(kk)][j*sj+dw(kk)]
+struct IgemmArgs {
+    const float* A; const float* X; float* Y; const float* bias; const float* addend;
+    const KEntry* ktab;
+    long a_gs, x_gs, y_gs, bias_gs, add_gs;      // signed group strides (floats)
+    long x_bs, y_bs;                              // batch strides (floats)
+    int nchunks;                                  // K rows / 32 (table is padded)
+    int M, a_ms;                                  // output rows, stride of m in A
+    int Hl, Wl;                                   // bounds of the gathered tensor
+    int xHW, xW;                                  // channel / row stride of the gathered tensor
+    int si, sj;                                   // pixel stride launch grid -> gathered tensor
+    int NPB, OWc, Ptot;                           // launch pixel grid: per sample, width, total
+    int yHW, yW;                                  // channel / row stride of the output tensor
+    int so_h, so_w, o_h0, o_w0;                   // launch pixel -> output pixel
+    int splitk, accumulate, mtiles, ntiles, groups, big;
+};
+
+// dW[a_off(kk) + co] += sum_{b,i,j} X[g][b][c(kk)][i*si+dh][j*sj+dw] * dY[g][b][co][i][j]
+struct WgradArgs {
+    const float* X; const float* dY; float* dW; const KEntry* ktab;
+    long x_gs, dy_gs, dw_gs; long x_bs, dy_bs;
+    int N;                                        // Cout
+    int Hl, Wl, xHW, xW, si, sj;
+    int NPB, OWc, Ptot;
+    int nchunks;                                  // ceil(Ptot/32)
+    int splitk, ktiles, ntiles, groups;
+};
+
+struct NormArgs {
+    const float* y; const float* res; const float* gamma; const float* beta;
+    const float* dout; const float* stats_in;
+    float* out; float* stats; float* dy; float* dgamma; float* dbeta; float* dbias;
+    long y_gs, res_gs, par_gs, out_gs, st_gs, do_gs, dy_gs, dpar_gs, dbias_gs;
+    int G, B, C, L, ps;
+};
+
+void igemm_config(IgemmArgs& a);   // picks tile size + split-K, fills mtiles/ntiles/splitk/big
+int launch_igemm(const IgemmArgs& a, bool a_trans, hipStream_t s, double flops);
+int launch_wgrad(const WgradArgs& a, hipStream_t s, double flops);
+int launch_norm_fwd(int mode, const NormArgs& a, hipStream_t s);
+int launch_norm_bwd(int mode, const NormArgs& a, hipStream_t s);
+int launch_bias_grad(const float* dy, long dy_gs, float* db, long db_gs, int G, int B, int C, int L, hipStream_t s);
+int launch_head_fwd(const float* x, long x_gs, const float* w, const float* b, long par_gs,
+                    float* o, long o_gs, int G, int B, int C, int HW, hipStream_t s);
+int launch_head_bwd(const float* x, long x_gs, const float* w, long par_gs, const float* o, long o_gs,
+                    const float* dout, long do_gs, float* dx, long dx_gs, float* dw, float* db,
+                    long dpar_gs, int G, int B, int C, int HW, hipStream_t s);
+int launch_adam(float* p, float* m, float* v, const float* g, long n, float alpha, float b1,
+                float b2, float eps, float gscale, hipStream_t s);
+
+struct LossArgs {
+    const float* A; const float* Bm;      // real [B][F][T]
+    const float* out1; long out1_gs;      // [2][2B][F][T]: g0 = A2B([A;B]) = [gen_B; id_B], g1 = B2A([B;A]) = [gen_A; id_A]
+    const float* cyc;  long cyc_gs;       // [2][B][F][T]:  g0 = A2B(gen_A) = cycle_B,      g1 = B2A(gen_B) = cycle_A
+    const float* dout; long dout_gs;      // [2][2B][HW]:   g0 = D_A([gen_A; A]),            g1 = D_B([gen_B; B])
+    float* d_out1; long d_out1_gs;        // identity halves written, generation halves zeroed
+    float* d_cyc;  long d_cyc_gs;
+    float* d_dout_D; long d_dout_D_gs;    // [2][2B][HW] seeds of discriminator_loss
+    float* d_dout_G; long d_dout_G_gs;    // [2][B][HW]  seeds of generator_loss_{B2A,A2B}
+    float* acc;                           // 10 fp32 partial sums (zeroed by the launcher)
+    float* losses;                        // 8 scalars
+    int B, FT, HW; float lambda_cycle, lambda_identity;
+};
+int launch_loss(const LossArgs& a, hipStream_t s);
+
+void vc_set_error(const char* fmt, ...);
+#define VC_HIP(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { \
+    vc_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    return (int)_e; } } while (0)

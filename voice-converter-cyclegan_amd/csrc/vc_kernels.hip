@@ -1,0 +1,792 @@
+// vc_kernels.hip -- gfx950 (MI355X / CDNA4) device kernels of the CycleGAN-VC hot path.
+//
+//  igemm_kernel  : table-driven implicit GEMM on v_mfma_f32_32x32x2_f32 (exact fp32, k-ordered
+//                  fma chain).  Serves tf.layers.conv1d/conv2d forward (module.py:32-40,54-62)
+//                  and their input gradients (autodiff of model.py:107-108).
+//  wgrad_kernel  : filter gradient, same MFMA, reduction over (batch, pixels).
+//  norm_*_kernel : instance_norm_layer + gated_linear_layer (+ pixel_shuffler, + residual add),
+//                  wavefront-shuffle reductions (module.py:3-20,81,135-146).
+//  head_*        : tf.layers.dense(1, sigmoid) (module.py:211).
+//  loss_kernel   : utils.py:6-12 + loss algebra model.py:57-90, fused with the seed gradients.
+//  adam_kernel   : ApplyAdam (model.py:107-108).
+//
+// Wavefront = 64 lanes everywhere.  No CUDA compatibility paths.
+#include "vc_internal.h"
+#include <vector>
+#include <mutex>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// =====================================================================================
+// Implicit-GEMM: D[m][n] = sum_k A[k][m] * Xg[k][n], m = output channel, n = launch pixel.
+// Workgroup = 4 waves (2x2), tile BM x BN, K chunk 32, LDS double buffer, register staging.
+// MFMA operand maps (32x32x2 f32): A[i=lane&31][k=lane>>5], B[k=lane>>5][j=lane&31],
+// D: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+// =====================================================================================
+template <int BM, int BN, bool AT>
+__global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
+    constexpr int KC = 32;
+    constexpr int LDA = AT ? BM + 1 : BM + 4;
+    constexpr int LDX = BN;
+    constexpr int WM = BM / 2, WN = BN / 2, MI = WM / 32, NJ = WN / 32;
+    constexpr int ASZ = KC * LDA, XSZ = KC * LDX;
+    __shared__ __attribute__((aligned(16))) float smem[2 * (ASZ + XSZ)];
+    float* As = smem;
+    float* Xs = smem + 2 * ASZ;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm = wid >> 1, wn = wid & 1;
+
+    // XCD-aware tile order: block b runs on XCD b%8; give each XCD whole m-tiles so a weight
+    // slab is fetched into one L2 only (speed only; any order is correct).
+    int tile = blockIdx.x, mt, nt;
+    if ((p.mtiles & 7) == 0) { const int xcd = tile & 7, k = tile >> 3; mt = xcd + 8 * (k / p.ntiles); nt = k % p.ntiles; }
+    else { nt = tile % p.ntiles; mt = tile / p.ntiles; }
+    const int g = blockIdx.z / p.splitk, sp = blockIdx.z - g * p.splitk;
+    const int cps = (p.nchunks + p.splitk - 1) / p.splitk;
+    const int c0 = sp * cps, c1 = min(p.nchunks, c0 + cps);
+    if (c0 >= c1) return;
+
+    // ---- gathered-operand loader: column n of the tile is one launch pixel, fixed per thread
+    constexpr int XRP = 256 / BN, XL = KC / XRP;
+    const int xn = tid % BN, xr0 = tid / BN;
+    const int P = nt * BN + xn;
+    const bool pv = P < p.Ptot;
+    int xb = 0, xi = 0, xj = 0;
+    if (pv) { xb = P / p.NPB; const int r = P - xb * p.NPB; xi = r / p.OWc; xj = r - xi * p.OWc; }
+    const int li0 = xi * p.si, lj0 = xj * p.sj;
+    const float* Xg = p.X + (long)g * p.x_gs + (long)xb * p.x_bs;
+    const float* Ag = p.A + (long)g * p.a_gs;
+
+    // ---- weight loader
+    constexpr int AV = BM / 4, ARP = 256 / AV, AL = KC / ARP;   // fwd: float4 along m
+    constexpr int ALT = BM / 8;                                  // transposed: scalar along k
+    const int am = (tid % AV) * 4, ar0 = tid / AV;
+    const int akk = tid & 31, am0 = tid >> 5;
+
+    float xr[XL];
+    float4 af[AT ? 1 : AL];
+    float at[AT ? ALT : 1];
+
+    auto load = [&](int c) {
+#pragma unroll
+        for (int q = 0; q < XL; ++q) {
+            const KEntry e = p.ktab[c * KC + xr0 + q * XRP];
+            const int li = li0 + e.dh, lj = lj0 + e.dw;
+            const bool v = pv && e.a_off >= 0 && (unsigned)li < (unsigned)p.Hl && (unsigned)lj < (unsigned)p.Wl;
+            xr[q] = v ? Xg[(long)e.c * p.xHW + li * p.xW + lj] : 0.f;
+        }
+        if constexpr (AT) {
+            const KEntry e = p.ktab[c * KC + akk];
+#pragma unroll
+            for (int q = 0; q < ALT; ++q) {
+                const int m = mt * BM + am0 + q * 8;
+                at[q] = (e.a_off >= 0 && m < p.M) ? Ag[(long)e.a_off + (long)m * p.a_ms] : 0.f;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < AL; ++q) {
+                const KEntry e = p.ktab[c * KC + ar0 + q * ARP];
+                const int m = mt * BM + am;
+                af[q] = (e.a_off >= 0 && m < p.M) ? *reinterpret_cast<const float4*>(Ag + e.a_off + m)
+                                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    };
+    auto store = [&](int buf) {
+        float* xs = Xs + buf * XSZ;
+        float* as = As + buf * ASZ;
+#pragma unroll
+        for (int q = 0; q < XL; ++q) xs[(xr0 + q * XRP) * LDX + xn] = xr[q];
+        if constexpr (AT) {
+#pragma unroll
+            for (int q = 0; q < ALT; ++q) as[akk * LDA + am0 + q * 8] = at[q];
+        } else {
+#pragma unroll
+            for (int q = 0; q < AL; ++q) *reinterpret_cast<float4*>(as + (ar0 + q * ARP) * LDA + am) = af[q];
+        }
+    };
+
+    f32x16 acc[MI][NJ];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int nj = 0; nj < NJ; ++nj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][nj][r] = 0.f;
+
+    load(c0);
+    store(0);
+    __syncthreads();
+    for (int c = c0; c < c1; ++c) {
+        const int buf = (c - c0) & 1;
+        if (c + 1 < c1) load(c + 1);           // global loads fly under the MFMAs below
+        const float* as = As + buf * ASZ + wm * WM + l31;
+        const float* xs = Xs + buf * XSZ + wn * WN + l31;
+#pragma unroll
+        for (int ks = 0; ks < KC / 2; ++ks) {
+            const int k = 2 * ks + h;
+            float a[MI], b[NJ];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) a[mi] = as[k * LDA + mi * 32];
+#pragma unroll
+            for (int nj = 0; nj < NJ; ++nj) b[nj] = xs[k * LDX + nj * 32];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int nj = 0; nj < NJ; ++nj)
+                    acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], b[nj], acc[mi][nj], 0, 0, 0);
+        }
+        if (c + 1 < c1) store(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: + bias[m] (+ addend) ; plain store or atomic add
+    const bool atomic = p.splitk > 1 || p.accumulate;
+    const bool first = sp == 0;
+    float* Yg = p.Y + (long)g * p.y_gs;
+    const float* Bg = (p.bias && first) ? p.bias + (long)g * p.bias_gs : nullptr;
+    const float* Dg = (p.addend && first) ? p.addend + (long)g * p.add_gs : nullptr;
+    long ybase[NJ]; bool yv[NJ];
+#pragma unroll
+    for (int nj = 0; nj < NJ; ++nj) {
+        const int Pn = nt * BN + wn * WN + nj * 32 + l31;
+        yv[nj] = Pn < p.Ptot;
+        int b = 0, i = 0, j = 0;
+        if (yv[nj]) { b = Pn / p.NPB; const int r = Pn - b * p.NPB; i = r / p.OWc; j = r - i * p.OWc; }
+        ybase[nj] = (long)b * p.y_bs + (long)(i * p.so_h + p.o_h0) * p.yW + (j * p.so_w + p.o_w0);
+    }
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = mt * BM + wm * WM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (m < p.M) {
+                const float bv = Bg ? Bg[m] : 0.f;
+#pragma unroll
+                for (int nj = 0; nj < NJ; ++nj) {
+                    if (yv[nj]) {
+                        const long idx = ybase[nj] + (long)m * p.yHW;
+                        float v = acc[mi][nj][r] + bv;
+                        if (Dg) v += Dg[idx];
+                        if (atomic) atomicAdd(Yg + idx, v); else Yg[idx] = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// =====================================================================================
+// Filter gradient: D[kk][co] = sum_P Xg[kk][P] * dY[co][P], P = (b, oh, ow).
+// rows = K rows of the forward table (64 per tile), cols = Cout (BN per tile).
+// =====================================================================================
+template <int BN>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
+    constexpr int BM = 64, KC = 32, LDA = BM + 1, LDB = BN + 1;
+    constexpr int WN = BN / 2, NJ = WN / 32;
+    constexpr int ASZ = KC * LDA, BSZ = KC * LDB;
+    __shared__ float smem[2 * (ASZ + BSZ)];
+    float* As = smem;
+    float* Bs = smem + 2 * ASZ;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int nt = blockIdx.x % p.ntiles, kt = blockIdx.x / p.ntiles;
+    const int g = blockIdx.z / p.splitk, sp = blockIdx.z - g * p.splitk;
+    const int cps = (p.nchunks + p.splitk - 1) / p.splitk;
+    const int c0 = sp * cps, c1 = min(p.nchunks, c0 + cps);
+    if (c0 >= c1) return;
+
+    const int pl = tid & 31, rg = tid >> 5;
+    KEntry e[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) e[q] = p.ktab[kt * BM + rg + q * 8];
+    const float* Xg = p.X + (long)g * p.x_gs;
+    const float* Yg = p.dY + (long)g * p.dy_gs;
+
+    float xr[8], dr[BN / 8];
+    auto load = [&](int c) {
+        const int P = c * KC + pl;
+        const bool pv = P < p.Ptot;
+        int b = 0, i = 0, j = 0, r = 0;
+        if (pv) { b = P / p.NPB; r = P - b * p.NPB; i = r / p.OWc; j = r - i * p.OWc; }
+        const float* xb = Xg + (long)b * p.x_bs;
+        const int li0 = i * p.si, lj0 = j * p.sj;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int li = li0 + e[q].dh, lj = lj0 + e[q].dw;
+            const bool v = pv && e[q].a_off >= 0 && (unsigned)li < (unsigned)p.Hl && (unsigned)lj < (unsigned)p.Wl;
+            xr[q] = v ? xb[(long)e[q].c * p.xHW + li * p.xW + lj] : 0.f;
+        }
+        const float* yb = Yg + (long)b * p.dy_bs + r;
+#pragma unroll
+        for (int q = 0; q < BN / 8; ++q) {
+            const int co = nt * BN + rg + q * 8;
+            dr[q] = (pv && co < p.N) ? yb[(long)co * p.NPB] : 0.f;
+        }
+    };
+    auto store = [&](int buf) {
+        float* as = As + buf * ASZ + pl * LDA + rg;
+        float* bs = Bs + buf * BSZ + pl * LDB + rg;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) as[q * 8] = xr[q];
+#pragma unroll
+        for (int q = 0; q < BN / 8; ++q) bs[q * 8] = dr[q];
+    };
+
+    f32x16 acc[NJ];
+#pragma unroll
+    for (int nj = 0; nj < NJ; ++nj)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nj][r] = 0.f;
+
+    load(c0);
+    store(0);
+    __syncthreads();
+    for (int c = c0; c < c1; ++c) {
+        const int buf = (c - c0) & 1;
+        if (c + 1 < c1) load(c + 1);
+        const float* as = As + buf * ASZ + wm * 32 + l31;
+        const float* bs = Bs + buf * BSZ + wn * WN + l31;
+#pragma unroll
+        for (int ks = 0; ks < KC / 2; ++ks) {
+            const int k = 2 * ks + h;
+            const float a = as[k * LDA];
+#pragma unroll
+            for (int nj = 0; nj < NJ; ++nj)
+                acc[nj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bs[k * LDB + nj * 32], acc[nj], 0, 0, 0);
+        }
+        if (c + 1 < c1) store(buf ^ 1);
+        __syncthreads();
+    }
+
+    float* Wg = p.dW + (long)g * p.dw_gs;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int kk = kt * BM + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int aoff = p.ktab[kk].a_off;
+        if (aoff >= 0) {
+#pragma unroll
+            for (int nj = 0; nj < NJ; ++nj) {
+                const int co = nt * BN + wn * WN + nj * 32 + l31;
+                if (co < p.N) atomicAdd(Wg + aoff + co, acc[nj][r]);
+            }
+        }
+    }
+}
+
+// =====================================================================================
+// instance norm / GLU / pixel shuffle / residual, one (g,b,c) row per LPR lanes,
+// whole row in registers, wavefront shuffles for the per-channel reductions.
+// =====================================================================================
+#define IN_EPS 1e-6f
+
+template <int LPR> __device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+
+// float offset of logical element (branch br, channel c, position l) of sample b in the raw conv output
+template <int NB> __device__ __forceinline__ long yoff(const NormArgs& p, int b, int br, int c, int l) {
+    if (p.ps) {
+        const int T = p.L >> 1;
+        return ((long)b * (NB * 2 * p.C) + br * 2 * p.C + (l & 1) * p.C + c) * T + (l >> 1);
+    }
+    return ((long)b * (NB * p.C) + br * p.C + c) * p.L + l;
+}
+
+template <int MODE, int LPR, int NE>
+__global__ __launch_bounds__(256) void norm_fwd_kernel(const NormArgs p) {
+    constexpr int NB = (MODE == 2) ? 1 : 2;
+    const int unit = blockIdx.x * (256 / LPR) + threadIdx.x / LPR;
+    const int sub = threadIdx.x % LPR;
+    const int total = p.G * p.B * p.C;
+    if (unit >= total) return;
+    const int g = unit / (p.B * p.C); const int rem = unit - g * (p.B * p.C);
+    const int b = rem / p.C, c = rem - b * p.C;
+    const float* y = p.y + (long)g * p.y_gs;
+    float* out = p.out + (long)g * p.out_gs + ((long)b * p.C + c) * p.L;
+    const float invL = 1.f / (float)p.L;
+
+    float v[NE], gt[NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+        const int l = sub + e * LPR;
+        const bool ok = l < p.L;
+        v[e] = ok ? y[yoff<NB>(p, b, 0, c, l)] : 0.f;
+        if (NB == 2) gt[e] = ok ? y[yoff<NB>(p, b, 1, c, l)] : 0.f;
+    }
+    if (MODE == 1) {
+#pragma unroll
+        for (int e = 0; e < NE; ++e) { const int l = sub + e * LPR; if (l < p.L) out[l] = v[e] * sigmoidf_(gt[e]); }
+        return;
+    }
+    const float* gam = p.gamma + (long)g * p.par_gs;
+    const float* bet = p.beta + (long)g * p.par_gs;
+    float* st = p.stats + (long)g * p.st_gs + ((long)b * NB * p.C) * 2;
+
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) s += v[e];
+    const float mu = group_sum<LPR>(s) * invL;
+    float q = 0.f;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) { const float d = (sub + e * LPR < p.L) ? v[e] - mu : 0.f; q += d * d; }
+    const float rs = rsqrtf(group_sum<LPR>(q) * invL + IN_EPS);
+    const float ga = gam[c], be = bet[c];
+    if (sub == 0) { st[2 * c] = mu; st[2 * c + 1] = rs; }
+
+    if (MODE == 2) {
+        const float* res = p.res + (long)g * p.res_gs + ((long)b * p.C + c) * p.L;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const int l = sub + e * LPR;
+            if (l < p.L) out[l] = res[l] + ((v[e] - mu) * rs * ga + be);
+        }
+        return;
+    }
+    float s2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) s2 += gt[e];
+    const float mu2 = group_sum<LPR>(s2) * invL;
+    float q2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) { const float d = (sub + e * LPR < p.L) ? gt[e] - mu2 : 0.f; q2 += d * d; }
+    const float rs2 = rsqrtf(group_sum<LPR>(q2) * invL + IN_EPS);
+    const float ga2 = gam[p.C + c], be2 = bet[p.C + c];
+    if (sub == 0) { st[2 * (p.C + c)] = mu2; st[2 * (p.C + c) + 1] = rs2; }
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+        const int l = sub + e * LPR;
+        if (l < p.L) out[l] = ((v[e] - mu) * rs * ga + be) * sigmoidf_((gt[e] - mu2) * rs2 * ga2 + be2);
+    }
+}
+
+template <int MODE, int LPR, int NE>
+__global__ __launch_bounds__(256) void norm_bwd_kernel(const NormArgs p) {
+    constexpr int NB = (MODE == 2) ? 1 : 2;
+    const int unit = blockIdx.x * (256 / LPR) + threadIdx.x / LPR;
+    const int sub = threadIdx.x % LPR;
+    const int total = p.G * p.B * p.C;
+    if (unit >= total) return;
+    const int g = unit / (p.B * p.C); const int rem = unit - g * (p.B * p.C);
+    const int b = rem / p.C, c = rem - b * p.C;
+    const float* y = p.y + (long)g * p.y_gs;
+    float* dy = p.dy + (long)g * p.dy_gs;
+    const float* dout = p.dout + (long)g * p.do_gs + ((long)b * p.C + c) * p.L;
+    const float invL = 1.f / (float)p.L;
+    const bool odd = sub & 1;   // LPR is even: every element this lane owns has parity sub&1
+
+    float v[NE], gt[NE], dO[NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+        const int l = sub + e * LPR;
+        const bool ok = l < p.L;
+        v[e] = ok ? y[yoff<NB>(p, b, 0, c, l)] : 0.f;
+        if (NB == 2) gt[e] = ok ? y[yoff<NB>(p, b, 1, c, l)] : 0.f;
+        dO[e] = ok ? dout[l] : 0.f;
+    }
+    float* dbias = p.dbias ? p.dbias + (long)g * p.dbias_gs : nullptr;
+    // conv channels whose bias gradient this row contributes to
+    const int cb0 = p.ps ? c : c;                       // branch 0, even l (or all l)
+    const int cstride_par = p.ps ? p.C : 0;             // odd l -> +C when shuffled
+    const int brstride = p.ps ? 2 * p.C : p.C;          // branch 1 offset in conv channels
+
+    if (MODE == 1) {
+        float sv = 0.f, sg = 0.f;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const int l = sub + e * LPR;
+            const float s = sigmoidf_(gt[e]);
+            const float dv = dO[e] * s, dg = dO[e] * v[e] * s * (1.f - s);
+            if (l < p.L) { dy[yoff<NB>(p, b, 0, c, l)] = dv; dy[yoff<NB>(p, b, 1, c, l)] = dg; }
+            sv += dv; sg += dg;
+        }
+        if (dbias) {
+            sv = group_sum<LPR>(sv); sg = group_sum<LPR>(sg);
+            if (sub == 0) { atomicAdd(dbias + c, sv); atomicAdd(dbias + p.C + c, sg); }
+        }
+        return;
+    }
+    const float* gam = p.gamma + (long)g * p.par_gs;
+    const float* bet = p.beta + (long)g * p.par_gs;
+    const float* st = p.stats_in + (long)g * p.st_gs + ((long)b * NB * p.C) * 2;
+    float* dgam = p.dgamma ? p.dgamma + (long)g * p.dpar_gs : nullptr;
+    float* dbet = p.dbeta ? p.dbeta + (long)g * p.dpar_gs : nullptr;
+    const float mu = st[2 * c], rs = st[2 * c + 1], ga = gam[c], be = bet[c];
+
+    if (MODE == 2) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) { const float xh = (v[e] - mu) * rs; s1 += dO[e]; s2 += dO[e] * xh; }
+        s1 = group_sum<LPR>(s1); s2 = group_sum<LPR>(s2);
+        float sb = 0.f;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const int l = sub + e * LPR;
+            const float xh = (v[e] - mu) * rs;
+            const float d = ga * rs * (dO[e] - s1 * invL - xh * s2 * invL);
+            if (l < p.L) { dy[yoff<NB>(p, b, 0, c, l)] = d; sb += d; }
+        }
+        sb = group_sum<LPR>(sb);
+        if (sub == 0) {
+            if (dgam) { atomicAdd(dgam + c, s2); atomicAdd(dbet + c, s1); }
+            if (dbias) atomicAdd(dbias + c, sb);
+        }
+        return;
+    }
+    const float mu2 = st[2 * (p.C + c)], rs2 = st[2 * (p.C + c) + 1], ga2 = gam[p.C + c], be2 = bet[p.C + c];
+    float s1v = 0.f, s2v = 0.f, s1g = 0.f, s2g = 0.f;
+    float dnv[NE], dng[NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+        const float xv = (v[e] - mu) * rs, xg = (gt[e] - mu2) * rs2;
+        const float nv = ga * xv + be, ng = ga2 * xg + be2;
+        const float s = sigmoidf_(ng);
+        dnv[e] = dO[e] * s; dng[e] = dO[e] * nv * s * (1.f - s);
+        s1v += dnv[e]; s2v += dnv[e] * xv; s1g += dng[e]; s2g += dng[e] * xg;
+    }
+    s1v = group_sum<LPR>(s1v); s2v = group_sum<LPR>(s2v);
+    s1g = group_sum<LPR>(s1g); s2g = group_sum<LPR>(s2g);
+    float sbv = 0.f, sbg = 0.f;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+        const int l = sub + e * LPR;
+        const float xv = (v[e] - mu) * rs, xg = (gt[e] - mu2) * rs2;
+        const float dv = ga * rs * (dnv[e] - s1v * invL - xv * s2v * invL);
+        const float dg = ga2 * rs2 * (dng[e] - s1g * invL - xg * s2g * invL);
+        if (l < p.L) { dy[yoff<NB>(p, b, 0, c, l)] = dv; dy[yoff<NB>(p, b, 1, c, l)] = dg; sbv += dv; sbg += dg; }
+    }
+    if (dbias) {
+        // conv-channel sums; with pixel shuffle even/odd positions belong to different conv channels
+        float ev = group_sum<LPR>((p.ps && odd) ? 0.f : sbv), eg = group_sum<LPR>((p.ps && odd) ? 0.f : sbg);
+        float ov = 0.f, og = 0.f;
+        if (p.ps) { ov = group_sum<LPR>(odd ? sbv : 0.f); og = group_sum<LPR>(odd ? sbg : 0.f); }
+        if (sub == 0) {
+            atomicAdd(dbias + cb0, ev); atomicAdd(dbias + brstride + cb0, eg);
+            if (p.ps) { atomicAdd(dbias + cstride_par + cb0, ov); atomicAdd(dbias + brstride + cstride_par + cb0, og); }
+        }
+    }
+    if (sub == 0 && dgam) {
+        atomicAdd(dgam + c, s2v); atomicAdd(dbet + c, s1v);
+        atomicAdd(dgam + p.C + c, s2g); atomicAdd(dbet + p.C + c, s1g);
+    }
+}
+
+// =====================================================================================
+// small kernels
+// =====================================================================================
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float block_sum_256(float v, float* red /*[4]*/) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void bias_grad_kernel(const float* dy, long dy_gs, float* db, long db_gs,
+                                                        int B, int C, int L) {
+    __shared__ float red[4];
+    const int c = blockIdx.x, g = blockIdx.y;
+    const float* d = dy + (long)g * dy_gs;
+    float s = 0.f;
+    const int n = B * L;
+    for (int i = threadIdx.x; i < n; i += 256) { const int b = i / L, l = i - b * L; s += d[((long)b * C + c) * L + l]; }
+    s = block_sum_256(s, red);
+    if (threadIdx.x == 0) atomicAdd(db + (long)g * db_gs + c, s);
+}
+
+__global__ __launch_bounds__(256) void head_fwd_kernel(const float* x, long x_gs, const float* w, const float* bias,
+                                                       long par_gs, float* o, long o_gs, int C, int HW) {
+    __shared__ float red[4][64];
+    const int g = blockIdx.z, b = blockIdx.y;
+    const int px = blockIdx.x * 64 + (threadIdx.x & 63), cq = threadIdx.x >> 6;
+    const float* xb = x + (long)g * x_gs + (long)b * C * HW;
+    const float* wg = w + (long)g * par_gs;
+    float s = 0.f;
+    if (px < HW) for (int c = cq; c < C; c += 4) s += xb[(long)c * HW + px] * wg[c];
+    red[cq][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (cq == 0 && px < HW) {
+        const float z = red[0][px & 63] + red[1][px & 63] + red[2][px & 63] + red[3][px & 63] + bias[(long)g * par_gs];
+        o[(long)g * o_gs + (long)b * HW + px] = sigmoidf_(z);
+    }
+}
+
+// dx[b][c][p] = dz[b][p] * w[c], dz = dout*o*(1-o)
+__global__ __launch_bounds__(256) void head_bwd_dx_kernel(const float* w, long par_gs, const float* o, long o_gs,
+                                                          const float* dout, long do_gs, float* dx, long dx_gs, int B, int C, int HW) {
+    const int g = blockIdx.y;
+    const long n = (long)B * C * HW;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int pxl = (int)(i % HW); const long bc = i / HW; const int c = (int)(bc % C); const int b = (int)(bc / C);
+        const float ov = o[(long)g * o_gs + (long)b * HW + pxl];
+        const float dz = dout[(long)g * do_gs + (long)b * HW + pxl] * ov * (1.f - ov);
+        dx[(long)g * dx_gs + i] = dz * w[(long)g * par_gs + c];
+    }
+}
+// one wave per channel: dw[c] += sum_{b,p} dz*x ; the wave of channel 0 also does db
+__global__ __launch_bounds__(256) void head_bwd_dw_kernel(const float* x, long x_gs, const float* o, long o_gs, const float* dout,
+                                                          long do_gs, float* dw, float* db, long dpar_gs, int B, int C, int HW) {
+    const int g = blockIdx.y;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (c >= C) return;
+    const int n = B * HW;
+    float s = 0.f, sb = 0.f;
+    for (int i = lane; i < n; i += 64) {
+        const int b = i / HW, pxl = i - b * HW;
+        const float ov = o[(long)g * o_gs + i];
+        const float dz = dout[(long)g * do_gs + i] * ov * (1.f - ov);
+        s += dz * x[(long)g * x_gs + ((long)b * C + c) * HW + pxl];
+        sb += dz;
+    }
+    s = wave_sum(s);
+    if (lane == 0) atomicAdd(dw + (long)g * dpar_gs + c, s);
+    if (c == 0) { sb = wave_sum(sb); if (lane == 0) atomicAdd(db + (long)g * dpar_gs, sb); }
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
+                                                   const float* __restrict__ g, long n4, long n, float alpha,
+                                                   float b1, float b2, float eps, float gs) {
+    const float omb1 = 1.f - b1, omb2 = 1.f - b2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        float4 P = reinterpret_cast<float4*>(p)[i], M = reinterpret_cast<float4*>(m)[i], V = reinterpret_cast<float4*>(v)[i];
+        float4 G = reinterpret_cast<const float4*>(g)[i];
+#define VC_ADAM1(x) { const float gg = G.x * gs; M.x += (gg - M.x) * omb1; V.x += (gg * gg - V.x) * omb2; \
+                      P.x -= (M.x * alpha) / (sqrtf(V.x) + eps); }
+        VC_ADAM1(x) VC_ADAM1(y) VC_ADAM1(z) VC_ADAM1(w)
+        reinterpret_cast<float4*>(p)[i] = P; reinterpret_cast<float4*>(m)[i] = M; reinterpret_cast<float4*>(v)[i] = V;
+    }
+    if (blockIdx.x == 0) {
+        for (long i = n4 * 4 + threadIdx.x; i < n; i += 256) {
+            const float gg = g[i] * gs;
+            float mm = m[i], vv = v[i];
+            mm += (gg - mm) * omb1; vv += (gg * gg - vv) * omb2;
+            p[i] -= (mm * alpha) / (sqrtf(vv) + eps);
+            m[i] = mm; v[i] = vv;
+        }
+    }
+}
+
+__device__ __forceinline__ float signf_(float x) { return (float)((x > 0.f) - (x < 0.f)); }
+
+// utils.py:6-12 + model.py:57-90, plus the gradients of every mean w.r.t. its input.
+__global__ __launch_bounds__(256) void loss_kernel(const LossArgs a) {
+    __shared__ float red[4];
+    float s[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) s[k] = 0.f;
+    const long n1 = (long)a.B * a.FT, n2 = (long)a.B * a.HW;
+    const float inv1 = 1.f / (float)n1, inv2 = 1.f / (float)n2;
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n1; i += stride) {
+        const float A = a.A[i], Bm = a.Bm[i];
+        const float cycB = a.cyc[i], cycA = a.cyc[a.cyc_gs + i];
+        const float idB = a.out1[n1 + i], idA = a.out1[a.out1_gs + n1 + i];
+        s[0] += fabsf(A - cycA); s[1] += fabsf(Bm - cycB); s[2] += fabsf(A - idA); s[3] += fabsf(Bm - idB);
+        a.d_cyc[i] = a.lambda_cycle * signf_(cycB - Bm) * inv1;
+        a.d_cyc[a.d_cyc_gs + i] = a.lambda_cycle * signf_(cycA - A) * inv1;
+        a.d_out1[n1 + i] = a.lambda_identity * signf_(idB - Bm) * inv1;
+        a.d_out1[a.d_out1_gs + n1 + i] = a.lambda_identity * signf_(idA - A) * inv1;
+    }
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n2; i += stride) {
+        const float dAf = a.dout[i], dAr = a.dout[n2 + i];
+        const float dBf = a.dout[a.dout_gs + i], dBr = a.dout[a.dout_gs + n2 + i];
+        s[4] += (1.f - dBf) * (1.f - dBf); s[5] += (1.f - dAf) * (1.f - dAf);
+        s[6] += (1.f - dAr) * (1.f - dAr); s[7] += dAf * dAf;
+        s[8] += (1.f - dBr) * (1.f - dBr); s[9] += dBf * dBf;
+        a.d_dout_G[i] = -2.f * (1.f - dAf) * inv2;
+        a.d_dout_G[a.d_dout_G_gs + i] = -2.f * (1.f - dBf) * inv2;
+        a.d_dout_D[i] = dAf * inv2;                 a.d_dout_D[n2 + i] = -(1.f - dAr) * inv2;
+        a.d_dout_D[a.d_dout_D_gs + i] = dBf * inv2; a.d_dout_D[a.d_dout_D_gs + n2 + i] = -(1.f - dBr) * inv2;
+    }
+#pragma unroll
+    for (int k = 0; k < 10; ++k) {
+        const float t = block_sum_256(s[k], red);
+        if (threadIdx.x == 0) atomicAdd(a.acc + k, t);
+    }
+}
+__global__ void loss_finalize_kernel(const float* acc, float* L, float n1, float n2, float lc, float li) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const float cyc = acc[0] / n1 + acc[1] / n1;
+        const float idl = acc[2] / n1 + acc[3] / n1;
+        const float gA2B = acc[4] / n2, gB2A = acc[5] / n2;
+        const float dA = (acc[6] / n2 + acc[7] / n2) * 0.5f, dB = (acc[8] / n2 + acc[9] / n2) * 0.5f;
+        L[0] = cyc; L[1] = idl; L[2] = gA2B; L[3] = gB2A;
+        L[4] = gA2B + gB2A + lc * cyc + li * idl;
+        L[5] = dA; L[6] = dB; L[7] = dA + dB;
+    }
+}
+
+// =====================================================================================
+// launchers
+// =====================================================================================
+namespace {
+struct ProfRec { hipEvent_t a, b; double flops; int kind; };
+std::mutex g_prof_mu;
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof;
+struct ProfScope {
+    bool on; ProfRec r; hipStream_t s;
+    ProfScope(int kind, double flops, hipStream_t st) : on(g_prof_on), s(st) {
+        if (on) { hipEventCreate(&r.a); hipEventCreate(&r.b); r.flops = flops; r.kind = kind; hipEventRecord(r.a, s); }
+    }
+    ~ProfScope() { if (on) { hipEventRecord(r.b, s); std::lock_guard<std::mutex> l(g_prof_mu); g_prof.push_back(r); } }
+};
+}  // namespace
+
+extern "C" int vc_prof_enable(int on) {
+    std::lock_guard<std::mutex> l(g_prof_mu);
+    for (auto& r : g_prof) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+    g_prof.clear();
+    g_prof_on = on != 0;
+    return 0;
+}
+extern "C" int vc_prof_collect(int kind, double* ms, long long* launches, double* flops) {
+    std::lock_guard<std::mutex> l(g_prof_mu);
+    double t = 0, f = 0; long long n = 0;
+    for (auto& r : g_prof) {
+        if (r.kind != kind) continue;
+        VC_HIP(hipEventSynchronize(r.b));
+        float e = 0; VC_HIP(hipEventElapsedTime(&e, r.a, r.b));
+        t += e; f += r.flops; ++n;
+    }
+    if (ms) *ms = t; if (launches) *launches = n; if (flops) *flops = f;
+    return 0;
+}
+
+static int pick_splitk(long tiles, int nchunks) {
+    // fill ~2 workgroups per CU (256 CUs); keep >= 4 chunks per split
+    int sk = 1;
+    while (tiles * sk < 512 && nchunks / (sk * 2) >= 4 && sk < 16) sk *= 2;
+    return sk;
+}
+
+void igemm_config(IgemmArgs& a) {
+    // large tiles only when they still fill the chip (256 CUs, >= 2 workgroups each)
+    const long t128 = (long)((a.M + 127) / 128) * ((a.Ptot + 127) / 128) * a.groups;
+    a.big = (t128 >= 512 && a.M >= 128) ? 1 : 0;
+    const int BM = a.big ? 128 : 64, BN = BM;
+    a.mtiles = (a.M + BM - 1) / BM; a.ntiles = (a.Ptot + BN - 1) / BN;
+    a.splitk = pick_splitk((long)a.mtiles * a.ntiles * a.groups, a.nchunks);
+}
+
+int launch_igemm(const IgemmArgs& a, bool a_trans, hipStream_t s, double flops) {
+    if (a.splitk > 1 && !a.accumulate) { vc_set_error("launch_igemm: split-K requires accumulate semantics"); return -1; }
+    dim3 grid(a.mtiles * a.ntiles, 1, a.groups * a.splitk), block(256);
+    ProfScope ps(0, flops, s);
+    if (a.big) {
+        if (a_trans) igemm_kernel<128, 128, true><<<grid, block, 0, s>>>(a);
+        else         igemm_kernel<128, 128, false><<<grid, block, 0, s>>>(a);
+    } else {
+        if (a_trans) igemm_kernel<64, 64, true><<<grid, block, 0, s>>>(a);
+        else         igemm_kernel<64, 64, false><<<grid, block, 0, s>>>(a);
+    }
+    VC_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_wgrad(const WgradArgs& a0, hipStream_t s, double flops) {
+    WgradArgs a = a0;
+    const int BN = (a.N >= 128) ? 128 : 64;
+    a.ntiles = (a.N + BN - 1) / BN;
+    const long tiles = (long)a.ktiles * a.ntiles * a.groups;
+    a.splitk = pick_splitk(tiles, a.nchunks);
+    dim3 grid(a.ktiles * a.ntiles, 1, a.groups * a.splitk), block(256);
+    ProfScope ps(1, flops, s);
+    if (BN == 128) wgrad_kernel<128><<<grid, block, 0, s>>>(a);
+    else           wgrad_kernel<64><<<grid, block, 0, s>>>(a);
+    VC_HIP(hipGetLastError());
+    return 0;
+}
+
+template <int MODE, bool FWD>
+static int norm_dispatch(const NormArgs& a, hipStream_t s) {
+    const int units = a.G * a.B * a.C;
+    dim3 block(256);
+#define VC_NORM_CASE(LPR, NE) { dim3 grid((units + (256 / LPR) - 1) / (256 / LPR)); \
+        if (FWD) norm_fwd_kernel<MODE, LPR, NE><<<grid, block, 0, s>>>(a); \
+        else     norm_bwd_kernel<MODE, LPR, NE><<<grid, block, 0, s>>>(a); }
+    if (a.L <= 32) VC_NORM_CASE(32, 1)
+    else if (a.L <= 64) VC_NORM_CASE(64, 1)
+    else if (a.L <= 128) VC_NORM_CASE(64, 2)
+    else if (a.L <= 256) VC_NORM_CASE(64, 4)
+    else if (a.L <= 512) VC_NORM_CASE(64, 8)
+    else if (a.L <= 1024) VC_NORM_CASE(64, 16)
+    else if (a.L <= 2048) VC_NORM_CASE(64, 32)
+    else { vc_set_error("instnorm_glu: row length %d > 2048 not supported yet", a.L); return -1; }
+#undef VC_NORM_CASE
+    VC_HIP(hipGetLastError());
+    return 0;
+}
+int launch_norm_fwd(int mode, const NormArgs& a, hipStream_t s) {
+    if (a.ps && (a.L & 1)) { vc_set_error("pixel shuffle needs even L"); return -1; }
+    switch (mode) {
+        case 0: return norm_dispatch<0, true>(a, s);
+        case 1: return norm_dispatch<1, true>(a, s);
+        case 2: return norm_dispatch<2, true>(a, s);
+    }
+    vc_set_error("bad norm mode %d", mode); return -1;
+}
+int launch_norm_bwd(int mode, const NormArgs& a, hipStream_t s) {
+    if (a.ps && (a.L & 1)) { vc_set_error("pixel shuffle needs even L"); return -1; }
+    switch (mode) {
+        case 0: return norm_dispatch<0, false>(a, s);
+        case 1: return norm_dispatch<1, false>(a, s);
+        case 2: return norm_dispatch<2, false>(a, s);
+    }
+    vc_set_error("bad norm mode %d", mode); return -1;
+}
+
+int launch_bias_grad(const float* dy, long dy_gs, float* db, long db_gs, int G, int B, int C, int L, hipStream_t s) {
+    bias_grad_kernel<<<dim3(C, G), 256, 0, s>>>(dy, dy_gs, db, db_gs, B, C, L);
+    VC_HIP(hipGetLastError());
+    return 0;
+}
+int launch_head_fwd(const float* x, long x_gs, const float* w, const float* b, long par_gs,
+                    float* o, long o_gs, int G, int B, int C, int HW, hipStream_t s) {
+    head_fwd_kernel<<<dim3((HW + 63) / 64, B, G), 256, 0, s>>>(x, x_gs, w, b, par_gs, o, o_gs, C, HW);
+    VC_HIP(hipGetLastError());
+    return 0;
+}
+int launch_head_bwd(const float* x, long x_gs, const float* w, long par_gs, const float* o, long o_gs,
+                    const float* dout, long do_gs, float* dx, long dx_gs, float* dw, float* db,
+                    long dpar_gs, int G, int B, int C, int HW, hipStream_t s) {
+    if (dx) {
+        const long n = (long)B * C * HW;
+        const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+        head_bwd_dx_kernel<<<dim3(blocks, G), 256, 0, s>>>(w, par_gs, o, o_gs, dout, do_gs, dx, dx_gs, B, C, HW);
+    }
+    if (dw) head_bwd_dw_kernel<<<dim3((C + 3) / 4, G), 256, 0, s>>>(x, x_gs, o, o_gs, dout, do_gs, dw, db, dpar_gs, B, C, HW);
+    VC_HIP(hipGetLastError());
+    return 0;
+}
+int launch_adam(float* p, float* m, float* v, const float* g, long n, float alpha, float b1,
+                float b2, float eps, float gscale, hipStream_t s) {
+    const long n4 = n / 4;
+    long blocks = (n4 + 255) / 256; if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
+    adam_kernel<<<dim3((unsigned)blocks), 256, 0, s>>>(p, m, v, g, n4, n, alpha, b1, b2, eps, gscale);
+    VC_HIP(hipGetLastError());
+    return 0;
+}
+int launch_loss(const LossArgs& a, hipStream_t s) {
+    VC_HIP(hipMemsetAsync(a.acc, 0, 10 * sizeof(float), s));
+    const long n1 = (long)a.B * a.FT;
+    long blocks = (n1 + 255) / 256; if (blocks > 1024) blocks = 1024; if (blocks < 1) blocks = 1;
+    loss_kernel<<<dim3((unsigned)blocks), 256, 0, s>>>(a);
+    loss_finalize_kernel<<<1, 64, 0, s>>>(a.acc, a.losses, (float)n1, (float)((long)a.B * a.HW),
+                                          a.lambda_cycle, a.lambda_identity);
+    VC_HIP(hipGetLastError());
+    return 0;
+}

@@ -1,0 +1,217 @@
+"""CycleGANEngine: owns the flat fp32 parameter / gradient / Adam buffers on one
+GPU and drives the C-ABI hot path (include/vc_cyclegan.h).
+
+It is the object behind `model.CycleGAN` (reference: model.py:9-150): one engine ==
+one reference `tf.Session` with its four variable scopes `generator_A2B`,
+`generator_B2A`, `discriminator_A`, `discriminator_B` (model.py:44-54).
+
+torch is used for device memory, streams and torch.distributed only; every
+arithmetic op of the step runs in libvcgan_hip.so.  There is no CPU fallback.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import lib, ptr, check
+from .layout import ParamLayout, GENERATOR, DISCRIMINATOR
+
+ADAM_BETA1, ADAM_BETA2, ADAM_EPS = 0.5, 0.999, 1e-8      # model.py:107-108 + TF defaults
+SCOPES = ('generator_A2B', 'generator_B2A', 'discriminator_A', 'discriminator_B')
+LOSS_NAMES = ('cycle_loss', 'identity_loss', 'generator_loss_A2B', 'generator_loss_B2A', 'generator_loss',
+              'discriminator_loss_A', 'discriminator_loss_B', 'discriminator_loss')   # model.py:155-167
+
+
+class GradSync:
+    """Data-parallel gradient exchange: one SUM all-reduce per flat segment, the 1/world
+    factor is folded into the Adam kernel (grad_scale).  Works on any backend (RCCL on
+    GPUs via backend 'nccl'; gloo in the CPU tests)."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+
+    @property
+    def scale(self):
+        return 1.0 / self.world
+
+    def all_reduce(self, t, async_op=False):
+        if self.world == 1:
+            return None
+        return self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+
+    def broadcast(self, t, src=0):
+        if self.world > 1:
+            self.dist.broadcast(t, src=src, group=self.group)
+
+
+class CycleGANEngine:
+    def __init__(self, num_features=24, device='cuda:0', seed=None, group=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError('CycleGANEngine needs an MI355X: the hot path is HIP-only (no CPU fallback)')
+        self.F = int(num_features)
+        self.device = torch.device(device)
+        torch.cuda.set_device(self.device)
+        self.lg = ParamLayout(GENERATOR, self.F)
+        self.ld = ParamLayout(DISCRIMINATOR, self.F)
+        nG, nD = self.lg.n_floats, self.ld.n_floats
+        self.offsets = (0, nG, 2 * nG, 2 * nG + nD)
+        self.n_flat = 2 * nG + 2 * nD
+        self.nG2 = 2 * nG
+        self.params = torch.zeros(self.n_flat, device=self.device)
+        self.grads = torch.zeros(self.n_flat, device=self.device)
+        self.m = torch.zeros(self.n_flat, device=self.device)
+        self.v = torch.zeros(self.n_flat, device=self.device)
+        self.losses = torch.zeros(8, device=self.device)
+        self._plans, self._ws = {}, None
+        self.sync = GradSync(group)
+        self._comm_stream = torch.cuda.Stream(device=self.device) if self.sync.world > 1 else None
+        # tf.train.AdamOptimizer keeps beta1_power/beta2_power as fp32 variables (one pair per optimizer)
+        self.b1p = [np.float32(ADAM_BETA1), np.float32(ADAM_BETA1)]
+        self.b2p = [np.float32(ADAM_BETA2), np.float32(ADAM_BETA2)]
+        self.init_parameters(np.random.default_rng(seed))
+        self.sync.broadcast(self.params, 0)       # identical replicas
+
+    # ------------------------------------------------------------------ parameters
+    def init_parameters(self, rng):
+        blocks = [self.lg.init_block(rng), self.lg.init_block(rng), self.ld.init_block(rng), self.ld.init_block(rng)]
+        self.params.copy_(torch.from_numpy(np.concatenate(blocks)))
+
+    def _layout(self, i):
+        return self.lg if i < 2 else self.ld
+
+    def load_tf_variables(self, tf_vars):
+        """{'generator_A2B/h1_conv/kernel': ndarray, ...} (TF names/shapes) -> device."""
+        blocks = [self._layout(i).pack(tf_vars, s) for i, s in enumerate(SCOPES)]
+        self.params.copy_(torch.from_numpy(np.concatenate(blocks)))
+
+    def _unpack(self, flat_t):
+        flat = flat_t.detach().cpu().numpy()
+        out = {}
+        for i, s in enumerate(SCOPES):
+            lay = self._layout(i)
+            out.update(lay.unpack(flat[self.offsets[i]:self.offsets[i] + lay.n_floats], s))
+        return out
+
+    def tf_variables(self):
+        return self._unpack(self.params)
+
+    def tf_gradients(self):
+        return self._unpack(self.grads)
+
+    # ------------------------------------------------------------------ plans / workspace
+    def plan(self, T):
+        p = self._plans.get(T)
+        if p is None:
+            h = _lib.vp()
+            check(lib.vc_plan_create(self.F, int(T), C.byref(h)), 'vc_plan_create')
+            assert lib.vc_flat_param_floats(h) == self.n_flat
+            self._plans[T] = p = h
+        return p
+
+    def _workspace(self, n):
+        if self._ws is None or self._ws.numel() < n:
+            self._ws = torch.empty(int(n), device=self.device)
+        return self._ws
+
+    def _stream(self):
+        return _lib.vp(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _to_dev(self, a):
+        if isinstance(a, torch.Tensor):
+            return a.to(device=self.device, dtype=torch.float32).contiguous()
+        return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(self.device)
+
+    # ------------------------------------------------------------------ the hot path
+    def step_grads(self, A, Bm, lambda_cycle, lambda_identity, gen_A=None, gen_B=None):
+        """forward + every gradient of one train step (model.py:44-95) on the current stream."""
+        A, Bm = self._to_dev(A), self._to_dev(Bm)
+        assert A.shape == Bm.shape and A.dim() == 3 and A.shape[1] == self.F, (A.shape, Bm.shape)
+        B, _, T = A.shape
+        p = self.plan(T)
+        n = lib.vc_step_workspace_floats(p, B)
+        ws = self._workspace(n)
+        check(lib.vc_cyclegan_step_grads(p, ptr(self.params), ptr(self.grads), ptr(A), ptr(Bm), B,
+                                         float(lambda_cycle), float(lambda_identity), ptr(self.losses),
+                                         ptr(gen_A), ptr(gen_B), ptr(ws), ws.numel(), self._stream()),
+              'vc_cyclegan_step_grads')
+        self._keep = (A, Bm)     # keep inputs alive until the stream has consumed them
+        return p
+
+    def _alpha(self, lr, k):
+        one = np.float32(1)
+        return float(np.float32(lr) * np.sqrt(one - self.b2p[k]) / (one - self.b1p[k]))
+
+    def apply_adam(self, generator_learning_rate, discriminator_learning_rate):
+        """ApplyAdam over both optimizers' variable lists (model.py:107-108)."""
+        s, gs = self._stream(), float(self.sync.scale)
+        for k, (lo, hi, lr) in enumerate(((0, self.nG2, generator_learning_rate),
+                                          (self.nG2, self.n_flat, discriminator_learning_rate))):
+            check(lib.vc_adam_tf_update(ptr(self.params[lo:hi]), ptr(self.m[lo:hi]), ptr(self.v[lo:hi]),
+                                        ptr(self.grads[lo:hi]), hi - lo, self._alpha(lr, k),
+                                        ADAM_BETA1, ADAM_BETA2, ADAM_EPS, gs, s), 'vc_adam_tf_update')
+            self.b1p[k] = np.float32(self.b1p[k] * np.float32(ADAM_BETA1))
+            self.b2p[k] = np.float32(self.b2p[k] * np.float32(ADAM_BETA2))
+
+    def exchange_grads(self, plan):
+        """One gradient exchange per step, issued as two segments so the discriminator
+        half (final before the generator backward starts) rides under that backward."""
+        if self.sync.world == 1:
+            return
+        main = torch.cuda.current_stream(self.device)
+        with torch.cuda.stream(self._comm_stream):
+            check(lib.vc_step_wait_d_grads(plan, _lib.vp(self._comm_stream.cuda_stream)), 'vc_step_wait_d_grads')
+            wd = self.sync.all_reduce(self.grads[self.nG2:], async_op=True)
+        wg = self.sync.all_reduce(self.grads[:self.nG2], async_op=True)
+        wd.wait(); wg.wait()
+        main.wait_stream(self._comm_stream)
+
+    def train_step(self, A, Bm, lambda_cycle, lambda_identity, generator_learning_rate,
+                   discriminator_learning_rate, sync=True, gen_A=None, gen_B=None):
+        """model.CycleGAN.train (model.py:110-125): returns (generator_loss, discriminator_loss).
+        sync=False returns the 8-element device tensor of losses without a host round trip."""
+        p = self.step_grads(A, Bm, lambda_cycle, lambda_identity, gen_A, gen_B)
+        self.exchange_grads(p)
+        self.apply_adam(generator_learning_rate, discriminator_learning_rate)
+        if not sync:
+            return self.losses
+        l = self.losses.cpu().numpy()
+        if self.sync.world > 1:        # scalars are per-shard means -> global mean
+            t = self.losses.clone(); self.sync.all_reduce(t); l = (t / self.sync.world).cpu().numpy()
+        self.last_losses = dict(zip(LOSS_NAMES, (float(x) for x in l)))
+        return float(l[4]), float(l[7])
+
+    def generate(self, inputs, direction):
+        """model.CycleGAN.test (model.py:128-137): [B, F, T] -> np.ndarray [B, F, T]."""
+        if direction == 'A2B':
+            off = self.offsets[0]
+        elif direction == 'B2A':
+            off = self.offsets[1]
+        else:
+            raise Exception('Conversion direction must be specified.')
+        x = self._to_dev(inputs)
+        assert x.dim() == 3 and x.shape[1] == self.F, x.shape
+        B, _, T = x.shape
+        p = self.plan(T)
+        save = self._workspace(lib.vc_generator_save_floats(p, B))
+        y = torch.empty_like(x)
+        check(lib.vc_generator_forward(p, ptr(self.params[off:]), 0, ptr(x), 0, ptr(y), 0, ptr(save), 1, B,
+                                       self._stream()), 'vc_generator_forward')
+        return y.cpu().numpy()
+
+    # ------------------------------------------------------------------ checkpoint state
+    def state_dict(self):
+        return dict(params=self.params.cpu().numpy(), m=self.m.cpu().numpy(), v=self.v.cpu().numpy(),
+                    b1p=np.array(self.b1p, np.float32), b2p=np.array(self.b2p, np.float32),
+                    num_features=self.F)
+
+    def load_state_dict(self, sd):
+        assert int(sd['num_features']) == self.F
+        self.params.copy_(torch.from_numpy(np.asarray(sd['params'], np.float32)))
+        self.m.copy_(torch.from_numpy(np.asarray(sd['m'], np.float32)))
+        self.v.copy_(torch.from_numpy(np.asarray(sd['v'], np.float32)))
+        self.b1p = [np.float32(x) for x in sd['b1p']]
+        self.b2p = [np.float32(x) for x in sd['b2p']]
