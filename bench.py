@@ -1,0 +1,175 @@
+#!/usr/bin/env python
+"""bench.py -- MCEP frames/sec of the CycleGAN-VC train step on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one call of the hot path behind model.CycleGAN.train (reference
+model.py:110-125): forward of the 6 generator + 6 discriminator applications,
+fused cycle/identity/LSGAN losses, every gradient, the gradient all-reduce (N>1)
+and both Adam updates, on one synthetic [B, 24, 128] minibatch per domain that is
+already resident in HBM.  Workload = BASELINE.json configs[1]: fp32, batch 8 per GPU.
+Weak scaling: every rank runs batch 8, ranks all-reduce the 479 MB fp32 gradient.
+
+Prints ONE JSON line on rank 0 (see --help of the driver contract in the task):
+  value          whole-job frames/s = n_gpus * B * n_frames * K / max-over-ranks time
+  roofline       dominant kernel (implicit-GEMM conv fwd+dgrad on v_mfma_f32_32x32x2_f32):
+                 algorithmic FLOPs / HIP-event time, against the 157.3 TFLOP/s fp32 MFMA peak
+  cpu_baseline   the numpy oracle (a port of the reference arithmetic; TF1 itself cannot
+                 run here) timed on this host's cores on a bounded sample (B=1)
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: Peak FP32 (matrix)
+HBM_PEAK_GBS = 8000.0
+
+
+def cpu_baseline(n_steps=4):
+    """oracle/cyclegan_oracle.py on the host cores: B=1, 24x128 (BASELINE configs[0]), 1 warm-up + n timed."""
+    import numpy as np
+    from oracle import cyclegan_oracle as O
+    P = O.init_params(seed=42)
+    A, Bm = O.synthetic_batch(1, 24, 128)
+    orc = O.CycleGANOracle(P)
+    orc.train(A, Bm, 10.0, 5.0, 2e-4, 1e-4)
+    ts = []
+    for _ in range(n_steps):
+        t = time.perf_counter()
+        orc.train(A, Bm, 10.0, 5.0, 2e-4, 1e-4)
+        ts.append(time.perf_counter() - t)
+    med = float(np.median(ts))
+    return dict(value=128.0 / med, unit='frames/s', cores=os.cpu_count(), kind='port',
+                sample='numpy oracle (oracle/cyclegan_oracle.py), B=1 x 24x128, 1 warm-up + %d timed full '
+                       'train steps, median %.2f s/step; TF1 reference not runnable (no tensorflow)' % (n_steps, med))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=8, help='per-GPU minibatch (BASELINE configs[1])')
+    ap.add_argument('--frames', type=int, default=128)
+    ap.add_argument('--features', type=int, default=24)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as ge
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus:
+        if rank == 0:
+            print('bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N>1)'
+                  % (args.gpus, world), file=sys.stderr)
+        sys.exit(2)
+    if rank == 0:
+        ge.build()
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))   # RCCL
+        dist.barrier()
+    ge.build()
+    from voice_converter_cyclegan_amd.engine import CycleGANEngine
+    from voice_converter_cyclegan_amd._lib import lib
+
+    dev = 'cuda:%d' % local_rank
+    eng = CycleGANEngine(num_features=args.features, device=dev, seed=42)
+    B, F, T = args.batch, args.features, args.frames
+    rng = np.random.default_rng(1234 + rank)
+    A = torch.from_numpy(rng.standard_normal((B, F, T)).astype(np.float32)).to(dev)
+    Bm = torch.from_numpy(rng.standard_normal((B, F, T)).astype(np.float32)).to(dev)
+    hp = (10.0, 5.0, 2e-4, 1e-4)        # train.py:17-26
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        eng.train_step(A, Bm, *hp, sync=False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.train_step(A, Bm, *hp, sync=False)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    losses = eng.losses.cpu().numpy()
+    assert np.isfinite(losses).all(), losses
+
+    out = None
+    if rank == 0:
+        frames = world * B * T * args.steps
+        out = {
+            'metric': 'MCEP frames/sec per train step (G+D fwd/bwd)',
+            'value': frames / dt, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'BASELINE configs[1]: full CycleGAN-VC train step (2G+2D fwd/bwd + losses + '
+                                   'TF-Adam), fp32, batch %d per GPU, %dx%d MCEP, random-init weights' % (B, F, T),
+                       'global_batch': world * B, 'frames_per_step_per_domain': world * B * T,
+                       'parallelism': 'dp%d' % world,
+                       'gflop_per_step': 91.41 * world * B if (F, T) == (24, 128) else None},
+            'step_flop_frac_of_fp32_peak': (91.41e9 * B / (dt / args.steps)) / (FP32_MFMA_PEAK_TFLOPS * 1e12)
+            if (F, T) == (24, 128) else None,
+        }
+
+    # ---- roofline leg: the same steps again with HIP events around every implicit-GEMM launch
+    if not args.no_roofline:
+        barrier()
+        lib.vc_prof_enable(1)
+        n_prof = 3
+        for _ in range(n_prof):
+            eng.train_step(A, Bm, *hp, sync=False)
+        torch.cuda.synchronize()
+        stats = {}
+        for kind, name in ((0, 'igemm_kernel (conv fwd + dgrad)'), (1, 'wgrad_kernel')):
+            ms, n, fl = C.c_double(0), C.c_longlong(0), C.c_double(0)
+            lib.vc_prof_collect(kind, C.byref(ms), C.byref(n), C.byref(fl))
+            stats[kind] = (name, ms.value, n.value, fl.value)
+        lib.vc_prof_enable(0)
+        if rank == 0:
+            name, ms, n, fl = stats[0]
+            ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            out['roofline'] = {
+                'bound': 'mfma', 'achieved': ach, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': ach / FP32_MFMA_PEAK_TFLOPS, 'traffic': None,
+                'kernel': name, 'launches_per_step': n // n_prof,
+                'avg_launch_us': 1e3 * ms / max(n, 1), 'algorithmic_gflop_per_step': fl / n_prof / 1e9,
+                'kernel_ms_per_step': ms / n_prof,
+            }
+            name, ms, n, fl = stats[1]
+            ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            out['roofline_wgrad'] = {'bound': 'mfma', 'achieved': ach, 'peak': FP32_MFMA_PEAK_TFLOPS,
+                                     'unit': 'TFLOP/s', 'frac': ach / FP32_MFMA_PEAK_TFLOPS, 'kernel': name,
+                                     'launches_per_step': n // n_prof, 'kernel_ms_per_step': ms / n_prof}
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -44,13 +44,26 @@ static Geom make_geom(int Cin, int H, int W, int Cout, int kh, int kw, int sh, i
 // ------------------------------------------------------------------------------------
 // K tables (device resident, cached per geometry)
 // ------------------------------------------------------------------------------------
-struct Table { KEntry* dev = nullptr; int rows = 0; int valid = 0; };
+struct Table { KEntry* dev = nullptr; unsigned* xpk = nullptr; int* aoff = nullptr; int rows = 0; int valid = 0; };
 static std::mutex g_tab_mu;
 static std::map<std::array<int, 12>, Table> g_tabs;
 
 static int upload_table(const std::vector<KEntry>& h, int valid, Table* t) {
     VC_HIP(hipMalloc((void**)&t->dev, h.size() * sizeof(KEntry)));
     VC_HIP(hipMemcpy(t->dev, h.data(), h.size() * sizeof(KEntry), hipMemcpyHostToDevice));
+    std::vector<unsigned> xp(h.size()); std::vector<int> ao(h.size());
+    for (size_t i = 0; i < h.size(); ++i) {
+        if (h[i].a_off >= 0 && (h[i].c >= 0xffff || h[i].dh < -128 || h[i].dh > 127 || h[i].dw < -128 || h[i].dw > 127)) {
+            vc_set_error("geometry exceeds the packed gather table range"); return VC_E_ARG;
+        }
+        xp[i] = h[i].a_off < 0 ? VC_XPK_INVALID
+                               : ((unsigned)h[i].c & 0xffffu) | (((unsigned)h[i].dh & 0xffu) << 16) | (((unsigned)h[i].dw & 0xffu) << 24);
+        ao[i] = h[i].a_off;
+    }
+    VC_HIP(hipMalloc((void**)&t->xpk, xp.size() * sizeof(unsigned)));
+    VC_HIP(hipMemcpy(t->xpk, xp.data(), xp.size() * sizeof(unsigned), hipMemcpyHostToDevice));
+    VC_HIP(hipMalloc((void**)&t->aoff, ao.size() * sizeof(int)));
+    VC_HIP(hipMemcpy(t->aoff, ao.data(), ao.size() * sizeof(int), hipMemcpyHostToDevice));
     t->rows = (int)h.size(); t->valid = valid;
     return 0;
 }
@@ -118,7 +131,8 @@ static int conv_fwd(const float* x, long x_gs, const float* w, long w_gs, const 
                     float* y, long y_gs, int G, int B, const Geom& g, hipStream_t s) {
     Table t; VC_CHECK(get_fwd_table(g, &t));
     IgemmArgs a{};
-    a.A = w; a.X = x; a.Y = y; a.bias = bias; a.addend = nullptr; a.ktab = t.dev;
+    a.A = w; a.X = x; a.Y = y; a.bias = bias; a.addend = nullptr; a.xtab = t.xpk; a.atab = nullptr;
+    a.kk_valid = t.valid; a.a_ks = g.Cout;
     a.a_gs = w_gs; a.x_gs = x_gs; a.y_gs = y_gs; a.bias_gs = b_gs; a.add_gs = 0;
     a.x_bs = (long)g.Cin * g.H * g.W; a.y_bs = (long)g.Cout * g.OH * g.OW;
     a.nchunks = t.rows / 32; a.M = g.Cout; a.a_ms = 1;
@@ -141,7 +155,8 @@ static int conv_dgrad(const float* dy, long dy_gs, const float* w, long w_gs, fl
         if (Hc <= 0 || Wc <= 0) continue;
         Table t; VC_CHECK(get_dgrad_table(g, ph, pw, &t));
         IgemmArgs a{};
-        a.A = w; a.X = dy; a.Y = dx; a.bias = nullptr; a.addend = addend; a.ktab = t.dev;
+        a.A = w; a.X = dy; a.Y = dx; a.bias = nullptr; a.addend = addend; a.xtab = t.xpk; a.atab = t.aoff;
+        a.kk_valid = t.valid; a.a_ks = 0;
         a.a_gs = w_gs; a.x_gs = dy_gs; a.y_gs = dx_gs; a.bias_gs = 0; a.add_gs = add_gs;
         a.x_bs = (long)g.Cout * g.OH * g.OW; a.y_bs = (long)g.Cin * g.H * g.W;
         a.nchunks = t.rows / 32; a.M = g.Cin; a.a_ms = g.Cout;

@@ -11,9 +11,14 @@
 struct __attribute__((aligned(16))) KEntry { int c, dh, dw, a_off; };
 
 // Y[g][b][m][P(i,j)] (+)= sum_kk A[a_off(kk) + m*a_ms] * X[g][b][c(kk)][i*si+dh(kk)][j*sj+dw(kk)]
+// Packed gather entry (one dword, read through the scalar cache): c | (dh & 0xff) << 16 | (dw & 0xff) << 24,
+// c == 0xffff marks a padding row.
+#define VC_XPK_INVALID 0xffffu
 struct IgemmArgs {
     const float* A; const float* X; float* Y; const float* bias; const float* addend;
-    const KEntry* ktab;
+    const unsigned* xtab;                         // packed gather table, nchunks*32 entries
+    const int* atab;                              // transposed-A mode: a_off per K row (-1 = padding)
+    int kk_valid, a_ks;                           // plain-A mode: a_off = kk * a_ks for kk < kk_valid
     long a_gs, x_gs, y_gs, bias_gs, add_gs;      // signed group strides (floats)
     long x_bs, y_bs;                              // batch strides (floats)
     int nchunks;                                  // K rows / 32 (table is padded)

@@ -48,57 +48,82 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
     const int c0 = sp * cps, c1 = min(p.nchunks, c0 + cps);
     if (c0 >= c1) return;
 
-    // ---- gathered-operand loader: column n of the tile is one launch pixel, fixed per thread
-    constexpr int XRP = 256 / BN, XL = KC / XRP;
-    const int xn = tid % BN, xr0 = tid / BN;
+    // ---- gathered-operand loader: column n of the tile is one launch pixel, fixed per thread.
+    // Each wave owns XL consecutive K rows of the chunk, so its table entries are wave-uniform:
+    // they are fetched through the scalar cache, one chunk ahead of their use.
+    constexpr int XL = (KC * BN) / 256;                       // 8 (BN=64) or 16 (BN=128)
+    const int xrow0 = __builtin_amdgcn_readfirstlane((BN == 64) ? wid * XL : (wid >> 1) * XL);
+    const int xn = (BN == 64) ? lane : (wid & 1) * 64 + lane;
     const int P = nt * BN + xn;
     const bool pv = P < p.Ptot;
     int xb = 0, xi = 0, xj = 0;
     if (pv) { xb = P / p.NPB; const int r = P - xb * p.NPB; xi = r / p.OWc; xj = r - xi * p.OWc; }
     const int li0 = xi * p.si, lj0 = xj * p.sj;
     const float* Xg = p.X + (long)g * p.x_gs + (long)xb * p.x_bs;
+    const int xpix = li0 * p.xW + lj0;
     const float* Ag = p.A + (long)g * p.a_gs;
+    typedef const __attribute__((address_space(4))) unsigned* cuptr;
+    cuptr xtab = (cuptr)p.xtab;
 
     // ---- weight loader
-    constexpr int AV = BM / 4, ARP = 256 / AV, AL = KC / ARP;   // fwd: float4 along m
-    constexpr int ALT = BM / 8;                                  // transposed: scalar along k
+    constexpr int AV = BM / 4, ARP = 256 / AV, AL = KC / ARP;   // plain: float4 along m, a_off = kk*a_ks
+    constexpr int ALT = BM / 8;                                  // transposed: scalar along k, a_off from atab
     const int am = (tid % AV) * 4, ar0 = tid / AV;
     const int akk = tid & 31, am0 = tid >> 5;
 
     float xr[XL];
+    unsigned xvalid = 0;
+    unsigned pe[XL];                 // table entries of the chunk the NEXT load() call will fetch
+    int ao = -1;                     // transposed mode: a_off of this lane's K row, same pipelining
     float4 af[AT ? 1 : AL];
     float at[AT ? ALT : 1];
 
-    auto load = [&](int c) {
+    auto fetch_tab = [&](int c) {
+#pragma unroll
+        for (int q = 0; q < XL; ++q) pe[q] = xtab[c * KC + xrow0 + q];
+        if constexpr (AT) ao = p.atab[c * KC + akk];
+    };
+    auto load = [&](int c, bool more) {
+        xvalid = 0;
 #pragma unroll
         for (int q = 0; q < XL; ++q) {
-            const KEntry e = p.ktab[c * KC + xr0 + q * XRP];
-            const int li = li0 + e.dh, lj = lj0 + e.dw;
-            const bool v = pv && e.a_off >= 0 && (unsigned)li < (unsigned)p.Hl && (unsigned)lj < (unsigned)p.Wl;
-            xr[q] = v ? Xg[(long)e.c * p.xHW + li * p.xW + lj] : 0.f;
+            const unsigned e = pe[q];
+            const int ch = (int)(e & 0xffffu), dh = (int)(signed char)(e >> 16), dw = (int)(signed char)(e >> 24);
+            const int li = li0 + dh, lj = lj0 + dw;
+            const bool v = pv && ch != (int)VC_XPK_INVALID && (unsigned)li < (unsigned)p.Hl && (unsigned)lj < (unsigned)p.Wl;
+            const int soff = ch * p.xHW + dh * p.xW + dw;               // wave-uniform (SALU)
+            const float* src = v ? Xg + (soff + xpix) : Xg;            // clamp instead of branching
+            xr[q] = *src;
+            xvalid |= (unsigned)v << q;
         }
         if constexpr (AT) {
-            const KEntry e = p.ktab[c * KC + akk];
+            const bool kv = ao >= 0;
 #pragma unroll
             for (int q = 0; q < ALT; ++q) {
                 const int m = mt * BM + am0 + q * 8;
-                at[q] = (e.a_off >= 0 && m < p.M) ? Ag[(long)e.a_off + (long)m * p.a_ms] : 0.f;
+                const bool v = kv && m < p.M;
+                const float* src = v ? Ag + ((long)ao + (long)m * p.a_ms) : Ag;
+                const float t = *src;
+                at[q] = v ? t : 0.f;
             }
         } else {
 #pragma unroll
             for (int q = 0; q < AL; ++q) {
-                const KEntry e = p.ktab[c * KC + ar0 + q * ARP];
+                const int kk = c * KC + ar0 + q * ARP;
                 const int m = mt * BM + am;
-                af[q] = (e.a_off >= 0 && m < p.M) ? *reinterpret_cast<const float4*>(Ag + e.a_off + m)
-                                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+                const bool v = kk < p.kk_valid && m < p.M;
+                const float4* src = reinterpret_cast<const float4*>(v ? Ag + ((long)kk * p.a_ks + m) : Ag);
+                const float4 t = *src;
+                af[q] = v ? t : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
+        if (more) fetch_tab(c + 1);
     };
     auto store = [&](int buf) {
         float* xs = Xs + buf * XSZ;
         float* as = As + buf * ASZ;
 #pragma unroll
-        for (int q = 0; q < XL; ++q) xs[(xr0 + q * XRP) * LDX + xn] = xr[q];
+        for (int q = 0; q < XL; ++q) xs[(xrow0 + q) * LDX + xn] = ((xvalid >> q) & 1u) ? xr[q] : 0.f;
         if constexpr (AT) {
 #pragma unroll
             for (int q = 0; q < ALT; ++q) as[akk * LDA + am0 + q * 8] = at[q];
@@ -116,12 +141,13 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][nj][r] = 0.f;
 
-    load(c0);
+    fetch_tab(c0);
+    load(c0, c0 + 1 < c1);
     store(0);
     __syncthreads();
     for (int c = c0; c < c1; ++c) {
         const int buf = (c - c0) & 1;
-        if (c + 1 < c1) load(c + 1);           // global loads fly under the MFMAs below
+        if (c + 1 < c1) load(c + 1, c + 2 < c1);   // global loads fly under the MFMAs below
         const float* as = As + buf * ASZ + wm * WM + l31;
         const float* xs = Xs + buf * XSZ + wn * WN + l31;
 #pragma unroll
@@ -219,13 +245,18 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
         for (int q = 0; q < 8; ++q) {
             const int li = li0 + e[q].dh, lj = lj0 + e[q].dw;
             const bool v = pv && e[q].a_off >= 0 && (unsigned)li < (unsigned)p.Hl && (unsigned)lj < (unsigned)p.Wl;
-            xr[q] = v ? xb[(long)e[q].c * p.xHW + li * p.xW + lj] : 0.f;
+            const float* src = v ? xb + ((long)e[q].c * p.xHW + li * p.xW + lj) : Xg;   // clamp, no branch
+            const float t = *src;
+            xr[q] = v ? t : 0.f;
         }
         const float* yb = Yg + (long)b * p.dy_bs + r;
 #pragma unroll
         for (int q = 0; q < BN / 8; ++q) {
             const int co = nt * BN + rg + q * 8;
-            dr[q] = (pv && co < p.N) ? yb[(long)co * p.NPB] : 0.f;
+            const bool v = pv && co < p.N;
+            const float* src = v ? yb + (long)co * p.NPB : Yg;
+            const float t = *src;
+            dr[q] = v ? t : 0.f;
         }
     };
     auto store = [&](int buf) {
