@@ -126,6 +126,11 @@ int vc_disc_head_bwd(const float* x, int64_t x_gs, const float* w, int64_t par_g
                      float* dx, int64_t dx_gs, float* dw, float* db, int64_t dpar_gs,
                      int G, int B, int C, int HW, void* stream);
 
+/* utils.l1_loss / utils.l2_loss (utils.py:6-12): *loss = mean(|y - y_hat|) resp. mean((y - y_hat)^2) over n
+ * elements; d_yhat (NULL to skip) receives d loss / d y_hat (sign(0) = 0). */
+int vc_l1_loss(const float* y, const float* y_hat, int64_t n, float* loss, float* d_yhat, void* stream);
+int vc_l2_loss(const float* y, const float* y_hat, int64_t n, float* loss, float* d_yhat, void* stream);
+
 /* tf.train.AdamOptimizer(lr, beta1=0.5).minimize -> ApplyAdam (model.py:107-108):
  *   m += (g-m)(1-b1); v += (g*g-v)(1-b2); p -= alpha*m/(sqrt(v)+eps)
  * alpha = lr*sqrt(1-b2^t)/(1-b1^t) is computed by the caller in fp32 (TF keeps

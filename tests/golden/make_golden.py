@@ -1,0 +1,78 @@
+"""Generates tests/golden/*.npz from the CPU oracle (run from the repo root:
+`python tests/golden/make_golden.py`).  The reference itself cannot be executed (no
+TensorFlow in the container), so these vectors pin the ORACLE (regression)
+and give the GPU tests an oracle-free comparison target; they are not reference outputs.
+
+ golden_shrunk_f64.npz : width/16 networks, float64, B=2, T=16 -- losses + every gradient.
+ golden_full_f32.npz   : the real architecture, float32, B=1, 24x128, seed 42 weights with
+                         randomised bias/beta/gamma -- 8 losses, generation_A/B, per-tensor
+                         gradient L2 norms, and losses of train steps 1..3.
+ train_log_pins.npz    : five numbers copied from the reference's TensorBoard export
+                         (train_log/*.csv row 2, step 167) that pin model.py:72's loss weights.
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import cyclegan_oracle as O  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def probe(a, i):
+    r = np.random.default_rng(1000 + i).standard_normal(a.size)
+    return float(a.reshape(-1).astype(np.float64) @ r)
+
+
+def shrunk():
+    P = O.init_params(seed=3, dtype=np.float64, randomize_affine=True, wd=16)
+    rng = np.random.default_rng(4)
+    A, B = rng.standard_normal((2, 24, 16)), rng.standard_normal((2, 24, 16))
+    Sg, Gg, gA, gB = O.generator_losses_and_grads(P, A, B, 10.0, 5.0)
+    Sd, Gd = O.discriminator_losses_and_grads(P, A, B, gA, gB)
+    out = {'A': A, 'B': B, 'gen_A': gA, 'gen_B': gB}
+    out.update({'loss/' + k: np.float64(v) for k, v in {**Sg, **Sd}.items()})
+    # every gradient tensor is pinned by two numbers: its L2 norm and its projection on a fixed
+    # pseudo-random direction (keeps the fixture small; any wrong element moves both)
+    names = sorted({**Gg, **Gd})
+    out['grad_names'] = np.array(names)
+    out['grad_l2'] = np.array([np.linalg.norm({**Gg, **Gd}[n]) for n in names])
+    out['grad_proj'] = np.array([probe({**Gg, **Gd}[n], i) for i, n in enumerate(names)])
+    np.savez_compressed(os.path.join(HERE, 'golden_shrunk_f64.npz'), **out)
+
+
+def full():
+    P = O.init_params(seed=42, randomize_affine=True)
+    A, B = O.synthetic_batch(1, 24, 128)
+    orc = O.CycleGANOracle({k: v.copy() for k, v in P.items()})
+    out = {}
+    for step in range(3):
+        g, d = orc.train(A, B, 10.0, 5.0, 2e-4, 1e-4)
+        out['step%d/losses' % step] = np.array([orc.last[k] for k in (
+            'cycle_loss', 'identity_loss', 'generator_loss_A2B', 'generator_loss_B2A', 'generator_loss',
+            'discriminator_loss_A', 'discriminator_loss_B', 'discriminator_loss')], np.float32)
+        if step == 0:
+            out['gen_A'], out['gen_B'] = orc.last_fakes
+            Gg, Gd = orc.last_grads
+            names = sorted({**Gg, **Gd})
+            out['grad_names'] = np.array(names)
+            out['grad_l2'] = np.array([np.linalg.norm({**Gg, **Gd}[n].astype(np.float64)) for n in names])
+            out['grad_proj'] = np.array([probe({**Gg, **Gd}[n], i) for i, n in enumerate(names)])
+    np.savez_compressed(os.path.join(HERE, 'golden_full_f32.npz'), **out)
+
+
+def train_log_pins():
+    # /root/reference/train_log/run_20180619-011402-tag-generator_summaries_*.csv, line 2 (step 167)
+    np.savez(os.path.join(HERE, 'train_log_pins.npz'), step=167, cycle_loss=1.444779872894287,
+             identity_loss=1.3221745491027832, generator_loss_A2B=0.8852359652519226,
+             generator_loss_B2A=0.9709569811820984, generator_loss=22.91486358642578,
+             lambda_cycle=10.0, lambda_identity=5.0)
+
+
+if __name__ == '__main__':
+    shrunk(); full(); train_log_pins()
+    for f in sorted(os.listdir(HERE)):
+        print(f, os.path.getsize(os.path.join(HERE, f)))

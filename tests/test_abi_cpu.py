@@ -1,0 +1,87 @@
+"""CPU: the C-ABI library builds for gfx950, loads without a GPU, exports every symbol the
+public header declares, and its parameter layout speaks the reference's TF variable names."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_functions():
+    src = open(os.path.join(ROOT, 'include', 'vc_cyclegan.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(vc_[a-z0-9_]+)\s*\(', src)))
+
+
+def test_header_symbols_exported_and_bound(built_lib):
+    names = _header_functions()
+    assert len(names) >= 30
+    bound = {n for n, _, _ in built_lib.SIGNATURES}
+    for n in names:
+        assert hasattr(built_lib.lib, n), 'symbol %s declared in include/vc_cyclegan.h is not exported' % n
+        assert n in bound, 'symbol %s has no ctypes signature in _lib.SIGNATURES' % n
+    assert bound <= set(names), 'python binds symbols the header does not declare: %s' % (bound - set(names))
+    assert built_lib.lib.vc_version() >= 100
+
+
+def test_library_is_gfx950_only(built_lib):
+    """no multi-arch / CUDA dual paths: the fat binary carries exactly one device target."""
+    blob = open(built_lib.LIB_PATH, 'rb').read()
+    targets = set(re.findall(rb'amdgcn-amd-amdhsa--(gfx[0-9a-f]+)', blob))
+    assert targets == {b'gfx950'}, targets
+
+
+def test_layout_matches_oracle_names_and_counts(built_lib):
+    from voice_converter_cyclegan_amd.layout import ParamLayout, GENERATOR, DISCRIMINATOR
+    from oracle import cyclegan_oracle as O
+    G, D = ParamLayout(GENERATOR, 24), ParamLayout(DISCRIMINATOR, 24)
+    assert (G.n_params, len(G.recs)) == (38055704, 110)
+    assert (D.n_params, len(D.recs)) == (21837825, 30)
+    assert G.n_floats % 4 == 0 and D.n_floats % 4 == 0
+    assert [r['name'] for r in G.recs and sorted(G.recs, key=lambda r: r['name'])] == \
+        sorted(n for n, _ in O.generator_layout(24))
+    assert {r['name']: r['shape'] for r in G.recs} == dict(O.generator_layout(24))
+    assert {r['name']: r['shape'] for r in D.recs} == dict(O.discriminator_layout())
+    # 36-dim MCEP (BASELINE config 5): only h1 / o1 change
+    G36 = ParamLayout(GENERATOR, 36)
+    assert {r['name']: r['shape'] for r in G36.recs} == dict(O.generator_layout(36))
+    # pack/unpack round trip with value and gate kernels interleaved in one stored tensor
+    P = O.init_params(seed=1, randomize_affine=True)
+    flat = G.pack(P, 'generator_B2A')
+    back = G.unpack(flat, 'generator_B2A')
+    assert all(np.array_equal(back[k], P[k]) for k in back)
+    r = {x['name']: x for x in G.recs}
+    a, b = r['residual1d_block2_h1_conv/kernel'], r['residual1d_block2_h1_gates/kernel']
+    assert b['offset'] == a['offset'] + 1024 and a['ld'] == b['ld'] == 2048
+
+
+def test_argument_errors_without_gpu(built_lib):
+    lib = built_lib.lib
+    n = built_lib.i64(0)
+    assert lib.vc_param_layout(7, 24, None, 0, C.byref(n)) == -1
+    assert b'kind' in lib.vc_last_error()
+    assert lib.vc_param_layout(0, 25, None, 0, C.byref(n)) == -1          # num_features % 4
+    h = built_lib.vp()
+    assert lib.vc_plan_create(24, 130, C.byref(h)) == -1                  # n_frames % 4 (preprocess.py:146-156)
+    assert lib.vc_conv2d_fwd(None, 0, None, 0, None, 0, None, 0, 1, 1, 1, 1, 1, 4, 1, 1, 1, 1, None) == -1
+    assert lib.vc_adam_tf_update(None, None, None, None, 0, 0.0, 0.5, 0.999, 1e-8, 1.0, None) == -1
+
+
+def test_engine_fails_loudly_without_gpu(built_lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    from voice_converter_cyclegan_amd.engine import CycleGANEngine
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        CycleGANEngine(24)
+
+
+def test_product_path_never_imports_oracle():
+    pkg = os.path.join(ROOT, 'voice-converter-cyclegan_amd')
+    for f in os.listdir(pkg) + ['../module.py', '../model.py', '../utils.py', '../vcgan_pkg.py']:
+        if f.endswith('.py'):
+            src = open(os.path.join(pkg, f)).read()
+            assert 'oracle' not in src, f

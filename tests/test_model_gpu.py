@@ -1,0 +1,166 @@
+"""-m gpu: the reference-facing API (root module.py / model.py / utils.py) -- same names, argument
+meaning, return types and error behaviour as the reference, checked the way the reference's
+train.py / convert.py use it (train.py:76,107,113,132; convert.py:14,16,46)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def fresh(built_lib):
+    import module
+    module.reset_default_graph()
+    yield
+    module.reset_default_graph()
+
+
+def _load_oracle_weights(model, seed=21):
+    from oracle import cyclegan_oracle as O
+    P = O.init_params(seed=seed, randomize_affine=True)
+    model.engine.load_tf_variables(P)
+    return O, P
+
+
+def test_train_signature_and_parity(fresh, tmp_path):
+    from model import CycleGAN
+    model = CycleGAN(num_features=24, log_dir=str(tmp_path / 'log'))           # train.py:76
+    O, P = _load_oracle_weights(model)
+    orc = O.CycleGANOracle({k: v.copy() for k, v in P.items()})
+    rng = np.random.default_rng(0)
+    dataset_A = rng.standard_normal((2, 24, 128)); dataset_B = rng.standard_normal((2, 24, 128))   # float64 like preprocess.py:235
+    for i in range(2):
+        g, d = model.train(input_A=dataset_A[i:i + 1], input_B=dataset_B[i:i + 1], lambda_cycle=10, lambda_identity=5,
+                           generator_learning_rate=0.0002, discriminator_learning_rate=0.0001)      # train.py:107
+        g0, d0 = orc.train(dataset_A[i:i + 1], dataset_B[i:i + 1], 10, 5, 0.0002, 0.0001)
+        assert isinstance(g, np.floating) and isinstance(d, np.floating)
+        assert abs(g - g0) < 1e-3 * abs(g0) and abs(d - d0) < 1e-3 * max(1.0, abs(d0))
+        '{:.3f}'.format(g)                                                                          # train.py:111
+    assert model.train_step == 2
+    # a second model in the same process collides on reuse=False, as the TF default graph would
+    with pytest.raises(ValueError, match='already exists'):
+        CycleGAN(num_features=24)
+    # per-step scalar summaries under ./log/<timestamp> (model.py:26-29,116,121)
+    model.writer.flush()
+    files = os.listdir(model.log_dir)
+    assert len(files) == 8 and any(f.endswith('generator_summaries_cycle_loss.csv') for f in files)
+    rows = open(os.path.join(model.log_dir, [f for f in files if f.endswith('discriminator_loss.csv')][0])).read().split('\n')
+    assert rows[0] == 'Wall time,Step,Value' and len(rows) == 4
+
+
+def test_test_save_load(fresh, tmp_path):
+    from model import CycleGAN
+    import module
+    model = CycleGAN(num_features=24, mode='test')                              # convert.py:14
+    O, P = _load_oracle_weights(model)
+    x = np.random.default_rng(1).standard_normal((24, 132))                      # any T % 4 == 0 (preprocess.py:146-156)
+    y = model.test(inputs=np.array([x]), direction='A2B')[0]                     # convert.py:46
+    assert isinstance(y, np.ndarray) and y.shape == (24, 132) and y.dtype == np.float32
+    ref = O.generator_fwd(P, 'generator_A2B', np.array([x], np.float32))[0][0]
+    assert np.abs(y - ref).max() < 1e-3 * np.abs(ref).max()
+    with pytest.raises(Exception, match='Conversion direction must be specified.'):
+        model.test(inputs=np.array([x]), direction='A2A')                        # model.py:134-135
+    path = model.save(directory=str(tmp_path / 'ckpt'), filename='sf1_tf2.ckpt')  # train.py:113
+    assert path == os.path.join(str(tmp_path / 'ckpt'), 'sf1_tf2.ckpt')
+    before = model.engine.params.clone()
+    model.engine.params.mul_(0.5)
+    model.load(filepath=path)                                                    # convert.py:16
+    assert torch.equal(model.engine.params, before)
+    z = np.load(path + '.npz')
+    assert 'generator_A2B/h1_conv/kernel' in z.files and 'discriminator_B/dense/bias/Adam_1' in z.files
+    assert z['generator_B2A/upsample1d_block2_h1_gates/kernel'].shape == (5, 512, 512)
+    module.reset_default_graph()
+    m2 = CycleGAN(num_features=24, mode='test')
+    m2.load(path)
+    # not bitwise: small launches combine split-K partial sums with fp32 atomics (order varies run to run)
+    a, b = m2.test(np.array([x]), 'A2B'), model.test(np.array([x]), 'A2B')
+    assert np.abs(a - b).max() < 1e-5 * np.abs(b).max()
+
+
+def test_resume_is_exact(fresh, tmp_path):
+    """save() keeps the Adam slots and beta powers (model.py:21), so load() + train() continues the run."""
+    from model import CycleGAN
+    import module
+    rng = np.random.default_rng(2)
+    A, B = rng.standard_normal((1, 24, 128)), rng.standard_normal((1, 24, 128))
+    m = CycleGAN(num_features=24, seed=5)
+    m.train(A, B, 10, 5, 2e-4, 1e-4)
+    path = m.save(str(tmp_path), 'c')
+    ga, da = m.train(A, B, 10, 5, 2e-4, 1e-4)
+    module.reset_default_graph()
+    m2 = CycleGAN(num_features=24, seed=77)
+    m2.load(path)
+    gb, db = m2.train(A, B, 10, 5, 2e-4, 1e-4)
+    assert abs(ga - gb) < 1e-4 * abs(ga) and abs(da - db) < 1e-4 * max(abs(da), 1e-3)
+
+
+def test_injected_callables_take_the_autograd_path(fresh):
+    """model.py:9,14-15: generator / discriminator are constructor arguments.  Wrapping the native
+    callables forces the composed (autograd) schedule; it must agree with the fused schedule."""
+    from model import CycleGAN
+    import module
+    rng = np.random.default_rng(3)
+    A, B = rng.standard_normal((2, 24, 64)), rng.standard_normal((2, 24, 64))
+    calls = []
+
+    def my_generator(inputs, reuse=False, scope_name='generator_gatedcnn'):
+        calls.append(scope_name)
+        return module.generator_gatedcnn(inputs=inputs, reuse=reuse, scope_name=scope_name)
+
+    def my_discriminator(inputs, reuse=False, scope_name='discriminator'):
+        calls.append(scope_name)
+        return module.discriminator(inputs=inputs, reuse=reuse, scope_name=scope_name)
+
+    m1 = CycleGAN(num_features=24, discriminator=my_discriminator, generator=my_generator, seed=4)
+    assert not m1._native
+    p0 = m1.engine.params.clone()
+    g1, d1 = m1.train(A, B, 10, 5, 2e-4, 1e-4)
+    assert calls.count('generator_A2B') == 3 and calls.count('discriminator_A') == 3      # model.py:44-54,75-78
+    l1 = dict(m1.engine.last_losses) if hasattr(m1.engine, 'last_losses') else None
+    step1 = (m1.engine.params - p0).clone()
+    module.reset_default_graph()
+    m2 = CycleGAN(num_features=24, seed=4)
+    assert m2._native and torch.equal(m2.engine.params, p0)
+    g2, d2 = m2.train(A, B, 10, 5, 2e-4, 1e-4)
+    assert abs(g1 - g2) < 1e-4 * abs(g2) and abs(d1 - d2) < 1e-4 * abs(d2)
+    step2 = m2.engine.params - p0
+    # Adam's first step is ~lr*sign(g): identical up to near-zero gradients
+    frac = float(((step1 - step2).abs() > 2e-5).float().mean())
+    assert frac < 5e-3, frac
+
+
+def test_module_callables_and_utils(fresh):
+    import module
+    import utils
+    from oracle import cyclegan_oracle as O
+    x = np.random.default_rng(5).standard_normal((2, 24, 32)).astype(np.float32)
+    y = module.generator_gatedcnn(inputs=x, reuse=False, scope_name='generator_X')        # creates the scope
+    assert tuple(y.shape) == (2, 24, 32) and y.is_cuda
+    with pytest.raises(ValueError, match='already exists'):
+        module.generator_gatedcnn(inputs=x, reuse=False, scope_name='generator_X')
+    with pytest.raises(ValueError, match='does not exist'):
+        module.discriminator(inputs=x, reuse=True, scope_name='discriminator_Y')
+    o = module.discriminator(inputs=y, reuse=False, scope_name='discriminator_X')
+    assert tuple(o.shape) == (2, 6, 2, 1)                                                 # [B, F/4, T/16, 1]
+    # the outputs are differentiable w.r.t. the scope's variables and the inputs
+    store = module.get_variable_store()
+    sc = store.get('generator_X')
+    P = sc['layout'].unpack(sc['params'].detach().cpu().numpy(), 'generator_X')
+    xt = torch.tensor(x, device='cuda:0', requires_grad=True)
+    out = module.generator_gatedcnn(inputs=xt, reuse=True, scope_name='generator_X')
+    tgt = torch.zeros_like(out)
+    loss = utils.l1_loss(y=tgt, y_hat=out) + 3.0 * utils.l2_loss(y=tgt + 1.0, y_hat=out)
+    gx, gp = torch.autograd.grad(loss, [xt, sc['params']])
+    ref, cache = O.generator_fwd(P, 'generator_X', x)
+    n = ref.size
+    dref = np.sign(ref) / n + 3.0 * 2.0 * (ref - 1.0) / n
+    Gr = {}
+    dx = O.generator_bwd(P, Gr, dref.astype(np.float32), cache)
+    assert abs(float(loss) - (np.abs(ref).mean() + 3.0 * np.square(ref - 1.0).mean())) < 1e-4 * float(loss)
+    assert np.linalg.norm(gx.cpu().numpy() - dx) < 1e-3 * np.linalg.norm(dx)
+    got = sc['layout'].unpack(gp.cpu().numpy(), 'generator_X')
+    for k in ('generator_X/o1_conv/kernel', 'generator_X/residual1d_block1_h1_gates/kernel', 'generator_X/InstanceNorm_9/gamma'):
+        assert np.linalg.norm(got[k] - Gr[k]) < 1e-3 * np.linalg.norm(Gr[k]), k

@@ -263,6 +263,14 @@ extern "C" int vc_disc_head_bwd(const float* x, int64_t x_gs, const float* w, in
     VC_ARG(x && w && o && dout, "vc_disc_head_bwd: bad args");
     return launch_head_bwd(x, x_gs, w, par_gs, o, o_gs, dout, do_gs, dx, dx_gs, dw, db, dpar_gs, G, B, C, HW, (hipStream_t)stream);
 }
+extern "C" int vc_l1_loss(const float* y, const float* y_hat, int64_t n, float* loss, float* d_yhat, void* stream) {
+    VC_ARG(y && y_hat && loss && n > 0, "vc_l1_loss: bad args");
+    return launch_mean_loss(y, y_hat, n, 0, loss, d_yhat, (hipStream_t)stream);
+}
+extern "C" int vc_l2_loss(const float* y, const float* y_hat, int64_t n, float* loss, float* d_yhat, void* stream) {
+    VC_ARG(y && y_hat && loss && n > 0, "vc_l2_loss: bad args");
+    return launch_mean_loss(y, y_hat, n, 1, loss, d_yhat, (hipStream_t)stream);
+}
 extern "C" int vc_adam_tf_update(float* p, float* m, float* v, const float* g, int64_t n,
                                  float alpha, float beta1, float beta2, float eps, float grad_scale, void* stream) {
     VC_ARG(p && m && v && g && n > 0, "vc_adam_tf_update: bad args");

@@ -79,6 +79,7 @@ struct LossArgs {
     int B, FT, HW; float lambda_cycle, lambda_identity;
 };
 int launch_loss(const LossArgs& a, hipStream_t s);
+int launch_mean_loss(const float* y, const float* yh, long n, int squared, float* loss, float* d_yhat, hipStream_t s);
 
 void vc_set_error(const char* fmt, ...);
 #define VC_HIP(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { \

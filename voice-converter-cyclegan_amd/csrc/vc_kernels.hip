@@ -660,6 +660,22 @@ __global__ void loss_finalize_kernel(const float* acc, float* L, float n1, float
     }
 }
 
+// utils.l1_loss / utils.l2_loss (utils.py:6-12) as stand-alone ops for the plug-in path:
+// loss = mean(|y - y_hat|) or mean((y - y_hat)^2); d_yhat = d loss / d y_hat.
+__global__ __launch_bounds__(256) void mean_loss_kernel(const float* y, const float* yh, long n, int squared,
+                                                        float* loss, float* d_yhat) {
+    __shared__ float red[4];
+    float s = 0.f;
+    const float inv = 1.f / (float)n;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float d = y[i] - yh[i];
+        if (squared) { s += d * d; if (d_yhat) d_yhat[i] = -2.f * d * inv; }
+        else { s += fabsf(d); if (d_yhat) d_yhat[i] = -signf_(d) * inv; }
+    }
+    s = block_sum_256(s, red);
+    if (threadIdx.x == 0) atomicAdd(loss, s * inv);
+}
+
 // =====================================================================================
 // launchers
 // =====================================================================================
@@ -808,6 +824,13 @@ int launch_adam(float* p, float* m, float* v, const float* g, long n, float alph
     const long n4 = n / 4;
     long blocks = (n4 + 255) / 256; if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
     adam_kernel<<<dim3((unsigned)blocks), 256, 0, s>>>(p, m, v, g, n4, n, alpha, b1, b2, eps, gscale);
+    VC_HIP(hipGetLastError());
+    return 0;
+}
+int launch_mean_loss(const float* y, const float* yh, long n, int squared, float* loss, float* d_yhat, hipStream_t s) {
+    VC_HIP(hipMemsetAsync(loss, 0, sizeof(float), s));
+    long blocks = (n + 255) / 256; if (blocks > 1024) blocks = 1024; if (blocks < 1) blocks = 1;
+    mean_loss_kernel<<<dim3((unsigned)blocks), 256, 0, s>>>(y, yh, n, squared, loss, d_yhat);
     VC_HIP(hipGetLastError());
     return 0;
 }
