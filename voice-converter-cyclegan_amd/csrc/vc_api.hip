@@ -44,53 +44,60 @@ static Geom make_geom(int Cin, int H, int W, int Cout, int kh, int kw, int sh, i
 // ------------------------------------------------------------------------------------
 // K tables (device resident, cached per geometry)
 // ------------------------------------------------------------------------------------
-struct Table { KEntry* dev = nullptr; unsigned* xpk = nullptr; int* aoff = nullptr; int rows = 0; int valid = 0; };
+struct HostRow { int c, dh, dw, a_off, tap; };
+struct Table { KEntry* dev = nullptr; XEntry* xe = nullptr; Tap* taps = nullptr; unsigned* atab = nullptr;
+               int ntaps = 0, rows = 0, valid = 0; };
 static std::mutex g_tab_mu;
-static std::map<std::array<int, 12>, Table> g_tabs;
+static std::map<std::array<int, 14>, Table> g_tabs;
 
-static int upload_table(const std::vector<KEntry>& h, int valid, Table* t) {
-    VC_HIP(hipMalloc((void**)&t->dev, h.size() * sizeof(KEntry)));
-    VC_HIP(hipMemcpy(t->dev, h.data(), h.size() * sizeof(KEntry), hipMemcpyHostToDevice));
-    std::vector<unsigned> xp(h.size()); std::vector<int> ao(h.size());
-    for (size_t i = 0; i < h.size(); ++i) {
-        if (h[i].a_off >= 0 && (h[i].c >= 0xffff || h[i].dh < -128 || h[i].dh > 127 || h[i].dw < -128 || h[i].dw > 127)) {
-            vc_set_error("geometry exceeds the packed gather table range"); return VC_E_ARG;
-        }
-        xp[i] = h[i].a_off < 0 ? VC_XPK_INVALID
-                               : ((unsigned)h[i].c & 0xffffu) | (((unsigned)h[i].dh & 0xffu) << 16) | (((unsigned)h[i].dw & 0xffu) << 24);
-        ao[i] = h[i].a_off;
-    }
-    VC_HIP(hipMalloc((void**)&t->xpk, xp.size() * sizeof(unsigned)));
-    VC_HIP(hipMemcpy(t->xpk, xp.data(), xp.size() * sizeof(unsigned), hipMemcpyHostToDevice));
-    VC_HIP(hipMalloc((void**)&t->aoff, ao.size() * sizeof(int)));
-    VC_HIP(hipMemcpy(t->aoff, ao.data(), ao.size() * sizeof(int), hipMemcpyHostToDevice));
-    t->rows = (int)h.size(); t->valid = valid;
+template <class T> static int to_device(const std::vector<T>& h, T** d) {
+    VC_HIP(hipMalloc((void**)d, h.size() * sizeof(T)));
+    VC_HIP(hipMemcpy(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
     return 0;
 }
-// forward / wgrad table: row kk = ((i*kw + j)*Cin + ci)
+// xH, xW: dims of the tensor the K rows gather from (forward: the input; input-gradient: dY)
+static int upload_table(const std::vector<HostRow>& rows, const std::vector<Tap>& taps, int pad_to, int xH, int xW, Table* t) {
+    if (taps.size() > 32) { vc_set_error("conv kernel has %d taps; at most 32 supported", (int)taps.size()); return VC_E_ARG; }
+    std::vector<KEntry> ke; std::vector<XEntry> xe; std::vector<unsigned> at;
+    for (const HostRow& r : rows) {
+        ke.push_back(KEntry{r.c, r.dh, r.dw, r.a_off});
+        const long soff = ((long)r.c * xH * xW + (long)r.dh * xW + r.dw) * 4;
+        if (soff > 0x7fffffffL || soff < -0x7fffffffL || (long)r.a_off * 4 > 0x7fffffffL) {
+            vc_set_error("tensor too large for 32-bit byte offsets"); return VC_E_ARG; }
+        xe.push_back(XEntry{(int)soff, 1u << r.tap});
+        at.push_back((unsigned)r.a_off * 4u);
+    }
+    t->valid = (int)rows.size();
+    while (ke.size() % pad_to || ke.empty()) { ke.push_back(KEntry{0, 0, 0, -1}); xe.push_back(XEntry{0, 0u}); at.push_back(0x80000000u); }
+    t->rows = (int)ke.size(); t->ntaps = (int)taps.size();
+    VC_CHECK(to_device(ke, &t->dev)); VC_CHECK(to_device(xe, &t->xe)); VC_CHECK(to_device(at, &t->atab));
+    std::vector<Tap> tp = taps; if (tp.empty()) tp.push_back(Tap{0, 0});
+    VC_CHECK(to_device(tp, &t->taps));
+    return 0;
+}
+// forward / wgrad table: row kk = ((i*kw + j)*Cin + ci), tap = i*kw + j
 static int get_fwd_table(const Geom& g, Table* out) {
-    std::array<int, 12> key{0, g.Cin, g.Cout, g.kh, g.kw, g.sh, g.sw, g.pt, g.pl, 0, 0, 0};
+    std::array<int, 14> key{0, g.Cin, g.Cout, g.kh, g.kw, g.sh, g.sw, g.pt, g.pl, 0, 0, g.H, g.W, 0};
     std::lock_guard<std::mutex> l(g_tab_mu);
     auto it = g_tabs.find(key);
     if (it != g_tabs.end()) { *out = it->second; return 0; }
-    std::vector<KEntry> h;
-    for (int i = 0; i < g.kh; ++i) for (int j = 0; j < g.kw; ++j) for (int ci = 0; ci < g.Cin; ++ci) {
-        const int kk = (i * g.kw + j) * g.Cin + ci;
-        h.push_back(KEntry{ci, i - g.pt, j - g.pl, kk * g.Cout});
+    std::vector<HostRow> rows; std::vector<Tap> taps;
+    for (int i = 0; i < g.kh; ++i) for (int j = 0; j < g.kw; ++j) {
+        taps.push_back(Tap{i - g.pt, j - g.pl});
+        for (int ci = 0; ci < g.Cin; ++ci)
+            rows.push_back(HostRow{ci, i - g.pt, j - g.pl, ((i * g.kw + j) * g.Cin + ci) * g.Cout, i * g.kw + j});
     }
-    const int valid = (int)h.size();
-    while (h.size() % 64) h.push_back(KEntry{0, 0, 0, -1});
-    Table t; VC_CHECK(upload_table(h, valid, &t));
+    Table t; VC_CHECK(upload_table(rows, taps, 64, g.H, g.W, &t));
     g_tabs[key] = t; *out = t;
     return 0;
 }
-// input-gradient table of parity class (ph, pw): rows (tap in class, co)
+// input-gradient table of parity class (ph, pw): rows (tap in class, co), gathered tensor = dY [Cout][OH][OW]
 static int get_dgrad_table(const Geom& g, int ph, int pw, Table* out) {
-    std::array<int, 12> key{1, g.Cin, g.Cout, g.kh, g.kw, g.sh, g.sw, g.pt, g.pl, ph, pw, 0};
+    std::array<int, 14> key{1, g.Cin, g.Cout, g.kh, g.kw, g.sh, g.sw, g.pt, g.pl, ph, pw, g.OH, g.OW, 0};
     std::lock_guard<std::mutex> l(g_tab_mu);
     auto it = g_tabs.find(key);
     if (it != g_tabs.end()) { *out = it->second; return 0; }
-    std::vector<KEntry> h;
+    std::vector<HostRow> rows; std::vector<Tap> taps;
     for (int i = 0; i < g.kh; ++i) {
         const int nh = ph + g.pt - i;
         if (((nh % g.sh) + g.sh) % g.sh) continue;
@@ -98,13 +105,13 @@ static int get_dgrad_table(const Geom& g, int ph, int pw, Table* out) {
             const int nw = pw + g.pl - j;
             if (((nw % g.sw) + g.sw) % g.sw) continue;
             const int dh = nh / g.sh, dw = nw / g.sw;   // exact
+            const int tap = (int)taps.size();
+            taps.push_back(Tap{dh, dw});
             for (int co = 0; co < g.Cout; ++co)
-                h.push_back(KEntry{co, dh, dw, ((i * g.kw + j) * g.Cin) * g.Cout + co});
+                rows.push_back(HostRow{co, dh, dw, ((i * g.kw + j) * g.Cin) * g.Cout + co, tap});
         }
     }
-    const int valid = (int)h.size();
-    while (h.size() % 32 || h.empty()) h.push_back(KEntry{0, 0, 0, -1});
-    Table t; VC_CHECK(upload_table(h, valid, &t));
+    Table t; VC_CHECK(upload_table(rows, taps, 32, g.OH, g.OW, &t));
     g_tabs[key] = t; *out = t;
     return 0;
 }
@@ -131,8 +138,11 @@ static int conv_fwd(const float* x, long x_gs, const float* w, long w_gs, const 
                     float* y, long y_gs, int G, int B, const Geom& g, hipStream_t s) {
     Table t; VC_CHECK(get_fwd_table(g, &t));
     IgemmArgs a{};
-    a.A = w; a.X = x; a.Y = y; a.bias = bias; a.addend = nullptr; a.xtab = t.xpk; a.atab = nullptr;
-    a.kk_valid = t.valid; a.a_ks = g.Cout;
+    a.A = w; a.X = x; a.Y = y; a.bias = bias; a.addend = nullptr;
+    a.xtab = t.xe; a.taps = t.taps; a.ntaps = t.ntaps; a.atab = nullptr;
+    a.a_ks_bytes = (unsigned)g.Cout * 4u;
+    VC_ARG((long)B * g.Cin * g.H * g.W * 4 < 0xffffff00L, "conv: input tensor of one group exceeds 4 GiB");
+    a.x_bytes = (unsigned)((long)B * g.Cin * g.H * g.W * 4); a.a_bytes = (unsigned)((long)t.valid * g.Cout * 4);
     a.a_gs = w_gs; a.x_gs = x_gs; a.y_gs = y_gs; a.bias_gs = b_gs; a.add_gs = 0;
     a.x_bs = (long)g.Cin * g.H * g.W; a.y_bs = (long)g.Cout * g.OH * g.OW;
     a.nchunks = t.rows / 32; a.M = g.Cout; a.a_ms = 1;
@@ -155,8 +165,11 @@ static int conv_dgrad(const float* dy, long dy_gs, const float* w, long w_gs, fl
         if (Hc <= 0 || Wc <= 0) continue;
         Table t; VC_CHECK(get_dgrad_table(g, ph, pw, &t));
         IgemmArgs a{};
-        a.A = w; a.X = dy; a.Y = dx; a.bias = nullptr; a.addend = addend; a.xtab = t.xpk; a.atab = t.aoff;
-        a.kk_valid = t.valid; a.a_ks = 0;
+        a.A = w; a.X = dy; a.Y = dx; a.bias = nullptr; a.addend = addend;
+        a.xtab = t.xe; a.taps = t.taps; a.ntaps = t.ntaps; a.atab = t.atab; a.a_ks_bytes = 0;
+        VC_ARG((long)B * g.Cout * g.OH * g.OW * 4 < 0xffffff00L, "conv: dy tensor of one group exceeds 4 GiB");
+        a.x_bytes = (unsigned)((long)B * g.Cout * g.OH * g.OW * 4);
+        a.a_bytes = (unsigned)((long)g.kh * g.kw * g.Cin * g.Cout * 4);
         a.a_gs = w_gs; a.x_gs = dy_gs; a.y_gs = dx_gs; a.bias_gs = 0; a.add_gs = add_gs;
         a.x_bs = (long)g.Cout * g.OH * g.OW; a.y_bs = (long)g.Cin * g.H * g.W;
         a.nchunks = t.rows / 32; a.M = g.Cin; a.a_ms = g.Cout;
@@ -188,6 +201,9 @@ static int conv_wgrad(const float* x, long x_gs, const float* dy, long dy_gs, fl
     a.N = g.Cout; a.Hl = g.H; a.Wl = g.W; a.xHW = g.H * g.W; a.xW = g.W; a.si = g.sh; a.sj = g.sw;
     a.NPB = g.OH * g.OW; a.OWc = g.OW; a.Ptot = B * a.NPB; a.nchunks = (a.Ptot + 31) / 32;
     a.ktiles = t.rows / 64; a.groups = G;
+    VC_ARG((long)B * a.x_bs * 4 < 0xffffff00L && (long)B * a.dy_bs * 4 < 0xffffff00L, "conv: tensor of one group exceeds 4 GiB");
+    a.x_bytes = (unsigned)((long)B * a.x_bs * 4); a.dy_bytes = (unsigned)((long)B * a.dy_bs * 4);
+    a.inv_ow = 1.0f / (float)g.OW;
     const double flops = 2.0 * G * B * a.NPB * (double)g.Cout * t.valid;
     return launch_wgrad(a, s, flops);
 }

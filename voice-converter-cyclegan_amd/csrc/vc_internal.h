@@ -11,14 +11,22 @@
 struct __attribute__((aligned(16))) KEntry { int c, dh, dw, a_off; };
 
 // Y[g][b][m][P(i,j)] (+)= sum_kk A[a_off(kk) + m*a_ms] * X[g][b][c(kk)][i*si+dh(kk)][j*sj+dw(kk)]
-// Packed gather entry (one dword, read through the scalar cache): c | (dh & 0xff) << 16 | (dw & 0xff) << 24,
-// c == 0xffff marks a padding row.
-#define VC_XPK_INVALID 0xffffu
+// Gather-table entry of one GEMM-K row, read through the scalar cache:
+//   soff   : byte offset (c*xHW + dh*xW + dw)*4 added to the lane's pixel byte offset
+//   tapbit : 1 << tap index; 0 marks a padding row.  A lane keeps a bitmask of the taps that fall inside the
+//            gathered tensor for ITS pixel, so the per-element bounds check is one AND.
+struct __attribute__((aligned(8))) XEntry { int soff; unsigned tapbit; };
+struct Tap { int dh, dw; };
+#define VC_OOB 0xffffffffu     // buffer-load offset beyond num_records: the hardware returns 0
+
+// Y[g][b][m][P(i,j)] (+)= sum_kk A[a_off(kk) + m*a_ms] * X[g][b][c(kk)][i*si+dh(kk)][j*sj+dw(kk)]
 struct IgemmArgs {
     const float* A; const float* X; float* Y; const float* bias; const float* addend;
-    const unsigned* xtab;                         // packed gather table, nchunks*32 entries
-    const int* atab;                              // transposed-A mode: a_off per K row (-1 = padding)
-    int kk_valid, a_ks;                           // plain-A mode: a_off = kk * a_ks for kk < kk_valid
+    const XEntry* xtab;                           // nchunks*32 entries
+    const Tap* taps; int ntaps;                   // <= 32 taps
+    const unsigned* atab;                         // transposed-A mode: byte offset of each K row (0x80000000 = padding)
+    unsigned a_ks_bytes;                          // plain-A mode: byte stride between K rows
+    unsigned x_bytes, a_bytes;                    // buffer sizes (per group) for the hardware range check
     long a_gs, x_gs, y_gs, bias_gs, add_gs;      // signed group strides (floats)
     long x_bs, y_bs;                              // batch strides (floats)
     int nchunks;                                  // K rows / 32 (table is padded)
@@ -36,6 +44,8 @@ struct IgemmArgs {
 struct WgradArgs {
     const float* X; const float* dY; float* dW; const KEntry* ktab;
     long x_gs, dy_gs, dw_gs; long x_bs, dy_bs;
+    unsigned x_bytes, dy_bytes;
+    float inv_ow;                                 // 1/OWc for the pixel decode
     int N;                                        // Cout
     int Hl, Wl, xHW, xW, si, sj;
     int NPB, OWc, Ptot;

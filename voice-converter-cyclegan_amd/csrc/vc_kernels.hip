@@ -12,10 +12,14 @@
 //
 // Wavefront = 64 lanes everywhere.  No CUDA compatibility paths.
 #include "vc_internal.h"
+#include <cstdlib>
+#include <type_traits>
 #include <vector>
 #include <mutex>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // =====================================================================================
 // Implicit-GEMM: D[m][n] = sum_k A[k][m] * Xg[k][n], m = output channel, n = launch pixel.
@@ -48,9 +52,13 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
     const int c0 = sp * cps, c1 = min(p.nchunks, c0 + cps);
     if (c0 >= c1) return;
 
-    // ---- gathered-operand loader: column n of the tile is one launch pixel, fixed per thread.
-    // Each wave owns XL consecutive K rows of the chunk, so its table entries are wave-uniform:
-    // they are fetched through the scalar cache, one chunk ahead of their use.
+    // ---- gathered-operand loader (instruction diet: the K loop is issue-bound otherwise).
+    //  * column n of the tile is one launch pixel, fixed per thread -> its byte offset and a bitmask of the
+    //    taps that land inside the gathered tensor are computed ONCE;
+    //  * each wave owns XL consecutive K rows of a chunk, so table entries are wave-uniform (scalar cache),
+    //    fetched one load() ahead;
+    //  * loads are buffer loads: an invalid tap gets offset VC_OOB and the hardware range check returns 0,
+    //    so there is no branch, no clamp and no select on the way to LDS.
     constexpr int XL = (KC * BN) / 256;                       // 8 (BN=64) or 16 (BN=128)
     const int xrow0 = __builtin_amdgcn_readfirstlane((BN == 64) ? wid * XL : (wid >> 1) * XL);
     const int xn = (BN == 64) ? lane : (wid & 1) * 64 + lane;
@@ -59,77 +67,77 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
     int xb = 0, xi = 0, xj = 0;
     if (pv) { xb = P / p.NPB; const int r = P - xb * p.NPB; xi = r / p.OWc; xj = r - xi * p.OWc; }
     const int li0 = xi * p.si, lj0 = xj * p.sj;
-    const float* Xg = p.X + (long)g * p.x_gs + (long)xb * p.x_bs;
-    const int xpix = li0 * p.xW + lj0;
-    const float* Ag = p.A + (long)g * p.a_gs;
-    typedef const __attribute__((address_space(4))) unsigned* cuptr;
-    cuptr xtab = (cuptr)p.xtab;
+    const unsigned xoffb = (unsigned)(((long)xb * p.x_bs + (long)li0 * p.xW + lj0) * 4);
+    unsigned tapmask = 0;
+    {
+        typedef const __attribute__((address_space(4))) Tap* ctap;
+        ctap taps = (ctap)p.taps;
+        for (int t = 0; t < p.ntaps; ++t) {
+            const int dh = taps[t].dh, dw = taps[t].dw;
+            const bool ok = pv && (unsigned)(li0 + dh) < (unsigned)p.Hl && (unsigned)(lj0 + dw) < (unsigned)p.Wl;
+            tapmask |= (unsigned)ok << t;
+        }
+    }
+    const __amdgpu_buffer_rsrc_t xrs =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(p.X + (long)g * p.x_gs), 0, (int)p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ars =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (long)g * p.a_gs), 0, (int)p.a_bytes, 0x00020000);
+    typedef const __attribute__((address_space(4))) XEntry* cxptr;
+    cxptr xtab = (cxptr)p.xtab;
 
-    // ---- weight loader
-    constexpr int AV = BM / 4, ARP = 256 / AV, AL = KC / ARP;   // plain: float4 along m, a_off = kk*a_ks
-    constexpr int ALT = BM / 8;                                  // transposed: scalar along k, a_off from atab
+    // ---- weight loader.  Rows m >= M read whatever lies there (range-checked, never stored): no predicate.
+    constexpr int AV = BM / 4, ARP = 256 / AV, AL = KC / ARP;   // plain: 16-B loads along m
+    constexpr int ALT = BM / 8;                                  // transposed: 4-B loads along k
     const int am = (tid % AV) * 4, ar0 = tid / AV;
     const int akk = tid & 31, am0 = tid >> 5;
+    const unsigned avoff0 = AT ? (unsigned)((mt * BM + am0) * p.a_ms) * 4u
+                               : (unsigned)ar0 * p.a_ks_bytes + (unsigned)(mt * BM + am) * 4u;
+    const unsigned astep = AT ? (unsigned)(8 * p.a_ms) * 4u : (unsigned)ARP * p.a_ks_bytes;
 
-    float xr[XL];
-    unsigned xvalid = 0;
-    unsigned pe[XL];                 // table entries of the chunk the NEXT load() call will fetch
-    int ao = -1;                     // transposed mode: a_off of this lane's K row, same pipelining
-    float4 af[AT ? 1 : AL];
-    float at[AT ? ALT : 1];
+    // PF register sets: global loads are issued PF chunks ahead of the chunk being multiplied
+    constexpr int PF = (BM * BN <= 64 * 64) ? 2 : 1;
+    float xr[PF][XL];
+    XEntry pe[XL];                   // table entries of the chunk the NEXT load() call will fetch
+    unsigned ao = 0x80000000u;       // transposed mode: byte offset of this lane's K row (same pipelining)
+    f32x4 af[PF][AT ? 1 : AL];
+    float at[PF][AT ? ALT : 1];
 
     auto fetch_tab = [&](int c) {
 #pragma unroll
-        for (int q = 0; q < XL; ++q) pe[q] = xtab[c * KC + xrow0 + q];
+        for (int q = 0; q < XL; ++q) { pe[q].soff = xtab[c * KC + xrow0 + q].soff; pe[q].tapbit = xtab[c * KC + xrow0 + q].tapbit; }
         if constexpr (AT) ao = p.atab[c * KC + akk];
     };
-    auto load = [&](int c, bool more) {
-        xvalid = 0;
+    auto load = [&](auto SETC, int c, bool more) {
+        constexpr int S = decltype(SETC)::value;
 #pragma unroll
         for (int q = 0; q < XL; ++q) {
-            const unsigned e = pe[q];
-            const int ch = (int)(e & 0xffffu), dh = (int)(signed char)(e >> 16), dw = (int)(signed char)(e >> 24);
-            const int li = li0 + dh, lj = lj0 + dw;
-            const bool v = pv && ch != (int)VC_XPK_INVALID && (unsigned)li < (unsigned)p.Hl && (unsigned)lj < (unsigned)p.Wl;
-            const int soff = ch * p.xHW + dh * p.xW + dw;               // wave-uniform (SALU)
-            const float* src = v ? Xg + (soff + xpix) : Xg;            // clamp instead of branching
-            xr[q] = *src;
-            xvalid |= (unsigned)v << q;
+            const unsigned voff = (tapmask & pe[q].tapbit) ? xoffb + (unsigned)pe[q].soff : VC_OOB;
+            xr[S][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, voff, 0, 0));
         }
         if constexpr (AT) {
-            const bool kv = ao >= 0;
 #pragma unroll
-            for (int q = 0; q < ALT; ++q) {
-                const int m = mt * BM + am0 + q * 8;
-                const bool v = kv && m < p.M;
-                const float* src = v ? Ag + ((long)ao + (long)m * p.a_ms) : Ag;
-                const float t = *src;
-                at[q] = v ? t : 0.f;
-            }
+            for (int q = 0; q < ALT; ++q)
+                at[S][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ars, ao + avoff0 + q * astep, 0, 0));
         } else {
+            const unsigned base = avoff0 + (unsigned)(c * KC) * p.a_ks_bytes;
 #pragma unroll
-            for (int q = 0; q < AL; ++q) {
-                const int kk = c * KC + ar0 + q * ARP;
-                const int m = mt * BM + am;
-                const bool v = kk < p.kk_valid && m < p.M;
-                const float4* src = reinterpret_cast<const float4*>(v ? Ag + ((long)kk * p.a_ks + m) : Ag);
-                const float4 t = *src;
-                af[q] = v ? t : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
+            for (int q = 0; q < AL; ++q)
+                af[S][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ars, base + q * astep, 0, 0));
         }
         if (more) fetch_tab(c + 1);
     };
-    auto store = [&](int buf) {
-        float* xs = Xs + buf * XSZ;
+    auto store = [&](auto SETC, int buf) {
+        constexpr int S = decltype(SETC)::value;
+        float* xs = Xs + buf * XSZ + xrow0 * LDX + xn;
         float* as = As + buf * ASZ;
 #pragma unroll
-        for (int q = 0; q < XL; ++q) xs[(xrow0 + q) * LDX + xn] = ((xvalid >> q) & 1u) ? xr[q] : 0.f;
+        for (int q = 0; q < XL; ++q) xs[q * LDX] = xr[S][q];
         if constexpr (AT) {
 #pragma unroll
-            for (int q = 0; q < ALT; ++q) as[akk * LDA + am0 + q * 8] = at[q];
+            for (int q = 0; q < ALT; ++q) as[akk * LDA + am0 + q * 8] = at[S][q];
         } else {
 #pragma unroll
-            for (int q = 0; q < AL; ++q) *reinterpret_cast<float4*>(as + (ar0 + q * ARP) * LDA + am) = af[q];
+            for (int q = 0; q < AL; ++q) *reinterpret_cast<f32x4*>(as + (ar0 + q * ARP) * LDA + am) = af[S][q];
         }
     };
 
@@ -141,31 +149,65 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][nj][r] = 0.f;
 
-    fetch_tab(c0);
-    load(c0, c0 + 1 < c1);
-    store(0);
-    __syncthreads();
-    for (int c = c0; c < c1; ++c) {
-        const int buf = (c - c0) & 1;
-        if (c + 1 < c1) load(c + 1, c + 2 < c1);   // global loads fly under the MFMAs below
+    auto compute = [&](int buf) {
         const float* as = As + buf * ASZ + wm * WM + l31;
         const float* xs = Xs + buf * XSZ + wn * WN + l31;
+        // fetch a whole batch of fragments first, then issue the MFMAs back to back
+        constexpr int KSB = (MI * NJ >= 4) ? 8 : 16;
 #pragma unroll
-        for (int ks = 0; ks < KC / 2; ++ks) {
-            const int k = 2 * ks + h;
-            float a[MI], b[NJ];
+        for (int kb = 0; kb < KC / 2; kb += KSB) {
+            float a[KSB][MI], b[KSB][NJ];
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi) a[mi] = as[k * LDA + mi * 32];
+            for (int ks = 0; ks < KSB; ++ks) {
+                const int k = 2 * (kb + ks) + h;
 #pragma unroll
-            for (int nj = 0; nj < NJ; ++nj) b[nj] = xs[k * LDX + nj * 32];
+                for (int mi = 0; mi < MI; ++mi) a[ks][mi] = as[k * LDA + mi * 32];
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
+                for (int nj = 0; nj < NJ; ++nj) b[ks][nj] = xs[k * LDX + nj * 32];
+            }
+            __builtin_amdgcn_sched_barrier(0);      // keep every ds_read above the MFMA chain
 #pragma unroll
-                for (int nj = 0; nj < NJ; ++nj)
-                    acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], b[nj], acc[mi][nj], 0, 0, 0);
+            for (int ks = 0; ks < KSB; ++ks)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int nj = 0; nj < NJ; ++nj)
+                        acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks][mi], b[ks][nj], acc[mi][nj], 0, 0, 0);
         }
-        if (c + 1 < c1) store(buf ^ 1);
+    };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, PF - 1>;
+    fetch_tab(c0);
+    if constexpr (PF == 1) {
+        load(S0{}, c0, c0 + 1 < c1);
+        store(S0{}, 0);
         __syncthreads();
+        for (int c = c0; c < c1; ++c) {
+            const int buf = (c - c0) & 1;
+            if (c + 1 < c1) load(S0{}, c + 1, c + 2 < c1);
+            compute(buf);
+            if (c + 1 < c1) store(S0{}, buf ^ 1);
+            __syncthreads();
+        }
+    } else {
+        // chunk c0 -> set 0 -> LDS[0]; chunk c0+1 -> set 1 (in flight)
+        load(S0{}, c0, c0 + 1 < c1);
+        if (c0 + 1 < c1) load(S1{}, c0 + 1, c0 + 2 < c1);
+        store(S0{}, 0);
+        __syncthreads();
+        // iteration pair: even step multiplies LDS[0] while set 0 refills (chunk c+2) and set 1 (chunk c+1) is
+        // written to LDS[1]; the odd step mirrors it
+        for (int c = c0; c < c1; c += 2) {
+            if (c + 2 < c1) load(S0{}, c + 2, c + 3 < c1);
+            compute(0);
+            if (c + 1 < c1) store(S1{}, 1);
+            __syncthreads();
+            if (c + 1 >= c1) break;
+            if (c + 3 < c1) load(S1{}, c + 3, c + 4 < c1);
+            compute(1);
+            if (c + 2 < c1) store(S0{}, 0);
+            __syncthreads();
+        }
     }
 
     // ---- epilogue: + bias[m] (+ addend) ; plain store or atomic add
@@ -207,6 +249,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
 // =====================================================================================
 // Filter gradient: D[kk][co] = sum_P Xg[kk][P] * dY[co][P], P = (b, oh, ow).
 // rows = K rows of the forward table (64 per tile), cols = Cout (BN per tile).
+// Same instruction diet as the igemm: buffer loads with hardware range check, incremental pixel decode.
 // =====================================================================================
 template <int BN>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
@@ -227,37 +270,43 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
     if (c0 >= c1) return;
 
     const int pl = tid & 31, rg = tid >> 5;
-    KEntry e[8];
+    unsigned rowoff[8]; int rdh[8], rdw[8];          // loop-invariant per K row of this thread
 #pragma unroll
-    for (int q = 0; q < 8; ++q) e[q] = p.ktab[kt * BM + rg + q * 8];
-    const float* Xg = p.X + (long)g * p.x_gs;
-    const float* Yg = p.dY + (long)g * p.dy_gs;
+    for (int q = 0; q < 8; ++q) {
+        const KEntry e = p.ktab[kt * BM + rg + q * 8];
+        rowoff[q] = (unsigned)((e.c * p.xHW + e.dh * p.xW + e.dw) * 4);
+        rdh[q] = e.a_off >= 0 ? e.dh : (1 << 28);    // padding row: bounds check always fails
+        rdw[q] = e.dw;
+    }
+    const __amdgpu_buffer_rsrc_t xrs =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(p.X + (long)g * p.x_gs), 0, (int)p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t yrs =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(p.dY + (long)g * p.dy_gs), 0, (int)p.dy_bytes, 0x00020000);
+    const unsigned cooff0 = (unsigned)(nt * BN + rg) * (unsigned)p.NPB * 4u;
+    const unsigned costep = 8u * (unsigned)p.NPB * 4u;
+
+    // pixel of this lane in the chunk being loaded: (pb, pr), advanced by 32 pixels per load()
+    int pP = c0 * KC + pl;
+    int pb = pP / p.NPB, pr = pP - pb * p.NPB;
 
     float xr[8], dr[BN / 8];
-    auto load = [&](int c) {
-        const int P = c * KC + pl;
-        const bool pv = P < p.Ptot;
-        int b = 0, i = 0, j = 0, r = 0;
-        if (pv) { b = P / p.NPB; r = P - b * p.NPB; i = r / p.OWc; j = r - i * p.OWc; }
-        const float* xb = Xg + (long)b * p.x_bs;
+    auto load = [&]() {
+        const bool pv = pP < p.Ptot;
+        const int i = (int)(((float)pr + 0.5f) * p.inv_ow);          // pr / OWc, exact for pr < 2^22
+        const int j = pr - i * p.OWc;
         const int li0 = i * p.si, lj0 = j * p.sj;
+        const unsigned xoffb = (unsigned)(((long)pb * p.x_bs + (long)li0 * p.xW + lj0) * 4);
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            const int li = li0 + e[q].dh, lj = lj0 + e[q].dw;
-            const bool v = pv && e[q].a_off >= 0 && (unsigned)li < (unsigned)p.Hl && (unsigned)lj < (unsigned)p.Wl;
-            const float* src = v ? xb + ((long)e[q].c * p.xHW + li * p.xW + lj) : Xg;   // clamp, no branch
-            const float t = *src;
-            xr[q] = v ? t : 0.f;
+            const bool ok = pv && (unsigned)(li0 + rdh[q]) < (unsigned)p.Hl && (unsigned)(lj0 + rdw[q]) < (unsigned)p.Wl;
+            xr[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, ok ? xoffb + rowoff[q] : VC_OOB, 0, 0));
         }
-        const float* yb = Yg + (long)b * p.dy_bs + r;
+        const unsigned yoffb = pv ? (unsigned)(((long)pb * p.dy_bs + pr) * 4) + cooff0 : VC_OOB;
 #pragma unroll
-        for (int q = 0; q < BN / 8; ++q) {
-            const int co = nt * BN + rg + q * 8;
-            const bool v = pv && co < p.N;
-            const float* src = v ? yb + (long)co * p.NPB : Yg;
-            const float t = *src;
-            dr[q] = v ? t : 0.f;
-        }
+        for (int q = 0; q < BN / 8; ++q)      // columns co >= N read neighbouring data or 0 (range check); never stored
+            dr[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yrs, pv ? yoffb + q * costep : VC_OOB, 0, 0));
+        pP += KC; pr += KC;
+        while (pr >= p.NPB) { pr -= p.NPB; ++pb; }
     };
     auto store = [&](int buf) {
         float* as = As + buf * ASZ + pl * LDA + rg;
@@ -274,21 +323,29 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[nj][r] = 0.f;
 
-    load(c0);
+    load();
     store(0);
     __syncthreads();
     for (int c = c0; c < c1; ++c) {
         const int buf = (c - c0) & 1;
-        if (c + 1 < c1) load(c + 1);
+        if (c + 1 < c1) load();
         const float* as = As + buf * ASZ + wm * 32 + l31;
         const float* bs = Bs + buf * BSZ + wn * WN + l31;
+        {
+            float a[KC / 2], b[KC / 2][NJ];
 #pragma unroll
-        for (int ks = 0; ks < KC / 2; ++ks) {
-            const int k = 2 * ks + h;
-            const float a = as[k * LDA];
+            for (int ks = 0; ks < KC / 2; ++ks) {
+                const int k = 2 * ks + h;
+                a[ks] = as[k * LDA];
 #pragma unroll
-            for (int nj = 0; nj < NJ; ++nj)
-                acc[nj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bs[k * LDB + nj * 32], acc[nj], 0, 0, 0);
+                for (int nj = 0; nj < NJ; ++nj) b[ks][nj] = bs[k * LDB + nj * 32];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < KC / 2; ++ks)
+#pragma unroll
+                for (int nj = 0; nj < NJ; ++nj)
+                    acc[nj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks], b[ks][nj], acc[nj], 0, 0, 0);
         }
         if (c + 1 < c1) store(buf ^ 1);
         __syncthreads();
@@ -720,6 +777,8 @@ static int pick_splitk(long tiles, int nchunks) {
     return sk;
 }
 
+static int env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
+
 void igemm_config(IgemmArgs& a) {
     // large tiles only when they still fill the chip (256 CUs, >= 2 workgroups each)
     const long t128 = (long)((a.M + 127) / 128) * ((a.Ptot + 127) / 128) * a.groups;
@@ -727,18 +786,28 @@ void igemm_config(IgemmArgs& a) {
     const int BM = a.big ? 128 : 64, BN = BM;
     a.mtiles = (a.M + BM - 1) / BM; a.ntiles = (a.Ptot + BN - 1) / BN;
     a.splitk = pick_splitk((long)a.mtiles * a.ntiles * a.groups, a.nchunks);
+    // tuning overrides (tools/tune_conv.py); unset in production
+    const int ft = env_int("VC_IGEMM_TILE", 0);
+    if (ft == 64 || ft == 128) {
+        a.big = ft == 128; const int B2 = ft;
+        a.mtiles = (a.M + B2 - 1) / B2; a.ntiles = (a.Ptot + B2 - 1) / B2;
+        a.splitk = pick_splitk((long)a.mtiles * a.ntiles * a.groups, a.nchunks);
+    }
+    const int fs = env_int("VC_IGEMM_SPLITK", 0);
+    if (fs > 0) a.splitk = fs;
 }
 
 int launch_igemm(const IgemmArgs& a, bool a_trans, hipStream_t s, double flops) {
     if (a.splitk > 1 && !a.accumulate) { vc_set_error("launch_igemm: split-K requires accumulate semantics"); return -1; }
     dim3 grid(a.mtiles * a.ntiles, 1, a.groups * a.splitk), block(256);
+    const int pad = env_int("VC_IGEMM_LDS_PAD", 0);      // extra dynamic LDS: caps workgroups per CU (tuning)
     ProfScope ps(0, flops, s);
     if (a.big) {
-        if (a_trans) igemm_kernel<128, 128, true><<<grid, block, 0, s>>>(a);
-        else         igemm_kernel<128, 128, false><<<grid, block, 0, s>>>(a);
+        if (a_trans) igemm_kernel<128, 128, true><<<grid, block, pad, s>>>(a);
+        else         igemm_kernel<128, 128, false><<<grid, block, pad, s>>>(a);
     } else {
-        if (a_trans) igemm_kernel<64, 64, true><<<grid, block, 0, s>>>(a);
-        else         igemm_kernel<64, 64, false><<<grid, block, 0, s>>>(a);
+        if (a_trans) igemm_kernel<64, 64, true><<<grid, block, pad, s>>>(a);
+        else         igemm_kernel<64, 64, false><<<grid, block, pad, s>>>(a);
     }
     VC_HIP(hipGetLastError());
     return 0;
