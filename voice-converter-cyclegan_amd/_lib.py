@@ -7,6 +7,11 @@ libamdhip64, so loading and symbol checks work there; launching does not.)
 import ctypes as C
 import os
 
+# torch bundles its own libamdhip64; load it FIRST so libvcgan_hip.so (linked against the SONAME
+# libamdhip64.so.7) binds to that already-loaded runtime.  The other order leaves two HIP runtimes in
+# the process and the second one to initialise reports "no ROCm-capable device".
+import torch  # noqa: F401,E402
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'csrc', 'libvcgan_hip.so')
 

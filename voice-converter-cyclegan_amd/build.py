@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(CSRC, 'libvcgan_hip.so')
 SOURCES = ['vc_kernels.hip', 'vc_api.hip']
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-munsafe-fp-atomics', '-shared', '-fPIC',
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++20', '-munsafe-fp-atomics', '-shared', '-fPIC',
          '-Wno-unused-value']
 
 

@@ -70,6 +70,8 @@ static int upload_table(const std::vector<HostRow>& rows, const std::vector<Tap>
     t->valid = (int)rows.size();
     while (ke.size() % pad_to || ke.empty()) { ke.push_back(KEntry{0, 0, 0, -1}); xe.push_back(XEntry{0, 0u}); at.push_back(0x80000000u); }
     t->rows = (int)ke.size(); t->ntaps = (int)taps.size();
+    // 3 extra padding chunks: the igemm loader runs ahead of the K range without branching
+    for (int i = 0; i < 96; ++i) { ke.push_back(KEntry{0, 0, 0, -1}); xe.push_back(XEntry{0, 0u}); at.push_back(0x80000000u); }
     VC_CHECK(to_device(ke, &t->dev)); VC_CHECK(to_device(xe, &t->xe)); VC_CHECK(to_device(at, &t->atab));
     std::vector<Tap> tp = taps; if (tp.empty()) tp.push_back(Tap{0, 0});
     VC_CHECK(to_device(tp, &t->taps));

@@ -14,6 +14,7 @@
 #include "vc_internal.h"
 #include <cstdlib>
 #include <type_traits>
+#include <utility>
 #include <vector>
 #include <mutex>
 
@@ -28,7 +29,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // D: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
 // =====================================================================================
 template <int BM, int BN, bool AT>
-__global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
+__global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
     constexpr int KC = 32;
     constexpr int LDA = AT ? BM + 1 : BM + 4;
     constexpr int LDX = BN;
@@ -102,45 +103,6 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
     f32x4 af[PF][AT ? 1 : AL];
     float at[PF][AT ? ALT : 1];
 
-    auto fetch_tab = [&](int c) {
-#pragma unroll
-        for (int q = 0; q < XL; ++q) { pe[q].soff = xtab[c * KC + xrow0 + q].soff; pe[q].tapbit = xtab[c * KC + xrow0 + q].tapbit; }
-        if constexpr (AT) ao = p.atab[c * KC + akk];
-    };
-    auto load = [&](auto SETC, int c, bool more) {
-        constexpr int S = decltype(SETC)::value;
-#pragma unroll
-        for (int q = 0; q < XL; ++q) {
-            const unsigned voff = (tapmask & pe[q].tapbit) ? xoffb + (unsigned)pe[q].soff : VC_OOB;
-            xr[S][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, voff, 0, 0));
-        }
-        if constexpr (AT) {
-#pragma unroll
-            for (int q = 0; q < ALT; ++q)
-                at[S][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ars, ao + avoff0 + q * astep, 0, 0));
-        } else {
-            const unsigned base = avoff0 + (unsigned)(c * KC) * p.a_ks_bytes;
-#pragma unroll
-            for (int q = 0; q < AL; ++q)
-                af[S][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ars, base + q * astep, 0, 0));
-        }
-        if (more) fetch_tab(c + 1);
-    };
-    auto store = [&](auto SETC, int buf) {
-        constexpr int S = decltype(SETC)::value;
-        float* xs = Xs + buf * XSZ + xrow0 * LDX + xn;
-        float* as = As + buf * ASZ;
-#pragma unroll
-        for (int q = 0; q < XL; ++q) xs[q * LDX] = xr[S][q];
-        if constexpr (AT) {
-#pragma unroll
-            for (int q = 0; q < ALT; ++q) as[akk * LDA + am0 + q * 8] = at[S][q];
-        } else {
-#pragma unroll
-            for (int q = 0; q < AL; ++q) *reinterpret_cast<f32x4*>(as + (ar0 + q * ARP) * LDA + am) = af[S][q];
-        }
-    };
-
     f32x16 acc[MI][NJ];
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
@@ -149,63 +111,106 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][nj][r] = 0.f;
 
-    auto compute = [&](int buf) {
+    auto fetch_tab = [&](int c) {
+#pragma unroll
+        for (int q = 0; q < XL; ++q) { pe[q].soff = xtab[c * KC + xrow0 + q].soff; pe[q].tapbit = xtab[c * KC + xrow0 + q].tapbit; }
+        if constexpr (AT) ao = p.atab[c * KC + akk];
+    };
+    // The loader is cut into NITEMS single-instruction-ish items: [X loads | A loads | X stores | A stores].
+    constexpr int NA = AT ? ALT : AL;
+    constexpr int NLOAD = XL + NA, NITEMS = 2 * NLOAD;
+    auto item = [&](auto IC, auto SLC, auto SSC, int cl, int sbuf) {
+        constexpr int I = decltype(IC)::value, SL = decltype(SLC)::value, SS = decltype(SSC)::value;
+        if constexpr (I < XL) {
+            const unsigned voff = (tapmask & pe[I].tapbit) ? xoffb + (unsigned)pe[I].soff : VC_OOB;
+            xr[SL][I] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, voff, 0, 0));
+        } else if constexpr (I < NLOAD) {
+            constexpr int q = I - XL;
+            if constexpr (AT)
+                at[SL][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ars, ao + avoff0 + q * astep, 0, 0));
+            else
+                af[SL][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                    ars, avoff0 + (unsigned)(cl * KC) * p.a_ks_bytes + q * astep, 0, 0));
+        } else if constexpr (I < NLOAD + XL) {
+            constexpr int q = I - NLOAD;
+            Xs[sbuf * XSZ + (xrow0 + q) * LDX + xn] = xr[SS][q];
+        } else {
+            constexpr int q = I - NLOAD - XL;
+            if constexpr (AT) As[sbuf * ASZ + akk * LDA + am0 + q * 8] = at[SS][q];
+            else *reinterpret_cast<f32x4*>(As + sbuf * ASZ + (ar0 + q * ARP) * LDA + am) = af[SS][q];
+        }
+    };
+    // items [I0, I0+N) -- expanded at compile time so every register index stays static
+    auto items = [&](auto I0C, auto CNT, auto SLC, auto SSC, int cl, int sbuf) {
+        constexpr int I0 = decltype(I0C)::value, N = decltype(CNT)::value;
+        [&]<int... Ix>(std::integer_sequence<int, Ix...>) {
+            ((I0 + Ix < NITEMS ? item(std::integral_constant<int, (I0 + Ix < NITEMS ? I0 + Ix : 0)>{}, SLC, SSC, cl, sbuf)
+                               : (void)0), ...);
+        }(std::make_integer_sequence<int, N>{});
+    };
+    // One K chunk: MFMAs on LDS[buf]; behind every MFMA group one slice of the loader runs in its shadow:
+    // global loads of chunk `cl` into register set SL, and LDS stores of set SS into LDS[buf^1].
+    // (an fp32 MFMA occupies the pipe for 64 cycles and the accumulate chain is dependent, so those issue
+    //  slots are free; without this the two co-resident workgroups phase-lock and the pipe idles ~50 %.)
+    constexpr int KSB = (MI * NJ >= 4) ? 8 : 16;
+    constexpr int NSLOT = KC / 2;
+    constexpr int IPS = (NITEMS + NSLOT - 1) / NSLOT;
+    auto chunk = [&](auto SLC, auto SSC, int buf, int cl) {
         const float* as = As + buf * ASZ + wm * WM + l31;
         const float* xs = Xs + buf * XSZ + wn * WN + l31;
-        // fetch a whole batch of fragments first, then issue the MFMAs back to back
-        constexpr int KSB = (MI * NJ >= 4) ? 8 : 16;
+        float a[KSB][MI], b[KSB][NJ];
+        auto slot = [&](auto SC) {
+            constexpr int sidx = decltype(SC)::value;
+            constexpr int ks = sidx % KSB;
+            if constexpr (ks == 0) {
 #pragma unroll
-        for (int kb = 0; kb < KC / 2; kb += KSB) {
-            float a[KSB][MI], b[KSB][NJ];
+                for (int k2 = 0; k2 < KSB; ++k2) {
+                    const int k = 2 * (sidx + k2) + h;
 #pragma unroll
-            for (int ks = 0; ks < KSB; ++ks) {
-                const int k = 2 * (kb + ks) + h;
+                    for (int mi = 0; mi < MI; ++mi) a[k2][mi] = as[k * LDA + mi * 32];
 #pragma unroll
-                for (int mi = 0; mi < MI; ++mi) a[ks][mi] = as[k * LDA + mi * 32];
-#pragma unroll
-                for (int nj = 0; nj < NJ; ++nj) b[ks][nj] = xs[k * LDX + nj * 32];
+                    for (int nj = 0; nj < NJ; ++nj) b[k2][nj] = xs[k * LDX + nj * 32];
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);      // keep every ds_read above the MFMA chain
 #pragma unroll
-            for (int ks = 0; ks < KSB; ++ks)
+            for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                    for (int nj = 0; nj < NJ; ++nj)
-                        acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks][mi], b[ks][nj], acc[mi][nj], 0, 0, 0);
-        }
+                for (int nj = 0; nj < NJ; ++nj)
+                    acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks][mi], b[ks][nj], acc[mi][nj], 0, 0, 0);
+            items(std::integral_constant<int, sidx * IPS>{}, std::integral_constant<int, IPS>{}, SLC, SSC, cl, buf ^ 1);
+            if constexpr (sidx * IPS < NLOAD && (sidx + 1) * IPS >= NLOAD) fetch_tab(cl + 1);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        [&]<int... Sx>(std::integer_sequence<int, Sx...>) { (slot(std::integral_constant<int, Sx>{}), ...); }
+            (std::make_integer_sequence<int, NSLOT>{});
     };
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, PF - 1>;
+    using ZERO = std::integral_constant<int, 0>;
+    using LD0 = std::integral_constant<int, NLOAD>;
+
+    // The loader never branches: it may run up to 3 chunks past the K range.  The tables carry 3 padding
+    // chunks (tap bit 0 / offset beyond the buffer -> zeros), and the LDS buffer it then fills is never read.
     fetch_tab(c0);
+    // prologue: chunk c0 -> set 0 -> LDS[0]   (items [0,NLOAD) are loads, [NLOAD,NITEMS) stores)
+    items(ZERO{}, LD0{}, S0{}, S0{}, c0, 0);
+    fetch_tab(c0 + 1);
+    if constexpr (PF == 2) { items(ZERO{}, LD0{}, S1{}, S1{}, c0 + 1, 0); fetch_tab(c0 + 2); }
+    items(LD0{}, LD0{}, S0{}, S0{}, c0, 0);
+    __syncthreads();
     if constexpr (PF == 1) {
-        load(S0{}, c0, c0 + 1 < c1);
-        store(S0{}, 0);
-        __syncthreads();
         for (int c = c0; c < c1; ++c) {
-            const int buf = (c - c0) & 1;
-            if (c + 1 < c1) load(S0{}, c + 1, c + 2 < c1);
-            compute(buf);
-            if (c + 1 < c1) store(S0{}, buf ^ 1);
+            chunk(S0{}, S0{}, (c - c0) & 1, c + 1);      // load chunk c+1 and store it before the barrier
             __syncthreads();
         }
     } else {
-        // chunk c0 -> set 0 -> LDS[0]; chunk c0+1 -> set 1 (in flight)
-        load(S0{}, c0, c0 + 1 < c1);
-        if (c0 + 1 < c1) load(S1{}, c0 + 1, c0 + 2 < c1);
-        store(S0{}, 0);
-        __syncthreads();
-        // iteration pair: even step multiplies LDS[0] while set 0 refills (chunk c+2) and set 1 (chunk c+1) is
-        // written to LDS[1]; the odd step mirrors it
         for (int c = c0; c < c1; c += 2) {
-            if (c + 2 < c1) load(S0{}, c + 2, c + 3 < c1);
-            compute(0);
-            if (c + 1 < c1) store(S1{}, 1);
+            // LDS[0] = chunk c; set 1 holds chunk c+1 (in flight); set 0 is free
+            chunk(S0{}, S1{}, 0, c + 2);
             __syncthreads();
             if (c + 1 >= c1) break;
-            if (c + 3 < c1) load(S1{}, c + 3, c + 4 < c1);
-            compute(1);
-            if (c + 2 < c1) store(S0{}, 0);
+            chunk(S1{}, S0{}, 1, c + 3);
             __syncthreads();
         }
     }
