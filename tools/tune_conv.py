@@ -24,6 +24,17 @@ SHAPES = {
     'd_h1': (2, 16, 1, 24, 128, 256, 3, 3, 1, 2), 'd_d1': (2, 16, 128, 24, 64, 512, 3, 3, 2, 2),
     'd_d2': (2, 16, 256, 12, 32, 1024, 3, 3, 2, 2), 'd_d3': (2, 16, 512, 6, 16, 2048, 6, 3, 1, 2),
     'g_h1_b256': (1, 256, 24, 1, 128, 256, 1, 15, 1, 1),
+    'r1_b4': (2, 4, 512, 1, 32, 2048, 1, 3, 1, 1),
+    'r1_b8': (2, 8, 512, 1, 32, 2048, 1, 3, 1, 1),
+    'r1_b12': (2, 12, 512, 1, 32, 2048, 1, 3, 1, 1),
+    'r1_b16': (2, 16, 512, 1, 32, 2048, 1, 3, 1, 1),
+    'r1_b20': (2, 20, 512, 1, 32, 2048, 1, 3, 1, 1),
+    'r1_b24': (2, 24, 512, 1, 32, 2048, 1, 3, 1, 1),
+    'r1_b32': (2, 32, 512, 1, 32, 2048, 1, 3, 1, 1),
+    'r1_b48': (2, 48, 512, 1, 32, 2048, 1, 3, 1, 1),
+    'r1_b64': (2, 64, 512, 1, 32, 2048, 1, 3, 1, 1),
+    'r1_b128': (2, 128, 512, 1, 32, 2048, 1, 3, 1, 1),
+
 }
 
 

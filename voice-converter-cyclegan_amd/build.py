@@ -25,7 +25,7 @@ def build(force=False, verbose=True):
     if not force and not needs_build():
         return LIB
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    cmd = [hipcc] + FLAGS + ['-o', LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    cmd = [hipcc] + FLAGS + os.environ.get('VC_EXTRA_FLAGS', '').split() + ['-o', LIB] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print('[vcgan] ' + ' '.join(cmd), flush=True)
     subprocess.check_call(cmd, cwd=CSRC)

@@ -71,7 +71,7 @@ static int upload_table(const std::vector<HostRow>& rows, const std::vector<Tap>
     while (ke.size() % pad_to || ke.empty()) { ke.push_back(KEntry{0, 0, 0, -1}); xe.push_back(XEntry{0, 0u}); at.push_back(0x80000000u); }
     t->rows = (int)ke.size(); t->ntaps = (int)taps.size();
     // 3 extra padding chunks: the igemm loader runs ahead of the K range without branching
-    for (int i = 0; i < 96; ++i) { ke.push_back(KEntry{0, 0, 0, -1}); xe.push_back(XEntry{0, 0u}); at.push_back(0x80000000u); }
+    for (int i = 0; i < 192; ++i) { ke.push_back(KEntry{0, 0, 0, -1}); xe.push_back(XEntry{0, 0u}); at.push_back(0x80000000u); }
     VC_CHECK(to_device(ke, &t->dev)); VC_CHECK(to_device(xe, &t->xe)); VC_CHECK(to_device(at, &t->atab));
     std::vector<Tap> tp = taps; if (tp.empty()) tp.push_back(Tap{0, 0});
     VC_CHECK(to_device(tp, &t->taps));
@@ -113,7 +113,7 @@ static int get_dgrad_table(const Geom& g, int ph, int pw, Table* out) {
                 rows.push_back(HostRow{co, dh, dw, ((i * g.kw + j) * g.Cin) * g.Cout + co, tap});
         }
     }
-    Table t; VC_CHECK(upload_table(rows, taps, 32, g.OH, g.OW, &t));
+    Table t; VC_CHECK(upload_table(rows, taps, 64, g.OH, g.OW, &t));
     g_tabs[key] = t; *out = t;
     return 0;
 }
@@ -147,7 +147,7 @@ static int conv_fwd(const float* x, long x_gs, const float* w, long w_gs, const 
     a.x_bytes = (unsigned)((long)B * g.Cin * g.H * g.W * 4); a.a_bytes = (unsigned)((long)t.valid * g.Cout * 4);
     a.a_gs = w_gs; a.x_gs = x_gs; a.y_gs = y_gs; a.bias_gs = b_gs; a.add_gs = 0;
     a.x_bs = (long)g.Cin * g.H * g.W; a.y_bs = (long)g.Cout * g.OH * g.OW;
-    a.nchunks = t.rows / 32; a.M = g.Cout; a.a_ms = 1;
+    a.krows = t.rows; a.M = g.Cout; a.a_ms = 1;
     a.Hl = g.H; a.Wl = g.W; a.xHW = g.H * g.W; a.xW = g.W; a.si = g.sh; a.sj = g.sw;
     a.NPB = g.OH * g.OW; a.OWc = g.OW; a.Ptot = B * a.NPB;
     a.yHW = g.OH * g.OW; a.yW = g.OW; a.so_h = 1; a.so_w = 1; a.o_h0 = 0; a.o_w0 = 0;
@@ -174,7 +174,7 @@ static int conv_dgrad(const float* dy, long dy_gs, const float* w, long w_gs, fl
         a.a_bytes = (unsigned)((long)g.kh * g.kw * g.Cin * g.Cout * 4);
         a.a_gs = w_gs; a.x_gs = dy_gs; a.y_gs = dx_gs; a.bias_gs = 0; a.add_gs = add_gs;
         a.x_bs = (long)g.Cout * g.OH * g.OW; a.y_bs = (long)g.Cin * g.H * g.W;
-        a.nchunks = t.rows / 32; a.M = g.Cin; a.a_ms = g.Cout;
+        a.krows = t.rows; a.M = g.Cin; a.a_ms = g.Cout;
         a.Hl = g.OH; a.Wl = g.OW; a.xHW = g.OH * g.OW; a.xW = g.OW; a.si = 1; a.sj = 1;
         a.NPB = Hc * Wc; a.OWc = Wc; a.Ptot = B * a.NPB;
         a.yHW = g.H * g.W; a.yW = g.W; a.so_h = g.sh; a.so_w = g.sw; a.o_h0 = ph; a.o_w0 = pw;

@@ -29,7 +29,8 @@ struct IgemmArgs {
     unsigned x_bytes, a_bytes;                    // buffer sizes (per group) for the hardware range check
     long a_gs, x_gs, y_gs, bias_gs, add_gs;      // signed group strides (floats)
     long x_bs, y_bs;                              // batch strides (floats)
-    int nchunks;                                  // K rows / 32 (table is padded)
+    int krows;                                    // K rows of the table (padded to a multiple of 64)
+    int kc;                                       // K chunk chosen by igemm_config (32 or 64)
     int M, a_ms;                                  // output rows, stride of m in A
     int Hl, Wl;                                   // bounds of the gathered tensor
     int xHW, xW;                                  // channel / row stride of the gathered tensor

@@ -28,9 +28,8 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // MFMA operand maps (32x32x2 f32): A[i=lane&31][k=lane>>5], B[k=lane>>5][j=lane&31],
 // D: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
 // =====================================================================================
-template <int BM, int BN, bool AT>
+template <int BM, int BN, int KC, bool AT>
 __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
-    constexpr int KC = 32;
     constexpr int LDA = AT ? BM + 1 : BM + 4;
     constexpr int LDX = BN;
     constexpr int WM = BM / 2, WN = BN / 2, MI = WM / 32, NJ = WN / 32;
@@ -49,8 +48,9 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
     if ((p.mtiles & 7) == 0) { const int xcd = tile & 7, k = tile >> 3; mt = xcd + 8 * (k / p.ntiles); nt = k % p.ntiles; }
     else { nt = tile % p.ntiles; mt = tile / p.ntiles; }
     const int g = blockIdx.z / p.splitk, sp = blockIdx.z - g * p.splitk;
-    const int cps = (p.nchunks + p.splitk - 1) / p.splitk;
-    const int c0 = sp * cps, c1 = min(p.nchunks, c0 + cps);
+    const int nchunks = p.krows / KC;
+    const int cps = (nchunks + p.splitk - 1) / p.splitk;
+    const int c0 = sp * cps, c1 = min(nchunks, c0 + cps);
     if (c0 >= c1) return;
 
     // ---- gathered-operand loader (instruction diet: the K loop is issue-bound otherwise).
@@ -88,28 +88,34 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
 
     // ---- weight loader.  Rows m >= M read whatever lies there (range-checked, never stored): no predicate.
     constexpr int AV = BM / 4, ARP = 256 / AV, AL = KC / ARP;   // plain: 16-B loads along m
-    constexpr int ALT = BM / 8;                                  // transposed: 4-B loads along k
+    constexpr int MP = 256 / KC, ALT = BM / MP;                  // transposed: 4-B loads along k, MP m-rows per pass
     const int am = (tid % AV) * 4, ar0 = tid / AV;
-    const int akk = tid & 31, am0 = tid >> 5;
+    const int akk = tid % KC, am0 = tid / KC;
     const unsigned avoff0 = AT ? (unsigned)((mt * BM + am0) * p.a_ms) * 4u
                                : (unsigned)ar0 * p.a_ks_bytes + (unsigned)(mt * BM + am) * 4u;
-    const unsigned astep = AT ? (unsigned)(8 * p.a_ms) * 4u : (unsigned)ARP * p.a_ks_bytes;
+    const unsigned astep = AT ? (unsigned)(MP * p.a_ms) * 4u : (unsigned)ARP * p.a_ks_bytes;
 
     // PF register sets: global loads are issued PF chunks ahead of the chunk being multiplied
-    constexpr int PF = (BM * BN <= 64 * 64) ? 2 : 1;
+    constexpr int PF = 2;
     float xr[PF][XL];
     XEntry pe[XL];                   // table entries of the chunk the NEXT load() call will fetch
     unsigned ao = 0x80000000u;       // transposed mode: byte offset of this lane's K row (same pipelining)
     f32x4 af[PF][AT ? 1 : AL];
     float at[PF][AT ? ALT : 1];
 
-    f32x16 acc[MI][NJ];
+    // NACC independent accumulator banks (even / odd k-steps): loader slices are issued between MFMAs, and an MFMA
+    // that follows a non-MFMA instruction loses the back-to-back accumulator forwarding (~+43 cycles) when it depends
+    // on the MFMA just before it.  With two banks the dependency distance is two MFMAs.  Banks are summed at the end.
+    constexpr int NACC = (MI * NJ == 1) ? 2 : 1;
+    f32x16 accb[NACC][MI][NJ];
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
+    for (int bk = 0; bk < NACC; ++bk)
 #pragma unroll
-        for (int nj = 0; nj < NJ; ++nj)
+        for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mi][nj][r] = 0.f;
+            for (int nj = 0; nj < NJ; ++nj)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accb[bk][mi][nj][r] = 0.f;
 
     auto fetch_tab = [&](int c) {
 #pragma unroll
@@ -136,7 +142,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
             Xs[sbuf * XSZ + (xrow0 + q) * LDX + xn] = xr[SS][q];
         } else {
             constexpr int q = I - NLOAD - XL;
-            if constexpr (AT) As[sbuf * ASZ + akk * LDA + am0 + q * 8] = at[SS][q];
+            if constexpr (AT) As[sbuf * ASZ + akk * LDA + am0 + q * MP] = at[SS][q];
             else *reinterpret_cast<f32x4*>(As + sbuf * ASZ + (ar0 + q * ARP) * LDA + am) = af[SS][q];
         }
     };
@@ -155,6 +161,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
     constexpr int KSB = (MI * NJ >= 4) ? 8 : 16;
     constexpr int NSLOT = KC / 2;
     constexpr int IPS = (NITEMS + NSLOT - 1) / NSLOT;
+    unsigned dbg_v[4] = {0, 1, 2, 3}; unsigned dbg_s = 0; (void)dbg_v; (void)dbg_s;
     auto chunk = [&](auto SLC, auto SSC, int buf, int cl) {
         const float* as = As + buf * ASZ + wm * WM + l31;
         const float* xs = Xs + buf * XSZ + wn * WN + l31;
@@ -177,8 +184,22 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int nj = 0; nj < NJ; ++nj)
-                    acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks][mi], b[ks][nj], acc[mi][nj], 0, 0, 0);
+#ifndef VC_DBG_NOMFMA
+                    accb[sidx % NACC][mi][nj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks][mi], b[ks][nj], accb[sidx % NACC][mi][nj], 0, 0, 0);
+#else
+                    accb[sidx % NACC][mi][nj][ks & 15] += a[ks][mi] * b[ks][nj];
+#endif
+#ifndef VC_DBG_NOLOADER
             items(std::integral_constant<int, sidx * IPS>{}, std::integral_constant<int, IPS>{}, SLC, SSC, cl, buf ^ 1);
+#endif
+#ifdef VC_DBG_FILL_VALU
+#pragma unroll
+            for (int f = 0; f < VC_DBG_FILL_VALU; ++f) asm volatile("v_add_u32 %0, %0, %1" : "+v"(dbg_v[f & 3]) : "v"(tid));
+#endif
+#ifdef VC_DBG_FILL_SALU
+#pragma unroll
+            for (int f = 0; f < VC_DBG_FILL_SALU; ++f) asm volatile("s_add_u32 %0, %0, 1" : "+s"(dbg_s));
+#endif
             if constexpr (sidx * IPS < NLOAD && (sidx + 1) * IPS >= NLOAD) fetch_tab(cl + 1);
             __builtin_amdgcn_sched_barrier(0);
         };
@@ -215,6 +236,14 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
         }
     }
 
+    f32x16 acc[MI][NJ];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int nj = 0; nj < NJ; ++nj) {
+            acc[mi][nj] = accb[0][mi][nj];
+            if constexpr (NACC == 2) acc[mi][nj] += accb[1][mi][nj];
+        }
     // ---- epilogue: + bias[m] (+ addend) ; plain store or atomic add
     const bool atomic = p.splitk > 1 || p.accumulate;
     const bool first = sp == 0;
@@ -257,7 +286,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
 // Same instruction diet as the igemm: buffer loads with hardware range check, incremental pixel decode.
 // =====================================================================================
 template <int BN>
-__global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs p) {
     constexpr int BM = 64, KC = 32, LDA = BM + 1, LDB = BN + 1;
     constexpr int WN = BN / 2, NJ = WN / 32;
     constexpr int ASZ = KC * LDA, BSZ = KC * LDB;
@@ -275,13 +304,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
     if (c0 >= c1) return;
 
     const int pl = tid & 31, rg = tid >> 5;
-    unsigned rowoff[8]; int rdh[8], rdw[8];          // loop-invariant per K row of this thread
+    unsigned rowoff[8]; int rdhw[8];                 // loop-invariant per K row: byte offset, (dh << 16) | (dw & 0xffff)
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         const KEntry e = p.ktab[kt * BM + rg + q * 8];
         rowoff[q] = (unsigned)((e.c * p.xHW + e.dh * p.xW + e.dw) * 4);
-        rdh[q] = e.a_off >= 0 ? e.dh : (1 << 28);    // padding row: bounds check always fails
-        rdw[q] = e.dw;
+        rdhw[q] = ((e.a_off >= 0 ? e.dh : 0x4000) << 16) | (e.dw & 0xffff);    // padding row: dh = 16384 always fails the bounds check
     }
     const __amdgpu_buffer_rsrc_t xrs =
         __builtin_amdgcn_make_buffer_rsrc((void*)(p.X + (long)g * p.x_gs), 0, (int)p.x_bytes, 0x00020000);
@@ -290,37 +318,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
     const unsigned cooff0 = (unsigned)(nt * BN + rg) * (unsigned)p.NPB * 4u;
     const unsigned costep = 8u * (unsigned)p.NPB * 4u;
 
-    // pixel of this lane in the chunk being loaded: (pb, pr), advanced by 32 pixels per load()
+    // pixel of this lane in the chunk being loaded: (pb, pr), advanced by 32 pixels per chunk
     int pP = c0 * KC + pl;
     int pb = pP / p.NPB, pr = pP - pb * p.NPB;
-
-    float xr[8], dr[BN / 8];
-    auto load = [&]() {
-        const bool pv = pP < p.Ptot;
-        const int i = (int)(((float)pr + 0.5f) * p.inv_ow);          // pr / OWc, exact for pr < 2^22
-        const int j = pr - i * p.OWc;
-        const int li0 = i * p.si, lj0 = j * p.sj;
-        const unsigned xoffb = (unsigned)(((long)pb * p.x_bs + (long)li0 * p.xW + lj0) * 4);
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const bool ok = pv && (unsigned)(li0 + rdh[q]) < (unsigned)p.Hl && (unsigned)(lj0 + rdw[q]) < (unsigned)p.Wl;
-            xr[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, ok ? xoffb + rowoff[q] : VC_OOB, 0, 0));
-        }
-        const unsigned yoffb = pv ? (unsigned)(((long)pb * p.dy_bs + pr) * 4) + cooff0 : VC_OOB;
-#pragma unroll
-        for (int q = 0; q < BN / 8; ++q)      // columns co >= N read neighbouring data or 0 (range check); never stored
-            dr[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yrs, pv ? yoffb + q * costep : VC_OOB, 0, 0));
-        pP += KC; pr += KC;
-        while (pr >= p.NPB) { pr -= p.NPB; ++pb; }
-    };
-    auto store = [&](int buf) {
-        float* as = As + buf * ASZ + pl * LDA + rg;
-        float* bs = Bs + buf * BSZ + pl * LDB + rg;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) as[q * 8] = xr[q];
-#pragma unroll
-        for (int q = 0; q < BN / 8; ++q) bs[q * 8] = dr[q];
-    };
 
     f32x16 acc[NJ];
 #pragma unroll
@@ -328,31 +328,93 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[nj][r] = 0.f;
 
-    load();
-    store(0);
-    __syncthreads();
-    for (int c = c0; c < c1; ++c) {
-        const int buf = (c - c0) & 1;
-        if (c + 1 < c1) load();
+    // Loader cut into items [pixel decode + X loads | dY loads | X stores | dY stores]; one slice runs in the shadow
+    // of every MFMA group (same scheme as igemm_kernel).  Two register sets: loads run two chunks ahead.
+    constexpr int NY = BN / 8, NLOAD = 8 + NY, NITEMS = 2 * NLOAD;
+    float xr[2][8], dr[2][NY];
+    bool pv = false; int li0 = 0, lj0 = 0; unsigned xoffb = 0, yoffb = 0, pmask = 0;   // pmask: all-ones when the pixel is out of range
+    auto decode = [&]() {
+        pv = pP < p.Ptot;
+        pmask = pv ? 0u : VC_OOB;
+        const int i = (int)(((float)pr + 0.5f) * p.inv_ow);          // pr / OWc, exact for pr < 2^22
+        const int j = pr - i * p.OWc;
+        li0 = i * p.si; lj0 = j * p.sj;
+        xoffb = (unsigned)(((long)pb * p.x_bs + (long)li0 * p.xW + lj0) * 4);
+        yoffb = (unsigned)(((long)pb * p.dy_bs + pr) * 4) + cooff0;
+        pP += KC;
+        if (p.NPB >= KC) { pr += KC; const bool w = pr >= p.NPB; pr = w ? pr - p.NPB : pr; pb += (int)w; }   // at most one wrap
+        else { pb = pP / p.NPB; pr = pP - pb * p.NPB; }                                                    // tiny images (uniform branch)
+    };
+    auto item = [&](auto IC, auto SLC, auto SSC, int sbuf) {
+        constexpr int I = decltype(IC)::value, SL = decltype(SLC)::value, SS = decltype(SSC)::value;
+        if constexpr (I < 8) {
+            if constexpr (I == 0) decode();
+            // offsets are OR-ed with an all-ones mask when invalid (-> beyond num_records -> the load returns 0); plain
+            // arithmetic keeps the compiler from turning the select into control flow around the load
+            const bool ok = ((unsigned)(li0 + (rdhw[I] >> 16)) < (unsigned)p.Hl) & ((unsigned)(lj0 + (int)(short)(rdhw[I] & 0xffff)) < (unsigned)p.Wl);
+            const unsigned m = pmask | (0u - (unsigned)!ok);
+            xr[SL][I] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (xoffb + rowoff[I]) | m, 0, 0));
+        } else if constexpr (I < NLOAD) {
+            constexpr int q = I - 8;     // columns co >= N read neighbouring data or 0 (range check); never stored
+            dr[SL][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yrs, (yoffb + q * costep) | pmask, 0, 0));
+        } else if constexpr (I < NLOAD + 8) {
+            constexpr int q = I - NLOAD;
+            As[sbuf * ASZ + pl * LDA + rg + q * 8] = xr[SS][q];
+        } else {
+            constexpr int q = I - NLOAD - 8;
+            Bs[sbuf * BSZ + pl * LDB + rg + q * 8] = dr[SS][q];
+        }
+    };
+    auto items = [&](auto I0C, auto CNT, auto SLC, auto SSC, int sbuf) {
+        constexpr int I0 = decltype(I0C)::value, N = decltype(CNT)::value;
+        [&]<int... Ix>(std::integer_sequence<int, Ix...>) {
+            ((I0 + Ix < NITEMS ? item(std::integral_constant<int, (I0 + Ix < NITEMS ? I0 + Ix : 0)>{}, SLC, SSC, sbuf)
+                               : (void)0), ...);
+        }(std::make_integer_sequence<int, N>{});
+    };
+    constexpr int NSLOT = KC / 2;
+    constexpr int IPS = (NITEMS + NSLOT - 1) / NSLOT;
+    auto chunk = [&](auto SLC, auto SSC, int buf) {
         const float* as = As + buf * ASZ + wm * 32 + l31;
         const float* bs = Bs + buf * BSZ + wn * WN + l31;
-        {
-            float a[KC / 2], b[KC / 2][NJ];
+        constexpr int KSB = 8;                      // fragments in two half-batches: 24 fewer live registers
+        float a[KSB], b[KSB][NJ];
+        auto slot = [&](auto SC) {
+            constexpr int sidx = decltype(SC)::value;
+            constexpr int ks = sidx % KSB;
+            if constexpr (ks == 0) {
 #pragma unroll
-            for (int ks = 0; ks < KC / 2; ++ks) {
-                const int k = 2 * ks + h;
-                a[ks] = as[k * LDA];
+                for (int k2 = 0; k2 < KSB; ++k2) {
+                    const int k = 2 * (sidx + k2) + h;
+                    a[k2] = as[k * LDA];
 #pragma unroll
-                for (int nj = 0; nj < NJ; ++nj) b[ks][nj] = bs[k * LDB + nj * 32];
+                    for (int nj = 0; nj < NJ; ++nj) b[k2][nj] = bs[k * LDB + nj * 32];
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
+#pragma unroll
+            for (int nj = 0; nj < NJ; ++nj)
+                acc[nj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks], b[ks][nj], acc[nj], 0, 0, 0);
+            items(std::integral_constant<int, sidx * IPS>{}, std::integral_constant<int, IPS>{}, SLC, SSC, buf ^ 1);
             __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int ks = 0; ks < KC / 2; ++ks)
-#pragma unroll
-                for (int nj = 0; nj < NJ; ++nj)
-                    acc[nj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks], b[ks][nj], acc[nj], 0, 0, 0);
-        }
-        if (c + 1 < c1) store(buf ^ 1);
+        };
+        [&]<int... Sx>(std::integer_sequence<int, Sx...>) { (slot(std::integral_constant<int, Sx>{}), ...); }
+            (std::make_integer_sequence<int, NSLOT>{});
+    };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    using ZERO = std::integral_constant<int, 0>;
+    using LD0 = std::integral_constant<int, NLOAD>;
+    // the loader never branches: it runs up to 3 chunks past the pixel range (pv false -> zeros)
+    items(ZERO{}, LD0{}, S0{}, S0{}, 0);        // chunk c0   -> set 0
+    items(ZERO{}, LD0{}, S1{}, S1{}, 0);        // chunk c0+1 -> set 1
+    items(LD0{}, LD0{}, S0{}, S0{}, 0);         // set 0 -> LDS[0]
+    __syncthreads();
+    for (int c = c0; c < c1; c += 2) {
+        chunk(S0{}, S1{}, 0);                   // multiply chunk c, load c+2 -> set 0, store set 1 (c+1) -> LDS[1]
+        __syncthreads();
+        if (c + 1 >= c1) break;
+        chunk(S1{}, S0{}, 1);                   // multiply chunk c+1, load c+3 -> set 1, store set 0 (c+2) -> LDS[0]
         __syncthreads();
     }
 
@@ -784,20 +846,32 @@ static int pick_splitk(long tiles, int nchunks) {
 
 static int env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
 
+// Tile choice.  Measured on MI355X: nothing co-issues with an in-flight f32 MFMA (independent VALU/SALU fillers add
+// their full issue time), so a K chunk costs  MFMA cycles + overhead(tile)  and bigger per-wave tiles win as long as
+// the grid still covers the 256 CUs.  cost = rounds(workgroups / 256) * (MI*NJ*1024 + overhead).
+struct TileCfg { int bm, bn, id; double overhead; };
+static const TileCfg kTiles[3] = {{64, 64, 0, 1150.0}, {128, 64, 1, 1500.0}, {128, 128, 2, 2000.0}};
+
 void igemm_config(IgemmArgs& a) {
-    // large tiles only when they still fill the chip (256 CUs, >= 2 workgroups each)
-    const long t128 = (long)((a.M + 127) / 128) * ((a.Ptot + 127) / 128) * a.groups;
-    a.big = (t128 >= 512 && a.M >= 128) ? 1 : 0;
-    const int BM = a.big ? 128 : 64, BN = BM;
-    a.mtiles = (a.M + BM - 1) / BM; a.ntiles = (a.Ptot + BN - 1) / BN;
-    a.splitk = pick_splitk((long)a.mtiles * a.ntiles * a.groups, a.nchunks);
-    // tuning overrides (tools/tune_conv.py); unset in production
-    const int ft = env_int("VC_IGEMM_TILE", 0);
-    if (ft == 64 || ft == 128) {
-        a.big = ft == 128; const int B2 = ft;
-        a.mtiles = (a.M + B2 - 1) / B2; a.ntiles = (a.Ptot + B2 - 1) / B2;
-        a.splitk = pick_splitk((long)a.mtiles * a.ntiles * a.groups, a.nchunks);
+    int best = 0; double best_cost = 1e300;
+    const int ft = env_int("VC_IGEMM_TILE", -1);          // tuning override: 0 = 64x64, 1 = 128x64, 2 = 128x128
+    for (int t = 0; t < 3; ++t) {
+        const TileCfg& c = kTiles[t];
+        const long wgs = (long)((a.M + c.bm - 1) / c.bm) * ((a.Ptot + c.bn - 1) / c.bn) * a.groups;
+        int sk = pick_splitk(wgs, a.krows / 32);
+        const double rounds = (double)((wgs * sk + 255) / 256);
+        const double per_chunk = (c.bm / 64) * (c.bn / 64) * 1024.0 + c.overhead;
+        const double cost = rounds * per_chunk * ((a.krows / 32 + sk - 1) / sk) + (sk > 1 ? 3000.0 * rounds : 0.0);
+        if (ft == t) { best = t; break; }
+        // measured (tools/tune_conv.py, B=8..64 shapes): the 64x64 tile with >= 2 co-resident workgroups wins on every
+        // layer -- the second wave per SIMD covers barrier / wait gaps; the cost model stays for future tiles
+        if (ft < 0 && t == 0 && cost < best_cost) { best_cost = cost; best = t; }
     }
+    a.big = best;
+    const int BM = kTiles[best].bm, BN = kTiles[best].bn;
+    a.mtiles = (a.M + BM - 1) / BM; a.ntiles = (a.Ptot + BN - 1) / BN;
+    a.kc = 32;
+    a.splitk = pick_splitk((long)a.mtiles * a.ntiles * a.groups, a.krows / a.kc);
     const int fs = env_int("VC_IGEMM_SPLITK", 0);
     if (fs > 0) a.splitk = fs;
 }
@@ -807,12 +881,13 @@ int launch_igemm(const IgemmArgs& a, bool a_trans, hipStream_t s, double flops) 
     dim3 grid(a.mtiles * a.ntiles, 1, a.groups * a.splitk), block(256);
     const int pad = env_int("VC_IGEMM_LDS_PAD", 0);      // extra dynamic LDS: caps workgroups per CU (tuning)
     ProfScope ps(0, flops, s);
-    if (a.big) {
-        if (a_trans) igemm_kernel<128, 128, true><<<grid, block, pad, s>>>(a);
-        else         igemm_kernel<128, 128, false><<<grid, block, pad, s>>>(a);
-    } else {
-        if (a_trans) igemm_kernel<64, 64, true><<<grid, block, pad, s>>>(a);
-        else         igemm_kernel<64, 64, false><<<grid, block, pad, s>>>(a);
+    switch (a.big * 2 + (a_trans ? 1 : 0)) {
+        case 0: igemm_kernel<64, 64, 32, false><<<grid, block, pad, s>>>(a); break;
+        case 1: igemm_kernel<64, 64, 32, true><<<grid, block, pad, s>>>(a); break;
+        case 2: igemm_kernel<128, 64, 32, false><<<grid, block, pad, s>>>(a); break;
+        case 3: igemm_kernel<128, 64, 32, true><<<grid, block, pad, s>>>(a); break;
+        case 4: igemm_kernel<128, 128, 32, false><<<grid, block, pad, s>>>(a); break;
+        default: igemm_kernel<128, 128, 32, true><<<grid, block, pad, s>>>(a); break;
     }
     VC_HIP(hipGetLastError());
     return 0;
