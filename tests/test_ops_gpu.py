@@ -116,6 +116,7 @@ NORM_CASES = [
     (0, 0, 256, 64, 2), (0, 0, 1024, 32, 3), (0, 1, 512, 64, 2), (0, 1, 256, 128, 2),
     (0, 0, 256, 384, 2), (0, 0, 512, 96, 2), (0, 0, 1024, 48, 3), (0, 0, 16, 1000, 1),
     (1, 0, 128, 128, 2), (1, 0, 128, 1536, 2), (2, 0, 512, 32, 3), (2, 0, 64, 33, 2), (0, 1, 8, 6, 2),
+    (1, 0, 64, 4608, 2), (0, 0, 32, 2304, 2), (2, 0, 16, 3000, 1), (0, 1, 8, 4100, 2), (1, 0, 8, 2049, 1),   # rows > 2048: streaming kernels
     (0, 0, 512, 2, 3), (0, 0, 256, 4, 3), (2, 0, 512, 2, 3), (0, 1, 512, 4, 3), (0, 1, 256, 8, 3), (1, 0, 128, 8, 3),
 ]
 

@@ -154,6 +154,32 @@ def test_train_step_losses_grads_and_updates(built_lib, B):
             assert frac < 5e-3, (step, n, frac)
 
 
+def test_config5_geometry_36x256(built_lib):
+    """BASELINE configs[4] geometry: 36-dim MCEP x 256-frame windows (o1 filters = num_features).
+    One whole train step against the oracle at B=1; exercises the streaming norm kernels (D.h1 rows = 4608)."""
+    from tests import gpu_util as U
+    O, P, A, Bm, eng = _setup(1, T=256, F=36, seed=31)
+    orc = O.CycleGANOracle({k: v.copy() for k, v in P.items()})
+    g0, d0 = orc.train(A, Bm, 10.0, 5.0, 2e-4, 1e-4)
+    g, d = eng.train_step(A, Bm, 10.0, 5.0, 2e-4, 1e-4)
+    for k, v in orc.last.items():
+        assert abs(eng.last_losses[k] - v) <= TOL * max(1.0, abs(v)), (k, eng.last_losses[k], float(v))
+    ref = dict(orc.last_grads[0]); ref.update(orc.last_grads[1])
+    bad = _cmp_grads(eng.tf_gradients(), ref)
+    assert not bad, bad[:8]
+
+
+def test_long_utterance_inference(built_lib):
+    """model.test on a whole utterance (convert.py:46): T = 2200 frames (> 2048: streaming GLU rows), T % 4 == 0."""
+    from tests import gpu_util as U
+    O, P, A, Bm, eng = _setup(1, T=2200)
+    ref, _ = O.generator_fwd(P, 'generator_B2A', A)
+    got = eng.generate(A, 'B2A')
+    assert got.shape == (1, 24, 2200)
+    e = U.rel_err(got, ref)
+    assert e < TOL, 'rel err %g' % e
+
+
 def test_full_size_properties(built_lib):
     """BASELINE config sizes (B=8) without the oracle: size-independent properties.
     (a) data-parallel identity: gradients of the B=8 batch == mean of two B=4 shard

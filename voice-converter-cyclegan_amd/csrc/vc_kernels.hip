@@ -633,6 +633,135 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const NormArgs p) {
     }
 }
 
+// ---- streaming variants for rows longer than 2048 (36x256 discriminator, long utterances): one 256-thread block
+// per (g, b, c) row, the row is re-read from L2 for each pass instead of living in registers.
+__device__ __forceinline__ float block_sum_256s(float v, float* red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void norm_fwd_stream_kernel(const NormArgs p) {
+    constexpr int NB = (MODE == 2) ? 1 : 2;
+    __shared__ float red[4];
+    const int unit = blockIdx.x;
+    const int g = unit / (p.B * p.C); const int rem = unit - g * (p.B * p.C);
+    const int b = rem / p.C, c = rem - b * p.C;
+    const float* y = p.y + (long)g * p.y_gs;
+    float* out = p.out + (long)g * p.out_gs + ((long)b * p.C + c) * p.L;
+    const float invL = 1.f / (float)p.L;
+    if (MODE == 1) {
+        for (int l = threadIdx.x; l < p.L; l += 256) out[l] = y[yoff<NB>(p, b, 0, c, l)] * sigmoidf_(y[yoff<NB>(p, b, 1, c, l)]);
+        return;
+    }
+    const float* gam = p.gamma + (long)g * p.par_gs;
+    const float* bet = p.beta + (long)g * p.par_gs;
+    float* st = p.stats + (long)g * p.st_gs + ((long)b * NB * p.C) * 2;
+    float mu[NB], rs[NB];
+#pragma unroll
+    for (int br = 0; br < NB; ++br) {
+        float s = 0.f;
+        for (int l = threadIdx.x; l < p.L; l += 256) s += y[yoff<NB>(p, b, br, c, l)];
+        mu[br] = block_sum_256s(s, red) * invL;
+        float q = 0.f;
+        for (int l = threadIdx.x; l < p.L; l += 256) { const float d = y[yoff<NB>(p, b, br, c, l)] - mu[br]; q += d * d; }
+        rs[br] = rsqrtf(block_sum_256s(q, red) * invL + IN_EPS);
+        if (threadIdx.x == 0) { st[2 * (br * p.C + c)] = mu[br]; st[2 * (br * p.C + c) + 1] = rs[br]; }
+    }
+    const float ga = gam[c], be = bet[c];
+    if (MODE == 2) {
+        const float* res = p.res + (long)g * p.res_gs + ((long)b * p.C + c) * p.L;
+        for (int l = threadIdx.x; l < p.L; l += 256) out[l] = res[l] + ((y[yoff<NB>(p, b, 0, c, l)] - mu[0]) * rs[0] * ga + be);
+    } else {
+        const float ga2 = gam[p.C + c], be2 = bet[p.C + c];
+        for (int l = threadIdx.x; l < p.L; l += 256)
+            out[l] = ((y[yoff<NB>(p, b, 0, c, l)] - mu[0]) * rs[0] * ga + be) *
+                     sigmoidf_((y[yoff<NB>(p, b, NB - 1, c, l)] - mu[NB - 1]) * rs[NB - 1] * ga2 + be2);
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void norm_bwd_stream_kernel(const NormArgs p) {
+    constexpr int NB = (MODE == 2) ? 1 : 2;
+    __shared__ float red[4];
+    const int unit = blockIdx.x;
+    const int g = unit / (p.B * p.C); const int rem = unit - g * (p.B * p.C);
+    const int b = rem / p.C, c = rem - b * p.C;
+    const float* y = p.y + (long)g * p.y_gs;
+    float* dy = p.dy + (long)g * p.dy_gs;
+    const float* dout = p.dout + (long)g * p.do_gs + ((long)b * p.C + c) * p.L;
+    const float invL = 1.f / (float)p.L;
+    float* dbias = p.dbias ? p.dbias + (long)g * p.dbias_gs : nullptr;
+    const int cstride_par = p.ps ? p.C : 0, brstride = p.ps ? 2 * p.C : p.C;
+    // conv-channel bias sums: [branch][parity]; without pixel shuffle only parity 0 is used
+    float sb[NB][2];
+#pragma unroll
+    for (int br = 0; br < NB; ++br) sb[br][0] = sb[br][1] = 0.f;
+    if (MODE == 1) {
+        for (int l = threadIdx.x; l < p.L; l += 256) {
+            const float v = y[yoff<NB>(p, b, 0, c, l)], s = sigmoidf_(y[yoff<NB>(p, b, 1, c, l)]);
+            const float dv = dout[l] * s, dg = dout[l] * v * s * (1.f - s);
+            dy[yoff<NB>(p, b, 0, c, l)] = dv; dy[yoff<NB>(p, b, 1, c, l)] = dg;
+            sb[0][0] += dv; sb[NB - 1][0] += (NB == 2) ? dg : 0.f;
+        }
+    } else {
+        const float* gam = p.gamma + (long)g * p.par_gs;
+        const float* bet = p.beta + (long)g * p.par_gs;
+        const float* st = p.stats_in + (long)g * p.st_gs + ((long)b * NB * p.C) * 2;
+        float* dgam = p.dgamma ? p.dgamma + (long)g * p.dpar_gs : nullptr;
+        float* dbet = p.dbeta ? p.dbeta + (long)g * p.dpar_gs : nullptr;
+        float mu[NB], rs[NB], ga[NB], be[NB], s1[NB], s2[NB];
+#pragma unroll
+        for (int br = 0; br < NB; ++br) {
+            mu[br] = st[2 * (br * p.C + c)]; rs[br] = st[2 * (br * p.C + c) + 1];
+            ga[br] = gam[br * p.C + c]; be[br] = bet[br * p.C + c]; s1[br] = s2[br] = 0.f;
+        }
+        auto dn = [&](int l, float* d) {     // gradient w.r.t. the normalised value(s) at position l
+            const float dO = dout[l];
+            if (MODE == 2) { d[0] = dO; return; }
+            const float nv = ga[0] * (y[yoff<NB>(p, b, 0, c, l)] - mu[0]) * rs[0] + be[0];
+            const float ng = ga[NB - 1] * (y[yoff<NB>(p, b, NB - 1, c, l)] - mu[NB - 1]) * rs[NB - 1] + be[NB - 1];
+            const float s = sigmoidf_(ng);
+            d[0] = dO * s; d[NB - 1] = dO * nv * s * (1.f - s);
+        };
+        for (int l = threadIdx.x; l < p.L; l += 256) {
+            float d[NB]; dn(l, d);
+#pragma unroll
+            for (int br = 0; br < NB; ++br) { s1[br] += d[br]; s2[br] += d[br] * (y[yoff<NB>(p, b, br, c, l)] - mu[br]) * rs[br]; }
+        }
+#pragma unroll
+        for (int br = 0; br < NB; ++br) { s1[br] = block_sum_256s(s1[br], red); s2[br] = block_sum_256s(s2[br], red); }
+        for (int l = threadIdx.x; l < p.L; l += 256) {
+            float d[NB]; dn(l, d);
+#pragma unroll
+            for (int br = 0; br < NB; ++br) {
+                const float xh = (y[yoff<NB>(p, b, br, c, l)] - mu[br]) * rs[br];
+                const float v = ga[br] * rs[br] * (d[br] - s1[br] * invL - xh * s2[br] * invL);
+                dy[yoff<NB>(p, b, br, c, l)] = v;
+                sb[br][p.ps ? (l & 1) : 0] += v;
+            }
+        }
+        if (threadIdx.x == 0 && dgam) {
+#pragma unroll
+            for (int br = 0; br < NB; ++br) { atomicAdd(dgam + br * p.C + c, s2[br]); atomicAdd(dbet + br * p.C + c, s1[br]); }
+        }
+    }
+    if (dbias) {
+#pragma unroll
+        for (int br = 0; br < NB; ++br) {
+            const float e = block_sum_256s(sb[br][0], red), o = block_sum_256s(sb[br][1], red);
+            if (threadIdx.x == 0) {
+                atomicAdd(dbias + br * brstride + c, e);
+                if (p.ps) atomicAdd(dbias + br * brstride + cstride_par + c, o);
+            }
+        }
+    }
+}
+
 // =====================================================================================
 // small kernels
 // =====================================================================================
@@ -921,7 +1050,10 @@ static int norm_dispatch(const NormArgs& a, hipStream_t s) {
     else if (a.L <= 512) VC_NORM_CASE(64, 8)
     else if (a.L <= 1024) VC_NORM_CASE(64, 16)
     else if (a.L <= 2048) VC_NORM_CASE(64, 32)
-    else { vc_set_error("instnorm_glu: row length %d > 2048 not supported yet", a.L); return -1; }
+    else {   // streaming: one block per row
+        if (FWD) norm_fwd_stream_kernel<MODE><<<dim3(units), block, 0, s>>>(a);
+        else     norm_bwd_stream_kernel<MODE><<<dim3(units), block, 0, s>>>(a);
+    }
 #undef VC_NORM_CASE
     VC_HIP(hipGetLastError());
     return 0;
