@@ -52,6 +52,38 @@ def cpu_baseline(n_steps=4):
                        'train steps, median %.2f s/step; TF1 reference not runnable (no tensorflow)' % (n_steps, med))
 
 
+def named_kernel_h1(lib, dev, B=256, reps=20):
+    """G.h1 value+gate convolution forward (module.py:161-162) at B=256: SURVEY 8d's named target.
+    algorithmic bytes 20.29 MB, algorithmic FLOPs 6.04 G; exact fp32 caps the HBM fraction at ~6.6 %."""
+    import numpy as np
+    import torch
+    from voice_converter_cyclegan_amd._lib import ptr, check, vp
+    x = torch.randn((1, B, 24, 1, 128), device=dev)
+    w = torch.randn((1, 1, 15, 24, 256), device=dev) * 0.05
+    b = torch.zeros((1, 256), device=dev)
+    y = torch.empty((1, B, 256, 1, 128), device=dev)
+    s = vp(torch.cuda.current_stream().cuda_stream)
+    call = lambda: check(lib.vc_conv2d_fwd(ptr(x), 0, ptr(w), 0, ptr(b), 0, ptr(y), 0, 1, B, 24, 1, 128, 256, 1, 15, 1, 1, s))
+    for _ in range(3):
+        call()
+    torch.cuda.synchronize()
+    lib.vc_prof_enable(1)
+    for _ in range(reps):
+        call()
+    torch.cuda.synchronize()
+    ms, n, fl = C.c_double(0), C.c_longlong(0), C.c_double(0)
+    lib.vc_prof_collect(0, C.byref(ms), C.byref(n), C.byref(fl))
+    lib.vc_prof_enable(0)
+    t = ms.value * 1e-3 / max(n.value, 1)
+    nbytes = B * (24 * 128 + 256 * 128) * 4 + (15 * 24 * 256 + 256) * 4
+    flops = 2.0 * B * 128 * 256 * 15 * 24
+    return {'kernel': 'igemm_kernel: G.h1 gated conv1d forward, B=%d' % B, 'us': t * 1e6,
+            'hbm': {'achieved_GBs': nbytes / t / 1e9, 'peak_GBs': HBM_PEAK_GBS, 'frac': nbytes / t / 1e9 / HBM_PEAK_GBS},
+            'mfma': {'achieved_TFLOPs': flops / t / 1e12, 'peak_TFLOPs': FP32_MFMA_PEAK_TFLOPS,
+                     'frac': flops / t / 1e12 / FP32_MFMA_PEAK_TFLOPS},
+            'note': 'exact-fp32 MFMA makes this kernel FLOP-bound: at fp32 peak it takes 38.4 us vs 2.5 us of HBM time'}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -151,7 +183,11 @@ def main():
             ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
             out['roofline'] = {
                 'bound': 'mfma', 'achieved': ach, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': ach / FP32_MFMA_PEAK_TFLOPS, 'traffic': None,
+                'frac': ach / FP32_MFMA_PEAK_TFLOPS,
+                # HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
+                # (profiles/r01_pmc_hbm_traffic_b8.txt; FETCH_SIZE doubled per MI355X_MICROARCH.md, L3 hits included)
+                'traffic': 122.82e6 if (B, F, T, world) == (8, 24, 128, 1) else None,
+                'traffic_unit': 'bytes/launch (offline PMC pass, upper bound: Infinity-Cache hits counted)',
                 'kernel': name, 'launches_per_step': n // n_prof,
                 'avg_launch_us': 1e3 * ms / max(n, 1), 'algorithmic_gflop_per_step': fl / n_prof / 1e9,
                 'kernel_ms_per_step': ms / n_prof,
@@ -161,6 +197,10 @@ def main():
             out['roofline_wgrad'] = {'bound': 'mfma', 'achieved': ach, 'peak': FP32_MFMA_PEAK_TFLOPS,
                                      'unit': 'TFLOP/s', 'frac': ach / FP32_MFMA_PEAK_TFLOPS, 'kernel': name,
                                      'launches_per_step': n // n_prof, 'kernel_ms_per_step': ms / n_prof}
+
+    # ---- the kernel the north_star names: gated-conv1d forward (G.h1: 24 -> 2x128, k=15) at B=256
+    if rank == 0 and not args.no_roofline:
+        out['named_kernel'] = named_kernel_h1(lib, dev)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline()

@@ -197,6 +197,14 @@ int vc_cyclegan_step_grads(const vc_plan* p, const float* params, float* grads,
  * vc_cyclegan_step_grads on this plan is final (it is produced before the generator backward). */
 int vc_step_wait_d_grads(const vc_plan* p, void* other_stream);
 
+/* Generator gradients become final bucket by bucket (layers in reverse order) during the last backward of
+ * vc_cyclegan_step_grads.  Bucket k covers floats [lo, hi) of EACH generator's block (add vc_flat_offset(p, 0|1));
+ * vc_step_wait_g_bucket makes `other_stream` wait until bucket k of the most recent step is final.  Buckets are
+ * numbered in the order they complete and together tile [0, generator block size). */
+int vc_step_num_g_buckets(const vc_plan* p);
+int vc_step_g_bucket(const vc_plan* p, int k, int64_t* lo, int64_t* hi);
+int vc_step_wait_g_bucket(const vc_plan* p, int k, void* other_stream);
+
 #ifdef __cplusplus
 }
 #endif

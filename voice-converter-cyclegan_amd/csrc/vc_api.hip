@@ -415,6 +415,11 @@ struct vc_plan {
     int d_hw;                     // discriminator output pixels per sample
     long g_scr, d_scr;            // per-sample scratch unit
     hipEvent_t d_ready = nullptr;
+    // generator gradient buckets: layers [first, last] of each generator become final (in reverse layer order) during
+    // the last backward of the step; an event per bucket lets the caller overlap their all-reduce with the rest of it
+    static constexpr int kBuckets = 4;
+    int bucket_first[kBuckets] = {15, 9, 3, 0};          // {u1,u2,o1}, {r4..r6}, {r1..r3}, {h1,d1,d2}
+    hipEvent_t g_ready[kBuckets] = {nullptr, nullptr, nullptr, nullptr};
 };
 
 static void plan_geos(const NetDesc& n, int C0, int H0, int W0, std::vector<LayerGeo>& out) {
@@ -451,11 +456,17 @@ extern "C" int vc_plan_create(int num_features, int n_frames, vc_plan** out) {
         for (int ph = 0; ph < l.g.sh; ++ph) for (int pw = 0; pw < l.g.sw; ++pw) { r = get_dgrad_table(l.g, ph, pw, &t); if (r) { delete p; return r; } }
     }
     hipError_t e = hipEventCreateWithFlags(&p->d_ready, hipEventDisableTiming);
+    for (int k = 0; k < vc_plan::kBuckets && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&p->g_ready[k], hipEventDisableTiming);
     if (e != hipSuccess) { vc_set_error("hipEventCreate failed: %s", hipGetErrorString(e)); delete p; return (int)e; }
     *out = p;
     return 0;
 }
-extern "C" void vc_plan_destroy(vc_plan* p) { if (p) { if (p->d_ready) hipEventDestroy(p->d_ready); delete p; } }
+extern "C" void vc_plan_destroy(vc_plan* p) {
+    if (!p) return;
+    if (p->d_ready) hipEventDestroy(p->d_ready);
+    for (hipEvent_t ev : p->g_ready) if (ev) hipEventDestroy(ev);
+    delete p;
+}
 
 static long align64(long x) { return (x + 63) & ~63L; }
 // save map: for every layer raw output, activation, stats -- offsets (floats) inside one group's save area
@@ -493,6 +504,7 @@ struct NetCtx {
     float* save; long save_gs; SaveMap sm; // layout batch = Bl
     int G, B, Bl;
     hipStream_t s;
+    const int* ev_first = nullptr; const hipEvent_t* ev = nullptr; int n_ev = 0;   // record ev[k] once layer ev_first[k] is done (backward)
 };
 
 static int net_forward(NetCtx& c, const float* x, long x_gs, float* y_plain, long y_plain_gs) {
@@ -555,6 +567,7 @@ static int net_backward(NetCtx& c, const float* x, long x_gs, const float* dtop,
             dyp = S[dyi]; dy_gs = scr_gs;
         }
         if (c.dparams) VC_CHECK(conv_wgrad(in, in_gs, dyp, dy_gs, c.dparams + L.w, c.dpar_gs, c.G, c.B, lg.g, c.s));
+        for (int k = 0; k < c.n_ev; ++k) if (c.ev_first[k] == i) VC_HIP(hipEventRecord(c.ev[k], c.s));
         if (i == 0) {
             if (dx) VC_CHECK(conv_dgrad(dyp, dy_gs, c.params + L.w, c.par_gs, dx, dx_gs, nullptr, 0, dx_acc, c.G, c.B, lg.g, c.s));
             break;
@@ -592,8 +605,9 @@ static int gen_forward(const vc_plan* p, const float* params, long par_gs, const
 }
 static int gen_backward(const vc_plan* p, const float* params, long par_gs, const float* x, long x_gs,
                         const float* dy, long dy_gs, float* save, int Bl, float* dparams, long dpar_gs,
-                        float* dx, long dx_gs, int dx_acc, float* scratch, int G, int B, hipStream_t s) {
+                        float* dx, long dx_gs, int dx_acc, float* scratch, int G, int B, hipStream_t s, bool record_buckets = false) {
     NetCtx c = gen_ctx(p, params, par_gs, dparams, dpar_gs, save, G, B, Bl, s);
+    if (record_buckets) { c.ev_first = p->bucket_first; c.ev = p->g_ready; c.n_ev = vc_plan::kBuckets; }
     const long unit = align64(std::max(p->g_scr, p->d_scr) * B);
     return net_backward(c, x, x_gs, dy, dy_gs, dx, dx_gs, dx_acc, scratch, 3 * unit, unit);
 }
@@ -752,10 +766,24 @@ extern "C" int vc_cyclegan_step_grads(const vc_plan* p, const float* params, flo
                           dO1 + dO1g, -dO1g, 1, SCR, 2, B, s));
     // 10. first-hop backward over [generation; identity]
     VC_CHECK(gen_backward(p, params, PG, X1, X1g, dO1, dO1g, S1, 2 * B, grads, PG,
-                          nullptr, 0, 0, SCR, 2, 2 * B, s));
+                          nullptr, 0, 0, SCR, 2, 2 * B, s, /*record_buckets=*/true));
     return 0;
 }
 
+extern "C" int vc_step_num_g_buckets(const vc_plan* p) { return p ? vc_plan::kBuckets : 0; }
+extern "C" int vc_step_g_bucket(const vc_plan* p, int k, int64_t* lo, int64_t* hi) {
+    VC_ARG(p && k >= 0 && k < vc_plan::kBuckets && lo && hi, "vc_step_g_bucket: bad args");
+    const int first = p->bucket_first[k];
+    const int last = (k == 0 ? (int)p->G.layers.size() : p->bucket_first[k - 1]) - 1;
+    *lo = p->G.layers[first].w;
+    *hi = (last + 1 < (int)p->G.layers.size()) ? p->G.layers[last + 1].w : p->G.total;
+    return 0;
+}
+extern "C" int vc_step_wait_g_bucket(const vc_plan* p, int k, void* other_stream) {
+    VC_ARG(p && k >= 0 && k < vc_plan::kBuckets, "vc_step_wait_g_bucket: bad args");
+    VC_HIP(hipStreamWaitEvent((hipStream_t)other_stream, p->g_ready[k], 0));
+    return 0;
+}
 extern "C" int vc_step_wait_d_grads(const vc_plan* p, void* other_stream) {
     VC_ARG(p, "vc_step_wait_d_grads: bad plan");
     VC_HIP(hipStreamWaitEvent((hipStream_t)other_stream, p->d_ready, 0));

@@ -28,11 +28,11 @@ class GradSync:
     factor is folded into the Adam kernel (grad_scale).  Works on any backend (RCCL on
     GPUs via backend 'nccl'; gloo in the CPU tests)."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, enabled=True):
         import torch.distributed as dist
         self.dist = dist
         self.group = group
-        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.world = dist.get_world_size(group) if enabled and dist.is_available() and dist.is_initialized() else 1
 
     @property
     def scale(self):
@@ -49,7 +49,7 @@ class GradSync:
 
 
 class CycleGANEngine:
-    def __init__(self, num_features=24, device='cuda:0', seed=None, group=None):
+    def __init__(self, num_features=24, device='cuda:0', seed=None, group=None, data_parallel=True):
         if not torch.cuda.is_available():
             raise RuntimeError('CycleGANEngine needs an MI355X: the hot path is HIP-only (no CPU fallback)')
         self.F = int(num_features)
@@ -67,7 +67,7 @@ class CycleGANEngine:
         self.v = torch.zeros(self.n_flat, device=self.device)
         self.losses = torch.zeros(8, device=self.device)
         self._plans, self._ws = {}, None
-        self.sync = GradSync(group)
+        self.sync = GradSync(group, enabled=data_parallel)
         self._comm_stream = torch.cuda.Stream(device=self.device) if self.sync.world > 1 else None
         # tf.train.AdamOptimizer keeps beta1_power/beta2_power as fp32 variables (one pair per optimizer)
         self.b1p = [np.float32(ADAM_BETA1), np.float32(ADAM_BETA1)]
@@ -156,17 +156,36 @@ class CycleGANEngine:
             self.b1p[k] = np.float32(self.b1p[k] * np.float32(ADAM_BETA1))
             self.b2p[k] = np.float32(self.b2p[k] * np.float32(ADAM_BETA2))
 
+    def grad_segments(self, plan):
+        """[(kind, index, [(lo, hi), ...])] in the order the segments become final inside step_grads:
+        the discriminator half first, then the generator buckets (each bucket = one range per generator)."""
+        segs = [('d', 0, [(self.nG2, self.n_flat)])]
+        lo, hi = _lib.i64(0), _lib.i64(0)
+        for k in range(lib.vc_step_num_g_buckets(plan)):
+            check(lib.vc_step_g_bucket(plan, k, C.byref(lo), C.byref(hi)), 'vc_step_g_bucket')
+            segs.append(('g', k, [(self.offsets[0] + lo.value, self.offsets[0] + hi.value),
+                                  (self.offsets[1] + lo.value, self.offsets[1] + hi.value)]))
+        return segs
+
     def exchange_grads(self, plan):
-        """One gradient exchange per step, issued as two segments so the discriminator
-        half (final before the generator backward starts) rides under that backward."""
+        """The one gradient exchange of the step (SUM all-reduce of the flat fp32 gradient), issued as segments in
+        the order they become final so that all but the last small bucket rides under the remaining backward:
+        the native schedule records a HIP event per segment, the comm stream waits on it, RCCL runs beside compute."""
         if self.sync.world == 1:
             return
         main = torch.cuda.current_stream(self.device)
+        works = []
         with torch.cuda.stream(self._comm_stream):
-            check(lib.vc_step_wait_d_grads(plan, _lib.vp(self._comm_stream.cuda_stream)), 'vc_step_wait_d_grads')
-            wd = self.sync.all_reduce(self.grads[self.nG2:], async_op=True)
-        wg = self.sync.all_reduce(self.grads[:self.nG2], async_op=True)
-        wd.wait(); wg.wait()
+            cs = _lib.vp(self._comm_stream.cuda_stream)
+            for kind, k, ranges in self.grad_segments(plan):
+                if kind == 'd':
+                    check(lib.vc_step_wait_d_grads(plan, cs), 'vc_step_wait_d_grads')
+                else:
+                    check(lib.vc_step_wait_g_bucket(plan, k, cs), 'vc_step_wait_g_bucket')
+                for lo, hi in ranges:
+                    works.append(self.sync.all_reduce(self.grads[lo:hi], async_op=True))
+        for w in works:
+            w.wait()
         main.wait_stream(self._comm_stream)
 
     def train_step(self, A, Bm, lambda_cycle, lambda_identity, generator_learning_rate,
