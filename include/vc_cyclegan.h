@@ -49,6 +49,8 @@ int  vc_prof_enable(int on);
 /* Collect: sum of kernel ms, launch count and algorithmic FLOPs since enable/reset,
  * kind 0 = igemm (conv fwd + dgrad), 1 = wgrad.  Synchronises the recorded events. */
 int  vc_prof_collect(int kind, double* ms, long long* launches, double* flops);
+/* Per-launch records (in launch order) since enable: fills ms[i], flops[i] for i < max_n; returns the record count. */
+int  vc_prof_records(int kind, double* ms, double* flops, int max_n);
 
 /* ---- parameter layout (replaces tf.get_variable bookkeeping, module.py:154-159,
  *      194-199; variable names of SURVEY.md section 8a row 13) ------------------ */

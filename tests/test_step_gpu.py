@@ -154,6 +154,44 @@ def test_train_step_losses_grads_and_updates(built_lib, B):
             assert frac < 5e-3, (step, n, frac)
 
 
+def test_against_committed_golden_vectors(built_lib):
+    """oracle-free: three train steps on the synthetic batch of SURVEY 8d against tests/golden/golden_full_f32.npz
+    (generated by tests/golden/make_golden.py): the 8 logged scalars per step, generation_A/B of step 0 and the
+    L2 norm + random projection of every gradient tensor."""
+    import os
+    from tests import gpu_util as U
+    from oracle.cyclegan_oracle import init_params, synthetic_batch      # weights/inputs only (seeded generators)
+    from voice_converter_cyclegan_amd.engine import CycleGANEngine
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'golden_full_f32.npz'))
+    eng = CycleGANEngine(24, device='cuda:0')
+    eng.load_tf_variables(init_params(seed=42, randomize_affine=True))
+    A, Bm = synthetic_batch(1, 24, 128)
+    gen_A = torch.empty((1, 24, 128), device=U.DEV); gen_B = torch.empty_like(gen_A)
+    for step in range(3):
+        eng.train_step(A, Bm, 10.0, 5.0, 2e-4, 1e-4, gen_A=gen_A, gen_B=gen_B)
+        got = np.array([eng.last_losses[k] for k in ('cycle_loss', 'identity_loss', 'generator_loss_A2B', 'generator_loss_B2A',
+                                                      'generator_loss', 'discriminator_loss_A', 'discriminator_loss_B',
+                                                      'discriminator_loss')])
+        ref = z['step%d/losses' % step]
+        assert np.abs(got - ref).max() <= TOL * np.abs(ref).max(), (step, got, ref)
+        if step == 0:
+            assert U.rel_err(gen_A.cpu().numpy(), z['gen_A']) < TOL and U.rel_err(gen_B.cpu().numpy(), z['gen_B']) < TOL
+    # gradients of step 0 need a fresh engine (the loop above already updated the weights)
+    eng2 = CycleGANEngine(24, device='cuda:0')
+    eng2.load_tf_variables(init_params(seed=42, randomize_affine=True))
+    eng2.step_grads(A, Bm, 10.0, 5.0)
+    G = eng2.tf_gradients()
+    for i, n in enumerate(z['grad_names']):
+        n = str(n)
+        if _is_noise_bias(n):
+            continue
+        l2 = float(np.linalg.norm(G[n].astype(np.float64)))
+        assert abs(l2 - z['grad_l2'][i]) <= 5e-3 * z['grad_l2'][i], (n, l2, float(z['grad_l2'][i]))
+        r = np.random.default_rng(1000 + i).standard_normal(G[n].size)
+        proj = float(G[n].reshape(-1).astype(np.float64) @ r)
+        assert abs(proj - z['grad_proj'][i]) <= 5e-3 * z['grad_l2'][i] * np.sqrt(G[n].size) / np.sqrt(G[n].size) + 2e-2 * z['grad_l2'][i], n
+
+
 def test_config5_geometry_36x256(built_lib):
     """BASELINE configs[4] geometry: 36-dim MCEP x 256-frame windows (o1 filters = num_features).
     One whole train step against the oracle at B=1; exercises the streaming norm kernels (D.h1 rows = 4608)."""

@@ -36,6 +36,7 @@ SIGNATURES = [
     ('vc_last_error', C.c_char_p, []),
     ('vc_prof_enable', i32, [i32]),
     ('vc_prof_collect', i32, [i32, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_double)]),
+    ('vc_prof_records', i32, [i32, C.POINTER(C.c_double), C.POINTER(C.c_double), i32]),
     ('vc_param_layout', i32, [i32, i32, C.POINTER(ParamRec), i32, C.POINTER(i64)]),
     ('vc_conv2d_fwd', i32, [vp, i64, vp, i64, vp, i64, vp, i64] + [i32] * 10 + [vp]),
     ('vc_conv2d_dgrad', i32, [vp, i64, vp, i64, vp, i64, vp, i64, i32] + [i32] * 10 + [vp]),

@@ -966,6 +966,21 @@ extern "C" int vc_prof_collect(int kind, double* ms, long long* launches, double
     return 0;
 }
 
+extern "C" int vc_prof_records(int kind, double* ms, double* flops, int max_n) {
+    std::lock_guard<std::mutex> l(g_prof_mu);
+    int n = 0;
+    for (auto& r : g_prof) {
+        if (r.kind != kind) continue;
+        if (n < max_n) {
+            VC_HIP(hipEventSynchronize(r.b));
+            float e = 0; VC_HIP(hipEventElapsedTime(&e, r.a, r.b));
+            ms[n] = e; flops[n] = r.flops;
+        }
+        ++n;
+    }
+    return n;
+}
+
 static int pick_splitk(long tiles, int nchunks) {
     // fill ~2 workgroups per CU (256 CUs); keep >= 4 chunks per split
     int sk = 1;
