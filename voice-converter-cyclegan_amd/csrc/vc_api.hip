@@ -122,8 +122,9 @@ static int get_dgrad_table(const Geom& g, int ph, int pw, Table* out) {
 // conv operators
 // ------------------------------------------------------------------------------------
 static int igemm_run(IgemmArgs& a, bool a_trans, float* y_zero_base, long y_zero_gs, long y_zero_elems,
-                     hipStream_t s, double flops, bool* zeroed) {
+                     hipStream_t s, double flops, bool* zeroed, bool prezeroed = false) {
     igemm_config(a);
+    if (prezeroed) *zeroed = true;        // the caller zeroed the destination as part of a batched zero launch
     if (a.splitk > 1 && !a.accumulate) {
         // atomics need a zeroed destination; parity classes of one dgrad share the tensor -> zero once
         if (!*zeroed) {
@@ -136,8 +137,10 @@ static int igemm_run(IgemmArgs& a, bool a_trans, float* y_zero_base, long y_zero
     return launch_igemm(a, a_trans, s, flops);
 }
 
+// query != nullptr: do not launch, only report whether the launch would use split-K atomics (needs a zeroed y)
 static int conv_fwd(const float* x, long x_gs, const float* w, long w_gs, const float* bias, long b_gs,
-                    float* y, long y_gs, int G, int B, const Geom& g, hipStream_t s) {
+                    float* y, long y_gs, int G, int B, const Geom& g, hipStream_t s,
+                    bool prezeroed = false, bool* query = nullptr) {
     Table t; VC_CHECK(get_fwd_table(g, &t));
     IgemmArgs a{};
     a.A = w; a.X = x; a.Y = y; a.bias = bias; a.addend = nullptr;
@@ -154,11 +157,13 @@ static int conv_fwd(const float* x, long x_gs, const float* w, long w_gs, const 
     a.accumulate = 0; a.groups = G;
     bool zeroed = false;
     const double flops = 2.0 * G * B * a.NPB * (double)g.Cout * t.valid;
-    return igemm_run(a, false, y, y_gs, (long)B * a.y_bs, s, flops, &zeroed);
+    if (query) { igemm_config(a); *query = a.splitk > 1; return 0; }
+    return igemm_run(a, false, y, y_gs, (long)B * a.y_bs, s, flops, &zeroed, prezeroed);
 }
 
 static int conv_dgrad(const float* dy, long dy_gs, const float* w, long w_gs, float* dx, long dx_gs,
-                      const float* addend, long add_gs, int accumulate, int G, int B, const Geom& g, hipStream_t s) {
+                      const float* addend, long add_gs, int accumulate, int G, int B, const Geom& g, hipStream_t s,
+                      bool prezeroed = false, bool* query = nullptr) {
     // one launch per stride-parity class (ph, pw): inside a class the transposed conv is a dense stride-1 gather
     std::vector<IgemmArgs> cls; std::vector<double> fl;
     bool any_split = false;
@@ -183,10 +188,12 @@ static int conv_dgrad(const float* dy, long dy_gs, const float* w, long w_gs, fl
         any_split = any_split || a.splitk > 1;
         cls.push_back(a); fl.push_back(2.0 * G * B * a.NPB * (double)g.Cin * t.valid);
     }
+    if (query) { *query = any_split; return 0; }
     // the classes interleave inside dx: if ANY of them needs atomics, zero dx once up front and let all accumulate
     if (any_split && !accumulate) {
-        for (int gi = 0; gi < G; ++gi)
-            VC_HIP(hipMemsetAsync(dx + (long)gi * dx_gs, 0, (size_t)B * g.Cin * g.H * g.W * sizeof(float), s));
+        if (!prezeroed)
+            for (int gi = 0; gi < G; ++gi)
+                VC_HIP(hipMemsetAsync(dx + (long)gi * dx_gs, 0, (size_t)B * g.Cin * g.H * g.W * sizeof(float), s));
         for (auto& a : cls) a.accumulate = 1;
     }
     for (size_t i = 0; i < cls.size(); ++i) VC_CHECK(launch_igemm(cls[i], true, s, fl[i]));
@@ -488,9 +495,15 @@ static SaveMap save_map(const NetDesc& n, const std::vector<LayerGeo>& geo, int 
 }
 extern "C" int64_t vc_generator_save_floats(const vc_plan* p, int B) { return p ? save_map(p->G, p->gg, B, false).total : 0; }
 extern "C" int64_t vc_discriminator_save_floats(const vc_plan* p, int B) { return p ? save_map(p->D, p->dg, B, true).total : 0; }
+// backward scratch of one group: [dY: largest raw conv output][dA_i: gradient w.r.t. the activation of layer i, every i]
+static long scratch_floats_net(const std::vector<LayerGeo>& geo, long raw_max, int B) {
+    long o = align64(raw_max * B);
+    for (const LayerGeo& l : geo) o += align64(l.act_ps * B);
+    return o;
+}
 extern "C" int64_t vc_scratch_floats(const vc_plan* p, int B) {
     if (!p) return 0;
-    return 3 * align64(std::max(p->g_scr, p->d_scr) * B);
+    return std::max(scratch_floats_net(p->gg, p->g_scr, B), scratch_floats_net(p->dg, p->d_scr, B));
 }
 extern "C" int vc_discriminator_out_elems(const vc_plan* p) { return p ? p->d_hw : 0; }
 
@@ -508,6 +521,18 @@ struct NetCtx {
 };
 
 static int net_forward(NetCtx& c, const float* x, long x_gs, float* y_plain, long y_plain_gs) {
+    // one launch zeroes every raw conv output of this pass whose convolution will reduce over split-K with atomics
+    {
+        std::vector<std::pair<float*, long>> zl;
+        for (size_t i = 0; i < c.n->layers.size(); ++i) {
+            const Layer& L = c.n->layers[i];
+            if (L.mode == M_PLAIN) continue;
+            bool split = false;
+            VC_CHECK(conv_fwd(nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0, c.G, c.B, (*c.geo)[i].g, c.s, false, &split));
+            if (split) for (int g = 0; g < c.G; ++g) zl.push_back({c.save + c.sm.raw[i] + (long)g * c.save_gs, (*c.geo)[i].raw_ps * c.B});
+        }
+        if (!zl.empty()) VC_CHECK(launch_zero_list(zl, c.s));
+    }
     const float* in = x; long in_gs = x_gs;
     const float* blk_in = nullptr; long blk_in_gs = 0;
     for (size_t i = 0; i < c.n->layers.size(); ++i) {
@@ -515,7 +540,8 @@ static int net_forward(NetCtx& c, const float* x, long x_gs, float* y_plain, lon
         float* raw = (L.mode == M_PLAIN) ? y_plain : c.save + c.sm.raw[i];
         const long raw_gs = (L.mode == M_PLAIN) ? y_plain_gs : c.save_gs;
         if (L.mode == M_GATED_IN && i + 1 < c.n->layers.size() && c.n->layers[i + 1].mode == M_IN_RES) { blk_in = in; blk_in_gs = in_gs; }
-        VC_CHECK(conv_fwd(in, in_gs, c.params + L.w, c.par_gs, c.params + L.b, c.par_gs, raw, raw_gs, c.G, c.B, lg.g, c.s));
+        VC_CHECK(conv_fwd(in, in_gs, c.params + L.w, c.par_gs, c.params + L.b, c.par_gs, raw, raw_gs, c.G, c.B, lg.g, c.s,
+                          /*prezeroed=*/L.mode != M_PLAIN));
         if (L.mode == M_PLAIN) break;
         NormArgs a{};
         a.y = raw; a.y_gs = raw_gs; a.out = c.save + c.sm.act[i]; a.out_gs = c.save_gs;
@@ -535,27 +561,37 @@ static int net_forward(NetCtx& c, const float* x, long x_gs, float* y_plain, lon
 // dtop: gradient w.r.t. the network's last activation (for the generator: d o1 output, i.e. dy of the
 // plain layer; for the discriminator: gradient w.r.t. the last GLU output, produced by the head).
 static int net_backward(NetCtx& c, const float* x, long x_gs, const float* dtop, long dtop_gs,
-                        float* dx, long dx_gs, int dx_acc, float* scratch, long scr_gs, long scr_unit) {
-    float* S[3] = {scratch, scratch + scr_unit, scratch + 2 * scr_unit};
-    const float* dcur = dtop; long dcur_gs = dtop_gs;   // gradient w.r.t. output activation of layer i
-    int cur = -1;                                        // index of S holding dcur (-1: external)
-    const float* skip = nullptr; long skip_gs = 0; int skip_idx = -1;
-    auto pick = [&](int a, int b) { for (int k = 0; k < 3; ++k) if (k != a && k != b) return k; return 0; };
-    for (int i = (int)c.n->layers.size() - 1; i >= 0; --i) {
+                        float* dx, long dx_gs, int dx_acc, float* scratch, long scr_gs, long raw_max) {
+    const int nl = (int)c.n->layers.size();
+    // scratch map of one group: dY, then dA[i] = gradient w.r.t. the activation (output) of layer i
+    float* dY = scratch;
+    std::vector<float*> dA(nl);
+    { long o = align64(raw_max * c.B); for (int i = 0; i < nl; ++i) { dA[i] = scratch + o; o += align64((*c.geo)[i].act_ps * c.B); } }
+    // one launch zeroes every dA that a split-K input-gradient will accumulate into
+    {
+        std::vector<std::pair<float*, long>> zl;
+        for (int i = 1; i < nl; ++i) {
+            bool split = false;
+            VC_CHECK(conv_dgrad(nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, c.G, c.B, (*c.geo)[i].g, c.s, false, &split));
+            if (split) for (int g = 0; g < c.G; ++g) zl.push_back({dA[i - 1] + (long)g * scr_gs, (*c.geo)[i - 1].act_ps * c.B});
+        }
+        if (!zl.empty()) VC_CHECK(launch_zero_list(zl, c.s));
+    }
+    const float* dcur = dtop; long dcur_gs = dtop_gs;   // gradient w.r.t. the output activation of layer i
+    const float* skip = nullptr; long skip_gs = 0;      // gradient flowing around a residual block (module.py:81)
+    for (int i = nl - 1; i >= 0; --i) {
         const Layer& L = c.n->layers[i]; const LayerGeo& lg = (*c.geo)[i];
         const float* in = (i == 0) ? x : c.save + c.sm.act[i - 1];
         const long in_gs = (i == 0) ? x_gs : c.save_gs;
         const float* dyp; long dy_gs;
-        int dyi = -1;
         if (L.mode == M_PLAIN) {
             dyp = dcur; dy_gs = dcur_gs;
             if (c.dparams) VC_CHECK(launch_bias_grad(dyp, dy_gs, c.dparams + L.b, c.dpar_gs, c.G, c.B, L.cout, lg.g.OH * lg.g.OW, c.s));
         } else {
-            if (L.mode == M_IN_RES) { skip = dcur; skip_gs = dcur_gs; skip_idx = cur; }
-            dyi = pick(cur, skip_idx);
+            if (L.mode == M_IN_RES) { skip = dcur; skip_gs = dcur_gs; }
             NormArgs a{};
             a.y = c.save + c.sm.raw[i]; a.y_gs = c.save_gs; a.dout = dcur; a.do_gs = dcur_gs;
-            a.dy = S[dyi]; a.dy_gs = scr_gs;
+            a.dy = dY; a.dy_gs = scr_gs;
             a.G = c.G; a.B = c.B; a.C = L.C; a.ps = L.ps; a.L = lg.g.OH * lg.g.OW * (L.ps ? 2 : 1);
             if (L.mode != M_GATED) {
                 a.gamma = c.params + L.gamma; a.beta = c.params + L.beta; a.par_gs = c.par_gs;
@@ -564,7 +600,7 @@ static int net_backward(NetCtx& c, const float* x, long x_gs, const float* dtop,
             }
             if (c.dparams) { a.dbias = c.dparams + L.b; a.dbias_gs = c.dpar_gs; }
             VC_CHECK(launch_norm_bwd(L.mode, a, c.s));
-            dyp = S[dyi]; dy_gs = scr_gs;
+            dyp = dY; dy_gs = scr_gs;
         }
         if (c.dparams) VC_CHECK(conv_wgrad(in, in_gs, dyp, dy_gs, c.dparams + L.w, c.dpar_gs, c.G, c.B, lg.g, c.s));
         for (int k = 0; k < c.n_ev; ++k) if (c.ev_first[k] == i) VC_HIP(hipEventRecord(c.ev[k], c.s));
@@ -572,13 +608,12 @@ static int net_backward(NetCtx& c, const float* x, long x_gs, const float* dtop,
             if (dx) VC_CHECK(conv_dgrad(dyp, dy_gs, c.params + L.w, c.par_gs, dx, dx_gs, nullptr, 0, dx_acc, c.G, c.B, lg.g, c.s));
             break;
         }
-        // gradient w.r.t. this layer's input = output activation of layer i-1
-        const bool block_head = (L.mode == M_GATED_IN && i + 1 < (int)c.n->layers.size() && c.n->layers[i + 1].mode == M_IN_RES);
-        const int outi = pick(dyi, skip_idx);
-        VC_CHECK(conv_dgrad(dyp, dy_gs, c.params + L.w, c.par_gs, S[outi], scr_gs,
-                            block_head ? skip : nullptr, block_head ? skip_gs : 0, 0, c.G, c.B, lg.g, c.s));
-        if (block_head) { skip = nullptr; skip_idx = -1; }
-        dcur = S[outi]; dcur_gs = scr_gs; cur = outi;
+        // gradient w.r.t. this layer's input = activation of layer i-1; the head of a residual block adds the skip
+        const bool block_head = (L.mode == M_GATED_IN && i + 1 < nl && c.n->layers[i + 1].mode == M_IN_RES);
+        VC_CHECK(conv_dgrad(dyp, dy_gs, c.params + L.w, c.par_gs, dA[i - 1], scr_gs,
+                            block_head ? skip : nullptr, block_head ? skip_gs : 0, 0, c.G, c.B, lg.g, c.s, /*prezeroed=*/true));
+        if (block_head) skip = nullptr;
+        dcur = dA[i - 1]; dcur_gs = scr_gs;
     }
     return 0;
 }
@@ -608,8 +643,7 @@ static int gen_backward(const vc_plan* p, const float* params, long par_gs, cons
                         float* dx, long dx_gs, int dx_acc, float* scratch, int G, int B, hipStream_t s, bool record_buckets = false) {
     NetCtx c = gen_ctx(p, params, par_gs, dparams, dpar_gs, save, G, B, Bl, s);
     if (record_buckets) { c.ev_first = p->bucket_first; c.ev = p->g_ready; c.n_ev = vc_plan::kBuckets; }
-    const long unit = align64(std::max(p->g_scr, p->d_scr) * B);
-    return net_backward(c, x, x_gs, dy, dy_gs, dx, dx_gs, dx_acc, scratch, 3 * unit, unit);
+    return net_backward(c, x, x_gs, dy, dy_gs, dx, dx_gs, dx_acc, scratch, vc_scratch_floats(p, B), p->g_scr);
 }
 static int disc_forward(const vc_plan* p, const float* params, long par_gs, const float* x, long x_gs,
                         float* o, long o_gs, float* save, int G, int B, hipStream_t s) {
@@ -625,14 +659,16 @@ static int disc_backward(const vc_plan* p, const float* params, long par_gs, con
                          float* dparams, long dpar_gs, float* dx, long dx_gs, int dx_acc,
                          float* scratch, int G, int B, hipStream_t s) {
     NetCtx c = disc_ctx(p, params, par_gs, dparams, dpar_gs, save, G, B, Bl, s);
-    const long unit = align64(std::max(p->g_scr, p->d_scr) * B);
     const int last = (int)p->D.layers.size() - 1;
-    float* dtop = scratch + 2 * unit;   // slot 2: the discriminator has no skip links, so the chain only ever
-                                        // picks slots 0/1 while this external gradient is live
+    const long scr_gs = vc_scratch_floats(p, B);
+    // the head's input gradient goes where net_backward's scratch map puts dA[last]
+    long off = align64(p->d_scr * B);
+    for (int i = 0; i < last; ++i) off += align64(p->dg[i].act_ps * B);
+    float* dtop = scratch + off;
     VC_CHECK(launch_head_bwd(save + c.sm.act[last], c.save_gs, params + p->D.head_w, par_gs, o, o_gs, dout, do_gs,
-                             dtop, 3 * unit, dparams ? dparams + p->D.head_w : nullptr,
+                             dtop, scr_gs, dparams ? dparams + p->D.head_w : nullptr,
                              dparams ? dparams + p->D.head_b : nullptr, dpar_gs, G, B, p->D.head_c, p->d_hw, s));
-    return net_backward(c, x, x_gs, dtop, 3 * unit, dx, dx_gs, dx_acc, scratch, 3 * unit, unit);
+    return net_backward(c, x, x_gs, dtop, scr_gs, dx, dx_gs, dx_acc, scratch, scr_gs, p->d_scr);
 }
 
 extern "C" int vc_generator_forward(const vc_plan* p, const float* params, int64_t par_gs,
@@ -664,11 +700,11 @@ extern "C" int vc_discriminator_backward(const vc_plan* p, const float* params, 
     VC_ARG(p && params && x && dout && save && scratch && G > 0 && B > 0, "vc_discriminator_backward: bad args");
     // the sigmoid outputs are recomputed from the saved last activation (cheap) into the tail of scratch
     hipStream_t s = (hipStream_t)stream;
-    const long unit = align64(std::max(p->g_scr, p->d_scr) * B);
     SaveMap sm = save_map(p->D, p->dg, B, true);
     const int last = (int)p->D.layers.size() - 1;
-    // slot 1 is free until the first dgrad writes it; o only has to survive the head kernels (stream-ordered)
-    float* o = scratch + unit;
+    // the dY region of the scratch is free until the first norm backward writes it; o only has to survive the head
+    // kernels (stream-ordered)
+    float* o = scratch;
     const long o_gs = (long)B * p->d_hw;
     VC_CHECK(launch_head_fwd(save + sm.act[last], sm.total, params + p->D.head_w, params + p->D.head_b, par_gs,
                              o, o_gs, G, B, p->D.head_c, p->d_hw, s));
@@ -697,7 +733,7 @@ static StepMap step_map(const vc_plan* p, int B) {
     m.s1_gs = vc_generator_save_floats(p, 2 * B); m.S1 = take(m.s1_gs);
     m.s2_gs = vc_generator_save_floats(p, B);     m.S2 = take(m.s2_gs);
     m.sd_gs = vc_discriminator_save_floats(p, 2 * B); m.SD = take(m.sd_gs);
-    m.scr_gs = vc_scratch_floats(p, 2 * B); m.SCR = take(m.scr_gs);
+    m.scr_gs = vc_scratch_floats(p, 2 * B); m.SCR = take(m.scr_gs);   // backward calls with batch B use a smaller group stride inside it
     m.ACC = o; o += 64;
     m.total = o;
     return m;

@@ -65,6 +65,9 @@ struct NormArgs {
 void igemm_config(IgemmArgs& a);   // picks tile size + split-K, fills mtiles/ntiles/splitk/big
 int launch_igemm(const IgemmArgs& a, bool a_trans, hipStream_t s, double flops);
 int launch_wgrad(const WgradArgs& a, hipStream_t s, double flops);
+#include <utility>
+#include <vector>
+int launch_zero_list(const std::vector<std::pair<float*, long>>& bufs, hipStream_t s);
 int launch_norm_fwd(int mode, const NormArgs& a, hipStream_t s);
 int launch_norm_bwd(int mode, const NormArgs& a, hipStream_t s);
 int launch_bias_grad(const float* dy, long dy_gs, float* db, long db_gs, int G, int B, int C, int L, hipStream_t s);

@@ -12,6 +12,7 @@
 //
 // Wavefront = 64 lanes everywhere.  No CUDA compatibility paths.
 #include "vc_internal.h"
+#include <algorithm>
 #include <cstdlib>
 #include <type_traits>
 #include <utility>
@@ -963,6 +964,30 @@ extern "C" int vc_prof_collect(int kind, double* ms, long long* launches, double
         t += e; f += r.flops; ++n;
     }
     if (ms) *ms = t; if (launches) *launches = n; if (flops) *flops = f;
+    return 0;
+}
+
+// one launch zeroes a whole list of buffers (split-K destinations of a network pass)
+struct ZeroList { float* p[48]; long n[48]; int count; };
+__global__ __launch_bounds__(256) void zero_list_kernel(const ZeroList z) {
+    float* p = z.p[blockIdx.y]; const long n = z.n[blockIdx.y];
+    const long n4 = n >> 2;
+    f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) reinterpret_cast<f32x4*>(p)[i] = zero;
+    if (blockIdx.x == 0) for (long i = n4 * 4 + threadIdx.x; i < n; i += 256) p[i] = 0.f;
+}
+int launch_zero_list(const std::vector<std::pair<float*, long>>& bufs, hipStream_t s) {
+    for (size_t i0 = 0; i0 < bufs.size(); i0 += 48) {
+        ZeroList z{}; long mx = 0;
+        z.count = (int)std::min<size_t>(48, bufs.size() - i0);
+        for (int i = 0; i < z.count; ++i) {
+            z.p[i] = bufs[i0 + i].first; z.n[i] = bufs[i0 + i].second; mx = std::max(mx, z.n[i]);
+            if ((uintptr_t)z.p[i] % 16) { vc_set_error("zero list: buffer not 16-byte aligned"); return -1; }
+        }
+        long bx = (mx / 4 + 255) / 256; if (bx > 256) bx = 256; if (bx < 1) bx = 1;
+        zero_list_kernel<<<dim3((unsigned)bx, z.count), 256, 0, s>>>(z);
+    }
+    VC_HIP(hipGetLastError());
     return 0;
 }
 
