@@ -25,15 +25,17 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // =====================================================================================
 // Implicit-GEMM: D[m][n] = sum_k A[k][m] * Xg[k][n], m = output channel, n = launch pixel.
-// Workgroup = 4 waves (2x2), tile BM x BN, K chunk 32, LDS double buffer, register staging.
+// Workgroup = WMG x WNG waves (4 or 8), tile BM x BN, K chunk KC, LDS double buffer, register staging.
 // MFMA operand maps (32x32x2 f32): A[i=lane&31][k=lane>>5], B[k=lane>>5][j=lane&31],
 // D: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
 // =====================================================================================
-template <int BM, int BN, int KC, bool AT>
-__global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
+template <int BM, int BN, int KC, bool AT, int WMG = 2, int WNG = 2>
+__global__ __launch_bounds__(64 * WMG * WNG, 2) void igemm_kernel(const IgemmArgs p) {
+    constexpr int NT = 64 * WMG * WNG;                        // threads per workgroup
     constexpr int LDA = AT ? BM + 1 : BM + 4;
     constexpr int LDX = BN;
-    constexpr int WM = BM / 2, WN = BN / 2, MI = WM / 32, NJ = WN / 32;
+    constexpr int WM = BM / WMG, WN = BN / WNG, MI = WM / 32, NJ = WN / 32;
+    static_assert(BN == 64 || (WMG == 2 && WNG == 2), "8-wave workgroups are written for BN == 64");
     constexpr int ASZ = KC * LDA, XSZ = KC * LDX;
     __shared__ __attribute__((aligned(16))) float smem[2 * (ASZ + XSZ)];
     float* As = smem;
@@ -41,7 +43,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
-    const int wm = wid >> 1, wn = wid & 1;
+    const int wm = wid / WNG, wn = wid % WNG;
 
     // XCD-aware tile order: block b runs on XCD b%8; give each XCD whole m-tiles so a weight
     // slab is fetched into one L2 only (speed only; any order is correct).
@@ -61,7 +63,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
     //    fetched one load() ahead;
     //  * loads are buffer loads: an invalid tap gets offset VC_OOB and the hardware range check returns 0,
     //    so there is no branch, no clamp and no select on the way to LDS.
-    constexpr int XL = (KC * BN) / 256;                       // 8 (BN=64) or 16 (BN=128)
+    constexpr int XL = (KC * BN) / NT;                        // K rows of the chunk owned by this wave
     const int xrow0 = __builtin_amdgcn_readfirstlane((BN == 64) ? wid * XL : (wid >> 1) * XL);
     const int xn = (BN == 64) ? lane : (wid & 1) * 64 + lane;
     const int P = nt * BN + xn;
@@ -88,8 +90,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs p) {
     cxptr xtab = (cxptr)p.xtab;
 
     // ---- weight loader.  Rows m >= M read whatever lies there (range-checked, never stored): no predicate.
-    constexpr int AV = BM / 4, ARP = 256 / AV, AL = KC / ARP;   // plain: 16-B loads along m
-    constexpr int MP = 256 / KC, ALT = BM / MP;                  // transposed: 4-B loads along k, MP m-rows per pass
+    constexpr int AV = BM / 4, ARP = NT / AV, AL = KC / ARP;    // plain: 16-B loads along m
+    constexpr int MP = NT / KC, ALT = BM / MP;                  // transposed: 4-B loads along k, MP m-rows per pass
     const int am = (tid % AV) * 4, ar0 = tid / AV;
     const int akk = tid % KC, am0 = tid / KC;
     const unsigned avoff0 = AT ? (unsigned)((mt * BM + am0) * p.a_ms) * 4u
@@ -1015,27 +1017,21 @@ static int pick_splitk(long tiles, int nchunks) {
 
 static int env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
 
-// Tile choice.  Measured on MI355X: nothing co-issues with an in-flight f32 MFMA (independent VALU/SALU fillers add
-// their full issue time), so a K chunk costs  MFMA cycles + overhead(tile)  and bigger per-wave tiles win as long as
-// the grid still covers the 256 CUs.  cost = rounds(workgroups / 256) * (MI*NJ*1024 + overhead).
-struct TileCfg { int bm, bn, id; double overhead; };
-static const TileCfg kTiles[3] = {{64, 64, 0, 1150.0}, {128, 64, 1, 1500.0}, {128, 128, 2, 2000.0}};
+// Tile choice.  Measured on MI355X: nothing co-issues with an in-flight f32 MFMA (independent VALU/SALU fillers add their
+// full issue time), so a K chunk costs  MFMA cycles + per-wave loader/LDS overhead, and what pays is fewer non-MFMA
+// instructions per wave while keeping >= 2 waves per SIMD resident.
+//   id 0:  64 x 64, 4 waves      id 3: 128 x 64, 8 waves (per-wave loader work halves; each wave still owns one 32x32 tile)
+//   id 1: 128 x 64, 4 waves      id 2: 128 x 128, 4 waves   -- lose on every layer at B <= 64; kept for tuning
+struct TileCfg { int bm, bn; };
+static const TileCfg kTiles[4] = {{64, 64}, {128, 64}, {128, 128}, {128, 64}};
 
 void igemm_config(IgemmArgs& a) {
-    int best = 0; double best_cost = 1e300;
-    const int ft = env_int("VC_IGEMM_TILE", -1);          // tuning override: 0 = 64x64, 1 = 128x64, 2 = 128x128
-    for (int t = 0; t < 3; ++t) {
-        const TileCfg& c = kTiles[t];
-        const long wgs = (long)((a.M + c.bm - 1) / c.bm) * ((a.Ptot + c.bn - 1) / c.bn) * a.groups;
-        int sk = pick_splitk(wgs, a.krows / 32);
-        const double rounds = (double)((wgs * sk + 255) / 256);
-        const double per_chunk = (c.bm / 64) * (c.bn / 64) * 1024.0 + c.overhead;
-        const double cost = rounds * per_chunk * ((a.krows / 32 + sk - 1) / sk) + (sk > 1 ? 3000.0 * rounds : 0.0);
-        if (ft == t) { best = t; break; }
-        // measured (tools/tune_conv.py, B=8..64 shapes): the 64x64 tile with >= 2 co-resident workgroups wins on every
-        // layer -- the second wave per SIMD covers barrier / wait gaps; the cost model stays for future tiles
-        if (ft < 0 && t == 0 && cost < best_cost) { best_cost = cost; best = t; }
-    }
+    // measured selection (tools/tune_conv.py, every layer shape of both networks at B = 8/16): the 8-wave tile wins
+    // whenever the output has >= 512 rows; narrow outputs (stride-2 input gradients with Cin <= 256, the 24-row o1
+    // layer) stay on 64x64
+    int best = (a.M >= 512) ? 3 : 0;
+    const int ft = env_int("VC_IGEMM_TILE", -1);          // tuning override (unset in production)
+    if (ft >= 0 && ft < 4) best = ft;
     a.big = best;
     const int BM = kTiles[best].bm, BN = kTiles[best].bn;
     a.mtiles = (a.M + BM - 1) / BM; a.ntiles = (a.Ptot + BN - 1) / BN;
@@ -1047,10 +1043,12 @@ void igemm_config(IgemmArgs& a) {
 
 int launch_igemm(const IgemmArgs& a, bool a_trans, hipStream_t s, double flops) {
     if (a.splitk > 1 && !a.accumulate) { vc_set_error("launch_igemm: split-K requires accumulate semantics"); return -1; }
-    dim3 grid(a.mtiles * a.ntiles, 1, a.groups * a.splitk), block(256);
+    dim3 grid(a.mtiles * a.ntiles, 1, a.groups * a.splitk), block(a.big == 3 ? 512 : 256);
     const int pad = env_int("VC_IGEMM_LDS_PAD", 0);      // extra dynamic LDS: caps workgroups per CU (tuning)
     ProfScope ps(0, flops, s);
     switch (a.big * 2 + (a_trans ? 1 : 0)) {
+        case 6: igemm_kernel<128, 64, 32, false, 4, 2><<<grid, block, pad, s>>>(a); break;
+        case 7: igemm_kernel<128, 64, 32, true, 4, 2><<<grid, block, pad, s>>>(a); break;
         case 0: igemm_kernel<64, 64, 32, false><<<grid, block, pad, s>>>(a); break;
         case 1: igemm_kernel<64, 64, 32, true><<<grid, block, pad, s>>>(a); break;
         case 2: igemm_kernel<128, 64, 32, false><<<grid, block, pad, s>>>(a); break;
