@@ -41,6 +41,10 @@ struct IgemmArgs {
     int splitk, accumulate, mtiles, ntiles, groups, big;
 };
 
+// Up to 4 launches of the same tile configuration fused into one grid (blockIdx.y): the stride-parity classes of an
+// input gradient, which individually underfill the chip.
+struct IgemmMulti { IgemmArgs c[4]; int n; };
+
 // dW[a_off(kk) + co] += sum_{b,i,j} X[g][b][c(kk)][i*si+dh][j*sj+dw] * dY[g][b][co][i][j]
 struct WgradArgs {
     const float* X; const float* dY; float* dW; const KEntry* ktab;
@@ -64,6 +68,7 @@ struct NormArgs {
 
 void igemm_config(IgemmArgs& a);   // picks tile size + split-K, fills mtiles/ntiles/splitk/big
 int launch_igemm(const IgemmArgs& a, bool a_trans, hipStream_t s, double flops);
+int launch_igemm_multi(const IgemmArgs* cls, int n, bool a_trans, hipStream_t s, double flops);   // all configured alike
 int launch_wgrad(const WgradArgs& a, hipStream_t s, double flops);
 #include <utility>
 #include <vector>

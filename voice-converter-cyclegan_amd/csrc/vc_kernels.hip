@@ -30,7 +30,9 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // D: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
 // =====================================================================================
 template <int BM, int BN, int KC, bool AT, int WMG = 2, int WNG = 2>
-__global__ __launch_bounds__(64 * WMG * WNG, 2) void igemm_kernel(const IgemmArgs p) {
+__global__ __launch_bounds__(64 * WMG * WNG, 2) void igemm_kernel(const IgemmMulti mm) {
+    const IgemmArgs& p = mm.c[blockIdx.y];                    // blockIdx.y: which fused launch (parity class)
+    if (blockIdx.x >= (unsigned)(p.mtiles * p.ntiles) || blockIdx.z >= (unsigned)(p.groups * p.splitk)) return;
     constexpr int NT = 64 * WMG * WNG;                        // threads per workgroup
     constexpr int LDA = AT ? BM + 1 : BM + 4;
     constexpr int LDX = BN;
@@ -1041,24 +1043,34 @@ void igemm_config(IgemmArgs& a) {
     if (fs > 0) a.splitk = fs;
 }
 
-int launch_igemm(const IgemmArgs& a, bool a_trans, hipStream_t s, double flops) {
-    if (a.splitk > 1 && !a.accumulate) { vc_set_error("launch_igemm: split-K requires accumulate semantics"); return -1; }
-    dim3 grid(a.mtiles * a.ntiles, 1, a.groups * a.splitk), block(a.big == 3 ? 512 : 256);
+int launch_igemm_multi(const IgemmArgs* cls, int n, bool a_trans, hipStream_t s, double flops) {
+    if (n < 1 || n > 4) { vc_set_error("launch_igemm_multi: 1..4 launches can be fused"); return -1; }
+    IgemmMulti m{}; m.n = n;
+    int tiles = 0, z = 0;
+    for (int i = 0; i < n; ++i) {
+        const IgemmArgs& a = cls[i];
+        if (a.splitk > 1 && !a.accumulate) { vc_set_error("launch_igemm: split-K requires accumulate semantics"); return -1; }
+        if (a.big != cls[0].big || a.groups != cls[0].groups) { vc_set_error("launch_igemm_multi: mixed tile configurations"); return -1; }
+        m.c[i] = a; tiles = std::max(tiles, a.mtiles * a.ntiles); z = std::max(z, a.groups * a.splitk);
+    }
+    const int big = cls[0].big;
+    dim3 grid(tiles, n, z), block(big == 3 ? 512 : 256);
     const int pad = env_int("VC_IGEMM_LDS_PAD", 0);      // extra dynamic LDS: caps workgroups per CU (tuning)
     ProfScope ps(0, flops, s);
-    switch (a.big * 2 + (a_trans ? 1 : 0)) {
-        case 6: igemm_kernel<128, 64, 32, false, 4, 2><<<grid, block, pad, s>>>(a); break;
-        case 7: igemm_kernel<128, 64, 32, true, 4, 2><<<grid, block, pad, s>>>(a); break;
-        case 0: igemm_kernel<64, 64, 32, false><<<grid, block, pad, s>>>(a); break;
-        case 1: igemm_kernel<64, 64, 32, true><<<grid, block, pad, s>>>(a); break;
-        case 2: igemm_kernel<128, 64, 32, false><<<grid, block, pad, s>>>(a); break;
-        case 3: igemm_kernel<128, 64, 32, true><<<grid, block, pad, s>>>(a); break;
-        case 4: igemm_kernel<128, 128, 32, false><<<grid, block, pad, s>>>(a); break;
-        default: igemm_kernel<128, 128, 32, true><<<grid, block, pad, s>>>(a); break;
+    switch (big * 2 + (a_trans ? 1 : 0)) {
+        case 6: igemm_kernel<128, 64, 32, false, 4, 2><<<grid, block, pad, s>>>(m); break;
+        case 7: igemm_kernel<128, 64, 32, true, 4, 2><<<grid, block, pad, s>>>(m); break;
+        case 0: igemm_kernel<64, 64, 32, false><<<grid, block, pad, s>>>(m); break;
+        case 1: igemm_kernel<64, 64, 32, true><<<grid, block, pad, s>>>(m); break;
+        case 2: igemm_kernel<128, 64, 32, false><<<grid, block, pad, s>>>(m); break;
+        case 3: igemm_kernel<128, 64, 32, true><<<grid, block, pad, s>>>(m); break;
+        case 4: igemm_kernel<128, 128, 32, false><<<grid, block, pad, s>>>(m); break;
+        default: igemm_kernel<128, 128, 32, true><<<grid, block, pad, s>>>(m); break;
     }
     VC_HIP(hipGetLastError());
     return 0;
 }
+int launch_igemm(const IgemmArgs& a, bool a_trans, hipStream_t s, double flops) { return launch_igemm_multi(&a, 1, a_trans, s, flops); }
 
 int launch_wgrad(const WgradArgs& a0, hipStream_t s, double flops) {
     WgradArgs a = a0;
