@@ -208,7 +208,7 @@ static int conv_dgrad(const float* dy, long dy_gs, const float* w, long w_gs, fl
 }
 
 static int conv_wgrad(const float* x, long x_gs, const float* dy, long dy_gs, float* dw, long dw_gs,
-                      int G, int B, const Geom& g, hipStream_t s) {
+                      int G, int B, const Geom& g, hipStream_t s, bool first_touch = false) {
     Table t; VC_CHECK(get_fwd_table(g, &t));
     WgradArgs a{};
     a.X = x; a.dY = dy; a.dW = dw; a.ktab = t.dev;
@@ -220,6 +220,7 @@ static int conv_wgrad(const float* x, long x_gs, const float* dy, long dy_gs, fl
     VC_ARG((long)B * a.x_bs * 4 < 0xffffff00L && (long)B * a.dy_bs * 4 < 0xffffff00L, "conv: tensor of one group exceeds 4 GiB");
     a.x_bytes = (unsigned)((long)B * a.x_bs * 4); a.dy_bytes = (unsigned)((long)B * a.dy_bs * 4);
     a.inv_ow = 1.0f / (float)g.OW;
+    a.first_touch = first_touch ? 1 : 0;
     const double flops = 2.0 * G * B * a.NPB * (double)g.Cout * t.valid;
     return launch_wgrad(a, s, flops);
 }
@@ -524,6 +525,7 @@ struct NetCtx {
     float* save; long save_gs; SaveMap sm; // layout batch = Bl
     int G, B, Bl;
     hipStream_t s;
+    bool wgrad_first = false;              // this backward is the first contribution of the step to dparams' conv kernels
     const int* ev_first = nullptr; const hipEvent_t* ev = nullptr; int n_ev = 0;   // record ev[k] once layer ev_first[k] is done (backward)
 };
 
@@ -609,7 +611,7 @@ static int net_backward(NetCtx& c, const float* x, long x_gs, const float* dtop,
             VC_CHECK(launch_norm_bwd(L.mode, a, c.s));
             dyp = dY; dy_gs = scr_gs;
         }
-        if (c.dparams) VC_CHECK(conv_wgrad(in, in_gs, dyp, dy_gs, c.dparams + L.w, c.dpar_gs, c.G, c.B, lg.g, c.s));
+        if (c.dparams) VC_CHECK(conv_wgrad(in, in_gs, dyp, dy_gs, c.dparams + L.w, c.dpar_gs, c.G, c.B, lg.g, c.s, c.wgrad_first));
         for (int k = 0; k < c.n_ev; ++k) if (c.ev_first[k] == i) VC_HIP(hipEventRecord(c.ev[k], c.s));
         if (i == 0) {
             if (dx) VC_CHECK(conv_dgrad(dyp, dy_gs, c.params + L.w, c.par_gs, dx, dx_gs, nullptr, 0, dx_acc, c.G, c.B, lg.g, c.s));
@@ -647,8 +649,10 @@ static int gen_forward(const vc_plan* p, const float* params, long par_gs, const
 }
 static int gen_backward(const vc_plan* p, const float* params, long par_gs, const float* x, long x_gs,
                         const float* dy, long dy_gs, float* save, int Bl, float* dparams, long dpar_gs,
-                        float* dx, long dx_gs, int dx_acc, float* scratch, int G, int B, hipStream_t s, bool record_buckets = false) {
+                        float* dx, long dx_gs, int dx_acc, float* scratch, int G, int B, hipStream_t s, bool record_buckets = false,
+                        bool wgrad_first = false) {
     NetCtx c = gen_ctx(p, params, par_gs, dparams, dpar_gs, save, G, B, Bl, s);
+    c.wgrad_first = wgrad_first;
     if (record_buckets) { c.ev_first = p->bucket_first; c.ev = p->g_ready; c.n_ev = vc_plan::kBuckets; }
     return net_backward(c, x, x_gs, dy, dy_gs, dx, dx_gs, dx_acc, scratch, vc_scratch_floats(p, B), p->g_scr);
 }
@@ -664,8 +668,9 @@ static int disc_forward(const vc_plan* p, const float* params, long par_gs, cons
 static int disc_backward(const vc_plan* p, const float* params, long par_gs, const float* x, long x_gs,
                          const float* o, long o_gs, const float* dout, long do_gs, float* save, int Bl,
                          float* dparams, long dpar_gs, float* dx, long dx_gs, int dx_acc,
-                         float* scratch, int G, int B, hipStream_t s) {
+                         float* scratch, int G, int B, hipStream_t s, bool wgrad_first = false) {
     NetCtx c = disc_ctx(p, params, par_gs, dparams, dpar_gs, save, G, B, Bl, s);
+    c.wgrad_first = wgrad_first;
     const int last = (int)p->D.layers.size() - 1;
     const long scr_gs = vc_scratch_floats(p, B);
     // the head's input gradient goes where net_backward's scratch map puts dA[last]
@@ -798,7 +803,7 @@ extern "C" int vc_cyclegan_step_grads(const vc_plan* p, const float* params, flo
     VC_CHECK(launch_loss(la, s));
     // 7. discriminator_loss backward over [fake; real] -> D gradients (model.py:94,107)
     VC_CHECK(disc_backward(p, params + 2 * PG, PD, DX, DXg, DO, DOg, dDO_D, dDDg, SD, 2 * B,
-                           grads + 2 * PG, PD, nullptr, 0, 0, SCR, 2, 2 * B, s));
+                           grads + 2 * PG, PD, nullptr, 0, 0, SCR, 2, 2 * B, s, /*wgrad_first=*/true));
     VC_HIP(hipEventRecord(p->d_ready, s));
     // 8. adversarial generator terms: gradient through D's inputs only (var_list = generator_vars, model.py:95,108)
     //    g0 = D_A -> d gen_A = dO1[g1][0:B]; g1 = D_B -> d gen_B = dO1[g0][0:B]
@@ -806,7 +811,7 @@ extern "C" int vc_cyclegan_step_grads(const vc_plan* p, const float* params, flo
                            nullptr, 0, dO1 + dO1g, -dO1g, 0, SCR, 2, B, s));
     // 9. cycle hop backward: g0 = A2B on gen_A -> adds into d gen_A; g1 = B2A on gen_B -> d gen_B
     VC_CHECK(gen_backward(p, params, PG, O1 + O1g, -O1g, dCY, dCYg, S2, B, grads, PG,
-                          dO1 + dO1g, -dO1g, 1, SCR, 2, B, s));
+                          dO1 + dO1g, -dO1g, 1, SCR, 2, B, s, false, /*wgrad_first=*/true));
     // 10. first-hop backward over [generation; identity]
     VC_CHECK(gen_backward(p, params, PG, X1, X1g, dO1, dO1g, S1, 2 * B, grads, PG,
                           nullptr, 0, 0, SCR, 2, 2 * B, s, /*record_buckets=*/true));

@@ -56,6 +56,7 @@ struct WgradArgs {
     int NPB, OWc, Ptot;
     int nchunks;                                  // ceil(Ptot/32)
     int splitk, ktiles, ntiles, groups;
+    int first_touch;                              // dW holds no earlier contribution (it is zero): store instead of add
 };
 
 struct NormArgs {

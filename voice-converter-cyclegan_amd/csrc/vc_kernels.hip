@@ -292,10 +292,12 @@ __global__ __launch_bounds__(64 * WMG * WNG, 2) void igemm_kernel(const IgemmMul
 // =====================================================================================
 template <int BN>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs p) {
-    constexpr int BM = 64, KC = 32, LDA = BM + 1, LDB = BN + 1;
+    // LDS tiles are [row][pixel] with a 36-float row stride: the loader writes whole pixel runs (conflict-free), and a
+    // lane reads its 16 k values (pixels 16h..16h+15 of its row; MFMA step u pairs pixels u and 16+u) as 4 ds_read_b128
+    constexpr int BM = 64, KC = 32, LDT = KC + 4;
     constexpr int WN = BN / 2, NJ = WN / 32;
-    constexpr int ASZ = KC * LDA, BSZ = KC * LDB;
-    __shared__ float smem[2 * (ASZ + BSZ)];
+    constexpr int ASZ = BM * LDT, BSZ = BN * LDT;
+    __shared__ __attribute__((aligned(16))) float smem[2 * (ASZ + BSZ)];
     float* As = smem;
     float* Bs = smem + 2 * ASZ;
 
@@ -364,10 +366,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs p) {
             dr[SL][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yrs, (yoffb + q * costep) | pmask, 0, 0));
         } else if constexpr (I < NLOAD + 8) {
             constexpr int q = I - NLOAD;
-            As[sbuf * ASZ + pl * LDA + rg + q * 8] = xr[SS][q];
+            As[sbuf * ASZ + (rg + q * 8) * LDT + pl] = xr[SS][q];
         } else {
             constexpr int q = I - NLOAD - 8;
-            Bs[sbuf * BSZ + pl * LDB + rg + q * 8] = dr[SS][q];
+            Bs[sbuf * BSZ + (rg + q * 8) * LDT + pl] = dr[SS][q];
         }
     };
     auto items = [&](auto I0C, auto CNT, auto SLC, auto SSC, int sbuf) {
@@ -380,27 +382,28 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs p) {
     constexpr int NSLOT = KC / 2;
     constexpr int IPS = (NITEMS + NSLOT - 1) / NSLOT;
     auto chunk = [&](auto SLC, auto SSC, int buf) {
-        const float* as = As + buf * ASZ + wm * 32 + l31;
-        const float* bs = Bs + buf * BSZ + wn * WN + l31;
-        constexpr int KSB = 8;                      // fragments in two half-batches: 24 fewer live registers
-        float a[KSB], b[KSB][NJ];
+        const f32x4* as = reinterpret_cast<const f32x4*>(As + buf * ASZ + (wm * 32 + l31) * LDT + 16 * h);
+        const f32x4* bs = reinterpret_cast<const f32x4*>(Bs + buf * BSZ + (wn * WN + l31) * LDT + 16 * h);
+        f32x4 a4[4], b4[NJ][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            a4[j] = as[j];
+#pragma unroll
+            for (int nj = 0; nj < NJ; ++nj) b4[nj][j] = bs[nj * 32 * LDT / 4 + j];
+        }
+        __builtin_amdgcn_sched_barrier(0);
         auto slot = [&](auto SC) {
-            constexpr int sidx = decltype(SC)::value;
-            constexpr int ks = sidx % KSB;
-            if constexpr (ks == 0) {
-#pragma unroll
-                for (int k2 = 0; k2 < KSB; ++k2) {
-                    const int k = 2 * (sidx + k2) + h;
-                    a[k2] = as[k * LDA];
-#pragma unroll
-                    for (int nj = 0; nj < NJ; ++nj) b[k2][nj] = bs[k * LDB + nj * 32];
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            constexpr int u = decltype(SC)::value;      // MFMA step u multiplies pixels u (lanes 0-31) and 16+u (lanes 32-63)
 #pragma unroll
             for (int nj = 0; nj < NJ; ++nj)
-                acc[nj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks], b[ks][nj], acc[nj], 0, 0, 0);
-            items(std::integral_constant<int, sidx * IPS>{}, std::integral_constant<int, IPS>{}, SLC, SSC, buf ^ 1);
+#ifndef VC_DBG_NOMFMA
+                acc[nj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[u / 4][u % 4], b4[nj][u / 4][u % 4], acc[nj], 0, 0, 0);
+#else
+                acc[nj][u] += a4[u / 4][u % 4] * b4[nj][u / 4][u % 4];
+#endif
+#ifndef VC_DBG_NOLOADER
+            items(std::integral_constant<int, u * IPS>{}, std::integral_constant<int, IPS>{}, SLC, SSC, buf ^ 1);
+#endif
             __builtin_amdgcn_sched_barrier(0);
         };
         [&]<int... Sx>(std::integer_sequence<int, Sx...>) { (slot(std::integral_constant<int, Sx>{}), ...); }
@@ -423,7 +426,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs p) {
         __syncthreads();
     }
 
+    // accumulate into dW with fire-and-forget atomics (a plain read-add-write is exact when split-K is 1 but measured
+    // 5-10 % slower: it waits on the load latency)
     float* Wg = p.dW + (long)g * p.dw_gs;
+    const bool store = p.first_touch && p.splitk == 1;   // first contribution of the step to this tensor: plain stores (3 vs 11 us)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int kk = kt * BM + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -432,7 +438,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs p) {
 #pragma unroll
             for (int nj = 0; nj < NJ; ++nj) {
                 const int co = nt * BN + wn * WN + nj * 32 + l31;
-                if (co < p.N) atomicAdd(Wg + aoff + co, acc[nj][r]);
+                if (co < p.N) { if (store) Wg[aoff + co] = acc[nj][r]; else atomicAdd(Wg + aoff + co, acc[nj][r]); }
             }
         }
     }
