@@ -192,6 +192,20 @@ def test_against_committed_golden_vectors(built_lib):
         assert abs(proj - z['grad_proj'][i]) <= 5e-3 * z['grad_l2'][i] * np.sqrt(G[n].size) / np.sqrt(G[n].size) + 2e-2 * z['grad_l2'][i], n
 
 
+def test_zero_lambda_identity_schedule(built_lib):
+    """train.py:98-99: lambda_identity drops to 0 after 10 000 iterations.  The step then skips the backward of the
+    identity half (its seed gradient is exactly zero); losses and gradients must still match the oracle."""
+    O, P, A, Bm, eng = _setup(2)
+    orc = O.CycleGANOracle({k: v.copy() for k, v in P.items()})
+    orc.train(A, Bm, 10.0, 0.0, 2e-4, 1e-4)
+    eng.train_step(A, Bm, 10.0, 0.0, 2e-4, 1e-4)
+    for k, v in orc.last.items():
+        assert abs(eng.last_losses[k] - v) <= TOL * max(1.0, abs(v)), (k, eng.last_losses[k], float(v))
+    ref = dict(orc.last_grads[0]); ref.update(orc.last_grads[1])
+    bad = _cmp_grads(eng.tf_gradients(), ref)
+    assert not bad, bad[:8]
+
+
 def test_config5_geometry_36x256(built_lib):
     """BASELINE configs[4] geometry: 36-dim MCEP x 256-frame windows (o1 filters = num_features).
     One whole train step against the oracle at B=1; exercises the streaming norm kernels (D.h1 rows = 4608)."""

@@ -813,8 +813,11 @@ extern "C" int vc_cyclegan_step_grads(const vc_plan* p, const float* params, flo
     VC_CHECK(gen_backward(p, params, PG, O1 + O1g, -O1g, dCY, dCYg, S2, B, grads, PG,
                           dO1 + dO1g, -dO1g, 1, SCR, 2, B, s, false, /*wgrad_first=*/true));
     // 10. first-hop backward over [generation; identity]
+    //     With lambda_identity == 0 (train.py:98-99 after 10 000 iterations) the identity half carries an exactly-zero
+    //     seed gradient: only the generation half (the first B samples of every saved tensor) is propagated.
+    const int Bbwd = (lambda_identity == 0.0f) ? B : 2 * B;
     VC_CHECK(gen_backward(p, params, PG, X1, X1g, dO1, dO1g, S1, 2 * B, grads, PG,
-                          nullptr, 0, 0, SCR, 2, 2 * B, s, /*record_buckets=*/true));
+                          nullptr, 0, 0, SCR, 2, Bbwd, s, /*record_buckets=*/true));
     return 0;
 }
 
