@@ -128,6 +128,12 @@ int vc_disc_head_bwd(const float* x, int64_t x_gs, const float* w, int64_t par_g
                      float* dx, int64_t dx_gs, float* dw, float* db, int64_t dpar_gs,
                      int G, int B, int C, int HW, void* stream);
 
+/* The crop of preprocess.sample_train_data (preprocess.py:226-233) on GPU-resident utterances ("next" row 8f-1):
+ * utterance n is a row-major [F][len[n]] block at src + off[n]; out[n][f][t] = src[off[n] + f*len[n] + start[n] + t].
+ * off / len / start are DEVICE arrays of N entries. */
+int vc_crop_batch(const float* src, const int64_t* off, const int32_t* len, const int32_t* start, float* out,
+                  int N, int F, int n_frames, void* stream);
+
 /* utils.l1_loss / utils.l2_loss (utils.py:6-12): *loss = mean(|y - y_hat|) resp. mean((y - y_hat)^2) over n
  * elements; d_yhat (NULL to skip) receives d loss / d y_hat (sign(0) = 0). */
 int vc_l1_loss(const float* y, const float* y_hat, int64_t n, float* loss, float* d_yhat, void* stream);

@@ -47,6 +47,7 @@ SIGNATURES = [
                                   i32, i32, i32, i32, vp]),
     ('vc_disc_head_fwd', i32, [vp, i64, vp, vp, i64, vp, i64, i32, i32, i32, i32, vp]),
     ('vc_disc_head_bwd', i32, [vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, vp, vp, i64, i32, i32, i32, i32, vp]),
+    ('vc_crop_batch', i32, [vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     ('vc_l1_loss', i32, [vp, vp, i64, vp, vp, vp]),
     ('vc_l2_loss', i32, [vp, vp, i64, vp, vp, vp]),
     ('vc_adam_tf_update', i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp]),

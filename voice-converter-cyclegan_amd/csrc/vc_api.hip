@@ -296,6 +296,11 @@ extern "C" int vc_disc_head_bwd(const float* x, int64_t x_gs, const float* w, in
     VC_ARG(x && w && o && dout, "vc_disc_head_bwd: bad args");
     return launch_head_bwd(x, x_gs, w, par_gs, o, o_gs, dout, do_gs, dx, dx_gs, dw, db, dpar_gs, G, B, C, HW, (hipStream_t)stream);
 }
+extern "C" int vc_crop_batch(const float* src, const int64_t* off, const int32_t* len, const int32_t* start, float* out,
+                             int N, int F, int n_frames, void* stream) {
+    VC_ARG(src && off && len && start && out && N > 0 && F > 0 && n_frames > 0, "vc_crop_batch: bad args");
+    return launch_crop_batch(src, (const long*)off, len, start, out, N, F, n_frames, (hipStream_t)stream);
+}
 extern "C" int vc_l1_loss(const float* y, const float* y_hat, int64_t n, float* loss, float* d_yhat, void* stream) {
     VC_ARG(y && y_hat && loss && n > 0, "vc_l1_loss: bad args");
     return launch_mean_loss(y, y_hat, n, 0, loss, d_yhat, (hipStream_t)stream);

@@ -99,6 +99,8 @@ struct LossArgs {
     int B, FT, HW; float lambda_cycle, lambda_identity;
 };
 int launch_loss(const LossArgs& a, hipStream_t s);
+int launch_crop_batch(const float* src, const long* off, const int* len, const int* start, float* out,
+                      int N, int F, int n_frames, hipStream_t s);
 int launch_mean_loss(const float* y, const float* yh, long n, int squared, float* loss, float* d_yhat, hipStream_t s);
 
 void vc_set_error(const char* fmt, ...);

@@ -924,6 +924,25 @@ __global__ void loss_finalize_kernel(const float* acc, float* L, float n1, float
     }
 }
 
+// sample_train_data's crop (preprocess.py:226-233): out[n][f][t] = src[off[n] + f*len[n] + start[n] + t]
+__global__ __launch_bounds__(256) void crop_batch_kernel(const float* src, const long* off, const int* len, const int* start,
+                                                         float* out, int F, int n_frames) {
+    const int n = blockIdx.y;
+    const float* s = src + off[n] + start[n];
+    const int L = len[n], tot = F * n_frames;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < tot; i += gridDim.x * 256) {
+        const int f = i / n_frames, t = i - f * n_frames;
+        out[(long)n * tot + i] = s[(long)f * L + t];
+    }
+}
+int launch_crop_batch(const float* src, const long* off, const int* len, const int* start, float* out,
+                      int N, int F, int n_frames, hipStream_t s) {
+    int bx = (F * n_frames + 255) / 256; if (bx > 64) bx = 64;
+    crop_batch_kernel<<<dim3(bx, N), 256, 0, s>>>(src, off, len, start, out, F, n_frames);
+    VC_HIP(hipGetLastError());
+    return 0;
+}
+
 // utils.l1_loss / utils.l2_loss (utils.py:6-12) as stand-alone ops for the plug-in path:
 // loss = mean(|y - y_hat|) or mean((y - y_hat)^2); d_yhat = d loss / d y_hat.
 __global__ __launch_bounds__(256) void mean_loss_kernel(const float* y, const float* yh, long n, int squared,
