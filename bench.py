@@ -94,6 +94,9 @@ def main():
     ap.add_argument('--features', type=int, default=24)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--serial', action='store_true',
+                    help='serialise the step\'s two independent chains on one stream for the WHOLE run (the condition the '
+                         'roofline leg always uses; for rocprof summaries that must agree with it)')
     args = ap.parse_args()
 
     import numpy as np
@@ -121,6 +124,8 @@ def main():
 
     dev = 'cuda:%d' % local_rank
     eng = CycleGANEngine(num_features=args.features, device=dev, seed=42)
+    if args.serial:
+        eng.set_overlap(False)
     B, F, T = args.batch, args.features, args.frames
     rng = np.random.default_rng(1234 + rank)
     A = torch.from_numpy(rng.standard_normal((B, F, T)).astype(np.float32)).to(dev)
@@ -167,6 +172,12 @@ def main():
     # ---- roofline leg: the same steps again with HIP events around every implicit-GEMM launch
     if not args.no_roofline:
         barrier()
+        # per-kernel timing: serialise the step's chains so a launch is never time-sharing the chip with a launch of the
+        # other chain (the headline `value` above runs them on two streams)
+        eng.set_overlap(False)
+        for _ in range(2):
+            eng.train_step(A, Bm, *hp, sync=False)
+        torch.cuda.synchronize()
         lib.vc_prof_enable(1)
         n_prof = 3
         for _ in range(n_prof):
@@ -178,6 +189,7 @@ def main():
             lib.vc_prof_collect(kind, C.byref(ms), C.byref(n), C.byref(fl))
             stats[kind] = (name, ms.value, n.value, fl.value)
         lib.vc_prof_enable(0)
+        eng.set_overlap(not args.serial)
         if rank == 0:
             name, ms, n, fl = stats[0]
             ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
@@ -189,6 +201,7 @@ def main():
                 'traffic': 122.82e6 if (B, F, T, world) == (8, 24, 128, 1) else None,
                 'traffic_unit': 'bytes/launch (offline PMC pass, upper bound: Infinity-Cache hits counted)',
                 'kernel': name, 'launches_per_step': n // n_prof,
+                'condition': 'step chains serialised on one stream (no co-running launches); see --serial',
                 'avg_launch_us': 1e3 * ms / max(n, 1), 'algorithmic_gflop_per_step': fl / n_prof / 1e9,
                 'kernel_ms_per_step': ms / n_prof,
             }

@@ -201,6 +201,11 @@ int vc_cyclegan_step_grads(const vc_plan* p, const float* params, float* grads,
                            float lambda_cycle, float lambda_identity,
                            float* losses, float* gen_A, float* gen_B,
                            float* workspace, int64_t workspace_floats, void* stream);
+/* The step runs its independent chains (cycle-hop forward || D forward; generator_loss backward || discriminator_loss
+ * backward) on `stream` and an internal side stream, joined before it returns.  enabled = 0 serialises them on `stream`
+ * (used when timing individual kernels, so launches do not share the chip).  Default: enabled (env VC_STEP_STREAMS=1 disables). */
+int vc_plan_set_overlap(vc_plan* p, int enabled);
+
 /* Makes `other_stream` wait until the discriminator half of `grads` from the most recent
  * vc_cyclegan_step_grads on this plan is final (it is produced before the generator backward). */
 int vc_step_wait_d_grads(const vc_plan* p, void* other_stream);

@@ -7,6 +7,7 @@
 #include <array>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -435,6 +436,9 @@ struct vc_plan {
     int d_hw;                     // discriminator output pixels per sample
     long g_scr, d_scr;            // per-sample scratch unit
     hipEvent_t d_ready = nullptr;
+    // side stream for the chains of the step that do not depend on each other (fork / join with events)
+    hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int use_side = 1;
     // generator gradient buckets: layers [first, last] of each generator become final (in reverse layer order) during
     // the last backward of the step; an event per bucket lets the caller overlap their all-reduce with the rest of it
     static constexpr int kBuckets = 4;
@@ -476,6 +480,10 @@ extern "C" int vc_plan_create(int num_features, int n_frames, vc_plan** out) {
         for (int ph = 0; ph < l.g.sh; ++ph) for (int pw = 0; pw < l.g.sw; ++pw) { r = get_dgrad_table(l.g, ph, pw, &t); if (r) { delete p; return r; } }
     }
     hipError_t e = hipEventCreateWithFlags(&p->d_ready, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming);
+    { const char* v = getenv("VC_STEP_STREAMS"); if (v) p->use_side = atoi(v) > 1; }
     for (int k = 0; k < vc_plan::kBuckets && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&p->g_ready[k], hipEventDisableTiming);
     if (e != hipSuccess) { vc_set_error("hipEventCreate failed: %s", hipGetErrorString(e)); delete p; return (int)e; }
     *out = p;
@@ -484,6 +492,9 @@ extern "C" int vc_plan_create(int num_features, int n_frames, vc_plan** out) {
 extern "C" void vc_plan_destroy(vc_plan* p) {
     if (!p) return;
     if (p->d_ready) hipEventDestroy(p->d_ready);
+    if (p->ev_fork) hipEventDestroy(p->ev_fork);
+    if (p->ev_join) hipEventDestroy(p->ev_join);
+    if (p->side) hipStreamDestroy(p->side);
     for (hipEvent_t ev : p->g_ready) if (ev) hipEventDestroy(ev);
     delete p;
 }
@@ -738,7 +749,7 @@ extern "C" int64_t vc_flat_offset(const vc_plan* p, int net) {
     switch (net) { case 0: return 0; case 1: return p->G.total; case 2: return 2 * p->G.total; case 3: return 2 * p->G.total + p->D.total; }
     return -1;
 }
-struct StepMap { long X1, O1, CY, DX, DO, dO1, dCY, dDO_D, dDO_G, S1, S2, SD, SCR, ACC, total;
+struct StepMap { long X1, O1, CY, DX, DO, dO1, dCY, dDO_D, dDO_G, S1, S2, SD, SCR, SCR2, ACC, total;
                  long ft2, ft1, hw2, hw1, s1_gs, s2_gs, sd_gs, scr_gs; };
 static StepMap step_map(const vc_plan* p, int B) {
     StepMap m{}; long o = 0;
@@ -751,6 +762,7 @@ static StepMap step_map(const vc_plan* p, int B) {
     m.s2_gs = vc_generator_save_floats(p, B);     m.S2 = take(m.s2_gs);
     m.sd_gs = vc_discriminator_save_floats(p, 2 * B); m.SD = take(m.sd_gs);
     m.scr_gs = vc_scratch_floats(p, 2 * B); m.SCR = take(m.scr_gs);   // backward calls with batch B use a smaller group stride inside it
+    m.SCR2 = take(m.scr_gs);                      // scratch of the discriminator_loss backward (runs on the side stream)
     m.ACC = o; o += 64;
     m.total = o;
     return m;
@@ -787,17 +799,25 @@ extern "C" int vc_cyclegan_step_grads(const vc_plan* p, const float* params, flo
     VC_HIP(hipMemcpyAsync(X1 + X1g + ft1, A, FTb, hipMemcpyDeviceToDevice, s));
     // 2. O1[g0] = [gen_B; id_B], O1[g1] = [gen_A; id_A]
     VC_CHECK(gen_forward(p, params, PG, X1, X1g, O1, O1g, S1, 2, 2 * B, s));
+    // Two pairs of chains are independent and run side by side (main stream s / side stream s2, fork+join by events):
+    //   forward : [3. cycle hop G forward]            ||  [4-5. D inputs + D forward]
+    //   backward: [8-10. generator_loss backward]     ||  [7. discriminator_loss backward]
+    hipStream_t s2 = p->use_side ? p->side : s;
+    auto fork = [&]() -> int { if (s2 != s) { VC_HIP(hipEventRecord(p->ev_fork, s)); VC_HIP(hipStreamWaitEvent(s2, p->ev_fork, 0)); } return 0; };
+    auto join = [&]() -> int { if (s2 != s) { VC_HIP(hipEventRecord(p->ev_join, s2)); VC_HIP(hipStreamWaitEvent(s, p->ev_join, 0)); } return 0; };
+    VC_CHECK(fork());
     // 3. cycle hop: g0 = A2B(gen_A) = cycle_B, g1 = B2A(gen_B) = cycle_A   (model.py:45,48)
     VC_CHECK(gen_forward(p, params, PG, O1 + O1g, -O1g, CY, CYg, S2, 2, B, s));
-    // 4. discriminator inputs: g0 = D_A on [gen_A; A], g1 = D_B on [gen_B; B]   (model.py:53-54,75-78)
-    VC_HIP(hipMemcpyAsync(DX, O1 + O1g, FTb, hipMemcpyDeviceToDevice, s));
-    VC_HIP(hipMemcpyAsync(DX + ft1, A, FTb, hipMemcpyDeviceToDevice, s));
-    VC_HIP(hipMemcpyAsync(DX + DXg, O1, FTb, hipMemcpyDeviceToDevice, s));
-    VC_HIP(hipMemcpyAsync(DX + DXg + ft1, Bm, FTb, hipMemcpyDeviceToDevice, s));
     if (gen_A) VC_HIP(hipMemcpyAsync(gen_A, O1 + O1g, FTb, hipMemcpyDeviceToDevice, s));
     if (gen_B) VC_HIP(hipMemcpyAsync(gen_B, O1, FTb, hipMemcpyDeviceToDevice, s));
+    // 4. discriminator inputs: g0 = D_A on [gen_A; A], g1 = D_B on [gen_B; B]   (model.py:53-54,75-78)
+    VC_HIP(hipMemcpyAsync(DX, O1 + O1g, FTb, hipMemcpyDeviceToDevice, s2));
+    VC_HIP(hipMemcpyAsync(DX + ft1, A, FTb, hipMemcpyDeviceToDevice, s2));
+    VC_HIP(hipMemcpyAsync(DX + DXg, O1, FTb, hipMemcpyDeviceToDevice, s2));
+    VC_HIP(hipMemcpyAsync(DX + DXg + ft1, Bm, FTb, hipMemcpyDeviceToDevice, s2));
     // 5. D forward (the fake half doubles as D(fake) of the D sub-step: D weights are unchanged by the G update)
-    VC_CHECK(disc_forward(p, params + 2 * PG, PD, DX, DXg, DO, DOg, SD, 2, 2 * B, s));
+    VC_CHECK(disc_forward(p, params + 2 * PG, PD, DX, DXg, DO, DOg, SD, 2, 2 * B, s2));
+    VC_CHECK(join());
     // 6. losses + seed gradients
     LossArgs la{};
     la.A = A; la.Bm = Bm; la.out1 = O1; la.out1_gs = O1g; la.cyc = CY; la.cyc_gs = CYg; la.dout = DO; la.dout_gs = DOg;
@@ -806,10 +826,11 @@ extern "C" int vc_cyclegan_step_grads(const vc_plan* p, const float* params, flo
     la.acc = ws + m.ACC; la.losses = losses; la.B = B; la.FT = p->F * p->T; la.HW = p->d_hw;
     la.lambda_cycle = lambda_cycle; la.lambda_identity = lambda_identity;
     VC_CHECK(launch_loss(la, s));
-    // 7. discriminator_loss backward over [fake; real] -> D gradients (model.py:94,107)
+    VC_CHECK(fork());
+    // 7. discriminator_loss backward over [fake; real] -> D gradients (model.py:94,107)   [side stream, own scratch]
     VC_CHECK(disc_backward(p, params + 2 * PG, PD, DX, DXg, DO, DOg, dDO_D, dDDg, SD, 2 * B,
-                           grads + 2 * PG, PD, nullptr, 0, 0, SCR, 2, 2 * B, s, /*wgrad_first=*/true));
-    VC_HIP(hipEventRecord(p->d_ready, s));
+                           grads + 2 * PG, PD, nullptr, 0, 0, ws + m.SCR2, 2, 2 * B, s2, /*wgrad_first=*/true));
+    VC_HIP(hipEventRecord(p->d_ready, s2));
     // 8. adversarial generator terms: gradient through D's inputs only (var_list = generator_vars, model.py:95,108)
     //    g0 = D_A -> d gen_A = dO1[g1][0:B]; g1 = D_B -> d gen_B = dO1[g0][0:B]
     VC_CHECK(disc_backward(p, params + 2 * PG, PD, DX, DXg, DO, DOg, dDO_G, dDGg, SD, 2 * B,
@@ -823,9 +844,15 @@ extern "C" int vc_cyclegan_step_grads(const vc_plan* p, const float* params, flo
     const int Bbwd = (lambda_identity == 0.0f) ? B : 2 * B;
     VC_CHECK(gen_backward(p, params, PG, X1, X1g, dO1, dO1g, S1, 2 * B, grads, PG,
                           nullptr, 0, 0, SCR, 2, Bbwd, s, /*record_buckets=*/true));
+    VC_CHECK(join());      // the caller's next work on `stream` (Adam) sees the discriminator gradients
     return 0;
 }
 
+extern "C" int vc_plan_set_overlap(vc_plan* p, int enabled) {
+    VC_ARG(p, "vc_plan_set_overlap: bad plan");
+    p->use_side = enabled != 0;
+    return 0;
+}
 extern "C" int vc_step_num_g_buckets(const vc_plan* p) { return p ? vc_plan::kBuckets : 0; }
 extern "C" int vc_step_g_bucket(const vc_plan* p, int k, int64_t* lo, int64_t* hi) {
     VC_ARG(p && k >= 0 && k < vc_plan::kBuckets && lo && hi, "vc_step_g_bucket: bad args");

@@ -67,6 +67,7 @@ class CycleGANEngine:
         self.v = torch.zeros(self.n_flat, device=self.device)
         self.losses = torch.zeros(8, device=self.device)
         self._plans, self._ws = {}, None
+        self._overlap = True
         self.sync = GradSync(group, enabled=data_parallel)
         self._comm_stream = torch.cuda.Stream(device=self.device) if self.sync.world > 1 else None
         # tf.train.AdamOptimizer keeps beta1_power/beta2_power as fp32 variables (one pair per optimizer)
@@ -109,8 +110,16 @@ class CycleGANEngine:
             h = _lib.vp()
             check(lib.vc_plan_create(self.F, int(T), C.byref(h)), 'vc_plan_create')
             assert lib.vc_flat_param_floats(h) == self.n_flat
+            if not self._overlap:
+                lib.vc_plan_set_overlap(h, 0)
             self._plans[T] = p = h
         return p
+
+    def set_overlap(self, enabled):
+        """run the step's independent chains on two streams (default) or serialised (for per-kernel timing)"""
+        self._overlap = bool(enabled)
+        for h in self._plans.values():
+            lib.vc_plan_set_overlap(h, int(self._overlap))
 
     def _workspace(self, n):
         if self._ws is None or self._ws.numel() < n:
