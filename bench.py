@@ -198,7 +198,7 @@ def main():
                 'frac': ach / FP32_MFMA_PEAK_TFLOPS,
                 # HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
                 # (profiles/r01_pmc_hbm_traffic_b8.txt; FETCH_SIZE doubled per MI355X_MICROARCH.md, L3 hits included)
-                'traffic': 122.82e6 if (B, F, T, world) == (8, 24, 128, 1) else None,
+                'traffic': 108.02e6 if (B, F, T, world) == (8, 24, 128, 1) else None,
                 'traffic_unit': 'bytes/launch (offline PMC pass, upper bound: Infinity-Cache hits counted)',
                 'kernel': name, 'launches_per_step': n // n_prof,
                 'condition': 'step chains serialised on one stream (no co-running launches); see --serial',

@@ -47,11 +47,15 @@ __global__ __launch_bounds__(64 * WMG * WNG, 2) void igemm_kernel(const IgemmMul
     const int l31 = lane & 31, h = lane >> 5;
     const int wm = wid / WNG, wn = wid % WNG;
 
-    // XCD-aware tile order: block b runs on XCD b%8; give each XCD whole m-tiles so a weight
-    // slab is fetched into one L2 only (speed only; any order is correct).
-    int tile = blockIdx.x, mt, nt;
-    if ((p.mtiles & 7) == 0) { const int xcd = tile & 7, k = tile >> 3; mt = xcd + 8 * (k / p.ntiles); nt = k % p.ntiles; }
-    else { nt = tile % p.ntiles; mt = tile / p.ntiles; }
+    // XCD-aware tile order (speed only; any order is correct): block b runs on XCD b % 8 with a private L2.  Walk the
+    // tiles m-major (all pixel tiles of one weight slab are consecutive) and give every XCD one CONTIGUOUS range of that
+    // walk, so a weight slab is fetched into as few L2s as possible (one, or 8/mtiles of them when mtiles < 8).
+    int mt, nt;
+    {
+        const int total = p.mtiles * p.ntiles, per = total >> 3, tile = blockIdx.x;
+        const int idx = (tile < (per << 3)) ? (tile & 7) * per + (tile >> 3) : tile;   // the last total % 8 tiles keep their place
+        mt = idx / p.ntiles; nt = idx - mt * p.ntiles;
+    }
     const int g = blockIdx.z / p.splitk, sp = blockIdx.z - g * p.splitk;
     const int nchunks = p.krows / KC;
     const int cps = (nchunks + p.splitk - 1) / p.splitk;
