@@ -10,7 +10,7 @@ CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(CSRC, 'libvcgan_hip.so')
 SOURCES = ['vc_kernels.hip', 'vc_api.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++20', '-munsafe-fp-atomics', '-shared', '-fPIC',
-         '-Wno-unused-value']
+         '-Wall', '-Wextra', '-Wno-unused-parameter']
 
 
 def needs_build():

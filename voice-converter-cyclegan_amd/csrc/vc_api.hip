@@ -491,11 +491,11 @@ extern "C" int vc_plan_create(int num_features, int n_frames, vc_plan** out) {
 }
 extern "C" void vc_plan_destroy(vc_plan* p) {
     if (!p) return;
-    if (p->d_ready) hipEventDestroy(p->d_ready);
-    if (p->ev_fork) hipEventDestroy(p->ev_fork);
-    if (p->ev_join) hipEventDestroy(p->ev_join);
-    if (p->side) hipStreamDestroy(p->side);
-    for (hipEvent_t ev : p->g_ready) if (ev) hipEventDestroy(ev);
+    if (p->d_ready) (void)hipEventDestroy(p->d_ready);
+    if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
+    if (p->ev_join) (void)hipEventDestroy(p->ev_join);
+    if (p->side) (void)hipStreamDestroy(p->side);
+    for (hipEvent_t ev : p->g_ready) if (ev) (void)hipEventDestroy(ev);
     delete p;
 }
 

@@ -974,15 +974,15 @@ std::vector<ProfRec> g_prof;
 struct ProfScope {
     bool on; ProfRec r; hipStream_t s;
     ProfScope(int kind, double flops, hipStream_t st) : on(g_prof_on), s(st) {
-        if (on) { hipEventCreate(&r.a); hipEventCreate(&r.b); r.flops = flops; r.kind = kind; hipEventRecord(r.a, s); }
+        if (on) { (void)hipEventCreate(&r.a); (void)hipEventCreate(&r.b); r.flops = flops; r.kind = kind; (void)hipEventRecord(r.a, s); }
     }
-    ~ProfScope() { if (on) { hipEventRecord(r.b, s); std::lock_guard<std::mutex> l(g_prof_mu); g_prof.push_back(r); } }
+    ~ProfScope() { if (on) { (void)hipEventRecord(r.b, s); std::lock_guard<std::mutex> l(g_prof_mu); g_prof.push_back(r); } }
 };
 }  // namespace
 
 extern "C" int vc_prof_enable(int on) {
     std::lock_guard<std::mutex> l(g_prof_mu);
-    for (auto& r : g_prof) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+    for (auto& r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     g_prof.clear();
     g_prof_on = on != 0;
     return 0;
