@@ -438,6 +438,9 @@ struct vc_plan {
     hipEvent_t d_ready = nullptr;
     // side stream for the chains of the step that do not depend on each other (fork / join with events)
     hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // filter gradients are leaves of the backward chain: they run on their own stream behind one event per layer
+    hipStream_t wstream = nullptr; hipEvent_t ev_layer[24] = {}; hipEvent_t ev_wjoin = nullptr;
+    hipStream_t wstream_d = nullptr; hipEvent_t ev_layer_d[8] = {}; hipEvent_t ev_wjoin_d = nullptr;   // same for the discriminator chain
     int use_side = 1;
     // generator gradient buckets: layers [first, last] of each generator become final (in reverse layer order) during
     // the last backward of the step; an event per bucket lets the caller overlap their all-reduce with the rest of it
@@ -483,6 +486,12 @@ extern "C" int vc_plan_create(int num_features, int n_frames, vc_plan** out) {
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->wstream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_wjoin, hipEventDisableTiming);
+    for (int k = 0; k < 24 && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&p->ev_layer[k], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->wstream_d, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_wjoin_d, hipEventDisableTiming);
+    for (int k = 0; k < 8 && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&p->ev_layer_d[k], hipEventDisableTiming);
     { const char* v = getenv("VC_STEP_STREAMS"); if (v) p->use_side = atoi(v) > 1; }
     for (int k = 0; k < vc_plan::kBuckets && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&p->g_ready[k], hipEventDisableTiming);
     if (e != hipSuccess) { vc_set_error("hipEventCreate failed: %s", hipGetErrorString(e)); delete p; return (int)e; }
@@ -495,6 +504,12 @@ extern "C" void vc_plan_destroy(vc_plan* p) {
     if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
     if (p->ev_join) (void)hipEventDestroy(p->ev_join);
     if (p->side) (void)hipStreamDestroy(p->side);
+    if (p->wstream) (void)hipStreamDestroy(p->wstream);
+    if (p->ev_wjoin) (void)hipEventDestroy(p->ev_wjoin);
+    for (hipEvent_t ev : p->ev_layer) if (ev) (void)hipEventDestroy(ev);
+    if (p->wstream_d) (void)hipStreamDestroy(p->wstream_d);
+    if (p->ev_wjoin_d) (void)hipEventDestroy(p->ev_wjoin_d);
+    for (hipEvent_t ev : p->ev_layer_d) if (ev) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : p->g_ready) if (ev) (void)hipEventDestroy(ev);
     delete p;
 }
@@ -519,10 +534,13 @@ static SaveMap save_map(const NetDesc& n, const std::vector<LayerGeo>& geo, int 
 }
 extern "C" int64_t vc_generator_save_floats(const vc_plan* p, int B) { return p ? save_map(p->G, p->gg, B, false).total : 0; }
 extern "C" int64_t vc_discriminator_save_floats(const vc_plan* p, int B) { return p ? save_map(p->D, p->dg, B, true).total : 0; }
-// backward scratch of one group: [dY: largest raw conv output][dA_i: gradient w.r.t. the activation of layer i, every i]
+// backward scratch of one group: for every layer i [dY_i: gradient w.r.t. its raw conv output][dA_i: gradient w.r.t. its
+// activation].  Per-layer buffers (not a rotating pair) so a filter gradient on the side stream can still read dY_i
+// while the chain has moved on.
 static long scratch_floats_net(const std::vector<LayerGeo>& geo, long raw_max, int B) {
-    long o = align64(raw_max * B);
-    for (const LayerGeo& l : geo) o += align64(l.act_ps * B);
+    (void)raw_max;
+    long o = 0;
+    for (const LayerGeo& l : geo) o += align64(l.raw_ps * B) + align64(l.act_ps * B);
     return o;
 }
 extern "C" int64_t vc_scratch_floats(const vc_plan* p, int B) {
@@ -541,6 +559,7 @@ struct NetCtx {
     float* save; long save_gs; SaveMap sm; // layout batch = Bl
     int G, B, Bl;
     hipStream_t s;
+    hipStream_t ws = nullptr; const hipEvent_t* ev_layer = nullptr; hipEvent_t ev_wjoin = nullptr;   // wgrad stream (null: same stream)
     bool wgrad_first = false;              // this backward is the first contribution of the step to dparams' conv kernels
     const int* ev_first = nullptr; const hipEvent_t* ev = nullptr; int n_ev = 0;   // record ev[k] once layer ev_first[k] is done (backward)
 };
@@ -588,10 +607,12 @@ static int net_forward(NetCtx& c, const float* x, long x_gs, float* y_plain, lon
 static int net_backward(NetCtx& c, const float* x, long x_gs, const float* dtop, long dtop_gs,
                         float* dx, long dx_gs, int dx_acc, float* scratch, long scr_gs, long raw_max) {
     const int nl = (int)c.n->layers.size();
-    // scratch map of one group: dY, then dA[i] = gradient w.r.t. the activation (output) of layer i
-    float* dY = scratch;
-    std::vector<float*> dA(nl);
-    { long o = align64(raw_max * c.B); for (int i = 0; i < nl; ++i) { dA[i] = scratch + o; o += align64((*c.geo)[i].act_ps * c.B); } }
+    (void)raw_max;
+    // scratch map of one group: dY[i], dA[i] per layer (dA[i] = gradient w.r.t. the activation (output) of layer i)
+    std::vector<float*> dYb(nl), dA(nl);
+    { long o = 0; for (int i = 0; i < nl; ++i) { dYb[i] = scratch + o; o += align64((*c.geo)[i].raw_ps * c.B);
+                                                   dA[i] = scratch + o; o += align64((*c.geo)[i].act_ps * c.B); } }
+    hipStream_t ws = c.ws ? c.ws : c.s;       // the plan sizes its event pools for its own networks (18 / 4 layers)
     // one launch zeroes every dA that a split-K input-gradient will accumulate into
     {
         std::vector<std::pair<float*, long>> zl;
@@ -611,12 +632,15 @@ static int net_backward(NetCtx& c, const float* x, long x_gs, const float* dtop,
         const float* dyp; long dy_gs;
         if (L.mode == M_PLAIN) {
             dyp = dcur; dy_gs = dcur_gs;
-            if (c.dparams) VC_CHECK(launch_bias_grad(dyp, dy_gs, c.dparams + L.b, c.dpar_gs, c.G, c.B, L.cout, lg.g.OH * lg.g.OW, c.s));
+            if (c.dparams) {
+                if (ws != c.s) { VC_HIP(hipEventRecord(c.ev_layer[i], c.s)); VC_HIP(hipStreamWaitEvent(ws, c.ev_layer[i], 0)); }
+                VC_CHECK(launch_bias_grad(dyp, dy_gs, c.dparams + L.b, c.dpar_gs, c.G, c.B, L.cout, lg.g.OH * lg.g.OW, ws));
+            }
         } else {
             if (L.mode == M_IN_RES) { skip = dcur; skip_gs = dcur_gs; }
             NormArgs a{};
             a.y = c.save + c.sm.raw[i]; a.y_gs = c.save_gs; a.dout = dcur; a.do_gs = dcur_gs;
-            a.dy = dY; a.dy_gs = scr_gs;
+            a.dy = dYb[i]; a.dy_gs = scr_gs;
             a.G = c.G; a.B = c.B; a.C = L.C; a.ps = L.ps; a.L = lg.g.OH * lg.g.OW * (L.ps ? 2 : 1);
             if (L.mode != M_GATED) {
                 a.gamma = c.params + L.gamma; a.beta = c.params + L.beta; a.par_gs = c.par_gs;
@@ -625,13 +649,14 @@ static int net_backward(NetCtx& c, const float* x, long x_gs, const float* dtop,
             }
             if (c.dparams) { a.dbias = c.dparams + L.b; a.dbias_gs = c.dpar_gs; }
             VC_CHECK(launch_norm_bwd(L.mode, a, c.s));
-            dyp = dY; dy_gs = scr_gs;
+            dyp = dYb[i]; dy_gs = scr_gs;
+            if (c.dparams && ws != c.s) { VC_HIP(hipEventRecord(c.ev_layer[i], c.s)); VC_HIP(hipStreamWaitEvent(ws, c.ev_layer[i], 0)); }
         }
-        if (c.dparams) VC_CHECK(conv_wgrad(in, in_gs, dyp, dy_gs, c.dparams + L.w, c.dpar_gs, c.G, c.B, lg.g, c.s, c.wgrad_first));
-        for (int k = 0; k < c.n_ev; ++k) if (c.ev_first[k] == i) VC_HIP(hipEventRecord(c.ev[k], c.s));
+        if (c.dparams) VC_CHECK(conv_wgrad(in, in_gs, dyp, dy_gs, c.dparams + L.w, c.dpar_gs, c.G, c.B, lg.g, ws, c.wgrad_first));
+        for (int k = 0; k < c.n_ev; ++k) if (c.ev_first[k] == i) VC_HIP(hipEventRecord(c.ev[k], ws));
         if (i == 0) {
             if (dx) VC_CHECK(conv_dgrad(dyp, dy_gs, c.params + L.w, c.par_gs, dx, dx_gs, nullptr, 0, dx_acc, c.G, c.B, lg.g, c.s));
-            break;
+            break;        // falls through to the join below
         }
         // gradient w.r.t. this layer's input = activation of layer i-1; the head of a residual block adds the skip
         const bool block_head = (L.mode == M_GATED_IN && i + 1 < nl && c.n->layers[i + 1].mode == M_IN_RES);
@@ -640,6 +665,7 @@ static int net_backward(NetCtx& c, const float* x, long x_gs, const float* dtop,
         if (block_head) skip = nullptr;
         dcur = dA[i - 1]; dcur_gs = scr_gs;
     }
+    if (ws != c.s) { VC_HIP(hipEventRecord(c.ev_wjoin, ws)); VC_HIP(hipStreamWaitEvent(c.s, c.ev_wjoin, 0)); }   // join
     return 0;
 }
 
@@ -669,6 +695,7 @@ static int gen_backward(const vc_plan* p, const float* params, long par_gs, cons
                         bool wgrad_first = false) {
     NetCtx c = gen_ctx(p, params, par_gs, dparams, dpar_gs, save, G, B, Bl, s);
     c.wgrad_first = wgrad_first;
+    if (p->use_side && dparams) { c.ws = p->wstream; c.ev_layer = p->ev_layer; c.ev_wjoin = p->ev_wjoin; }
     if (record_buckets) { c.ev_first = p->bucket_first; c.ev = p->g_ready; c.n_ev = vc_plan::kBuckets; }
     return net_backward(c, x, x_gs, dy, dy_gs, dx, dx_gs, dx_acc, scratch, vc_scratch_floats(p, B), p->g_scr);
 }
@@ -687,11 +714,13 @@ static int disc_backward(const vc_plan* p, const float* params, long par_gs, con
                          float* scratch, int G, int B, hipStream_t s, bool wgrad_first = false) {
     NetCtx c = disc_ctx(p, params, par_gs, dparams, dpar_gs, save, G, B, Bl, s);
     c.wgrad_first = wgrad_first;
+    if (p->use_side && dparams) { c.ws = p->wstream_d; c.ev_layer = p->ev_layer_d; c.ev_wjoin = p->ev_wjoin_d; }
     const int last = (int)p->D.layers.size() - 1;
     const long scr_gs = vc_scratch_floats(p, B);
     // the head's input gradient goes where net_backward's scratch map puts dA[last]
-    long off = align64(p->d_scr * B);
-    for (int i = 0; i < last; ++i) off += align64(p->dg[i].act_ps * B);
+    long off = 0;
+    for (int i = 0; i < last; ++i) off += align64(p->dg[i].raw_ps * B) + align64(p->dg[i].act_ps * B);
+    off += align64(p->dg[last].raw_ps * B);
     float* dtop = scratch + off;
     VC_CHECK(launch_head_bwd(save + c.sm.act[last], c.save_gs, params + p->D.head_w, par_gs, o, o_gs, dout, do_gs,
                              dtop, scr_gs, dparams ? dparams + p->D.head_w : nullptr,
@@ -791,7 +820,11 @@ extern "C" int vc_cyclegan_step_grads(const vc_plan* p, const float* params, flo
     // the save/scratch areas were sized with take(): group stride = align64(size)
     // (save_map totals are already multiples of 64, so align64 is the identity there)
 
-    VC_HIP(hipMemsetAsync(grads, 0, (size_t)vc_flat_param_floats(p) * sizeof(float), s));
+    hipStream_t s2 = p->use_side ? p->side : s;
+    // 0. zero the flat gradient on the side stream, under the first-hop forward (nothing touches it before step 7;
+    //    the fork/join pairs below order it before every consumer)
+    if (s2 != s) { VC_HIP(hipEventRecord(p->ev_fork, s)); VC_HIP(hipStreamWaitEvent(s2, p->ev_fork, 0)); }
+    VC_HIP(hipMemsetAsync(grads, 0, (size_t)vc_flat_param_floats(p) * sizeof(float), s2));
     // 1. first-hop inputs: g0 = A2B on [A;B], g1 = B2A on [B;A]   (model.py:44,51 / 47,50)
     VC_HIP(hipMemcpyAsync(X1, A, FTb, hipMemcpyDeviceToDevice, s));
     VC_HIP(hipMemcpyAsync(X1 + ft1, Bm, FTb, hipMemcpyDeviceToDevice, s));
@@ -802,7 +835,7 @@ extern "C" int vc_cyclegan_step_grads(const vc_plan* p, const float* params, flo
     // Two pairs of chains are independent and run side by side (main stream s / side stream s2, fork+join by events):
     //   forward : [3. cycle hop G forward]            ||  [4-5. D inputs + D forward]
     //   backward: [8-10. generator_loss backward]     ||  [7. discriminator_loss backward]
-    hipStream_t s2 = p->use_side ? p->side : s;
+    // (s2 is declared before step 1: the gradient zeroing already runs there)
     auto fork = [&]() -> int { if (s2 != s) { VC_HIP(hipEventRecord(p->ev_fork, s)); VC_HIP(hipStreamWaitEvent(s2, p->ev_fork, 0)); } return 0; };
     auto join = [&]() -> int { if (s2 != s) { VC_HIP(hipEventRecord(p->ev_join, s2)); VC_HIP(hipStreamWaitEvent(s, p->ev_join, 0)); } return 0; };
     VC_CHECK(fork());
