@@ -30,6 +30,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: Peak FP32 (matrix)
+BF16_MFMA_PEAK_TFLOPS = 2500.0     # same guide: Peak BF16 MFMA, dense
+MATH_TEXT = {'fp32': 'fp32', 'bf16': 'bf16 MFMA operands (fp32 accumulate, fp32 storage + instance-norm statistics)',
+             'bf16x3': 'fp32 emulated as 3 bf16 MFMAs per product (hi/lo operand split)'}
 HBM_PEAK_GBS = 8000.0
 
 
@@ -92,6 +95,9 @@ def main():
     ap.add_argument('--batch', type=int, default=8, help='per-GPU minibatch (BASELINE configs[1])')
     ap.add_argument('--frames', type=int, default=128)
     ap.add_argument('--features', type=int, default=24)
+    ap.add_argument('--math', choices=['fp32', 'bf16', 'bf16x3'], default='fp32',
+                    help='arithmetic of the conv kernels; fp32 (default) is the reference precision and the headline, '
+                         'bf16 is BASELINE configs[2] (bf16 MFMA operands, fp32 accumulate/storage/statistics)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--serial', action='store_true',
@@ -126,6 +132,8 @@ def main():
     eng = CycleGANEngine(num_features=args.features, device=dev, seed=42)
     if args.serial:
         eng.set_overlap(False)
+    eng.set_math(args.math)
+    peak = {'fp32': FP32_MFMA_PEAK_TFLOPS, 'bf16': BF16_MFMA_PEAK_TFLOPS, 'bf16x3': BF16_MFMA_PEAK_TFLOPS / 3}[args.math]
     B, F, T = args.batch, args.features, args.frames
     rng = np.random.default_rng(1234 + rank)
     A = torch.from_numpy(rng.standard_normal((B, F, T)).astype(np.float32)).to(dev)
@@ -159,9 +167,10 @@ def main():
             'metric': 'MCEP frames/sec per train step (G+D fwd/bwd)',
             'value': frames / dt, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'BASELINE configs[1]: full CycleGAN-VC train step (2G+2D fwd/bwd + losses + '
-                                   'TF-Adam), fp32, batch %d per GPU, %dx%d MCEP, random-init weights' % (B, F, T),
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': {'fp32': 'f32'}.get(args.math, args.math), 'data': 'synthetic',
+            'config': {'workload': 'BASELINE configs[%d]: full CycleGAN-VC train step (2G+2D fwd/bwd + losses + '
+                                   'TF-Adam), %s, batch %d per GPU, %dx%d MCEP, random-init weights'
+                                   % (1 if args.math == 'fp32' else 2, MATH_TEXT[args.math], B, F, T),
                        'global_batch': world * B, 'frames_per_step_per_domain': world * B * T,
                        'parallelism': 'dp%d' % world,
                        'gflop_per_step': 91.41 * world * B if (F, T) == (24, 128) else None},
@@ -194,11 +203,11 @@ def main():
             name, ms, n, fl = stats[0]
             ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
             out['roofline'] = {
-                'bound': 'mfma', 'achieved': ach, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': ach / FP32_MFMA_PEAK_TFLOPS,
+                'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s',
+                'frac': ach / peak,
                 # HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
                 # (profiles/r01_pmc_hbm_traffic_b8.txt; FETCH_SIZE doubled per MI355X_MICROARCH.md, L3 hits included)
-                'traffic': 108.02e6 if (B, F, T, world) == (8, 24, 128, 1) else None,
+                'traffic': 108.02e6 if (B, F, T, world, args.math) == (8, 24, 128, 1, 'fp32') else None,
                 'traffic_unit': 'bytes/launch (offline PMC pass, upper bound: Infinity-Cache hits counted)',
                 'kernel': name, 'launches_per_step': n // n_prof,
                 'condition': 'step chains serialised on one stream (no co-running launches); see --serial',
@@ -207,8 +216,8 @@ def main():
             }
             name, ms, n, fl = stats[1]
             ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-            out['roofline_wgrad'] = {'bound': 'mfma', 'achieved': ach, 'peak': FP32_MFMA_PEAK_TFLOPS,
-                                     'unit': 'TFLOP/s', 'frac': ach / FP32_MFMA_PEAK_TFLOPS, 'kernel': name,
+            out['roofline_wgrad'] = {'bound': 'mfma', 'achieved': ach, 'peak': peak,
+                                     'unit': 'TFLOP/s', 'frac': ach / peak, 'kernel': name,
                                      'launches_per_step': n // n_prof, 'kernel_ms_per_step': ms / n_prof}
 
     # ---- the kernel the north_star names: gated-conv1d forward (G.h1: 24 -> 2x128, k=15) at B=256

@@ -43,6 +43,14 @@ typedef struct vc_plan vc_plan;   /* opaque: geometry tables + workspace map for
 /* ---- library ------------------------------------------------------------- */
 int         vc_version(void);
 const char* vc_last_error(void);
+/* Arithmetic of the two MFMA kernels (conv forward / input gradient / filter gradient), process-wide, read at launch:
+ *   0 fp32   (default) v_mfma_f32_32x32x2_f32 -- exact fp32 products; the reference's precision (model.py:35-42 float32)
+ *   1 bf16   operands rounded to bf16 (round-to-nearest-even) on the way into v_mfma_f32_32x32x16_bf16, fp32 accumulate;
+ *            tensors in HBM, instance-norm statistics, losses and Adam state stay fp32 (BASELINE config 3)
+ *   2 bf16x3 operands split hi+lo into two bf16, three MFMAs (hi*hi + hi*lo + lo*hi): ~2^-16 relative per product
+ * Returns -1 on an unknown mode. */
+int  vc_set_math_mode(int mode);
+int  vc_get_math_mode(void);
 /* Opt-in per-launch timing of the implicit-GEMM kernels (bench.py roofline leg).
  * While enabled every igemm/wgrad launch is bracketed by hipEvents on its stream. */
 int  vc_prof_enable(int on);
@@ -207,13 +215,16 @@ int vc_cyclegan_step_grads(const vc_plan* p, const float* params, float* grads,
 int vc_plan_set_overlap(vc_plan* p, int enabled);
 
 /* Makes `other_stream` wait until the discriminator half of `grads` from the most recent
- * vc_cyclegan_step_grads on this plan is final (it is produced before the generator backward). */
+ * vc_cyclegan_step_grads on this plan is final (it is produced before the generator backward) AND the step has
+ * finished reading the discriminator weights -- after it the caller may all-reduce that half and update those
+ * parameters in place while the generator backward is still running. */
 int vc_step_wait_d_grads(const vc_plan* p, void* other_stream);
 
 /* Generator gradients become final bucket by bucket (layers in reverse order) during the last backward of
  * vc_cyclegan_step_grads.  Bucket k covers floats [lo, hi) of EACH generator's block (add vc_flat_offset(p, 0|1));
- * vc_step_wait_g_bucket makes `other_stream` wait until bucket k of the most recent step is final.  Buckets are
- * numbered in the order they complete and together tile [0, generator block size). */
+ * vc_step_wait_g_bucket makes `other_stream` wait until bucket k of the most recent step is final and the step no
+ * longer reads the weights of those layers (same guarantee as above: all-reduce + in-place update may start).  Buckets
+ * are numbered in the order they complete and together tile [0, generator block size). */
 int vc_step_num_g_buckets(const vc_plan* p);
 int vc_step_g_bucket(const vc_plan* p, int k, int64_t* lo, int64_t* hi);
 int vc_step_wait_g_bucket(const vc_plan* p, int k, void* other_stream);

@@ -54,6 +54,35 @@ def sigmoid(x):
 
 
 # ----------------------------------------------------------------------------
+# Matmul-operand rounding for BASELINE config 3 ("bf16 MFMA, fp32 accumulate,
+# fp32 instance-norm statistics").  The reference itself is float32 everywhere
+# (model.py:35-42); this switch restates what the bf16 mode of the HIP path
+# defines: BOTH operands of every conv contraction (forward, input gradient,
+# filter gradient) are rounded to bfloat16, round-to-nearest-even, products and
+# sums stay in the working dtype.  None (default) = no rounding.
+# ----------------------------------------------------------------------------
+OPERAND_ROUNDING = None
+
+
+def set_operand_rounding(kind):
+    global OPERAND_ROUNDING
+    if kind not in (None, 'bf16'):
+        raise ValueError('operand rounding must be None or "bf16"')
+    OPERAND_ROUNDING = kind
+
+
+def round_bf16(x):
+    """float -> nearest bfloat16 (ties to even), returned in x's dtype."""
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)
+    u = (u + np.uint32(0x7fff) + ((u >> np.uint32(16)) & np.uint32(1))) & np.uint32(0xffff0000)
+    return u.view(np.float32).astype(x.dtype, copy=False)
+
+
+def _rop(x):
+    return round_bf16(x) if OPERAND_ROUNDING == 'bf16' else x
+
+
+# ----------------------------------------------------------------------------
 # conv1d_layer (module.py:22-42): tf.layers.conv1d(padding='same') + bias.
 # S2: cross-correlation, kernel [k, Cin, Cout].
 # ----------------------------------------------------------------------------
@@ -63,8 +92,8 @@ def conv1d_fwd(x, w, b, stride):
     To, pl, pr = same_pad(T, k, stride)
     xp = np.pad(x, ((0, 0), (pl, pr), (0, 0)))
     idx = np.arange(To)[:, None] * stride + np.arange(k)[None, :]
-    cols = xp[:, idx, :].reshape(B * To, k * Cin)
-    y = cols @ w.reshape(k * Cin, Cout) + b
+    cols = _rop(xp[:, idx, :].reshape(B * To, k * Cin))
+    y = cols @ _rop(w.reshape(k * Cin, Cout)) + b
     return y.reshape(B, To, Cout), (cols, x.shape, stride, pl, pr)
 
 
@@ -74,11 +103,12 @@ def conv1d_bwd(dy, w, cache, need_dx=True):
     k, _, Cout = w.shape
     To = dy.shape[1]
     dy2 = dy.reshape(B * To, Cout)
-    dw = (cols.T @ dy2).reshape(k, Cin, Cout)
+    dyr = _rop(dy2)                                   # cols were rounded in the forward (rounding is idempotent)
+    dw = (cols.T @ dyr).reshape(k, Cin, Cout)
     db = dy2.sum(axis=0)
     dx = None
     if need_dx:
-        dcols = (dy2 @ w.reshape(k * Cin, Cout).T).reshape(B, To, k, Cin)
+        dcols = (dyr @ _rop(w.reshape(k * Cin, Cout)).T).reshape(B, To, k, Cin)
         dxp = np.zeros((B, T + pl + pr, Cin), dtype=dy.dtype)
         for tap in range(k):
             dxp[:, tap:tap + (To - 1) * stride + 1:stride, :] += dcols[:, :, tap, :]
@@ -101,8 +131,8 @@ def conv2d_fwd(x, w, b, strides):
         for j in range(kw):
             cols[:, :, :, i, j, :] = xp[:, i:i + (Ho - 1) * sh + 1:sh,
                                         j:j + (Wo - 1) * sw + 1:sw, :]
-    cols = cols.reshape(B * Ho * Wo, kh * kw * Cin)
-    y = cols @ w.reshape(kh * kw * Cin, Cout) + b
+    cols = _rop(cols.reshape(B * Ho * Wo, kh * kw * Cin))
+    y = cols @ _rop(w.reshape(kh * kw * Cin, Cout)) + b
     return y.reshape(B, Ho, Wo, Cout), (cols, x.shape, strides, (pt, pb, pl, pr))
 
 
@@ -114,11 +144,12 @@ def conv2d_bwd(dy, w, cache, need_dx=True):
     pt, pb, pl, pr = pads
     _, Ho, Wo, _ = dy.shape
     dy2 = dy.reshape(B * Ho * Wo, Cout)
-    dw = (cols.T @ dy2).reshape(kh, kw, Cin, Cout)
+    dyr = _rop(dy2)
+    dw = (cols.T @ dyr).reshape(kh, kw, Cin, Cout)
     db = dy2.sum(axis=0)
     dx = None
     if need_dx:
-        dcols = (dy2 @ w.reshape(kh * kw * Cin, Cout).T).reshape(B, Ho, Wo, kh, kw, Cin)
+        dcols = (dyr @ _rop(w.reshape(kh * kw * Cin, Cout)).T).reshape(B, Ho, Wo, kh, kw, Cin)
         dxp = np.zeros((B, H + pt + pb, W + pl + pr, Cin), dtype=dy.dtype)
         for i in range(kh):
             for j in range(kw):

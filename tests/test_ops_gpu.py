@@ -52,6 +52,51 @@ def _np_conv(O, x_cl, w, b, kh, sh, sw):
 
 @pytest.mark.parametrize('case', CONV_CASES)
 def test_conv_fwd_dgrad_wgrad(built_lib, case):
+    _conv_check(case)
+
+
+# bf16 MFMA modes (vc_set_math_mode): 'bf16' is checked against the oracle with the SAME operand rounding (so only the
+# fp32 accumulation order differs -> same tolerance as fp32); 'bf16x3' against the unrounded oracle (2^-16 per product).
+MATH_CASES = [CONV_CASES[i] for i in (0, 1, 3, 4, 6, 7, 8, 9, 11, 13, 15, 16)]
+
+
+@pytest.mark.parametrize('mode', ['bf16', 'bf16x3'])
+@pytest.mark.parametrize('case', MATH_CASES)
+def test_conv_bf16_modes(built_lib, case, mode):
+    from voice_converter_cyclegan_amd._lib import lib, check
+    O = _oracle()
+    check(lib.vc_set_math_mode({'bf16': 1, 'bf16x3': 2}[mode]))
+    O.set_operand_rounding('bf16' if mode == 'bf16' else None)
+    try:
+        assert lib.vc_get_math_mode() == {'bf16': 1, 'bf16x3': 2}[mode]
+        _conv_check(case)
+    finally:
+        O.set_operand_rounding(None)
+        check(lib.vc_set_math_mode(0))
+    assert lib.vc_set_math_mode(3) != 0 and lib.vc_get_math_mode() == 0      # unknown mode is refused
+
+
+def test_bf16_mode_is_really_bf16(built_lib):
+    """The bf16 mode must differ from fp32 by bf16-sized errors (guards against a silent fp32 fallback)."""
+    from tests import gpu_util as U
+    from voice_converter_cyclegan_amd._lib import lib, check
+    rng = np.random.default_rng(3)
+    x = U.dev(rng.standard_normal((1, 2, 512, 1, 32)).astype(np.float32))
+    w = U.dev((rng.standard_normal((1, 1, 3, 512, 2048)) / 40).astype(np.float32))
+    b = U.dev(np.zeros((1, 2048), np.float32))
+    y32 = U.conv_fwd(x, w, b, 1, 3, 1, 1).cpu().numpy()
+    errs = {}
+    for mode in (1, 2):
+        check(lib.vc_set_math_mode(mode))
+        try:
+            errs[mode] = U.rel_err(U.conv_fwd(x, w, b, 1, 3, 1, 1).cpu().numpy(), y32)
+        finally:
+            check(lib.vc_set_math_mode(0))
+    assert 1e-4 < errs[1] < 2e-2, errs
+    assert errs[2] < 1e-4, errs
+
+
+def _conv_check(case):
     from tests import gpu_util as U
     O = _oracle()
     Cin, H, W, Cout, kh, kw, sh, sw, B = case

@@ -186,3 +186,23 @@ def test_golden_full_fp32_step0():
                                          'discriminator_loss')])
     assert np.abs(got - z['step0/losses']).max() < 1e-4 * np.abs(z['step0/losses']).max()   # BLAS thread count may differ
     assert np.abs(orc.last_fakes[0] - z['gen_A']).max() < 1e-4 * np.abs(z['gen_A']).max()
+
+
+def test_bf16_operand_rounding_is_round_to_nearest_even():
+    """oracle.round_bf16 (the BASELINE config-3 operand rounding) against torch's float32 -> bfloat16 cast."""
+    import torch
+    from oracle import cyclegan_oracle as O
+    x = np.random.default_rng(0).standard_normal(200000).astype(np.float32) * np.float32(3.7)
+    x[:4] = [0.0, -0.0, 1.0 + 2.0 ** -8, 1.0 + 3 * 2.0 ** -8]          # exact ties: to even
+    want = torch.from_numpy(x).to(torch.bfloat16).to(torch.float32).numpy()
+    assert np.array_equal(O.round_bf16(x), want)
+    assert O.round_bf16(x.astype(np.float64)).dtype == np.float64
+    O.set_operand_rounding('bf16')
+    try:
+        y, _ = O.conv1d_fwd(x[:2 * 16 * 8].reshape(2, 16, 8), x[1000:1000 + 3 * 8 * 4].reshape(3, 8, 4), np.zeros(4, np.float32), 1)
+    finally:
+        O.set_operand_rounding(None)
+    y32, _ = O.conv1d_fwd(x[:2 * 16 * 8].reshape(2, 16, 8), x[1000:1000 + 3 * 8 * 4].reshape(3, 8, 4), np.zeros(4, np.float32), 1)
+    assert 1e-4 < np.abs(y - y32).max() / np.abs(y32).max() < 3e-2
+    with pytest.raises(ValueError):
+        O.set_operand_rounding('fp8')

@@ -25,6 +25,27 @@ def _setup(B, T=128, F=24, seed=11):
     return O, P, A, Bm, eng
 
 
+import contextlib
+
+
+@contextlib.contextmanager
+def _math(mode, O):
+    """run the HIP path in a math mode and the oracle with the matching operand rounding"""
+    from voice_converter_cyclegan_amd.engine import CycleGANEngine
+    CycleGANEngine.set_math(mode)
+    O.set_operand_rounding('bf16' if mode == 'bf16' else None)
+    try:
+        yield
+    finally:
+        O.set_operand_rounding(None)
+        CycleGANEngine.set_math('fp32')
+
+
+# bf16 mode vs the oracle with the same operand rounding: what differs is fp32 summation order plus the occasional
+# element that rounds to the neighbouring bf16 on one side only (a 4e-3 relative kick that later layers spread)
+BF16_TOL = 2e-2
+
+
 def _is_noise_bias(name):
     """conv biases DIRECTLY under an instance norm (down-sample and residual blocks) have an exactly-zero
     gradient; up-sample convs are pixel-shuffled before the norm and keep a real one."""
@@ -65,15 +86,29 @@ def test_generator_forward(built_lib, B, T):
         eng.generate(A, 'sideways')          # model.py:134-135
 
 
-def test_generator_backward(built_lib):
+@pytest.mark.parametrize('mode', ['fp32', 'bf16'])
+def test_generator_backward(built_lib, mode):
     from tests import gpu_util as U
     from voice_converter_cyclegan_amd._lib import lib, ptr, check
     B, T = 2, 64
     O, P, A, Bm, eng = _setup(B, T)
-    y, cache = O.generator_fwd(P, 'generator_B2A', A)
-    dy = np.random.default_rng(5).standard_normal(y.shape).astype(np.float32)
-    Gr = {}
-    dx = O.generator_bwd(P, Gr, dy, cache)
+    tol = TOL if mode == 'fp32' else BF16_TOL
+    with _math(mode, O):
+        y, cache = O.generator_fwd(P, 'generator_B2A', A)
+        dy = np.random.default_rng(5).standard_normal(y.shape).astype(np.float32)
+        Gr = {}
+        dx = O.generator_bwd(P, Gr, dy, cache)
+        y_d, dx_d = _gen_fwd_bwd_gpu(eng, A, dy, T, B)
+    assert U.rel_err(y_d.cpu().numpy(), y) < tol
+    e = U.rel_err(dx_d.cpu().numpy(), dx)
+    assert e < tol, 'dx rel err %g' % e
+    bad = _cmp_grads(eng.tf_gradients(), Gr, tol=tol)
+    assert not bad, bad[:8]
+
+
+def _gen_fwd_bwd_gpu(eng, A, dy, T, B):
+    from tests import gpu_util as U
+    from voice_converter_cyclegan_amd._lib import lib, ptr, check
     p = eng.plan(T)
     off = eng.offsets[1]
     x_d, dy_d = U.dev(A), U.dev(dy)
@@ -84,39 +119,39 @@ def test_generator_backward(built_lib):
     check(lib.vc_generator_forward(p, ptr(eng.params[off:]), 0, ptr(x_d), 0, ptr(y_d), 0, ptr(save), 1, B, U.stream()))
     check(lib.vc_generator_backward(p, ptr(eng.params[off:]), 0, ptr(x_d), 0, ptr(dy_d), 0, ptr(save),
                                     ptr(eng.grads[off:]), 0, ptr(dx_d), 0, 0, ptr(scr), 1, B, U.stream()))
-    assert U.rel_err(y_d.cpu().numpy(), y) < TOL
-    e = U.rel_err(dx_d.cpu().numpy(), dx)
-    assert e < TOL, 'dx rel err %g' % e
-    got = eng.tf_gradients()
-    bad = _cmp_grads(got, Gr)
-    assert not bad, bad[:8]
+    torch.cuda.synchronize()
+    return y_d, dx_d
 
 
-def test_discriminator_forward_backward(built_lib):
+@pytest.mark.parametrize('mode', ['fp32', 'bf16'])
+def test_discriminator_forward_backward(built_lib, mode):
     from tests import gpu_util as U
     from voice_converter_cyclegan_amd._lib import lib, ptr, check
     B, T = 2, 128
     O, P, A, Bm, eng = _setup(B, T)
-    o, cache = O.discriminator_fwd(P, 'discriminator_B', A)
-    dout = np.random.default_rng(6).standard_normal(o.shape).astype(np.float32)
-    Gr = {}
-    dx = O.discriminator_bwd(P, Gr, dout, cache)
+    tol = TOL if mode == 'fp32' else BF16_TOL
     p = eng.plan(T)
     off = eng.offsets[3]
     hw = lib.vc_discriminator_out_elems(p)
-    assert hw == o.shape[1] * o.shape[2] == 48
-    x_d, do_d = U.dev(A), U.dev(dout.reshape(B, hw))
-    o_d = torch.empty((B, hw), device=U.DEV); dx_d = torch.full_like(x_d, float('nan'))
-    save = torch.empty(lib.vc_discriminator_save_floats(p, B), device=U.DEV)
-    scr = torch.empty(lib.vc_scratch_floats(p, B), device=U.DEV)
-    eng.grads.zero_()
-    check(lib.vc_discriminator_forward(p, ptr(eng.params[off:]), 0, ptr(x_d), 0, ptr(o_d), 0, ptr(save), 1, B, U.stream()))
-    check(lib.vc_discriminator_backward(p, ptr(eng.params[off:]), 0, ptr(x_d), 0, ptr(do_d), 0, ptr(save),
-                                        ptr(eng.grads[off:]), 0, ptr(dx_d), 0, 0, ptr(scr), 1, B, U.stream()))
-    assert U.rel_err(o_d.cpu().numpy(), o.reshape(B, hw)) < TOL
+    with _math(mode, O):
+        o, cache = O.discriminator_fwd(P, 'discriminator_B', A)
+        dout = np.random.default_rng(6).standard_normal(o.shape).astype(np.float32)
+        Gr = {}
+        dx = O.discriminator_bwd(P, Gr, dout, cache)
+        assert hw == o.shape[1] * o.shape[2] == 48
+        x_d, do_d = U.dev(A), U.dev(dout.reshape(B, hw))
+        o_d = torch.empty((B, hw), device=U.DEV); dx_d = torch.full_like(x_d, float('nan'))
+        save = torch.empty(lib.vc_discriminator_save_floats(p, B), device=U.DEV)
+        scr = torch.empty(lib.vc_scratch_floats(p, B), device=U.DEV)
+        eng.grads.zero_()
+        check(lib.vc_discriminator_forward(p, ptr(eng.params[off:]), 0, ptr(x_d), 0, ptr(o_d), 0, ptr(save), 1, B, U.stream()))
+        check(lib.vc_discriminator_backward(p, ptr(eng.params[off:]), 0, ptr(x_d), 0, ptr(do_d), 0, ptr(save),
+                                            ptr(eng.grads[off:]), 0, ptr(dx_d), 0, 0, ptr(scr), 1, B, U.stream()))
+        torch.cuda.synchronize()
+    assert U.rel_err(o_d.cpu().numpy(), o.reshape(B, hw)) < tol
     e = U.rel_err(dx_d.cpu().numpy(), dx)
-    assert e < TOL, 'dx rel err %g' % e
-    bad = _cmp_grads(eng.tf_gradients(), Gr)
+    assert e < tol, 'dx rel err %g' % e
+    bad = _cmp_grads(eng.tf_gradients(), Gr, tol=tol)
     assert not bad, bad[:8]
 
 
@@ -152,6 +187,52 @@ def test_train_step_losses_grads_and_updates(built_lib, B):
             frac = float((diff > 0.05 * lr).mean())
             assert diff.max() <= 2.5 * lr * (step + 1), (step, n, float(diff.max()))
             assert frac < 5e-3, (step, n, frac)
+
+
+@pytest.mark.parametrize('mode', ['bf16', 'bf16x3'])
+def test_train_step_bf16_modes(built_lib, mode):
+    """BASELINE configs[2] arithmetic (vc_set_math_mode): one whole train step at B=2.
+    bf16x3 : against the plain fp32 oracle at the fp32 tolerances (1e-3 on losses/generations, 5e-3 rel-L2 on gradients).
+    bf16   : against the oracle with the same bf16 operand rounding: losses 2e-3, generations 2e-2 (max-norm; measured
+             6.4e-3).  Whole-step GRADIENTS only get a sanity bound (rel-L2 < 0.3, measured 0.11 on o1_conv): the two
+             sides' generations differ by ~1e-3 (neighbouring-bf16 roundings), which flips sign(cycle - real) of
+             utils.l1_loss for ~0.2 % of the elements and each flip moves the seed gradient by 2*lambda/N.  Gradient
+             parity of the bf16 kernels proper is pinned where the upstream gradient is given, not derived from a sign():
+             test_conv_bf16_modes (1e-4) and test_generator_backward / test_discriminator_forward_backward [bf16] (2e-2).
+             Also bounded against the fp32 oracle: bf16 must be a faithful approximation, and must not BE fp32."""
+    from tests import gpu_util as U
+    B = 2
+    O, P, A, Bm, eng = _setup(B)
+    orc32 = O.CycleGANOracle({k: v.copy() for k, v in P.items()})
+    orc32.train(A, Bm, 10.0, 5.0, 2e-4, 1e-4)
+    gen_A = torch.empty((B, 24, 128), device=U.DEV); gen_B = torch.empty_like(gen_A)
+    ref, tol_l, tol_g, tol_w = orc32, TOL, TOL, 5e-3
+    with _math(mode, O):
+        if mode == 'bf16':
+            ref = O.CycleGANOracle({k: v.copy() for k, v in P.items()})
+            ref.train(A, Bm, 10.0, 5.0, 2e-4, 1e-4)
+            tol_l, tol_g, tol_w = 2e-3, BF16_TOL, 0.3
+        eng.train_step(A, Bm, 10.0, 5.0, 2e-4, 1e-4, gen_A=gen_A, gen_B=gen_B)
+        torch.cuda.synchronize()
+    for k, v in ref.last.items():
+        assert abs(eng.last_losses[k] - v) <= tol_l * max(1.0, abs(v)), (k, eng.last_losses[k], float(v))
+    eA, eB = U.rel_err(gen_A.cpu().numpy(), ref.last_fakes[0]), U.rel_err(gen_B.cpu().numpy(), ref.last_fakes[1])
+    assert eA < tol_g and eB < tol_g, (eA, eB)
+    want = dict(ref.last_grads[0]); want.update(ref.last_grads[1])
+    got = eng.tf_gradients()
+    if mode == 'bf16x3':
+        bad = _cmp_grads(got, want, tol=tol_w)
+        assert not bad, bad[:8]
+    else:
+        for n, r in want.items():
+            if _is_noise_bias(n):
+                continue
+            e2 = np.linalg.norm(got[n].reshape(r.shape).astype(np.float64) - r) / (np.linalg.norm(r) + 1e-30)
+            assert e2 < tol_w, (n, float(e2))
+        e32 = U.rel_err(gen_A.cpu().numpy(), orc32.last_fakes[0])
+        assert 1e-4 < e32 < 5e-2, 'bf16 generation vs the fp32 oracle: %g' % e32
+        for k, v in orc32.last.items():
+            assert abs(eng.last_losses[k] - v) <= 3e-2 * max(1.0, abs(v)), (k, eng.last_losses[k], float(v))
 
 
 def test_against_committed_golden_vectors(built_lib):

@@ -34,6 +34,8 @@ class ParamRec(C.Structure):
 SIGNATURES = [
     ('vc_version', i32, []),
     ('vc_last_error', C.c_char_p, []),
+    ('vc_set_math_mode', i32, [i32]),
+    ('vc_get_math_mode', i32, []),
     ('vc_prof_enable', i32, [i32]),
     ('vc_prof_collect', i32, [i32, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_double)]),
     ('vc_prof_records', i32, [i32, C.POINTER(C.c_double), C.POINTER(C.c_double), i32]),

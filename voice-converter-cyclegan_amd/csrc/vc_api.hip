@@ -155,7 +155,7 @@ static int conv_fwd(const float* x, long x_gs, const float* w, long w_gs, const 
     a.Hl = g.H; a.Wl = g.W; a.xHW = g.H * g.W; a.xW = g.W; a.si = g.sh; a.sj = g.sw;
     a.NPB = g.OH * g.OW; a.OWc = g.OW; a.Ptot = B * a.NPB;
     a.yHW = g.OH * g.OW; a.yW = g.OW; a.so_h = 1; a.so_w = 1; a.o_h0 = 0; a.o_w0 = 0;
-    a.accumulate = 0; a.groups = G;
+    a.accumulate = 0; a.groups = G; a.kl_ok = 1;
     bool zeroed = false;
     const double flops = 2.0 * G * B * a.NPB * (double)g.Cout * t.valid;
     if (query) { igemm_config(a); *query = a.splitk > 1; return 0; }
@@ -184,7 +184,7 @@ static int conv_dgrad(const float* dy, long dy_gs, const float* w, long w_gs, fl
         a.Hl = g.OH; a.Wl = g.OW; a.xHW = g.OH * g.OW; a.xW = g.OW; a.si = 1; a.sj = 1;
         a.NPB = Hc * Wc; a.OWc = Wc; a.Ptot = B * a.NPB;
         a.yHW = g.H * g.W; a.yW = g.W; a.so_h = g.sh; a.so_w = g.sw; a.o_h0 = ph; a.o_w0 = pw;
-        a.accumulate = accumulate; a.groups = G;
+        a.accumulate = accumulate; a.groups = G; a.kl_ok = (g.Cout % 4 == 0) ? 1 : 0;
         igemm_config(a);
         any_split = any_split || a.splitk > 1;
         cls.push_back(a); fl.push_back(2.0 * G * B * a.NPB * (double)g.Cin * t.valid);
@@ -447,6 +447,10 @@ struct vc_plan {
     static constexpr int kBuckets = 4;
     int bucket_first[kBuckets] = {15, 9, 3, 0};          // {u1,u2,o1}, {r4..r6}, {r1..r3}, {h1,d1,d2}
     hipEvent_t g_ready[kBuckets] = {nullptr, nullptr, nullptr, nullptr};
+    // ... and the moment the step has issued its last READ of the same layers' weights (their input gradients run on
+    // the main stream, the filter gradients on the wgrad stream): after both, the caller may update them in place
+    hipEvent_t g_free[kBuckets] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t d_free = nullptr;                          // last read of the discriminator weights (generator_loss path)
 };
 
 static void plan_geos(const NetDesc& n, int C0, int H0, int W0, std::vector<LayerGeo>& out) {
@@ -494,6 +498,8 @@ extern "C" int vc_plan_create(int num_features, int n_frames, vc_plan** out) {
     for (int k = 0; k < 8 && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&p->ev_layer_d[k], hipEventDisableTiming);
     { const char* v = getenv("VC_STEP_STREAMS"); if (v) p->use_side = atoi(v) > 1; }
     for (int k = 0; k < vc_plan::kBuckets && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&p->g_ready[k], hipEventDisableTiming);
+    for (int k = 0; k < vc_plan::kBuckets && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&p->g_free[k], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&p->d_free, hipEventDisableTiming);
     if (e != hipSuccess) { vc_set_error("hipEventCreate failed: %s", hipGetErrorString(e)); delete p; return (int)e; }
     *out = p;
     return 0;
@@ -511,6 +517,8 @@ extern "C" void vc_plan_destroy(vc_plan* p) {
     if (p->ev_wjoin_d) (void)hipEventDestroy(p->ev_wjoin_d);
     for (hipEvent_t ev : p->ev_layer_d) if (ev) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : p->g_ready) if (ev) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : p->g_free) if (ev) (void)hipEventDestroy(ev);
+    if (p->d_free) (void)hipEventDestroy(p->d_free);
     delete p;
 }
 
@@ -562,6 +570,7 @@ struct NetCtx {
     hipStream_t ws = nullptr; const hipEvent_t* ev_layer = nullptr; hipEvent_t ev_wjoin = nullptr;   // wgrad stream (null: same stream)
     bool wgrad_first = false;              // this backward is the first contribution of the step to dparams' conv kernels
     const int* ev_first = nullptr; const hipEvent_t* ev = nullptr; int n_ev = 0;   // record ev[k] once layer ev_first[k] is done (backward)
+    const hipEvent_t* ev_free = nullptr;                                            // ... and ev_free[k] after its input gradient is issued
 };
 
 static int net_forward(NetCtx& c, const float* x, long x_gs, float* y_plain, long y_plain_gs) {
@@ -656,6 +665,7 @@ static int net_backward(NetCtx& c, const float* x, long x_gs, const float* dtop,
         for (int k = 0; k < c.n_ev; ++k) if (c.ev_first[k] == i) VC_HIP(hipEventRecord(c.ev[k], ws));
         if (i == 0) {
             if (dx) VC_CHECK(conv_dgrad(dyp, dy_gs, c.params + L.w, c.par_gs, dx, dx_gs, nullptr, 0, dx_acc, c.G, c.B, lg.g, c.s));
+            for (int k = 0; k < c.n_ev; ++k) if (c.ev_free && c.ev_first[k] == i) VC_HIP(hipEventRecord(c.ev_free[k], c.s));
             break;        // falls through to the join below
         }
         // gradient w.r.t. this layer's input = activation of layer i-1; the head of a residual block adds the skip
@@ -663,6 +673,7 @@ static int net_backward(NetCtx& c, const float* x, long x_gs, const float* dtop,
         VC_CHECK(conv_dgrad(dyp, dy_gs, c.params + L.w, c.par_gs, dA[i - 1], scr_gs,
                             block_head ? skip : nullptr, block_head ? skip_gs : 0, 0, c.G, c.B, lg.g, c.s, /*prezeroed=*/true));
         if (block_head) skip = nullptr;
+        for (int k = 0; k < c.n_ev; ++k) if (c.ev_free && c.ev_first[k] == i) VC_HIP(hipEventRecord(c.ev_free[k], c.s));
         dcur = dA[i - 1]; dcur_gs = scr_gs;
     }
     if (ws != c.s) { VC_HIP(hipEventRecord(c.ev_wjoin, ws)); VC_HIP(hipStreamWaitEvent(c.s, c.ev_wjoin, 0)); }   // join
@@ -696,7 +707,7 @@ static int gen_backward(const vc_plan* p, const float* params, long par_gs, cons
     NetCtx c = gen_ctx(p, params, par_gs, dparams, dpar_gs, save, G, B, Bl, s);
     c.wgrad_first = wgrad_first;
     if (p->use_side && dparams) { c.ws = p->wstream; c.ev_layer = p->ev_layer; c.ev_wjoin = p->ev_wjoin; }
-    if (record_buckets) { c.ev_first = p->bucket_first; c.ev = p->g_ready; c.n_ev = vc_plan::kBuckets; }
+    if (record_buckets) { c.ev_first = p->bucket_first; c.ev = p->g_ready; c.ev_free = p->g_free; c.n_ev = vc_plan::kBuckets; }
     return net_backward(c, x, x_gs, dy, dy_gs, dx, dx_gs, dx_acc, scratch, vc_scratch_floats(p, B), p->g_scr);
 }
 static int disc_forward(const vc_plan* p, const float* params, long par_gs, const float* x, long x_gs,
@@ -868,6 +879,7 @@ extern "C" int vc_cyclegan_step_grads(const vc_plan* p, const float* params, flo
     //    g0 = D_A -> d gen_A = dO1[g1][0:B]; g1 = D_B -> d gen_B = dO1[g0][0:B]
     VC_CHECK(disc_backward(p, params + 2 * PG, PD, DX, DXg, DO, DOg, dDO_G, dDGg, SD, 2 * B,
                            nullptr, 0, dO1 + dO1g, -dO1g, 0, SCR, 2, B, s));
+    VC_HIP(hipEventRecord(p->d_free, s));     // last read of the discriminator weights in this step
     // 9. cycle hop backward: g0 = A2B on gen_A -> adds into d gen_A; g1 = B2A on gen_B -> d gen_B
     VC_CHECK(gen_backward(p, params, PG, O1 + O1g, -O1g, dCY, dCYg, S2, B, grads, PG,
                           dO1 + dO1g, -dO1g, 1, SCR, 2, B, s, false, /*wgrad_first=*/true));
@@ -898,10 +910,12 @@ extern "C" int vc_step_g_bucket(const vc_plan* p, int k, int64_t* lo, int64_t* h
 extern "C" int vc_step_wait_g_bucket(const vc_plan* p, int k, void* other_stream) {
     VC_ARG(p && k >= 0 && k < vc_plan::kBuckets, "vc_step_wait_g_bucket: bad args");
     VC_HIP(hipStreamWaitEvent((hipStream_t)other_stream, p->g_ready[k], 0));
+    VC_HIP(hipStreamWaitEvent((hipStream_t)other_stream, p->g_free[k], 0));
     return 0;
 }
 extern "C" int vc_step_wait_d_grads(const vc_plan* p, void* other_stream) {
     VC_ARG(p, "vc_step_wait_d_grads: bad plan");
     VC_HIP(hipStreamWaitEvent((hipStream_t)other_stream, p->d_ready, 0));
+    VC_HIP(hipStreamWaitEvent((hipStream_t)other_stream, p->d_free, 0));
     return 0;
 }

@@ -39,6 +39,7 @@ struct IgemmArgs {
     int yHW, yW;                                  // channel / row stride of the output tensor
     int so_h, so_w, o_h0, o_w0;                   // launch pixel -> output pixel
     int splitk, accumulate, mtiles, ntiles, groups, big;
+    int kl_ok;                                    // the k-contiguous-LDS kernel may serve this launch (transposed A: K rows come in aligned runs of 4)
 };
 
 // Up to 4 launches of the same tile configuration fused into one grid (blockIdx.y): the stride-parity classes of an

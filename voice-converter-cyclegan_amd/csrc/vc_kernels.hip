@@ -18,10 +18,30 @@
 #include <utility>
 #include <vector>
 #include <mutex>
+#include <atomic>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// Arithmetic of the two MFMA kernels (vc_set_math_mode):
+//   0  fp32   v_mfma_f32_32x32x2_f32, exact fp32 products (default; the parity configuration)
+//   1  bf16   operands rounded to bf16 (RNE, v_cvt_pk_bf16_f32) on their way from LDS into v_mfma_f32_32x32x16_bf16,
+//             fp32 accumulate; tensors in HBM, instance-norm statistics, losses and Adam stay fp32
+//   2  bf16x3 every operand split x = hi + lo (two bf16), products hi*hi + hi*lo + lo*hi: ~2^-16 relative per product
+#define VC_MATH_FP32 0
+#define VC_MATH_BF16 1
+#define VC_MATH_BF16X3 2
+// 8 k-values of one operand row -> one bf16 MFMA fragment (and the residual fragment for the split mode)
+template <int MATH> __device__ __forceinline__ void to_frag(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        hi[e] = (__bf16)v[e];
+        if constexpr (MATH == VC_MATH_BF16X3) lo[e] = (__bf16)(v[e] - (float)hi[e]);
+    }
+}
+
 
 // =====================================================================================
 // Implicit-GEMM: D[m][n] = sum_k A[k][m] * Xg[k][n], m = output channel, n = launch pixel.
@@ -29,7 +49,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // MFMA operand maps (32x32x2 f32): A[i=lane&31][k=lane>>5], B[k=lane>>5][j=lane&31],
 // D: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
 // =====================================================================================
-template <int BM, int BN, int KC, bool AT, int WMG = 2, int WNG = 2>
+template <int BM, int BN, int KC, bool AT, int WMG = 2, int WNG = 2, int MATH = VC_MATH_FP32>
 __global__ __launch_bounds__(64 * WMG * WNG, 2) void igemm_kernel(const IgemmMulti mm) {
     const IgemmArgs& p = mm.c[blockIdx.y];                    // blockIdx.y: which fused launch (parity class)
     if (blockIdx.x >= (unsigned)(p.mtiles * p.ntiles) || blockIdx.z >= (unsigned)(p.groups * p.splitk)) return;
@@ -189,6 +209,7 @@ __global__ __launch_bounds__(64 * WMG * WNG, 2) void igemm_kernel(const IgemmMul
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if constexpr (MATH == VC_MATH_FP32) {
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -198,6 +219,36 @@ __global__ __launch_bounds__(64 * WMG * WNG, 2) void igemm_kernel(const IgemmMul
 #else
                     accb[sidx % NACC][mi][nj][ks & 15] += a[ks][mi] * b[ks][nj];
 #endif
+            } else if constexpr ((ks & 7) == 7) {
+                // bf16 modes: the 8 k-steps just passed (k = 2*step + h, the SAME set for A and B in either lane half)
+                // become one 32x32x16 MFMA; which 8 of the 16 k a lane half holds is free as long as A and B agree
+                constexpr int k0 = ks - 7, bank = (sidx >> 3) % NACC;
+                bf16x8 ah[MI], al[MI], bh[NJ], bl[NJ];
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = a[k0 + e][mi];
+                    to_frag<MATH>(v, ah[mi], al[mi]);
+                }
+#pragma unroll
+                for (int nj = 0; nj < NJ; ++nj) {
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = b[k0 + e][nj];
+                    to_frag<MATH>(v, bh[nj], bl[nj]);
+                }
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int nj = 0; nj < NJ; ++nj) {
+                        if constexpr (MATH == VC_MATH_BF16X3) {
+                            accb[bank][mi][nj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mi], bh[nj], accb[bank][mi][nj], 0, 0, 0);
+                            accb[bank][mi][nj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bl[nj], accb[bank][mi][nj], 0, 0, 0);
+                        }
+                        accb[bank][mi][nj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bh[nj], accb[bank][mi][nj], 0, 0, 0);
+                    }
+            }
 #ifndef VC_DBG_NOLOADER
             items(std::integral_constant<int, sidx * IPS>{}, std::integral_constant<int, IPS>{}, SLC, SSC, cl, buf ^ 1);
 #endif
@@ -290,11 +341,221 @@ __global__ __launch_bounds__(64 * WMG * WNG, 2) void igemm_kernel(const IgemmMul
 }
 
 // =====================================================================================
+// igemm_kl_kernel: the same implicit GEMM with K-CONTIGUOUS LDS tiles ([row][KC + 4], the wgrad layout).
+// A lane fetches its 16 k values of a chunk as 4 ds_read_b128 per operand row (k = 8q + 4h .. + 3; MFMA step 4q + e
+// pairs k = 8q + e in lanes 0-31 with k = 8q + 4 + e in lanes 32-63, the same for A and B), so a chunk costs 8 LDS
+// reads instead of 32, and the loaders write whole 16-byte k runs:
+//   gathered operand : a thread owns XL consecutive K rows of one pixel           -> XL/4 ds_write_b128
+//   weights, plain   : lanes along m (coalesced 4-B loads), 4 consecutive K rows  -> 1 ds_write_b128 per 4 loads
+//   weights, transp. : lanes along k, 16-B loads of 4 consecutive K rows (needs rows-per-tap % 4 == 0) -> 1 ds_write_b128
+// Row stride 36 floats: 8 consecutive rows start 36 banks apart -> every b128 access group is conflict-free.
+// =====================================================================================
+template <int BM, bool AT, int WMG, int WNG, int MATH = VC_MATH_FP32>
+__global__ __launch_bounds__(64 * WMG * WNG, 2) void igemm_kl_kernel(const IgemmMulti mm) {
+    const IgemmArgs& p = mm.c[blockIdx.y];
+    if (blockIdx.x >= (unsigned)(p.mtiles * p.ntiles) || blockIdx.z >= (unsigned)(p.groups * p.splitk)) return;
+    constexpr int BN = 64, KC = 32, LDK = KC + 4;
+    constexpr int NT = 64 * WMG * WNG;
+    constexpr int WM = BM / WMG, WN = BN / WNG, MI = WM / 32, NJ = WN / 32;
+    static_assert(MI == 1 && NJ == 1, "one 32x32 tile per wave");
+    constexpr int ASZ = BM * LDK, XSZ = BN * LDK;
+    __shared__ __attribute__((aligned(16))) float smem[2 * (ASZ + XSZ)];
+    float* As = smem;
+    float* Xs = smem + 2 * ASZ;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm = wid / WNG, wn = wid % WNG;
+    int mt, nt;
+    {   // XCD-contiguous m-major tile walk (see igemm_kernel)
+        const int total = p.mtiles * p.ntiles, per = total >> 3, tile = blockIdx.x;
+        const int idx = (tile < (per << 3)) ? (tile & 7) * per + (tile >> 3) : tile;
+        mt = idx / p.ntiles; nt = idx - mt * p.ntiles;
+    }
+    const int g = blockIdx.z / p.splitk, sp = blockIdx.z - g * p.splitk;
+    const int nchunks = p.krows / KC;
+    const int cps = (nchunks + p.splitk - 1) / p.splitk;
+    const int c0 = sp * cps, c1 = min(nchunks, c0 + cps);
+    if (c0 >= c1) return;
+
+    // ---- gathered-operand loader: as igemm_kernel (per-lane tap mask, scalar-cache table, range-checked buffer loads)
+    constexpr int XL = (KC * BN) / NT;                        // 4 (8 waves) or 8 (4 waves) consecutive K rows per thread
+    static_assert(XL % 4 == 0, "whole 16-byte k runs per thread");
+    const int xrow0 = __builtin_amdgcn_readfirstlane(wid * XL);
+    const int xn = lane;
+    const int P = nt * BN + xn;
+    const bool pv = P < p.Ptot;
+    int xb = 0, xi = 0, xj = 0;
+    if (pv) { xb = P / p.NPB; const int r = P - xb * p.NPB; xi = r / p.OWc; xj = r - xi * p.OWc; }
+    const int li0 = xi * p.si, lj0 = xj * p.sj;
+    const unsigned xoffb = (unsigned)(((long)xb * p.x_bs + (long)li0 * p.xW + lj0) * 4);
+    unsigned tapmask = 0;
+    {
+        typedef const __attribute__((address_space(4))) Tap* ctap;
+        ctap taps = (ctap)p.taps;
+        for (int t = 0; t < p.ntaps; ++t) {
+            const int dh = taps[t].dh, dw = taps[t].dw;
+            const bool ok = pv && (unsigned)(li0 + dh) < (unsigned)p.Hl && (unsigned)(lj0 + dw) < (unsigned)p.Wl;
+            tapmask |= (unsigned)ok << t;
+        }
+    }
+    const __amdgpu_buffer_rsrc_t xrs =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(p.X + (long)g * p.x_gs), 0, (int)p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ars =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (long)g * p.a_gs), 0, (int)p.a_bytes, 0x00020000);
+    typedef const __attribute__((address_space(4))) XEntry* cxptr;
+    cxptr xtab = (cxptr)p.xtab;
+
+    // ---- weight loader
+    //  plain : thread = (m = tid % BM, k quad tid / BM + q * QPP), 4 loads of 4 B (rows 4*quad .. +3), one 16-B LDS store
+    //  transp: thread = (k quad tid % 8, m = tid / 8 + q * MPP), one 16-B load along k, one 16-B LDS store
+    constexpr int QPP = NT / BM, NQ = (KC / 4) / QPP;         // plain: quads per pass, passes
+    constexpr int MPP = NT / 8, NMP = BM / MPP;               // transposed: m rows per pass, passes
+    const int am = AT ? tid / 8 : tid % BM;
+    const int aq = AT ? tid % 8 : tid / BM;
+    const unsigned avoff0 = AT ? (unsigned)((mt * BM + am) * p.a_ms) * 4u
+                               : (unsigned)(aq * 4) * p.a_ks_bytes + (unsigned)(mt * BM + am) * 4u;
+    const unsigned astep = AT ? (unsigned)(MPP * p.a_ms) * 4u : (unsigned)(QPP * 4) * p.a_ks_bytes;
+
+    constexpr int PF = 2;
+    float xr[PF][XL];
+    XEntry pe[XL];
+    unsigned ao = 0x80000000u;
+    float at[PF][AT ? 1 : NQ * 4];
+    f32x4 af[PF][AT ? NMP : 1];
+
+    constexpr int NACC = 2;
+    f32x16 accb[NACC];
+#pragma unroll
+    for (int bk = 0; bk < NACC; ++bk)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accb[bk][r] = 0.f;
+
+    auto fetch_tab = [&](int c) {
+#pragma unroll
+        for (int q = 0; q < XL; ++q) { pe[q].soff = xtab[c * KC + xrow0 + q].soff; pe[q].tapbit = xtab[c * KC + xrow0 + q].tapbit; }
+        if constexpr (AT) ao = p.atab[c * KC + aq * 4];
+    };
+    // loader items: [X loads | A loads | X stores | A stores]
+    constexpr int NAL = AT ? NMP : NQ * 4, NAS = AT ? NMP : NQ;
+    constexpr int NLOAD = XL + NAL, NSTORE = XL / 4 + NAS, NITEMS = NLOAD + NSTORE;
+    auto item = [&](auto IC, auto SLC, auto SSC, int cl, int sbuf) {
+        constexpr int I = decltype(IC)::value, SL = decltype(SLC)::value, SS = decltype(SSC)::value;
+        if constexpr (I < XL) {
+            const unsigned voff = (tapmask & pe[I].tapbit) ? xoffb + (unsigned)pe[I].soff : VC_OOB;
+            xr[SL][I] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, voff, 0, 0));
+        } else if constexpr (I < NLOAD) {
+            constexpr int q = I - XL;
+            if constexpr (AT)
+                af[SL][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ars, ao + avoff0 + q * astep, 0, 0));
+            else
+                at[SL][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                    ars, avoff0 + (unsigned)(cl * KC + (q & 3)) * p.a_ks_bytes + (q >> 2) * astep, 0, 0));
+        } else if constexpr (I < NLOAD + XL / 4) {
+            constexpr int q = I - NLOAD;
+            f32x4 v = {xr[SS][4 * q], xr[SS][4 * q + 1], xr[SS][4 * q + 2], xr[SS][4 * q + 3]};
+            *reinterpret_cast<f32x4*>(Xs + sbuf * XSZ + xn * LDK + xrow0 + 4 * q) = v;
+        } else {
+            constexpr int q = I - NLOAD - XL / 4;
+            if constexpr (AT) *reinterpret_cast<f32x4*>(As + sbuf * ASZ + (am + q * MPP) * LDK + aq * 4) = af[SS][q];
+            else {
+                f32x4 v = {at[SS][4 * q], at[SS][4 * q + 1], at[SS][4 * q + 2], at[SS][4 * q + 3]};
+                *reinterpret_cast<f32x4*>(As + sbuf * ASZ + am * LDK + (aq + q * QPP) * 4) = v;
+            }
+        }
+    };
+    auto items = [&](auto I0C, auto CNT, auto SLC, auto SSC, int cl, int sbuf) {
+        constexpr int I0 = decltype(I0C)::value, N = decltype(CNT)::value;
+        [&]<int... Ix>(std::integer_sequence<int, Ix...>) {
+            ((I0 + Ix < NITEMS ? item(std::integral_constant<int, (I0 + Ix < NITEMS ? I0 + Ix : 0)>{}, SLC, SSC, cl, sbuf)
+                               : (void)0), ...);
+        }(std::make_integer_sequence<int, N>{});
+    };
+    constexpr int NSLOT = KC / 2;
+    constexpr int IPS = (NITEMS + NSLOT - 1) / NSLOT;
+    auto chunk = [&](auto SLC, auto SSC, int buf, int cl) {
+        const f32x4* as = reinterpret_cast<const f32x4*>(As + buf * ASZ + (wm * WM + l31) * LDK + 4 * h);
+        const f32x4* xs = reinterpret_cast<const f32x4*>(Xs + buf * XSZ + (wn * WN + l31) * LDK + 4 * h);
+        f32x4 a4[4], b4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { a4[q] = as[2 * q]; b4[q] = xs[2 * q]; }
+        __builtin_amdgcn_sched_barrier(0);
+        auto slot = [&](auto SC) {
+            constexpr int sidx = decltype(SC)::value;
+            if constexpr (MATH == VC_MATH_FP32) {
+                accb[sidx % NACC] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[sidx / 4][sidx % 4], b4[sidx / 4][sidx % 4], accb[sidx % NACC], 0, 0, 0);
+            } else if constexpr ((sidx & 7) == 7) {
+                constexpr int q0 = (sidx >> 3) * 2, bank = (sidx >> 3) % NACC;
+                bf16x8 ah, al, bh, bl;
+                float va[8], vb[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { va[e] = a4[q0 + e / 4][e % 4]; vb[e] = b4[q0 + e / 4][e % 4]; }
+                to_frag<MATH>(va, ah, al); to_frag<MATH>(vb, bh, bl);
+                if constexpr (MATH == VC_MATH_BF16X3) {
+                    accb[bank] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, accb[bank], 0, 0, 0);
+                    accb[bank] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, accb[bank], 0, 0, 0);
+                }
+                accb[bank] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, accb[bank], 0, 0, 0);
+            }
+            items(std::integral_constant<int, sidx * IPS>{}, std::integral_constant<int, IPS>{}, SLC, SSC, cl, buf ^ 1);
+            if constexpr (sidx * IPS < NLOAD && (sidx + 1) * IPS >= NLOAD) fetch_tab(cl + 1);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        [&]<int... Sx>(std::integer_sequence<int, Sx...>) { (slot(std::integral_constant<int, Sx>{}), ...); }
+            (std::make_integer_sequence<int, NSLOT>{});
+    };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    using ZERO = std::integral_constant<int, 0>;
+    using LD0 = std::integral_constant<int, NLOAD>;
+    using ST0 = std::integral_constant<int, NSTORE>;
+
+    // the loader never branches: it runs up to 3 chunks past the K range (padded tables -> zeros, LDS never read)
+    fetch_tab(c0);
+    items(ZERO{}, LD0{}, S0{}, S0{}, c0, 0);
+    fetch_tab(c0 + 1);
+    items(ZERO{}, LD0{}, S1{}, S1{}, c0 + 1, 0);
+    fetch_tab(c0 + 2);
+    items(LD0{}, ST0{}, S0{}, S0{}, c0, 0);
+    __syncthreads();
+    for (int c = c0; c < c1; c += 2) {
+        chunk(S0{}, S1{}, 0, c + 2);        // multiply LDS[0] = chunk c; load c+2 -> set 0; store set 1 (c+1) -> LDS[1]
+        __syncthreads();
+        if (c + 1 >= c1) break;
+        chunk(S1{}, S0{}, 1, c + 3);
+        __syncthreads();
+    }
+
+    f32x16 acc = accb[0] + accb[1];
+    // ---- epilogue: + bias[m] (+ addend) ; plain store or atomic add
+    const bool atomic = p.splitk > 1 || p.accumulate;
+    const bool first = sp == 0;
+    float* Yg = p.Y + (long)g * p.y_gs;
+    const float* Bg = (p.bias && first) ? p.bias + (long)g * p.bias_gs : nullptr;
+    const float* Dg = (p.addend && first) ? p.addend + (long)g * p.add_gs : nullptr;
+    const int Pn = nt * BN + wn * WN + l31;
+    if (Pn < p.Ptot) {
+        const int b = Pn / p.NPB; const int r0 = Pn - b * p.NPB; const int i = r0 / p.OWc, j = r0 - i * p.OWc;
+        const long ybase = (long)b * p.y_bs + (long)(i * p.so_h + p.o_h0) * p.yW + (j * p.so_w + p.o_w0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = mt * BM + wm * WM + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (m < p.M) {
+                const long idx = ybase + (long)m * p.yHW;
+                float v = acc[r] + (Bg ? Bg[m] : 0.f);
+                if (Dg) v += Dg[idx];
+                if (atomic) atomicAdd(Yg + idx, v); else Yg[idx] = v;
+            }
+        }
+    }
+}
+
+// =====================================================================================
 // Filter gradient: D[kk][co] = sum_P Xg[kk][P] * dY[co][P], P = (b, oh, ow).
 // rows = K rows of the forward table (64 per tile), cols = Cout (BN per tile).
 // Same instruction diet as the igemm: buffer loads with hardware range check, incremental pixel decode.
 // =====================================================================================
-template <int BN>
+template <int BN, int MATH = VC_MATH_FP32>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs p) {
     // LDS tiles are [row][pixel] with a 36-float row stride: the loader writes whole pixel runs (conflict-free), and a
     // lane reads its 16 k values (pixels 16h..16h+15 of its row; MFMA step u pairs pixels u and 16+u) as 4 ds_read_b128
@@ -398,6 +659,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs p) {
         __builtin_amdgcn_sched_barrier(0);
         auto slot = [&](auto SC) {
             constexpr int u = decltype(SC)::value;      // MFMA step u multiplies pixels u (lanes 0-31) and 16+u (lanes 32-63)
+            if constexpr (MATH == VC_MATH_FP32) {
 #pragma unroll
             for (int nj = 0; nj < NJ; ++nj)
 #ifndef VC_DBG_NOMFMA
@@ -405,6 +667,29 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs p) {
 #else
                 acc[nj][u] += a4[u / 4][u % 4] * b4[nj][u / 4][u % 4];
 #endif
+            } else if constexpr ((u & 7) == 7) {
+                // bf16 modes: pixels 16h + 8*(u/8) .. +7 of this lane's row (same set for X and dY) -> one 32x32x16 MFMA
+                constexpr int j0 = (u >> 3) * 2;
+                bf16x8 ah, al, bh, bl;
+                {
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = a4[j0 + e / 4][e % 4];
+                    to_frag<MATH>(v, ah, al);
+                }
+#pragma unroll
+                for (int nj = 0; nj < NJ; ++nj) {
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = b4[nj][j0 + e / 4][e % 4];
+                    to_frag<MATH>(v, bh, bl);
+                    if constexpr (MATH == VC_MATH_BF16X3) {
+                        acc[nj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[nj], 0, 0, 0);
+                        acc[nj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[nj], 0, 0, 0);
+                    }
+                    acc[nj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[nj], 0, 0, 0);
+                }
+            }
 #ifndef VC_DBG_NOLOADER
             items(std::integral_constant<int, u * IPS>{}, std::integral_constant<int, IPS>{}, SLC, SSC, buf ^ 1);
 #endif
@@ -1039,11 +1324,36 @@ extern "C" int vc_prof_records(int kind, double* ms, double* flops, int max_n) {
     return n;
 }
 
+// arithmetic of the MFMA kernels, process-wide (read at launch time)
+static std::atomic<int> g_math{VC_MATH_FP32};
+extern "C" int vc_set_math_mode(int mode) {
+    if (mode < VC_MATH_FP32 || mode > VC_MATH_BF16X3) { vc_set_error("vc_set_math_mode: mode %d (0 fp32, 1 bf16, 2 bf16x3)", mode); return -1; }
+    g_math.store(mode);
+    return 0;
+}
+extern "C" int vc_get_math_mode(void) { return g_math.load(); }
+
+static int env_int(const char* name, int dflt);
+// Split-K factor.  512 workgroups are resident at once (2 per CU); a launch runs in ceil(blocks / 512) rounds, and a
+// workgroup costs its K chunks plus a fixed prologue/epilogue (first loads, accumulator write-out), about `ovh` chunks
+// (B=8 step: ovh 1 -> 9.32 ms, 3 -> 9.00, 6 -> 8.96; the round-1 rule 9.06).
+// Pick the factor with the least rounds * (chunks per split + ovh); ties go to the smaller factor (fewer atomics).
 static int pick_splitk(long tiles, int nchunks) {
-    // fill ~2 workgroups per CU (256 CUs); keep >= 4 chunks per split
-    int sk = 1;
-    while (tiles * sk < 512 && nchunks / (sk * 2) >= 4 && sk < 16) sk *= 2;
-    return sk;
+    if (env_int("VC_SPLITK_MODEL", 1) == 0) {                 // the round-1 rule: fill ~2 workgroups per CU, >= 4 chunks per split
+        int sk = 1;
+        while (tiles * sk < 512 && nchunks / (sk * 2) >= 4 && sk < 16) sk *= 2;
+        return sk;
+    }
+    if (tiles >= 512) return 1;                               // the chip is full without it
+    const double ovh = env_int("VC_SPLITK_OVH", 6);
+    int best = 1; double bestc = 1e30;
+    for (int sk = 1; sk <= 16; sk *= 2) {
+        if (sk > 1 && nchunks / sk < 2) break;
+        const double rounds = (double)((tiles * sk + 511) / 512);
+        const double c = rounds * ((nchunks + sk - 1) / sk + ovh);
+        if (c < bestc * 0.97) { best = sk; bestc = c; }
+    }
+    return best;
 }
 
 static int env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
@@ -1085,8 +1395,34 @@ int launch_igemm_multi(const IgemmArgs* cls, int n, bool a_trans, hipStream_t s,
     const int big = cls[0].big;
     dim3 grid(tiles, n, z), block(big == 3 ? 512 : 256);
     const int pad = env_int("VC_IGEMM_LDS_PAD", 0);      // extra dynamic LDS: caps workgroups per CU (tuning)
+    const int math = g_math.load();
+    if (math != VC_MATH_FP32 && big != 0 && big != 3) { vc_set_error("bf16 math modes are built for tile ids 0 and 3 only"); return -1; }
     ProfScope ps(0, flops, s);
-    switch (big * 2 + (a_trans ? 1 : 0)) {
+#define VC_IGEMM_MATH(MATH) \
+    switch (big * 2 + (a_trans ? 1 : 0)) { \
+        case 6: igemm_kernel<128, 64, 32, false, 4, 2, MATH><<<grid, block, pad, s>>>(m); break; \
+        case 7: igemm_kernel<128, 64, 32, true, 4, 2, MATH><<<grid, block, pad, s>>>(m); break; \
+        case 0: igemm_kernel<64, 64, 32, false, 2, 2, MATH><<<grid, block, pad, s>>>(m); break; \
+        default: igemm_kernel<64, 64, 32, true, 2, 2, MATH><<<grid, block, pad, s>>>(m); break; \
+    }
+    // k-contiguous LDS tiles (igemm_kl_kernel) whenever the launch qualifies; VC_IGEMM_KL=0 keeps the k-major kernel (A/B runs)
+    bool kl = (big == 0 || big == 3) && env_int("VC_IGEMM_KL", 1) != 0;
+    for (int i = 0; i < n; ++i) kl = kl && cls[i].kl_ok;
+#define VC_IGEMM_KL(MATH) \
+    switch (big * 2 + (a_trans ? 1 : 0)) { \
+        case 6: igemm_kl_kernel<128, false, 4, 2, MATH><<<grid, block, pad, s>>>(m); break; \
+        case 7: igemm_kl_kernel<128, true, 4, 2, MATH><<<grid, block, pad, s>>>(m); break; \
+        case 0: igemm_kl_kernel<64, false, 2, 2, MATH><<<grid, block, pad, s>>>(m); break; \
+        default: igemm_kl_kernel<64, true, 2, 2, MATH><<<grid, block, pad, s>>>(m); break; \
+    }
+    if (kl) {
+        if (math == VC_MATH_BF16) VC_IGEMM_KL(VC_MATH_BF16)
+        else if (math == VC_MATH_BF16X3) VC_IGEMM_KL(VC_MATH_BF16X3)
+        else VC_IGEMM_KL(VC_MATH_FP32)
+    }
+    else if (math == VC_MATH_BF16) VC_IGEMM_MATH(VC_MATH_BF16)
+    else if (math == VC_MATH_BF16X3) VC_IGEMM_MATH(VC_MATH_BF16X3)
+    else switch (big * 2 + (a_trans ? 1 : 0)) {
         case 6: igemm_kernel<128, 64, 32, false, 4, 2><<<grid, block, pad, s>>>(m); break;
         case 7: igemm_kernel<128, 64, 32, true, 4, 2><<<grid, block, pad, s>>>(m); break;
         case 0: igemm_kernel<64, 64, 32, false><<<grid, block, pad, s>>>(m); break;
@@ -1096,6 +1432,8 @@ int launch_igemm_multi(const IgemmArgs* cls, int n, bool a_trans, hipStream_t s,
         case 4: igemm_kernel<128, 128, 32, false><<<grid, block, pad, s>>>(m); break;
         default: igemm_kernel<128, 128, 32, true><<<grid, block, pad, s>>>(m); break;
     }
+#undef VC_IGEMM_MATH
+#undef VC_IGEMM_KL
     VC_HIP(hipGetLastError());
     return 0;
 }
@@ -1109,8 +1447,12 @@ int launch_wgrad(const WgradArgs& a0, hipStream_t s, double flops) {
     a.splitk = pick_splitk(tiles, a.nchunks);
     dim3 grid(a.ktiles * a.ntiles, 1, a.groups * a.splitk), block(256);
     ProfScope ps(1, flops, s);
-    if (BN == 128) wgrad_kernel<128><<<grid, block, 0, s>>>(a);
-    else           wgrad_kernel<64><<<grid, block, 0, s>>>(a);
+    const int math = g_math.load();
+#define VC_WGRAD_MATH(MATH) { if (BN == 128) wgrad_kernel<128, MATH><<<grid, block, 0, s>>>(a); else wgrad_kernel<64, MATH><<<grid, block, 0, s>>>(a); }
+    if (math == VC_MATH_BF16) VC_WGRAD_MATH(VC_MATH_BF16)
+    else if (math == VC_MATH_BF16X3) VC_WGRAD_MATH(VC_MATH_BF16X3)
+    else VC_WGRAD_MATH(VC_MATH_FP32)
+#undef VC_WGRAD_MATH
     VC_HIP(hipGetLastError());
     return 0;
 }

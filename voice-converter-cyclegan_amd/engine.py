@@ -69,7 +69,7 @@ class CycleGANEngine:
         self._plans, self._ws = {}, None
         self._overlap = True
         self.sync = GradSync(group, enabled=data_parallel)
-        self._comm_stream = torch.cuda.Stream(device=self.device) if self.sync.world > 1 else None
+        self._comm_stream = torch.cuda.Stream(device=self.device)      # gradient exchange + Adam, beside the backward
         # tf.train.AdamOptimizer keeps beta1_power/beta2_power as fp32 variables (one pair per optimizer)
         self.b1p = [np.float32(ADAM_BETA1), np.float32(ADAM_BETA1)]
         self.b2p = [np.float32(ADAM_BETA2), np.float32(ADAM_BETA2)]
@@ -120,6 +120,20 @@ class CycleGANEngine:
         self._overlap = bool(enabled)
         for h in self._plans.values():
             lib.vc_plan_set_overlap(h, int(self._overlap))
+
+    MATH_MODES = {'fp32': 0, 'bf16': 1, 'bf16x3': 2}
+
+    @staticmethod
+    def set_math(mode):
+        """Arithmetic of the conv kernels, process-wide (vc_set_math_mode): 'fp32' (default, the reference's precision),
+        'bf16' (bf16 MFMA operands, fp32 accumulate / storage / statistics; BASELINE config 3) or 'bf16x3'."""
+        if mode not in CycleGANEngine.MATH_MODES:
+            raise ValueError('math mode must be one of %s' % sorted(CycleGANEngine.MATH_MODES))
+        check(lib.vc_set_math_mode(CycleGANEngine.MATH_MODES[mode]), 'vc_set_math_mode')
+
+    @staticmethod
+    def get_math():
+        return {v: k for k, v in CycleGANEngine.MATH_MODES.items()}[lib.vc_get_math_mode()]
 
     def _workspace(self, n):
         if self._ws is None or self._ws.numel() < n:
@@ -197,13 +211,44 @@ class CycleGANEngine:
             w.wait()
         main.wait_stream(self._comm_stream)
 
+    def exchange_and_update(self, plan, generator_learning_rate, discriminator_learning_rate):
+        """Gradient exchange (data parallel) + ApplyAdam, segment by segment on the side stream, each as soon as the
+        native schedule says the segment's gradients are final AND its weights are no longer read (vc_step_wait_*):
+        the discriminator half rides under the whole generator backward, generator buckets under the rest of it.
+        Adam is HBM-bound (28 B/param), the backward MFMA-bound, so they share the chip well; only the last small
+        bucket (h1, d1, d2) is exposed.  Arithmetic is identical to exchange_grads() + apply_adam()."""
+        main = torch.cuda.current_stream(self.device)
+        side, gs = self._comm_stream, float(self.sync.scale)
+        alphas = (self._alpha(generator_learning_rate, 0), self._alpha(discriminator_learning_rate, 1))
+        with torch.cuda.stream(side):
+            cs = _lib.vp(side.cuda_stream)
+            for kind, k, ranges in self.grad_segments(plan):
+                if kind == 'd':
+                    check(lib.vc_step_wait_d_grads(plan, cs), 'vc_step_wait_d_grads')
+                else:
+                    check(lib.vc_step_wait_g_bucket(plan, k, cs), 'vc_step_wait_g_bucket')
+                if self.sync.world > 1:
+                    for w in [self.sync.all_reduce(self.grads[lo:hi], async_op=True) for lo, hi in ranges]:
+                        w.wait()                     # makes the side stream wait for the collective
+                for lo, hi in ranges:
+                    check(lib.vc_adam_tf_update(ptr(self.params[lo:hi]), ptr(self.m[lo:hi]), ptr(self.v[lo:hi]),
+                                                ptr(self.grads[lo:hi]), hi - lo, alphas[1 if kind == 'd' else 0],
+                                                ADAM_BETA1, ADAM_BETA2, ADAM_EPS, gs, cs), 'vc_adam_tf_update')
+        main.wait_stream(side)
+        for k in range(2):
+            self.b1p[k] = np.float32(self.b1p[k] * np.float32(ADAM_BETA1))
+            self.b2p[k] = np.float32(self.b2p[k] * np.float32(ADAM_BETA2))
+
     def train_step(self, A, Bm, lambda_cycle, lambda_identity, generator_learning_rate,
                    discriminator_learning_rate, sync=True, gen_A=None, gen_B=None):
         """model.CycleGAN.train (model.py:110-125): returns (generator_loss, discriminator_loss).
         sync=False returns the 8-element device tensor of losses without a host round trip."""
         p = self.step_grads(A, Bm, lambda_cycle, lambda_identity, gen_A, gen_B)
-        self.exchange_grads(p)
-        self.apply_adam(generator_learning_rate, discriminator_learning_rate)
+        if self._overlap:
+            self.exchange_and_update(p, generator_learning_rate, discriminator_learning_rate)
+        else:                                        # everything on the caller's stream (per-kernel timing, debugging)
+            self.exchange_grads(p)
+            self.apply_adam(generator_learning_rate, discriminator_learning_rate)
         if not sync:
             return self.losses
         l = self.losses.cpu().numpy()
