@@ -508,6 +508,15 @@ def generator_losses_and_grads(P, A, Bm, lambda_cycle, lambda_identity, want_gra
     g_loss = g_A2B + g_B2A + dt(lambda_cycle) * cycle_loss + dt(lambda_identity) * identity_loss  # :72
     S = dict(cycle_loss=cycle_loss, identity_loss=identity_loss, generator_loss_A2B=g_A2B,
              generator_loss_B2A=g_B2A, generator_loss=g_loss)
+    # test aid: distance of the closest L1 element to a tie.  d|x|/dx = sign(x) (S6) is discontinuous there, so an
+    # implementation whose forward differs by less than fp32 rounding may legitimately take the other sign of that one
+    # element; parity tests pick inputs whose gap is far above that noise (tests/test_step_gpu.py).
+    gaps = []
+    if lambda_cycle != 0:
+        gaps += [np.abs(cyc_A - A).min(), np.abs(cyc_B - Bm).min()]
+    if lambda_identity != 0:
+        gaps += [np.abs(id_A - A).min(), np.abs(id_B - Bm).min()]
+    generator_losses_and_grads.last_l1_gap = float(min(gaps)) if gaps else float('inf')
     if not want_grads:
         return S, None, gen_A, gen_B
 
@@ -612,6 +621,7 @@ class CycleGANOracle:
         self.last = dict(Sg); self.last.update(Sd)
         self.last_grads = (Gg, Gd)
         self.last_fakes = (gen_A, gen_B)
+        self.last_l1_gap = generator_losses_and_grads.last_l1_gap
         return Sg['generator_loss'], Sd['discriminator_loss']
 
     def test(self, inputs, direction):                                  # model.py:128-137

@@ -1,0 +1,19 @@
+#!/bin/bash
+# Round-end measurement set (run on the GPU box through gpurun): default bench line, rocprofv3 kernel stats (serial and
+# two-stream), and the separate FETCH_SIZE / WRITE_SIZE PMC passes.  Outputs land in gpurun_out/ (copied to profiles/ by hand).
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out/round
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+timeout 400 python $R/bench.py 2>$O/bench.err | tail -1 > $O/final_bench.json
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/serial -o serial -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --serial > $O/serial.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/streams -o streams -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline > $O/streams.log 2>&1
+timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -o fetch -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --serial > $O/fetch.log 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -o write -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --serial > $O/write.log 2>&1
+F=$(find $O/fetch -name '*counter_collection.csv' | head -1); W=$(find $O/write -name '*counter_collection.csv' | head -1)
+python $R/tools/summarize_pmc.py $F $W 4 > $O/pmc_hbm_traffic.txt 2>&1
+# keep only the small summaries
+find $O -name '*kernel_trace.csv' -delete; find $O -name '*counter_collection.csv' -delete; find $O -name '*.db' -delete
+find $O -type f | head -40
+cat $O/final_bench.json | cut -c1-600
+tail -3 $O/pmc_hbm_traffic.txt

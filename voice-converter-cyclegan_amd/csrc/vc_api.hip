@@ -138,10 +138,27 @@ static int igemm_run(IgemmArgs& a, bool a_trans, float* y_zero_base, long y_zero
     return launch_igemm(a, a_trans, s, flops);
 }
 
+// Cin = 1 with at most 9 taps (the discriminator's h1 layer) goes to the vector-ALU kernels; VC_C1_PATH=0 keeps it on MFMA
+static bool c1_path(const Geom& g) {
+    static const bool on = [] { const char* v = getenv("VC_C1_PATH"); return !v || atoi(v) != 0; }();
+    return on && g.Cin == 1 && g.kh * g.kw <= 9;
+}
+static C1Args c1_args(const Geom& g, int G, int B) {
+    C1Args c{};
+    c.B = B; c.H = g.H; c.W = g.W; c.Cout = g.Cout; c.kh = g.kh; c.kw = g.kw; c.sh = g.sh; c.sw = g.sw;
+    c.OH = g.OH; c.OW = g.OW; c.pt = g.pt; c.pl = g.pl; c.G = G; c.math = vc_math_mode();
+    return c;
+}
+
 // query != nullptr: do not launch, only report whether the launch would use split-K atomics (needs a zeroed y)
 static int conv_fwd(const float* x, long x_gs, const float* w, long w_gs, const float* bias, long b_gs,
                     float* y, long y_gs, int G, int B, const Geom& g, hipStream_t s,
                     bool prezeroed = false, bool* query = nullptr) {
+    if (c1_path(g)) {      // Cin = 1 (D.h1): vector-ALU kernel, plain stores, never needs a zeroed destination
+        if (query) { *query = false; return 0; }
+        C1Args c = c1_args(g, G, B); c.x = x; c.x_gs = x_gs; c.w = w; c.w_gs = w_gs; c.bias = bias; c.b_gs = b_gs; c.y = y; c.y_gs = y_gs;
+        return launch_c1_fwd(c, s);
+    }
     Table t; VC_CHECK(get_fwd_table(g, &t));
     IgemmArgs a{};
     a.A = w; a.X = x; a.Y = y; a.bias = bias; a.addend = nullptr;
@@ -165,6 +182,12 @@ static int conv_fwd(const float* x, long x_gs, const float* w, long w_gs, const 
 static int conv_dgrad(const float* dy, long dy_gs, const float* w, long w_gs, float* dx, long dx_gs,
                       const float* addend, long add_gs, int accumulate, int G, int B, const Geom& g, hipStream_t s,
                       bool prezeroed = false, bool* query = nullptr) {
+    if (c1_path(g) && !addend) {
+        if (query) { *query = false; return 0; }      // zeroes dx itself when it has to
+        C1Args c = c1_args(g, G, B); c.dy = dy; c.y_gs = dy_gs; c.w = w; c.w_gs = w_gs; c.dx = dx; c.dx_gs = dx_gs;
+        c.addend = addend; c.add_gs = add_gs;
+        return launch_c1_dgrad(c, accumulate || prezeroed, s);
+    }
     // one launch per stride-parity class (ph, pw): inside a class the transposed conv is a dense stride-1 gather
     std::vector<IgemmArgs> cls; std::vector<double> fl;
     bool any_split = false;
@@ -210,6 +233,10 @@ static int conv_dgrad(const float* dy, long dy_gs, const float* w, long w_gs, fl
 
 static int conv_wgrad(const float* x, long x_gs, const float* dy, long dy_gs, float* dw, long dw_gs,
                       int G, int B, const Geom& g, hipStream_t s, bool first_touch = false) {
+    if (c1_path(g)) {
+        C1Args c = c1_args(g, G, B); c.x = x; c.x_gs = x_gs; c.dy = dy; c.y_gs = dy_gs; c.dw = dw; c.dw_gs = dw_gs;
+        return launch_c1_wgrad(c, s);
+    }
     Table t; VC_CHECK(get_fwd_table(g, &t));
     WgradArgs a{};
     a.X = x; a.dY = dy; a.dW = dw; a.ktab = t.dev;

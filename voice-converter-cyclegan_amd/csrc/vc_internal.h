@@ -60,6 +60,20 @@ struct WgradArgs {
     int first_touch;                              // dW holds no earlier contribution (it is zero): store instead of add
 };
 
+// Single-input-channel convolution (the discriminator's first layer, module.py:201-202: Cin = 1, 3x3 -> K = 9): a
+// bandwidth job, done on the vector ALU instead of padding K = 9 up to an MFMA tile.  kh*kw <= 9.
+struct C1Args {
+    const float* x; const float* w; const float* bias; const float* addend; const float* dy;
+    float* y; float* dx; float* dw;
+    long x_gs, w_gs, b_gs, y_gs, dx_gs, add_gs, dw_gs;     // signed group strides (floats); y_gs also strides dy
+    int B, H, W, Cout, kh, kw, sh, sw, OH, OW, pt, pl, G;
+    int math;                                               // VC_MATH_*: bf16 mode rounds both operands like the MFMA kernels do
+};
+int launch_c1_fwd(const C1Args& a, hipStream_t s);
+int launch_c1_dgrad(const C1Args& a, int accumulate, hipStream_t s);   // dx (+)= ...; atomics into dx (zeroed here unless accumulate)
+int launch_c1_wgrad(const C1Args& a, hipStream_t s);                   // dw += ... (atomics)
+int vc_math_mode();
+
 struct NormArgs {
     const float* y; const float* res; const float* gamma; const float* beta;
     const float* dout; const float* stats_in;

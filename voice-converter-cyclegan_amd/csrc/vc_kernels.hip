@@ -1091,6 +1091,164 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const float* dy, long dy
     if (threadIdx.x == 0) atomicAdd(db + (long)g * db_gs + c, s);
 }
 
+// =====================================================================================
+// Cin = 1 convolution on the vector ALU (C1Args).  Lanes run along output pixels (coalesced y / dy rows); filter taps
+// and biases are wave-uniform scalar loads.
+// =====================================================================================
+__device__ __forceinline__ float c1_round(float v, int math) { return math == VC_MATH_BF16 ? (float)(__bf16)v : v; }
+
+// 64-lane sum on the DPP path (4 cross-lane VALU adds inside each row of 16, then one readlane per row) -- the
+// ds_bpermute route of __shfl_xor costs an LDS round trip per step, which dominates when 72 values are reduced
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    auto dpp = [](float x, auto CTRL) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(CTRL)::value, 0xf, 0xf, false));
+    };
+    v += dpp(v, std::integral_constant<int, 0xB1>{});      // quad_perm [1,0,3,2]
+    v += dpp(v, std::integral_constant<int, 0x4E>{});      // quad_perm [2,3,0,1]   -> every lane holds its quad's sum
+    v += dpp(v, std::integral_constant<int, 0x141>{});     // row_half_mirror       -> sum of 8
+    v += dpp(v, std::integral_constant<int, 0x140>{});     // row_mirror            -> sum of the row of 16
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0)) +
+           __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16)) +
+           __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32)) +
+           __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+}
+
+// window of output pixel (i, j): the kh*kw (<= 9) input values, zero outside the image / beyond the last tap
+__device__ __forceinline__ void c1_window(const C1Args& a, const float* x, int i, int j, bool pv, float (&xv)[9]) {
+    const int nt = a.kh * a.kw;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int di = t / a.kw, dj = t - di * a.kw;
+        const int h = i * a.sh + di - a.pt, w = j * a.sw + dj - a.pl;
+        const bool ok = pv && t < nt && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W;
+        const float v = x[ok ? h * a.W + w : 0];                 // unconditional load, select afterwards: no divergence
+        xv[t] = ok ? c1_round(v, a.math) : 0.f;
+    }
+}
+
+// y[g][b][co][p] = bias[co] + sum_t w[t][co] * window_t(p);  block = 256 pixels x 64 channels, filter slice in LDS
+__global__ __launch_bounds__(256) void c1_fwd_kernel(const C1Args a) {
+    __shared__ __attribute__((aligned(16))) float ws[10 * 64];       // [t][c] + bias row
+    const int nch = (a.Cout + 63) / 64;
+    const int g = blockIdx.z / nch, cc = blockIdx.z - g * nch, b = blockIdx.y;
+    const int P = a.OH * a.OW, p = blockIdx.x * 256 + threadIdx.x, nt = a.kh * a.kw;
+    const float* wt = a.w + (long)g * a.w_gs;
+    for (int idx = threadIdx.x; idx < 640; idx += 256) {
+        const int t = idx >> 6, c = idx & 63, co = cc * 64 + c;
+        float v = 0.f;
+        if (co < a.Cout) { if (t < nt) v = c1_round(wt[t * a.Cout + co], a.math); else if (t == 9 && a.bias) v = a.bias[(long)g * a.b_gs + co]; }
+        ws[idx] = v;
+    }
+    __syncthreads();
+    const bool pv = p < P;
+    const int i = pv ? p / a.OW : 0, j = pv ? p - i * a.OW : 0;
+    float xv[9];
+    c1_window(a, a.x + (long)g * a.x_gs + (long)b * a.H * a.W, i, j, pv, xv);
+    if (!pv) return;
+    float* y = a.y + (long)g * a.y_gs + (long)b * a.Cout * P + p;
+#pragma unroll 4
+    for (int c4 = 0; c4 < 16; ++c4) {
+        f32x4 acc = *reinterpret_cast<const f32x4*>(ws + 9 * 64 + c4 * 4);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc += xv[t] * *reinterpret_cast<const f32x4*>(ws + t * 64 + c4 * 4);
+        const int co = cc * 64 + c4 * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (co + e < a.Cout) y[(long)(co + e) * P] = acc[e];
+    }
+}
+
+// input gradient as a scatter from dy: z[t] = sum_co w[t][co] * dy[co][p] for the thread's pixel p (dy read once,
+// coalesced), then dx[window_t(p)] += z[t] (atomics; dx zeroed by the launcher unless it accumulates)
+__global__ __launch_bounds__(256) void c1_dgrad_kernel(const C1Args a) {
+    __shared__ __attribute__((aligned(16))) float ws[64 * 12];       // [c][t], t padded to 12
+    const int nch = (a.Cout + 63) / 64;
+    const int g = blockIdx.z / nch, cc = blockIdx.z - g * nch, b = blockIdx.y;
+    const int P = a.OH * a.OW, p = blockIdx.x * 256 + threadIdx.x, nt = a.kh * a.kw;
+    const float* wt = a.w + (long)g * a.w_gs;
+    for (int idx = threadIdx.x; idx < 768; idx += 256) {
+        const int c = idx / 12, t = idx - c * 12, co = cc * 64 + c;
+        ws[idx] = (t < nt && co < a.Cout) ? c1_round(wt[t * a.Cout + co], a.math) : 0.f;
+    }
+    __syncthreads();
+    if (p >= P) return;
+    const float* dy = a.dy + (long)g * a.y_gs + ((long)b * a.Cout + cc * 64) * P + p;
+    const int nc = min(64, a.Cout - cc * 64);
+    float z[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) z[t] = 0.f;
+#pragma unroll 8
+    for (int c = 0; c < nc; ++c) {
+        const float d = c1_round(dy[(long)c * P], a.math);
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(ws + c * 12), w1 = *reinterpret_cast<const f32x4*>(ws + c * 12 + 4);
+        const float w8 = ws[c * 12 + 8];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { z[t] = fmaf(d, w0[t], z[t]); z[4 + t] = fmaf(d, w1[t], z[4 + t]); }
+        z[8] = fmaf(d, w8, z[8]);
+    }
+    const int i = p / a.OW, j = p - i * a.OW;
+    float* dx = a.dx + (long)g * a.dx_gs + (long)b * a.H * a.W;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int di = t / a.kw, dj = t - di * a.kw;
+        const int h = i * a.sh + di - a.pt, w = j * a.sw + dj - a.pl;
+        if (t < nt && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W) atomicAdd(dx + h * a.W + w, z[t]);
+    }
+}
+
+// dw[g][t][co] += sum_{b,p} window_t(p) * dy[g][b][co][p].  A block owns 8 channels and C1_BPB samples; its 4 waves take a
+// quarter of the pixels each, gather the window of a pixel once for the 8 channels, reduce with wave shuffles and LDS,
+// and issue ONE atomic per (tap, channel) and block (atomics on one cache line serialise: per-wave atomics cost 80 us).
+#define C1_BPB 1
+__global__ __launch_bounds__(256) void c1_wgrad_kernel(const C1Args a) {
+    __shared__ float red[4][72];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int g = blockIdx.z, co0 = blockIdx.x * 8;
+    const int P = a.OH * a.OW, nt = a.kh * a.kw;
+    const int per = ((P + 4 * 64 - 1) / (4 * 64)) * 64, p0 = wid * per, p1 = min(P, p0 + per);
+    float acc[8][9];
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[c][t] = 0.f;
+    const int b1 = min(a.B, (int)(blockIdx.y + 1) * C1_BPB);
+    for (int b = blockIdx.y * C1_BPB; b < b1; ++b) {
+        const float* x = a.x + (long)g * a.x_gs + (long)b * a.H * a.W;
+        const float* dy = a.dy + (long)g * a.y_gs + (long)b * a.Cout * P;
+        // two pixels per lane and trip: 16 dy loads + 2 windows in flight before the first use (the kernel is latency-bound:
+        // ~64 KB per CU must be in flight to cover HBM latency); loads are unconditional (clamped), masked afterwards
+        for (int p = p0 + lane; p < p1; p += 128) {
+            const int q = p + 64; const bool qv = q < p1; const int qc = qv ? q : p;
+            float d0[8], d1[8], xv0[9], xv1[9];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const long row = (long)min(co0 + c, a.Cout - 1) * P;
+                d0[c] = dy[row + p]; d1[c] = dy[row + qc];
+            }
+            { const int i = p / a.OW, j = p - i * a.OW; c1_window(a, x, i, j, true, xv0); }
+            { const int i = qc / a.OW, j = qc - i * a.OW; c1_window(a, x, i, j, qv, xv1); }
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const float e0 = c1_round(d0[c], a.math), e1 = c1_round(d1[c], a.math);
+#pragma unroll
+                for (int t = 0; t < 9; ++t) acc[c][t] = fmaf(xv1[t], e1, fmaf(xv0[t], e0, acc[c][t]));
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const float v = wave_sum_dpp(acc[c][t]);
+            if (lane == 0) red[wid][c * 9 + t] = v;
+        }
+    __syncthreads();
+    if (threadIdx.x < 72) {
+        const int c = threadIdx.x / 9, t = threadIdx.x - c * 9;
+        const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        if (t < nt && co0 + c < a.Cout) atomicAdd(a.dw + (long)g * a.dw_gs + t * a.Cout + co0 + c, v);
+    }
+}
+
 __global__ __launch_bounds__(256) void head_fwd_kernel(const float* x, long x_gs, const float* w, const float* bias,
                                                        long par_gs, float* o, long o_gs, int C, int HW) {
     __shared__ float red[4][64];
@@ -1498,6 +1656,26 @@ int launch_norm_bwd(int mode, const NormArgs& a, hipStream_t s) {
     vc_set_error("bad norm mode %d", mode); return -1;
 }
 
+int vc_math_mode() { return g_math.load(); }
+int launch_c1_fwd(const C1Args& a, hipStream_t s) {
+    const int P = a.OH * a.OW, nch = (a.Cout + 63) / 64;
+    c1_fwd_kernel<<<dim3((P + 255) / 256, a.B, a.G * nch), 256, 0, s>>>(a);
+    VC_HIP(hipGetLastError());
+    return 0;
+}
+int launch_c1_dgrad(const C1Args& a, int accumulate, hipStream_t s) {
+    const int P = a.OH * a.OW, nch = (a.Cout + 63) / 64;
+    if (!accumulate)
+        for (int g = 0; g < a.G; ++g) VC_HIP(hipMemsetAsync(a.dx + (long)g * a.dx_gs, 0, (size_t)a.B * a.H * a.W * sizeof(float), s));
+    c1_dgrad_kernel<<<dim3((P + 255) / 256, a.B, a.G * nch), 256, 0, s>>>(a);
+    VC_HIP(hipGetLastError());
+    return 0;
+}
+int launch_c1_wgrad(const C1Args& a, hipStream_t s) {
+    c1_wgrad_kernel<<<dim3((a.Cout + 7) / 8, (a.B + C1_BPB - 1) / C1_BPB, a.G), 256, 0, s>>>(a);
+    VC_HIP(hipGetLastError());
+    return 0;
+}
 int launch_bias_grad(const float* dy, long dy_gs, float* db, long db_gs, int G, int B, int C, int L, hipStream_t s) {
     bias_grad_kernel<<<dim3(C, G), 256, 0, s>>>(dy, dy_gs, db, db_gs, B, C, L);
     VC_HIP(hipGetLastError());
