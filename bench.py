@@ -55,7 +55,7 @@ def cpu_baseline(n_steps=4):
                        'train steps, median %.2f s/step; TF1 reference not runnable (no tensorflow)' % (n_steps, med))
 
 
-def named_kernel_h1(lib, dev, B=256, reps=20):
+def named_kernel_h1(lib, dev, B=256, reps=20, peak=FP32_MFMA_PEAK_TFLOPS, math='fp32'):
     """G.h1 value+gate convolution forward (module.py:161-162) at B=256: SURVEY 8d's named target.
     algorithmic bytes 20.29 MB, algorithmic FLOPs 6.04 G; exact fp32 caps the HBM fraction at ~6.6 %."""
     import numpy as np
@@ -80,11 +80,12 @@ def named_kernel_h1(lib, dev, B=256, reps=20):
     t = ms.value * 1e-3 / max(n.value, 1)
     nbytes = B * (24 * 128 + 256 * 128) * 4 + (15 * 24 * 256 + 256) * 4
     flops = 2.0 * B * 128 * 256 * 15 * 24
-    return {'kernel': 'igemm_kernel: G.h1 gated conv1d forward, B=%d' % B, 'us': t * 1e6,
+    return {'kernel': 'igemm_kl_kernel: G.h1 gated conv1d forward, B=%d' % B, 'us': t * 1e6,
             'hbm': {'achieved_GBs': nbytes / t / 1e9, 'peak_GBs': HBM_PEAK_GBS, 'frac': nbytes / t / 1e9 / HBM_PEAK_GBS},
-            'mfma': {'achieved_TFLOPs': flops / t / 1e12, 'peak_TFLOPs': FP32_MFMA_PEAK_TFLOPS,
-                     'frac': flops / t / 1e12 / FP32_MFMA_PEAK_TFLOPS},
-            'note': 'exact-fp32 MFMA makes this kernel FLOP-bound: at fp32 peak it takes 38.4 us vs 2.5 us of HBM time'}
+            'mfma': {'achieved_TFLOPs': flops / t / 1e12, 'peak_TFLOPs': peak, 'frac': flops / t / 1e12 / peak},
+            'note': ('exact-fp32 MFMA makes this kernel FLOP-bound: at fp32 peak it takes 38.4 us vs 2.5 us of HBM time'
+                     if math == 'fp32' else 'bf16 MFMA operands but fp32 tensors in HBM and an fp32-sized loader: issue-bound, '
+                     'neither roof (see DESIGN.md section 4, bf16 mode)')}
 
 
 def main():
@@ -193,7 +194,7 @@ def main():
             eng.train_step(A, Bm, *hp, sync=False)
         torch.cuda.synchronize()
         stats = {}
-        for kind, name in ((0, 'igemm_kernel (conv fwd + dgrad)'), (1, 'wgrad_kernel')):
+        for kind, name in ((0, 'igemm_kl_kernel (conv fwd + dgrad, every Cin > 1 layer)'), (1, 'wgrad_kernel')):
             ms, n, fl = C.c_double(0), C.c_longlong(0), C.c_double(0)
             lib.vc_prof_collect(kind, C.byref(ms), C.byref(n), C.byref(fl))
             stats[kind] = (name, ms.value, n.value, fl.value)
@@ -207,7 +208,7 @@ def main():
                 'frac': ach / peak,
                 # HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
                 # (profiles/r01_pmc_hbm_traffic_b8.txt; FETCH_SIZE doubled per MI355X_MICROARCH.md, L3 hits included)
-                'traffic': 108.02e6 if (B, F, T, world, args.math) == (8, 24, 128, 1, 'fp32') else None,
+                'traffic': 107.98e6 if (B, F, T, world, args.math) == (8, 24, 128, 1, 'fp32') else None,
                 'traffic_unit': 'bytes/launch (offline PMC pass, upper bound: Infinity-Cache hits counted)',
                 'kernel': name, 'launches_per_step': n // n_prof,
                 'condition': 'step chains serialised on one stream (no co-running launches); see --serial',
@@ -222,7 +223,7 @@ def main():
 
     # ---- the kernel the north_star names: gated-conv1d forward (G.h1: 24 -> 2x128, k=15) at B=256
     if rank == 0 and not args.no_roofline:
-        out['named_kernel'] = named_kernel_h1(lib, dev)
+        out['named_kernel'] = named_kernel_h1(lib, dev, peak=peak, math=args.math)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline()
