@@ -43,6 +43,9 @@ typedef struct vc_plan vc_plan;   /* opaque: geometry tables + workspace map for
 /* ---- library ------------------------------------------------------------- */
 int         vc_version(void);
 const char* vc_last_error(void);
+/* CRC-32C (Castagnoli) of `n` host bytes, continuing from `crc` (0 to start): the checksum inside TensorFlow's
+ * checkpoint bundles and event files, which CycleGAN.save()/the summary writer emit (model.py:21,26-29).  Host only. */
+uint32_t vc_crc32c(const void* data, uint64_t n, uint32_t crc);
 /* Arithmetic of the two MFMA kernels (conv forward / input gradient / filter gradient), process-wide, read at launch:
  *   0 fp32   (default) v_mfma_f32_32x32x2_f32 -- exact fp32 products; the reference's precision (model.py:35-42 float32)
  *   1 bf16   operands rounded to bf16 (round-to-nearest-even) on the way into v_mfma_f32_32x32x16_bf16, fp32 accumulate;

@@ -46,7 +46,15 @@ def test_train_signature_and_parity(fresh, tmp_path):
     # per-step scalar summaries under ./log/<timestamp> (model.py:26-29,116,121)
     model.writer.flush()
     files = os.listdir(model.log_dir)
-    assert len(files) == 8 and any(f.endswith('generator_summaries_cycle_loss.csv') for f in files)
+    csvs = [f for f in files if f.endswith('.csv')]
+    assert len(csvs) == 8 and any(f.endswith('generator_summaries_cycle_loss.csv') for f in csvs)
+    # ... and a TensorBoard event file: per train step one Event with the 5 generator scalars, one with the 3 discriminator scalars
+    from voice_converter_cyclegan_amd import tfio
+    evs = [f for f in files if f.startswith('events.out.tfevents.')]
+    assert len(evs) == 1 and len(files) == 9
+    ev = tfio.read_event_file(os.path.join(model.log_dir, evs[0]))
+    assert [e[1] for e in ev[1:]] == [0, 0, 1, 1] and [len(e[2]) for e in ev[1:]] == [5, 3, 5, 3]
+    assert abs(ev[3][2]['generator_summaries/generator_loss'] - float(g)) < 1e-6 * abs(float(g))
     rows = open(os.path.join(model.log_dir, [f for f in files if f.endswith('discriminator_loss.csv')][0])).read().split('\n')
     assert rows[0] == 'Wall time,Step,Value' and len(rows) == 4
 
@@ -72,6 +80,18 @@ def test_test_save_load(fresh, tmp_path):
     z = np.load(path + '.npz')
     assert 'generator_A2B/h1_conv/kernel' in z.files and 'discriminator_B/dense/bias/Adam_1' in z.files
     assert z['generator_B2A/upsample1d_block2_h1_gates/kernel'].shape == (5, 512, 512)
+    # the same save() also wrote the files tf.train.Saver would (reference model.py:140-146); a model restores from them alone
+    from voice_converter_cyclegan_amd import tfio
+    assert tfio.is_tf_checkpoint(path) and os.path.exists(os.path.join(os.path.dirname(path), 'checkpoint'))
+    tfv = tfio.read_tf_checkpoint(path)
+    assert sorted(tfv) == sorted(z.files) and tfv['generator_A2B/h1_conv/kernel'].shape == (15, 24, 128)
+    assert tfv['beta1_power'].shape == () and np.array_equal(tfv['discriminator_A/dense/kernel'], z['discriminator_A/dense/kernel'])
+    os.rename(path + '.npz', path + '.npz.moved')
+    model.engine.params.mul_(0.25)
+    model.load(filepath=path)                                                    # now from <path>.index / .data-00000-of-00001
+    assert torch.equal(model.engine.params, before)
+    with pytest.raises(IOError):
+        model.load(filepath=path + '.nowhere')
     module.reset_default_graph()
     m2 = CycleGAN(num_features=24, mode='test')
     m2.load(path)
@@ -95,6 +115,13 @@ def test_resume_is_exact(fresh, tmp_path):
     m2.load(path)
     gb, db = m2.train(A, B, 10, 5, 2e-4, 1e-4)
     assert abs(ga - gb) < 1e-4 * abs(ga) and abs(da - db) < 1e-4 * max(abs(da), 1e-3)
+    # the same resume through the TF checkpoint files (weights + Adam slots + beta powers all travel)
+    os.remove(path + '.npz')
+    module.reset_default_graph()
+    m3 = CycleGAN(num_features=24, seed=78)
+    m3.load(path)
+    gc, dc = m3.train(A, B, 10, 5, 2e-4, 1e-4)
+    assert abs(ga - gc) < 1e-4 * abs(ga) and abs(da - dc) < 1e-4 * max(abs(da), 1e-3)
 
 
 def test_injected_callables_take_the_autograd_path(fresh):

@@ -34,6 +34,7 @@ class ParamRec(C.Structure):
 SIGNATURES = [
     ('vc_version', i32, []),
     ('vc_last_error', C.c_char_p, []),
+    ('vc_crc32c', C.c_uint32, [vp, C.c_uint64, C.c_uint32]),
     ('vc_set_math_mode', i32, [i32]),
     ('vc_get_math_mode', i32, []),
     ('vc_prof_enable', i32, [i32]),

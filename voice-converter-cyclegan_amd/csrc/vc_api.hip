@@ -23,6 +23,35 @@ void vc_set_error(const char* fmt, ...) {
 }
 extern "C" const char* vc_last_error(void) { return g_err; }
 extern "C" int vc_version(void) { return 100; }
+// CRC-32C (Castagnoli), slicing-by-8: the checksum of TensorFlow's checkpoint bundles and event files
+// (model.py:21,26-29 tf.train.Saver / tf.summary.FileWriter); host-only utility for the checkpoint / summary writers.
+extern "C" uint32_t vc_crc32c(const void* data, uint64_t n, uint32_t crc) {
+    static uint32_t T[8][256];
+    static const bool init = [] {
+        for (uint32_t i = 0; i < 256; ++i) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; ++k) c = (c >> 1) ^ (0x82F63B78u & (0u - (c & 1u)));
+            T[0][i] = c;
+        }
+        for (uint32_t i = 0; i < 256; ++i)
+            for (int t = 1; t < 8; ++t) T[t][i] = (T[t - 1][i] >> 8) ^ T[0][T[t - 1][i] & 0xff];
+        return true;
+    }();
+    (void)init;
+    const unsigned char* p = (const unsigned char*)data;
+    crc = ~crc;
+    while (n && ((uintptr_t)p & 7)) { crc = (crc >> 8) ^ T[0][(crc ^ *p++) & 0xff]; --n; }
+    while (n >= 8) {
+        uint64_t v; memcpy(&v, p, 8);
+        v ^= crc;
+        crc = T[7][v & 0xff] ^ T[6][(v >> 8) & 0xff] ^ T[5][(v >> 16) & 0xff] ^ T[4][(v >> 24) & 0xff] ^
+              T[3][(v >> 32) & 0xff] ^ T[2][(v >> 40) & 0xff] ^ T[1][(v >> 48) & 0xff] ^ T[0][(v >> 56) & 0xff];
+        p += 8; n -= 8;
+    }
+    while (n--) crc = (crc >> 8) ^ T[0][(crc ^ *p++) & 0xff];
+    return ~crc;
+}
+
 #define VC_CHECK(x) do { int _r = (x); if (_r != 0) return _r; } while (0)
 #define VC_ARG(cond, ...) do { if (!(cond)) { vc_set_error(__VA_ARGS__); return VC_E_ARG; } } while (0)
 

@@ -19,20 +19,31 @@ from . import module as _module
 from .module import discriminator, generator_gatedcnn
 from .utils import l1_loss, l2_loss
 from .engine import CycleGANEngine, SCOPES, LOSS_NAMES
+from . import tfio
 
 G_SUMMARIES = ('cycle_loss', 'identity_loss', 'generator_loss_A2B', 'generator_loss_B2A', 'generator_loss')
 D_SUMMARIES = ('discriminator_loss_A', 'discriminator_loss_B', 'discriminator_loss')
 
 
 class ScalarWriter:
-    """Stand-in for tf.summary.FileWriter: one CSV per scalar in the layout TensorBoard exports
-    (`Wall time,Step,Value`, same as the reference's train_log/*.csv) under log_dir."""
+    """Stand-in for tf.summary.FileWriter (model.py:26-29,116,121).  Writes both
+      * a TensorBoard event file `events.out.tfevents.<time>.<host>` (one Event per add_summary call of the reference:
+        the merged generator summaries, then the merged discriminator summaries; tags `<group>/<name>`), and
+      * one CSV per scalar in the layout TensorBoard exports (`Wall time,Step,Value`, same as the reference's
+        train_log/*.csv, so train_log/plot.py reads them unchanged)
+    under log_dir."""
 
     def __init__(self, log_dir, flush_every=200):
         self.log_dir, self.flush_every, self.rows, self.n = log_dir, flush_every, {}, 0
+        self.events, self.pending = None, []
 
     def add(self, group, tag, step, value):
-        self.rows.setdefault((group, tag), []).append((time.time(), step, value))
+        now = time.time()
+        self.rows.setdefault((group, tag), []).append((now, step, value))
+        if self.pending and self.pending[-1][:2] == (group, step):
+            self.pending[-1][3]['%s/%s' % (group, tag)] = value
+        else:
+            self.pending.append((group, step, now, {'%s/%s' % (group, tag): value}))
         self.n += 1
         if self.n >= self.flush_every:
             self.flush()
@@ -41,6 +52,12 @@ class ScalarWriter:
         if not self.n:
             return
         os.makedirs(self.log_dir, exist_ok=True)
+        if self.events is None:
+            self.events = tfio.EventFileWriter(self.log_dir)
+        for _, step, wall, scalars in self.pending:
+            self.events.add_scalars(step, scalars, wall)
+        self.events.flush()
+        self.pending = []
         for (group, tag), rows in self.rows.items():
             path = os.path.join(self.log_dir, 'run_%s-tag-%s_%s.csv' % (os.path.basename(self.log_dir), group, tag))
             new = not os.path.exists(path)
@@ -63,6 +80,8 @@ class CycleGAN(object):
         self.mode = mode
         self._device = device or ('cuda:%d' % int(os.environ.get('LOCAL_RANK', '0')))
         self._seed, self._group = seed, process_group
+        # save() also writes the TF V2 checkpoint files the reference's Saver would (set False to keep only the .npz)
+        self.save_tf_checkpoint = os.environ.get('VC_SAVE_TF_CHECKPOINT', '1') != '0'
 
         self.build_model()
         self.optimizer_initializer()
@@ -181,15 +200,28 @@ class CycleGAN(object):
         path = os.path.join(directory, filename)
         with open(path + '.npz', 'wb') as f:
             np.savez(f, **out)
+        if self.save_tf_checkpoint:
+            # the files tf.train.Saver writes (minus the .meta graph): `<path>.index`, `<path>.data-00000-of-00001`, `checkpoint`
+            tfio.write_tf_checkpoint(path, out)
         if self.mode == 'train':
             self.writer.flush()
         return path
 
     def load(self, filepath):
+        """tf.train.Saver().restore: `<filepath>.npz` (ours) or a TF V2 checkpoint `<filepath>.index` + `.data-*` (ours or
+        one written by the reference, e.g. its published pre-trained model); a checkpoint without optimizer slots (or a
+        model built with mode='test', whose graph has no optimizers) restores the weights only."""
         eng = self.engine
-        with np.load(filepath + '.npz') as z:
-            d = {k: z[k] for k in z.files}
+        if os.path.exists(filepath + '.npz'):
+            with np.load(filepath + '.npz') as z:
+                d = {k: z[k] for k in z.files}
+        elif tfio.is_tf_checkpoint(filepath):
+            d = tfio.read_tf_checkpoint(filepath)
+        else:
+            raise IOError('no checkpoint at %s(.npz|.index)' % filepath)
         eng.load_tf_variables(d)
+        if self.mode != 'train' or not any(k.endswith('/Adam') for k in d):
+            return
         blocks_m, blocks_v = [], []
         for i, s in enumerate(SCOPES):
             lay = eng._layout(i)
