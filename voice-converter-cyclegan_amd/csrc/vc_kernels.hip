@@ -739,9 +739,26 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs p) {
 // =====================================================================================
 #define IN_EPS 1e-6f
 
+// cross-lane add inside a row of 16 lanes on the DPP path (no LDS round trip): CTRL = quad_perm / row_mirror encodings
+template <int CTRL> __device__ __forceinline__ float dpp_read(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, false));
+}
+// after this every lane of a row of 16 holds the row's sum
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_read<0xB1>(v);       // quad_perm [1,0,3,2]
+    v += dpp_read<0x4E>(v);       // quad_perm [2,3,0,1]   -> quad sums
+    v += dpp_read<0x141>(v);      // row_half_mirror       -> sums of 8
+    v += dpp_read<0x140>(v);      // row_mirror            -> sum of the row
+    return v;
+}
+// sum over the LPR (32 or 64) consecutive lanes that share one (sample, channel) row; every lane gets the total.
+// Rows of 16 on DPP, the last one or two steps through ds_bpermute (was 5-6 bpermutes per sum: the norm kernels are
+// latency-bound and issue 4-8 of these per thread).
 template <int LPR> __device__ __forceinline__ float group_sum(float v) {
+    static_assert(LPR == 32 || LPR == 64, "a row group is 32 or 64 lanes");
+    v = row16_sum(v);
 #pragma unroll
-    for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    for (int o = 16; o < LPR; o <<= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
@@ -1100,13 +1117,7 @@ __device__ __forceinline__ float c1_round(float v, int math) { return math == VC
 // 64-lane sum on the DPP path (4 cross-lane VALU adds inside each row of 16, then one readlane per row) -- the
 // ds_bpermute route of __shfl_xor costs an LDS round trip per step, which dominates when 72 values are reduced
 __device__ __forceinline__ float wave_sum_dpp(float v) {
-    auto dpp = [](float x, auto CTRL) {
-        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(CTRL)::value, 0xf, 0xf, false));
-    };
-    v += dpp(v, std::integral_constant<int, 0xB1>{});      // quad_perm [1,0,3,2]
-    v += dpp(v, std::integral_constant<int, 0x4E>{});      // quad_perm [2,3,0,1]   -> every lane holds its quad's sum
-    v += dpp(v, std::integral_constant<int, 0x141>{});     // row_half_mirror       -> sum of 8
-    v += dpp(v, std::integral_constant<int, 0x140>{});     // row_mirror            -> sum of the row of 16
+    v = row16_sum(v);
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0)) +
            __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16)) +
            __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32)) +
