@@ -353,3 +353,32 @@ def test_full_size_properties(built_lib):
     # unless an L1-loss sign flips (see _cmp_grads), which is still far below 1e-3 in L2
     # measured: bimodal, 6.5e-6 (atomics order only) or 1.08e-3 (one sign(.) of the L1 seed flipped)
     assert e2 < 5e-3, 'run-to-run gradient drift (rel-L2) %g' % e2
+
+
+def test_error_behaviour_of_the_c_abi(built_lib):
+    """bad arguments come back as an error code + vc_last_error text, never as a launch (include/vc_cyclegan.h conventions)"""
+    from voice_converter_cyclegan_amd import _lib
+    from voice_converter_cyclegan_amd._lib import lib, ptr, check, VcError
+    from voice_converter_cyclegan_amd.engine import CycleGANEngine
+    from tests import gpu_util as U
+    eng = CycleGANEngine(24, device='cuda:0', seed=3)
+    # n_frames must be a multiple of 4 (the reference pads utterances to that, preprocess.py:146-156)
+    with pytest.raises(VcError, match='multiple of 4'):
+        eng.generate(np.zeros((1, 24, 130), np.float32), 'A2B')
+    h = _lib.vp()
+    assert lib.vc_plan_create(24, 0, C.byref(h)) != 0 and lib.vc_plan_create(23, 128, C.byref(h)) != 0
+    # empty batch
+    p = eng.plan(128)
+    x = torch.zeros((1, 24, 128), device=U.DEV)
+    ws = torch.empty(lib.vc_step_workspace_floats(p, 1), device=U.DEV)
+    args = lambda B, w, n: (p, ptr(eng.params), ptr(eng.grads), ptr(x), ptr(x), B, 10.0, 5.0, ptr(eng.losses), None, None, w, n, U.stream())
+    assert lib.vc_cyclegan_step_grads(*args(0, ptr(ws), ws.numel())) != 0
+    assert b'bad args' in lib.vc_last_error()
+    # workspace one float short / missing
+    assert lib.vc_cyclegan_step_grads(*args(1, ptr(ws), ws.numel() - 1)) != 0
+    assert b'workspace too small' in lib.vc_last_error()
+    assert lib.vc_cyclegan_step_grads(*args(1, None, ws.numel())) != 0
+    # the same call with everything in order succeeds afterwards (no sticky error state)
+    check(lib.vc_cyclegan_step_grads(*args(1, ptr(ws), ws.numel())))
+    torch.cuda.synchronize()
+    assert torch.isfinite(eng.losses).all()
