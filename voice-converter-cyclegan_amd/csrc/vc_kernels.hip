@@ -1,14 +1,17 @@
 // vc_kernels.hip -- gfx950 (MI355X / CDNA4) device kernels of the CycleGAN-VC hot path.
 //
-//  igemm_kernel  : table-driven implicit GEMM on v_mfma_f32_32x32x2_f32 (exact fp32, k-ordered
-//                  fma chain).  Serves tf.layers.conv1d/conv2d forward (module.py:32-40,54-62)
-//                  and their input gradients (autodiff of model.py:107-108).
-//  wgrad_kernel  : filter gradient, same MFMA, reduction over (batch, pixels).
-//  norm_*_kernel : instance_norm_layer + gated_linear_layer (+ pixel_shuffler, + residual add),
-//                  wavefront-shuffle reductions (module.py:3-20,81,135-146).
-//  head_*        : tf.layers.dense(1, sigmoid) (module.py:211).
-//  loss_kernel   : utils.py:6-12 + loss algebra model.py:57-90, fused with the seed gradients.
-//  adam_kernel   : ApplyAdam (model.py:107-108).
+//  igemm_kl_kernel : table-driven implicit GEMM on v_mfma_f32_32x32x2_f32 (exact fp32, k-ordered fma chain), LDS tiles
+//                    k-contiguous.  Serves tf.layers.conv1d/conv2d forward (module.py:32-40,54-62) and their input
+//                    gradients (autodiff of model.py:107-108).  igemm_kernel is the k-major-LDS predecessor, kept as the
+//                    fallback for input gradients whose Cout is not a multiple of 4 and for A/B runs (VC_IGEMM_KL=0).
+//  wgrad_kernel    : filter gradient, same MFMA, reduction over (batch, pixels).
+//  c1_*_kernel     : the one Cin = 1 convolution (discriminator h1, module.py:201-202) on the vector ALU.
+//  norm_*_kernel   : instance_norm_layer + gated_linear_layer (+ pixel_shuffler, + residual add),
+//                    DPP / wavefront-shuffle reductions (module.py:3-20,81,135-146).
+//  head_*          : tf.layers.dense(1, sigmoid) (module.py:211).
+//  loss_kernel     : utils.py:6-12 + loss algebra model.py:57-90, fused with the seed gradients.
+//  adam_kernel     : ApplyAdam (model.py:107-108).
+//  MATH template parameter of the MFMA kernels: fp32 (default) / bf16 / bf16x3, see vc_set_math_mode.
 //
 // Wavefront = 64 lanes everywhere.  No CUDA compatibility paths.
 #include "vc_internal.h"
@@ -350,8 +353,11 @@ __global__ __launch_bounds__(64 * WMG * WNG, 2) void igemm_kernel(const IgemmMul
 //   weights, transp. : lanes along k, 16-B loads of 4 consecutive K rows (needs rows-per-tap % 4 == 0) -> 1 ds_write_b128
 // Row stride 36 floats: 8 consecutive rows start 36 banks apart -> every b128 access group is conflict-free.
 // =====================================================================================
+#ifndef VC_KL_OCC4
+#define VC_KL_OCC4 2          // workgroups per CU the 4-wave (64x64) instantiations are compiled for
+#endif
 template <int BM, bool AT, int WMG, int WNG, int MATH = VC_MATH_FP32>
-__global__ __launch_bounds__(64 * WMG * WNG, 2) void igemm_kl_kernel(const IgemmMulti mm) {
+__global__ __launch_bounds__(64 * WMG * WNG, (WMG * WNG == 4) ? VC_KL_OCC4 : 2) void igemm_kl_kernel(const IgemmMulti mm) {
     const IgemmArgs& p = mm.c[blockIdx.y];
     if (blockIdx.x >= (unsigned)(p.mtiles * p.ntiles) || blockIdx.z >= (unsigned)(p.groups * p.splitk)) return;
     constexpr int BN = 64, KC = 32, LDK = KC + 4;
