@@ -172,6 +172,11 @@ static bool c1_path(const Geom& g) {
     static const bool on = [] { const char* v = getenv("VC_C1_PATH"); return !v || atoi(v) != 0; }();
     return on && g.Cin == 1 && g.kh * g.kw <= 9;
 }
+// 1-D, stride 1, 24 input channels, 15 taps (the generator's h1 layer): weight-stationary kernel; VC_WSCONV=0 keeps the igemm
+static bool wsconv_path(const Geom& g) {
+    static const bool on = [] { const char* v = getenv("VC_WSCONV"); return !v || atoi(v) != 0; }();
+    return on && g.H == 1 && g.kh == 1 && g.sh == 1 && g.sw == 1 && g.Cin == 24 && g.kw == 15 && g.W % 4 == 0;   // 16-byte output stores
+}
 static C1Args c1_args(const Geom& g, int G, int B) {
     C1Args c{};
     c.B = B; c.H = g.H; c.W = g.W; c.Cout = g.Cout; c.kh = g.kh; c.kw = g.kw; c.sh = g.sh; c.sw = g.sw;
@@ -187,6 +192,13 @@ static int conv_fwd(const float* x, long x_gs, const float* w, long w_gs, const 
         if (query) { *query = false; return 0; }
         C1Args c = c1_args(g, G, B); c.x = x; c.x_gs = x_gs; c.w = w; c.w_gs = w_gs; c.bias = bias; c.b_gs = b_gs; c.y = y; c.y_gs = y_gs;
         return launch_c1_fwd(c, s);
+    }
+    if (wsconv_path(g)) {  // few input channels, 1-D, stride 1 (G.h1): weight-stationary kernel, plain stores
+        if (query) { *query = false; return 0; }
+        WsConvArgs c{}; c.x = x; c.w = w; c.bias = bias; c.y = y; c.x_gs = x_gs; c.w_gs = w_gs; c.b_gs = b_gs; c.y_gs = y_gs;
+        c.B = B; c.T = g.W; c.Cout = g.Cout; c.G = G;
+        const int r = launch_wsconv1d(c, g.Cin, g.kw, s, 2.0 * G * B * g.W * (double)g.Cout * g.kw * g.Cin);
+        if (r != -2) return r;
     }
     Table t; VC_CHECK(get_fwd_table(g, &t));
     IgemmArgs a{};

@@ -74,6 +74,17 @@ int launch_c1_dgrad(const C1Args& a, int accumulate, hipStream_t s);   // dx (+)
 int launch_c1_wgrad(const C1Args& a, hipStream_t s);                   // dw += ... (atomics)
 int vc_math_mode();
 
+// Weight-stationary 1-D convolution forward for few input channels (the generator's h1 layer, module.py:161-162:
+// 24 -> 2x128 channels, k = 15, stride 1): K = Cin*k = 360 is too short a loop for the tiled implicit GEMM (12 chunks
+// per workgroup, mostly prologue/epilogue).  Here a workgroup keeps a 32-row filter slab in LDS and streams pixel tiles
+// through it; the k-fold window expansion happens in LDS, so HBM sees every input frame once per slab.
+struct WsConvArgs {
+    const float* x; const float* w; const float* bias; float* y;
+    long x_gs, w_gs, b_gs, y_gs;          // signed group strides (floats)
+    int B, T, Cout, G;
+};
+int launch_wsconv1d(const WsConvArgs& a, int cin, int kw, hipStream_t s, double flops);   // returns -2 when the geometry is not built
+
 struct NormArgs {
     const float* y; const float* res; const float* gamma; const float* beta;
     const float* dout; const float* stats_in;
