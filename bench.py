@@ -75,7 +75,9 @@ def named_kernel_h1(lib, dev, B=256, reps=20, peak=FP32_MFMA_PEAK_TFLOPS, math='
         call()
     torch.cuda.synchronize()
     ms, n, fl = C.c_double(0), C.c_longlong(0), C.c_double(0)
-    lib.vc_prof_collect(0, C.byref(ms), C.byref(n), C.byref(fl))
+    lib.vc_prof_collect(2, C.byref(ms), C.byref(n), C.byref(fl))      # wsconv1d_kernel ...
+    if n.value == 0:
+        lib.vc_prof_collect(0, C.byref(ms), C.byref(n), C.byref(fl))  # ... or the tiled igemm when VC_WSCONV=0
     lib.vc_prof_enable(0)
     t = ms.value * 1e-3 / max(n.value, 1)
     nbytes = B * (24 * 128 + 256 * 128) * 4 + (15 * 24 * 256 + 256) * 4
@@ -208,7 +210,7 @@ def main():
                 'frac': ach / peak,
                 # HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
                 # (profiles/r01_pmc_hbm_traffic_b8.txt; FETCH_SIZE doubled per MI355X_MICROARCH.md, L3 hits included)
-                'traffic': 107.98e6 if (B, F, T, world, args.math) == (8, 24, 128, 1, 'fp32') else None,
+                'traffic': 110.41e6 if (B, F, T, world, args.math) == (8, 24, 128, 1, 'fp32') else None,
                 'traffic_unit': 'bytes/launch (offline PMC pass, upper bound: Infinity-Cache hits counted)',
                 'kernel': name, 'launches_per_step': n // n_prof,
                 'condition': 'step chains serialised on one stream (no co-running launches); see --serial',

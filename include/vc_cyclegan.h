@@ -58,7 +58,7 @@ int  vc_get_math_mode(void);
  * While enabled every igemm/wgrad launch is bracketed by hipEvents on its stream. */
 int  vc_prof_enable(int on);
 /* Collect: sum of kernel ms, launch count and algorithmic FLOPs since enable/reset,
- * kind 0 = igemm (conv fwd + dgrad), 1 = wgrad.  Synchronises the recorded events. */
+ * kind 0 = igemm (conv fwd + dgrad), 1 = wgrad, 2 = wsconv1d (generator h1 forward).  Synchronises the recorded events. */
 int  vc_prof_collect(int kind, double* ms, long long* launches, double* flops);
 /* Per-launch records (in launch order) since enable: fills ms[i], flops[i] for i < max_n; returns the record count. */
 int  vc_prof_records(int kind, double* ms, double* flops, int max_n);

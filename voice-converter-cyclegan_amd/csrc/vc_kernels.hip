@@ -1866,7 +1866,7 @@ int launch_wsconv1d(const WsConvArgs& a, int cin, int kw, hipStream_t s, double 
     int parts = env_int("VC_WS_SLOTS", 512) / (slabs * a.G); if (parts < 1) parts = 1; if (parts > ntiles) parts = ntiles;
     dim3 grid(parts, slabs, a.G), block(256);
     const int math = g_math.load();
-    ProfScope ps(0, flops, s);
+    ProfScope ps(2, flops, s);                       // its own timing class: bench.py's roofline leg is about igemm_kl_kernel
     if (math == VC_MATH_BF16) wsconv1d_kernel<24, 15, VC_MATH_BF16><<<grid, block, 0, s>>>(a);
     else if (math == VC_MATH_BF16X3) wsconv1d_kernel<24, 15, VC_MATH_BF16X3><<<grid, block, 0, s>>>(a);
     else wsconv1d_kernel<24, 15, VC_MATH_FP32><<<grid, block, 0, s>>>(a);
