@@ -39,6 +39,12 @@ CONV_CASES = [
     (512, 1, 2, 2048, 1, 5, 1, 1, 3),
     (256, 1, 8, 24, 1, 15, 1, 1, 3),
     (24, 1, 8, 256, 1, 15, 1, 1, 3),
+    (512, 1, 32, 2048, 1, 3, 1, 1, 8),     # residual h1 at the B=8 step's sizes (cycle hop)
+    (1024, 1, 32, 512, 1, 3, 1, 1, 16),    # residual h2, first hop (2B)
+    (512, 1, 32, 2048, 1, 5, 1, 1, 4),     # up-sample 1 (k = 5)
+    (512, 1, 64, 1024, 1, 5, 1, 1, 8),     # up-sample 2 (T = 64)
+    (64, 1, 128, 48, 1, 3, 1, 1, 2),       # T = 128, narrow output
+    (32, 1, 16, 80, 1, 5, 1, 1, 4),        # T = 16: one pixel tile per sample
     (1, 9, 10, 64, 3, 3, 2, 2, 3),         # Cin = 1 -> vector-ALU kernels (c1_*): strided both ways, odd H
     (1, 1, 40, 40, 1, 5, 1, 1, 2),         # Cin = 1, 1-D, Cout not a multiple of 32
     (1, 5, 6, 8, 2, 2, 1, 1, 1),           # Cin = 1, even kernel (SAME pads only right/bottom)
@@ -60,7 +66,7 @@ def test_conv_fwd_dgrad_wgrad(built_lib, case):
 
 # bf16 MFMA modes (vc_set_math_mode): 'bf16' is checked against the oracle with the SAME operand rounding (so only the
 # fp32 accumulation order differs -> same tolerance as fp32); 'bf16x3' against the unrounded oracle (2^-16 per product).
-MATH_CASES = [CONV_CASES[i] for i in (0, 1, 3, 4, 6, 7, 8, 9, 11, 13, 15, 16, 22)]
+MATH_CASES = [CONV_CASES[i] for i in (0, 1, 3, 4, 6, 7, 8, 9, 11, 13, 15, 16, 22, 23, 28)]
 
 
 @pytest.mark.parametrize('mode', ['bf16', 'bf16x3'])
