@@ -356,8 +356,20 @@ __global__ __launch_bounds__(64 * WMG * WNG, 2) void igemm_kernel(const IgemmMul
 #ifndef VC_KL_OCC4
 #define VC_KL_OCC4 2          // workgroups per CU the 4-wave (64x64) instantiations are compiled for
 #endif
+#ifdef VC_DBG_TIMELINE
+// debug build: s_memtime at four points of every workgroup of the last igemm_kl launch (tools/timeline.py)
+__device__ unsigned long long g_timeline[4 * 8192];
+extern "C" int vc_dbg_timeline(unsigned long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_timeline), sizeof(unsigned long long) * n);
+}
+#define VC_TL(slot) do { if (threadIdx.x == 0) { const unsigned bid = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z); \
+    if (bid < 8192) g_timeline[4 * bid + (slot)] = __builtin_amdgcn_s_memtime(); } } while (0)
+#else
+#define VC_TL(slot) do { } while (0)
+#endif
 template <int BM, bool AT, int WMG, int WNG, int MATH = VC_MATH_FP32>
 __global__ __launch_bounds__(64 * WMG * WNG, (WMG * WNG == 4) ? VC_KL_OCC4 : 2) void igemm_kl_kernel(const IgemmMulti mm) {
+    VC_TL(0);
     const IgemmArgs& p = mm.c[blockIdx.y];
     if (blockIdx.x >= (unsigned)(p.mtiles * p.ntiles) || blockIdx.z >= (unsigned)(p.groups * p.splitk)) return;
     constexpr int BN = 64, KC = 32, LDK = KC + 4;
@@ -524,6 +536,7 @@ __global__ __launch_bounds__(64 * WMG * WNG, (WMG * WNG == 4) ? VC_KL_OCC4 : 2) 
     fetch_tab(c0 + 2);
     items(LD0{}, ST0{}, S0{}, S0{}, c0, 0);
     __syncthreads();
+    VC_TL(1);
     for (int c = c0; c < c1; c += 2) {
         chunk(S0{}, S1{}, 0, c + 2);        // multiply LDS[0] = chunk c; load c+2 -> set 0; store set 1 (c+1) -> LDS[1]
         __syncthreads();
@@ -532,9 +545,14 @@ __global__ __launch_bounds__(64 * WMG * WNG, (WMG * WNG == 4) ? VC_KL_OCC4 : 2) 
         __syncthreads();
     }
 
+    VC_TL(2);
     f32x16 acc = accb[0] + accb[1];
     // ---- epilogue: + bias[m] (+ addend) ; plain store or atomic add
+#ifdef VC_DBG_NOATOMIC
+    const bool atomic = false;       // timing experiment only (wrong sums under split-K)
+#else
     const bool atomic = p.splitk > 1 || p.accumulate;
+#endif
     const bool first = sp == 0;
     float* Yg = p.Y + (long)g * p.y_gs;
     const float* Bg = (p.bias && first) ? p.bias + (long)g * p.bias_gs : nullptr;
@@ -554,6 +572,7 @@ __global__ __launch_bounds__(64 * WMG * WNG, (WMG * WNG == 4) ? VC_KL_OCC4 : 2) 
             }
         }
     }
+    VC_TL(3);
 }
 
 // =====================================================================================
