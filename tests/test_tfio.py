@@ -110,3 +110,45 @@ def test_event_file_round_trip(tfio, tmp_path):
     open(w.path, 'wb').write(bad)
     with pytest.raises(ValueError, match='checksum'):
         tfio.read_event_file(w.path)
+
+
+def test_table_bytes_of_a_minimal_table_are_stable(tfio, tmp_path):
+    """Byte-level pin of the writer on the smallest table (one key, one block): block entry = varints (shared 0, non-shared 1,
+    value length 2) + key + value, one restart at offset 0, restart count 1, trailer = type 0 + masked CRC-32C; then the empty
+    metaindex block, the index block, and the 48-byte footer ending in the table magic."""
+    path = str(tmp_path / 'one.index')
+    tfio.write_table(path, [(b'k', b'vv')])
+    buf = open(path, 'rb').read()
+    block = bytes([0, 1, 2]) + b'k' + b'vv' + struct.pack('<II', 0, 1)
+    assert buf[:len(block)] == block and buf[len(block)] == 0
+    assert struct.unpack('<I', buf[len(block) + 1:len(block) + 5])[0] == tfio.mask_crc(tfio.crc32c(b'\x00', tfio.crc32c(block)))
+    meta_off = len(block) + 5
+    assert buf[meta_off:meta_off + 8] == struct.pack('<II', 0, 1)                     # empty metaindex block: restart array only
+    footer = buf[-48:]
+    assert footer[0] == meta_off and footer[1] == 8                                   # metaindex handle (offset, size) as varints
+    assert footer[2] == meta_off + 8 + 5                                              # index block follows the metaindex block + trailer
+    assert footer[40:] == struct.pack('<Q', 0xdb4775248b80fb57) and len(buf) == footer[2] + footer[3] + 5 + 48
+
+
+def test_checkpoint_round_trip_random(tfio, tmp_path):
+    """hypothesis: arbitrary variable names / shapes / dtypes survive write -> read, in key order, with scalars and empties."""
+    from hypothesis import given, settings, strategies as st
+    names = st.text(alphabet='abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMNOPQRSTUVWXYZ_/0123456789', min_size=1, max_size=40)
+    shapes = st.lists(st.integers(0, 5), min_size=0, max_size=4)
+    dts = st.sampled_from([np.float32, np.float64, np.int32, np.int64])
+    counter = [0]
+
+    @settings(max_examples=25, deadline=None)
+    @given(st.dictionaries(names, st.tuples(shapes, dts), min_size=1, max_size=40), st.integers(0, 2 ** 31 - 1))
+    def run(spec, seed):
+        rng = np.random.default_rng(seed)
+        V = {n: (rng.standard_normal(sh) * 100).astype(dt) for n, (sh, dt) in spec.items()}
+        counter[0] += 1
+        prefix = str(tmp_path / ('c%d' % counter[0]) / 'm.ckpt')
+        tfio.write_tf_checkpoint(prefix, V)
+        R = tfio.read_tf_checkpoint(prefix)
+        assert list(R) == sorted(V, key=lambda s: s.encode())
+        for k, v in V.items():
+            assert R[k].dtype == v.dtype and R[k].shape == v.shape and np.array_equal(R[k], v)
+
+    run()

@@ -305,7 +305,8 @@ def read_tf_checkpoint(prefix, verify=True):
                 shape.append(next((v for ff, _, v in _parse(dim) if ff == 1), 0))
         shard = e.get(3, 0)
         if shard not in shards:
-            shards[shard] = np.memmap('%s.data-%05d-of-%05d' % (prefix, shard, num_shards), dtype=np.uint8, mode='r')
+            fn = '%s.data-%05d-of-%05d' % (prefix, shard, num_shards)
+            shards[shard] = np.memmap(fn, dtype=np.uint8, mode='r') if os.path.getsize(fn) else np.zeros(0, np.uint8)   # (an empty file cannot be mapped)
         off, size = e.get(4, 0), e.get(5, 0)
         raw = np.asarray(shards[shard][off:off + size])
         if verify and 6 in e and crc32c(raw) != unmask_crc(struct.unpack('<I', e[6])[0]):
