@@ -53,6 +53,13 @@ def test_layout_matches_oracle_names_and_counts(built_lib):
     flat = G.pack(P, 'generator_B2A')
     back = G.unpack(flat, 'generator_B2A')
     assert all(np.array_equal(back[k], P[k]) for k in back)
+    # the records tile the block: every float belongs to exactly one variable (no overlap), the rest is alignment padding
+    for L, scope in ((G, 'generator_A2B'), (D, 'discriminator_A')):
+        ones = {scope + '/' + x['name']: np.ones(x['shape'], np.float32) for x in L.recs}
+        flat1 = L.pack(ones, scope)
+        twos = {k: 2 * v for k, v in ones.items()}
+        assert float(flat1.sum(dtype=np.float64)) == L.n_params and int((flat1 == 0).sum()) == L.n_floats - L.n_params
+        assert float(L.pack(twos, scope).sum(dtype=np.float64)) == 2 * L.n_params and L.n_floats - L.n_params < 64
     r = {x['name']: x for x in G.recs}
     a, b = r['residual1d_block2_h1_conv/kernel'], r['residual1d_block2_h1_gates/kernel']
     assert b['offset'] == a['offset'] + 1024 and a['ld'] == b['ld'] == 2048
