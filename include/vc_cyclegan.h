@@ -46,14 +46,21 @@ const char* vc_last_error(void);
 /* CRC-32C (Castagnoli) of `n` host bytes, continuing from `crc` (0 to start): the checksum inside TensorFlow's
  * checkpoint bundles and event files, which CycleGAN.save()/the summary writer emit (model.py:21,26-29).  Host only. */
 uint32_t vc_crc32c(const void* data, uint64_t n, uint32_t crc);
-/* Arithmetic of the two MFMA kernels (conv forward / input gradient / filter gradient), process-wide, read at launch:
+/* Arithmetic of the MFMA kernels (conv forward / input gradient / filter gradient):
  *   0 fp32   (default) v_mfma_f32_32x32x2_f32 -- exact fp32 products; the reference's precision (model.py:35-42 float32)
  *   1 bf16   operands rounded to bf16 (round-to-nearest-even) on the way into v_mfma_f32_32x32x16_bf16, fp32 accumulate;
  *            tensors in HBM, instance-norm statistics, losses and Adam state stay fp32 (BASELINE config 3)
  *   2 bf16x3 operands split hi+lo into two bf16, three MFMAs (hi*hi + hi*lo + lo*hi): ~2^-16 relative per product
- * Returns -1 on an unknown mode. */
+ * The mode is a property of a PLAN (vc_plan_set_math_mode): every launch made through a plan uses the plan's mode,
+ * so two plans in one process never interfere.  vc_set_math_mode sets the calling THREAD's default: the mode of the
+ * operator-level calls below (which carry no plan) and the initial mode of plans that thread creates.
+ * Returns VC_E_ARG on an unknown mode. */
 int  vc_set_math_mode(int mode);
 int  vc_get_math_mode(void);
+/* tools/tune_igemm.py ONLY: forces the tile rows (64 / 128), K groups per workgroup (1, 2, 4) and split-K factor of every
+ * following implicit-GEMM launch of the process; (0, 0, 0) restores the automatic choice.  Not thread-safe, not for
+ * production use -- it exists so that the measured table (csrc/vc_tuned_igemm.h) can be regenerated. */
+int  vc_tune_igemm_override(int tile_rows, int k_groups, int splitk);
 /* Opt-in per-launch timing of the implicit-GEMM kernels (bench.py roofline leg).
  * While enabled every igemm/wgrad launch is bracketed by hipEvents on its stream. */
 int  vc_prof_enable(int on);
@@ -159,9 +166,16 @@ int vc_adam_tf_update(float* p, float* m, float* v, const float* g, int64_t n,
                       float alpha, float beta1, float beta2, float eps, float grad_scale, void* stream);
 
 /* ---- network level --------------------------------------------------------- */
-/* Geometry plan for num_features x n_frames inputs (n_frames % 4 == 0). */
+/* Geometry plan for num_features x n_frames inputs (n_frames % 4 == 0): geometry tables of every layer of both networks
+ * (forward, input gradient, filter gradient), streams and events of the step schedule.  vc_plan_create_inference builds
+ * only what vc_generator_forward needs (CycleGAN.test, model.py:128-137: a new utterance length per call) -- the other
+ * network-level entry points refuse such a plan.  vc_plan_destroy gives the tables back (geometries are shared between
+ * plans and freed with their last user). */
 int  vc_plan_create(int num_features, int n_frames, vc_plan** out);
+int  vc_plan_create_inference(int num_features, int n_frames, vc_plan** out);
 void vc_plan_destroy(vc_plan* p);
+int  vc_plan_set_math_mode(vc_plan* p, int mode);     /* see vc_set_math_mode */
+int  vc_plan_get_math_mode(const vc_plan* p);
 /* Workspace sizes in floats for batch B per group. */
 int64_t vc_generator_save_floats(const vc_plan* p, int B);       /* activations kept for backward */
 int64_t vc_discriminator_save_floats(const vc_plan* p, int B);
@@ -199,14 +213,16 @@ int64_t vc_flat_param_floats(const vc_plan* p);
 int64_t vc_flat_offset(const vc_plan* p, int net /*0..3*/);
 int64_t vc_step_workspace_floats(const vc_plan* p, int B);
 /* One fused forward+backward of the whole CycleGAN graph (model.py:44-90):
- * inputs A,B [B][F][T]; params/grads flat buffers; grads are ZEROED then filled.
+ * inputs A,B [B][F][T]; params/grads flat buffers (16-byte aligned); every element of grads is (over)written: filter
+ * gradients by plain stores of their single launch, everything that is accumulated (biases, gamma/beta, padding) is
+ * zeroed first by one multi-buffer launch -- the caller never has to clear grads.
  * losses[8] (device) = cycle_loss, identity_loss, generator_loss_A2B,
  * generator_loss_B2A, generator_loss, discriminator_loss_A, discriminator_loss_B,
  * discriminator_loss (model.py:155-167).  gen_A/gen_B [B][F][T] receive
  * generation_A / generation_B (model.py:112).  The Adam updates (vc_adam_tf_update)
  * and, for N>1 ranks, the gradient all-reduce are issued by the caller.
- * d_first != 0 additionally records (hipEvent) when the discriminator gradients
- * are complete so the caller can overlap their all-reduce: see vc_step_d_grads_ready. */
+ * Events recorded inside let the caller overlap both with the backward: vc_step_wait_d_grads / vc_step_wait_g_bucket,
+ * or simply call vc_step_exchange_and_update. */
 int vc_cyclegan_step_grads(const vc_plan* p, const float* params, float* grads,
                            const float* A, const float* B, int batch,
                            float lambda_cycle, float lambda_identity,
@@ -214,7 +230,7 @@ int vc_cyclegan_step_grads(const vc_plan* p, const float* params, float* grads,
                            float* workspace, int64_t workspace_floats, void* stream);
 /* The step runs its independent chains (cycle-hop forward || D forward; generator_loss backward || discriminator_loss
  * backward) on `stream` and an internal side stream, joined before it returns.  enabled = 0 serialises them on `stream`
- * (used when timing individual kernels, so launches do not share the chip).  Default: enabled (env VC_STEP_STREAMS=1 disables). */
+ * (used when timing individual kernels, so launches do not share the chip).  Default: enabled. */
 int vc_plan_set_overlap(vc_plan* p, int enabled);
 
 /* Makes `other_stream` wait until the discriminator half of `grads` from the most recent
@@ -231,6 +247,27 @@ int vc_step_wait_d_grads(const vc_plan* p, void* other_stream);
 int vc_step_num_g_buckets(const vc_plan* p);
 int vc_step_g_bucket(const vc_plan* p, int k, int64_t* lo, int64_t* hi);
 int vc_step_wait_g_bucket(const vc_plan* p, int k, void* other_stream);
+
+/* ---- data parallel: the step's one gradient exchange (the reference itself is single-process, model.py:22) ----
+ * One process per GPU, replicas identical, global batch split contiguously over the ranks.  RCCL is bound at run time
+ * (dlopen librccl.so.1); single-GPU users never need it. */
+typedef struct vc_comm vc_comm;
+/* ncclGetUniqueId: rank 0 fills 128 bytes and ships them to the other ranks by any means (file, socket, MPI, a
+ * torch.distributed broadcast). */
+int vc_comm_unique_id(void* id128);
+/* ncclCommInitRank on the calling thread's current HIP device; collective over all `world` ranks. */
+int vc_comm_init(int rank, int world, const void* id128, vc_comm** out);
+int vc_comm_destroy(vc_comm* c);
+int vc_comm_world(const vc_comm* c);                   /* ranks RCCL reports for this communicator (1 for NULL) */
+/* in-place SUM all-reduce of n floats on `stream` (ncclAllReduce, fp32) */
+int vc_allreduce_f32(const vc_comm* c, float* buf, int64_t n, void* stream);
+/* After vc_cyclegan_step_grads: gradient exchange + both ApplyAdam updates (model.py:107-108 / 112-119), segment by
+ * segment on `update_stream` as soon as a segment's gradients are final and its weights no longer read (the events of
+ * vc_step_wait_*): SUM all-reduce over `comm` (NULL or world 1: none), then Adam with grad_scale 1/world.  alpha_g /
+ * alpha_d as in vc_adam_tf_update, one per optimizer.  The caller makes its main stream wait for `update_stream`
+ * before the next step. */
+int vc_step_exchange_and_update(const vc_plan* p, const vc_comm* comm, float* params, float* grads, float* m, float* v,
+                                float alpha_g, float alpha_d, float beta1, float beta2, float eps, void* update_stream);
 
 #ifdef __cplusplus
 }

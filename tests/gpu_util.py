@@ -45,10 +45,10 @@ def conv_dgrad(dy, w, H, W, kh, kw, sh, sw, addend=None, init=None):
     return dx
 
 
-def conv_wgrad(x, dy, kh, kw, sh, sw):
+def conv_wgrad(x, dy, kh, kw, sh, sw, init=None):
     G, B, Cin, H, W = x.shape
     Cout = dy.shape[2]
-    dw = torch.zeros((G, kh, kw, Cin, Cout), device=DEV)
+    dw = init.clone() if init is not None else torch.zeros((G, kh, kw, Cin, Cout), device=DEV)
     check(lib.vc_conv2d_wgrad(ptr(x), x[0].numel(), ptr(dy), dy[0].numel(), ptr(dw), dw[0].numel(),
                               G, B, Cin, H, W, Cout, kh, kw, sh, sw, stream()), 'conv_wgrad')
     return dw

@@ -48,6 +48,15 @@ CONV_CASES = [
     (1, 9, 10, 64, 3, 3, 2, 2, 3),         # Cin = 1 -> vector-ALU kernels (c1_*): strided both ways, odd H
     (1, 1, 40, 40, 1, 5, 1, 1, 2),         # Cin = 1, 1-D, Cout not a multiple of 32
     (1, 5, 6, 8, 2, 2, 1, 1, 1),           # Cin = 1, even kernel (SAME pads only right/bottom)
+    # the shapes bench.py TIMES (timed paths must be tested paths): the named north-star kernel, G.h1 at B=256
+    # (module.py:161-162; wsconv1d_kernel walks 8 tiles per workgroup), and an 8 x 2048-frame inference batch (16 tiles)
+    (24, 1, 128, 256, 1, 15, 1, 1, 256),
+    (24, 1, 2048, 256, 1, 15, 1, 1, 8),
+    (24, 1, 132, 256, 1, 15, 1, 1, 5),     # ragged last tile of every sample (T % 128 != 0), odd tile count
+    (36, 1, 256, 256, 1, 15, 1, 1, 2),     # config 5's h1 (36 MCEPs): taps of 36 rows padded to 64 in the K table
+    (256, 1, 256, 36, 1, 15, 1, 1, 2),     # config 5's o1
+    (1024, 1, 32, 512, 1, 3, 1, 1, 8),     # residual h2, cycle hop: K groups inside the workgroup + split-K
+    (256, 1, 128, 24, 1, 15, 1, 1, 8),     # o1 at B = 8: 24-row taps (padded to 32) in the input-gradient table
 ]
 
 
@@ -72,6 +81,7 @@ MATH_CASES = [CONV_CASES[i] for i in (0, 1, 3, 4, 6, 7, 8, 9, 11, 13, 15, 16, 22
 @pytest.mark.parametrize('mode', ['bf16', 'bf16x3'])
 @pytest.mark.parametrize('case', MATH_CASES)
 def test_conv_bf16_modes(built_lib, case, mode):
+    """operator-level calls carry no plan: they run in the calling thread's default mode (vc_set_math_mode)"""
     from voice_converter_cyclegan_amd._lib import lib, check
     O = _oracle()
     check(lib.vc_set_math_mode({'bf16': 1, 'bf16x3': 2}[mode]))
@@ -142,6 +152,10 @@ def _conv_check(case):
     dw_d = U.conv_wgrad(x_d, dy_d, kh, kw, sh, sw)
     e = U.rel_err(dw_d.cpu().numpy(), np.stack(dws))
     assert e < TOL, 'wgrad rel err %g' % e
+    # the operator ALWAYS accumulates: a second call doubles the result (atomics path on a non-zero destination)
+    check_acc = U.conv_wgrad(x_d, dy_d, kh, kw, sh, sw, init=dw_d)
+    e = U.rel_err(check_acc.cpu().numpy(), 2 * np.stack(dws))
+    assert e < TOL, 'wgrad accumulate rel err %g' % e
 
 
 def test_conv_group_stride_negative(built_lib):

@@ -1,6 +1,9 @@
 """-m gpu: network- and step-level parity of the HIP path (through the C-ABI / engine)
 against the numpy oracle on identical seeded inputs and weights.  fp32; tolerance 1e-3
-(BASELINE.json north_star), measured relative to each tensor's max magnitude."""
+(BASELINE.json north_star), measured relative to each tensor's max magnitude.
+
+What is timed is what is tested: the whole step vs the oracle at B = 1, 2 AND at the benched B = 8
+(BASELINE configs[1], reference model.py:110-125) -- 8 scalars, generation_A/B, all 119.8 M gradients."""
 import ctypes as C
 
 import numpy as np
@@ -14,9 +17,10 @@ IN_BIAS_SUFFIX = ('_h1_conv/bias', '_h1_gates/bias', '_h2_conv/bias')   # conv b
 
 
 L1_GAP_MIN = 5e-5
+BF16_GAP_MIN = 2e-3      # bf16 mode: the two sides' forwards differ by ~1e-3 (neighbouring-bf16 roundings); ties must be farther away
 
 
-def _setup(B, T=128, F=24, seed=11, lambda_identity=5.0, gap=True):
+def _setup(B, T=128, F=24, seed=11, lambda_identity=5.0, gap=True, rounding=None):
     """Seeded weights + inputs for both sides.  utils.l1_loss differentiates to sign(y_hat - y): an element whose
     |y_hat - y| is inside fp32 rounding noise (~3e-6 here) may take either sign in two correct implementations, and at
     B <= 2 ONE such element moves the o1 gradients by > 1 % (2 / sqrt(B*24*128) of the seed gradient).  So the seed is
@@ -31,8 +35,12 @@ def _setup(B, T=128, F=24, seed=11, lambda_identity=5.0, gap=True):
         Bm = rng.standard_normal((B, F, T)).astype(np.float32)
         if not gap:
             break
-        O.generator_losses_and_grads(P, A, Bm, 10.0, lambda_identity, want_grads=False)
-        if O.generator_losses_and_grads.last_l1_gap >= L1_GAP_MIN:
+        O.set_operand_rounding(rounding)          # the tie check runs in the arithmetic the comparison will use
+        try:
+            O.generator_losses_and_grads(P, A, Bm, 10.0, lambda_identity, want_grads=False)
+        finally:
+            O.set_operand_rounding(None)
+        if O.generator_losses_and_grads.last_l1_gap >= (L1_GAP_MIN if rounding is None else BF16_GAP_MIN):
             break
     else:
         pytest.fail('no seed with an L1 tie gap >= %g' % L1_GAP_MIN)
@@ -45,16 +53,15 @@ import contextlib
 
 
 @contextlib.contextmanager
-def _math(mode, O):
-    """run the HIP path in a math mode and the oracle with the matching operand rounding"""
-    from voice_converter_cyclegan_amd.engine import CycleGANEngine
-    CycleGANEngine.set_math(mode)
+def _math(mode, O, eng):
+    """run the engine's plans in a math mode (vc_plan_set_math_mode) and the oracle with the matching operand rounding"""
+    eng.set_math(mode)
     O.set_operand_rounding('bf16' if mode == 'bf16' else None)
     try:
         yield
     finally:
         O.set_operand_rounding(None)
-        CycleGANEngine.set_math('fp32')
+        eng.set_math('fp32')
 
 
 # bf16 mode vs the oracle with the same operand rounding: what differs is fp32 summation order plus the occasional
@@ -69,11 +76,11 @@ def _is_noise_bias(name):
             and not name.endswith(('/h1_conv/bias', '/h1_conv_gates/bias')))
 
 
-def _cmp_grads(got, ref, tol=TOL):
-    """per-tensor relative L2 error < tol, and max error < 5% of the tensor's max.
-    Why not max-norm at 1e-3: utils.l1_loss's gradient is sign(y_hat - y)/N, so one element whose
-    |difference| is below fp32 rounding may legitimately flip between two fp32 evaluations (GPU vs
-    oracle, or two GPU runs with different atomic order) and moves a few weights by ~2*lambda/N."""
+def _cmp_grads(got, ref, tol=TOL, tol_max=1e-2):
+    """per-tensor relative L2 error < tol (1e-3, the north_star figure) AND max error < 1 % of the tensor's max.
+    The seeds are tie-free (_setup: no L1 element of the oracle's forward within 5e-5 of a sign flip), so no flipped
+    sign(y_hat - y) of utils.l1_loss can hide in these bounds; what remains is fp32 summation order (measured ~1e-5
+    rel-L2, ~1e-4 max)."""
     bad = []
     for n, r in ref.items():
         g = got[n].reshape(r.shape).astype(np.float64)
@@ -82,7 +89,7 @@ def _cmp_grads(got, ref, tol=TOL):
         r = r.astype(np.float64)
         e2 = np.linalg.norm(g - r) / (np.linalg.norm(r) + 1e-30)
         em = np.abs(g - r).max() / (np.abs(r).max() + 1e-30)
-        if not (e2 < tol and em < 5e-2):
+        if not (e2 < tol and em < tol_max):
             bad.append((n, float(e2), float(em), float(np.abs(r).max())))
     return bad
 
@@ -109,7 +116,7 @@ def test_generator_backward(built_lib, mode):
     B, T = 2, 64
     O, P, A, Bm, eng = _setup(B, T, gap=False)
     tol = BF16_TOL if mode == 'bf16' else TOL          # bf16x3 is held to the fp32 tolerance
-    with _math(mode, O):
+    with _math(mode, O, eng):
         y, cache = O.generator_fwd(P, 'generator_B2A', A)
         dy = np.random.default_rng(5).standard_normal(y.shape).astype(np.float32)
         Gr = {}
@@ -118,7 +125,7 @@ def test_generator_backward(built_lib, mode):
     assert U.rel_err(y_d.cpu().numpy(), y) < tol
     e = U.rel_err(dx_d.cpu().numpy(), dx)
     assert e < tol, 'dx rel err %g' % e
-    bad = _cmp_grads(eng.tf_gradients(), Gr, tol=tol)
+    bad = _cmp_grads(eng.tf_gradients(), Gr, tol=tol, tol_max=10 * tol)
     assert not bad, bad[:8]
 
 
@@ -149,7 +156,7 @@ def test_discriminator_forward_backward(built_lib, mode):
     p = eng.plan(T)
     off = eng.offsets[3]
     hw = lib.vc_discriminator_out_elems(p)
-    with _math(mode, O):
+    with _math(mode, O, eng):
         o, cache = O.discriminator_fwd(P, 'discriminator_B', A)
         dout = np.random.default_rng(6).standard_normal(o.shape).astype(np.float32)
         Gr = {}
@@ -167,16 +174,16 @@ def test_discriminator_forward_backward(built_lib, mode):
     assert U.rel_err(o_d.cpu().numpy(), o.reshape(B, hw)) < tol
     e = U.rel_err(dx_d.cpu().numpy(), dx)
     assert e < tol, 'dx rel err %g' % e
-    bad = _cmp_grads(eng.tf_gradients(), Gr, tol=tol)
+    bad = _cmp_grads(eng.tf_gradients(), Gr, tol=tol, tol_max=10 * tol)
     assert not bad, bad[:8]
 
 
-@pytest.mark.parametrize('B', [1, 2])
+@pytest.mark.parametrize('B', [1, 2, 8])
 def test_train_step_losses_grads_and_updates(built_lib, B):
     """whole step: 8 logged scalars, generation_A/B, all 119.8 M gradients, parameters after
-    1 and 3 steps (model.py:110-125)."""
+    1 and 3 steps (model.py:110-125).  B = 8 is BASELINE configs[1], the configuration bench.py times."""
     from tests import gpu_util as U
-    O, P, A, Bm, eng = _setup(B)
+    O, P, A, Bm, eng = _setup(B, seed=16 if B == 8 else 11)      # seed 16: the first tie-free one at B = 8 (gap 6.9e-5)
     orc = O.CycleGANOracle({k: v.copy() for k, v in P.items()})
     gen_A = torch.empty((B, 24, 128), device=U.DEV); gen_B = torch.empty_like(gen_A)
     steps = 3 if B == 1 else 1
@@ -201,8 +208,10 @@ def test_train_step_losses_grads_and_updates(built_lib, B):
                 continue
             diff = np.abs(got[n] - r)
             frac = float((diff > 0.05 * lr).mean())
-            assert diff.max() <= 2.5 * lr * (step + 1), (step, n, float(diff.max()))
-            assert frac < 5e-3, (step, n, frac)
+            # Adam's first steps move every weight by ~lr * sign(g): a weight whose gradient is within rounding of zero
+            # may move the other way on the two sides (2 lr per step); they must be rare
+            assert diff.max() <= 2.02 * lr * (step + 1), (step, n, float(diff.max()))
+            assert frac < 1e-3, (step, n, frac)
 
 
 @pytest.mark.parametrize('mode', ['bf16', 'bf16x3'])
@@ -212,24 +221,24 @@ def test_train_step_bf16_modes(built_lib, mode):
              5e-2 rel-L2, because its ~1e-5 forward noise is no longer far below the L1 tie gap that _setup guarantees
              (fixed-upstream-gradient parity at 1e-3 is in test_generator_backward / test_discriminator_forward_backward).
     bf16   : against the oracle with the same bf16 operand rounding: losses 2e-3, generations 2e-2 (max-norm; measured
-             6.4e-3).  Whole-step GRADIENTS only get a sanity bound (rel-L2 < 0.3, measured 0.11 on o1_conv): the two
-             sides' generations differ by ~1e-3 (neighbouring-bf16 roundings), which flips sign(cycle - real) of
-             utils.l1_loss for ~0.2 % of the elements and each flip moves the seed gradient by 2*lambda/N.  Gradient
-             parity of the bf16 kernels proper is pinned where the upstream gradient is given, not derived from a sign():
-             test_conv_bf16_modes (1e-4) and test_generator_backward / test_discriminator_forward_backward [bf16] (2e-2).
+             6.4e-3), whole-step gradients 5e-2 rel-L2 -- on a seed whose *bf16* oracle forward has no L1 element
+             within 2e-3 of a sign flip (the two sides' generations differ by ~1e-3, neighbouring-bf16 roundings, so
+             the fp32 tie gap of 5e-5 would not protect sign(cycle - real) of utils.l1_loss).  Gradient parity of the
+             bf16 kernels with a GIVEN upstream gradient: test_conv_bf16_modes (1e-4) and test_generator_backward /
+             test_discriminator_forward_backward [bf16] (2e-2).
              Also bounded against the fp32 oracle: bf16 must be a faithful approximation, and must not BE fp32."""
     from tests import gpu_util as U
     B = 2
-    O, P, A, Bm, eng = _setup(B)
+    O, P, A, Bm, eng = _setup(B, rounding='bf16' if mode == 'bf16' else None)
     orc32 = O.CycleGANOracle({k: v.copy() for k, v in P.items()})
     orc32.train(A, Bm, 10.0, 5.0, 2e-4, 1e-4)
     gen_A = torch.empty((B, 24, 128), device=U.DEV); gen_B = torch.empty_like(gen_A)
     ref, tol_l, tol_g, tol_w = orc32, TOL, TOL, 5e-2
-    with _math(mode, O):
+    with _math(mode, O, eng):
         if mode == 'bf16':
             ref = O.CycleGANOracle({k: v.copy() for k, v in P.items()})
             ref.train(A, Bm, 10.0, 5.0, 2e-4, 1e-4)
-            tol_l, tol_g, tol_w = 2e-3, BF16_TOL, 0.3
+            tol_l, tol_g, tol_w = 2e-3, BF16_TOL, 5e-2
         eng.train_step(A, Bm, 10.0, 5.0, 2e-4, 1e-4, gen_A=gen_A, gen_B=gen_B)
         torch.cuda.synchronize()
     for k, v in ref.last.items():
@@ -282,10 +291,12 @@ def test_against_committed_golden_vectors(built_lib):
         if _is_noise_bias(n):
             continue
         l2 = float(np.linalg.norm(G[n].astype(np.float64)))
-        assert abs(l2 - z['grad_l2'][i]) <= 5e-3 * z['grad_l2'][i], (n, l2, float(z['grad_l2'][i]))
+        assert abs(l2 - z['grad_l2'][i]) <= 1e-3 * z['grad_l2'][i], (n, l2, float(z['grad_l2'][i]))
         r = np.random.default_rng(1000 + i).standard_normal(G[n].size)
         proj = float(G[n].reshape(-1).astype(np.float64) @ r)
-        assert abs(proj - z['grad_proj'][i]) <= 5e-3 * z['grad_l2'][i] * np.sqrt(G[n].size) / np.sqrt(G[n].size) + 2e-2 * z['grad_l2'][i], n
+        # a random projection of an n-vector has magnitude ~ its L2 norm; 1e-3 rel-L2 agreement bounds the difference
+        # of the projections by ~1e-3 * L2 (3 sigma: 3e-3)
+        assert abs(proj - z['grad_proj'][i]) <= 3e-3 * z['grad_l2'][i], (n, proj, float(z['grad_proj'][i]))
 
 
 def test_zero_lambda_identity_schedule(built_lib):

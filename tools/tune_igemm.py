@@ -1,0 +1,119 @@
+"""Measures every implicit-GEMM launch shape of the train step (conv forward + input gradient of every Cin > 1 layer at
+the batch sizes the step uses) under each built configuration (tile rows x K groups x split-K), and the filter
+gradients, through the C-ABI with HIP events (vc_prof_*).  Run on the GPU box:
+
+    python tools/tune_igemm.py [--batch 8] [--sweep] [--emit gpurun_out/vc_tuned_igemm.h]
+
+Without --sweep: one line per (layer, op) with the automatic configuration (what the step will run).
+With --sweep   : every configuration, the best one per shape, and (--emit) the table csrc/vc_tuned_igemm.h is made of.
+"""
+import argparse
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import __graft_entry__ as ge  # noqa: E402
+ge.build()
+from tests import gpu_util as U  # noqa: E402
+from voice_converter_cyclegan_amd._lib import lib, check  # noqa: E402
+
+# name: (Cin, H, W, Cout, kh, kw, sh, sw, batch factor: samples per group = factor * B)
+G_LAYERS = {'g_d1': (128, 1, 128, 512, 1, 5, 1, 2), 'g_d2': (256, 1, 64, 1024, 1, 5, 1, 2),
+            'g_r_h1': (512, 1, 32, 2048, 1, 3, 1, 1), 'g_r_h2': (1024, 1, 32, 512, 1, 3, 1, 1),
+            'g_u1': (512, 1, 32, 2048, 1, 5, 1, 1), 'g_u2': (512, 1, 64, 1024, 1, 5, 1, 1),
+            'g_o1': (256, 1, 128, 24, 1, 15, 1, 1), 'g_h1': (24, 1, 128, 256, 1, 15, 1, 1)}
+D_LAYERS = {'d_d1': (128, 24, 64, 512, 3, 3, 2, 2), 'd_d2': (256, 12, 32, 1024, 3, 3, 2, 2), 'd_d3': (512, 6, 16, 2048, 6, 3, 1, 2)}
+CONFIGS = [(bm, kg, sk) for bm in (128, 64) for kg in (1, 2, 4) for sk in (1, 2, 4, 8, 16) if not (bm == 128 and kg == 4)]
+
+
+def time_call(f, kind, reps):
+    for _ in range(2):
+        f()
+    torch.cuda.synchronize()
+    lib.vc_prof_enable(1)
+    for _ in range(reps):
+        f()
+    torch.cuda.synchronize()
+    ms, n, fl = C.c_double(0), C.c_longlong(0), C.c_double(0)
+    lib.vc_prof_collect(kind, C.byref(ms), C.byref(n), C.byref(fl))
+    lib.vc_prof_enable(0)
+    return 1e3 * ms.value / reps, int(n.value // reps)      # us per call, launches per call
+
+
+def shapes(B):
+    out = []
+    for nm, g in G_LAYERS.items():
+        for f in (1, 2):                                    # cycle hop (B) and first hop (2B)
+            out.append((nm + ('' if f == 1 else '_2B'), g, f * B))
+    for nm, g in D_LAYERS.items():
+        for f in (1, 2):                                    # generator-loss backward (B) and forward / D-loss backward (2B)
+            out.append((nm + ('' if f == 1 else '_2B'), g, f * B))
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--batch', type=int, default=8)
+    ap.add_argument('--sweep', action='store_true')
+    ap.add_argument('--emit', default='')
+    ap.add_argument('--reps', type=int, default=10)
+    ap.add_argument('--only', default='')
+    args = ap.parse_args()
+    rng = np.random.default_rng(0)
+    rows, table = [], []
+    for nm, (Cin, H, W, Cout, kh, kw, sh, sw), Bs in shapes(args.batch):
+        if args.only and args.only not in nm:
+            continue
+        G = 2
+        x = U.dev(rng.standard_normal((G, Bs, Cin, H, W)).astype(np.float32))
+        w = U.dev((rng.standard_normal((G, kh, kw, Cin, Cout)) / np.sqrt(kh * kw * Cin)).astype(np.float32))
+        b = U.dev(rng.standard_normal((G, Cout)).astype(np.float32))
+        y = U.conv_fwd(x, w, b, kh, kw, sh, sw)
+        dy = torch.randn_like(y)
+        OH, OW = y.shape[3], y.shape[4]
+        flops = 2.0 * G * Bs * OH * OW * Cout * kh * kw * Cin
+        ops = {'fwd': (lambda: U.conv_fwd(x, w, b, kh, kw, sh, sw), 0), 'dgrad': (lambda: U.conv_dgrad(dy, w, H, W, kh, kw, sh, sw), 0),
+               'wgrad': (lambda: U.conv_wgrad(x, dy, kh, kw, sh, sw), 1)}
+        for op, (f, kind) in ops.items():
+            if nm.startswith('g_h1') and op == 'fwd':
+                continue                                    # weight-stationary kernel, not the implicit GEMM
+            check(lib.vc_tune_igemm_override(0, 0, 0))
+            us, nl = time_call(f, kind, args.reps)
+            line = '%-10s %-5s %6.2f GFLOP ideal %6.1f us | auto %7.1f us %6.1f TF (%d launch)' % (
+                nm, op, flops / 1e9, flops / 157.3e12 * 1e6, us, flops / us / 1e6, nl)
+            if args.sweep and op != 'wgrad':
+                res = []
+                for bm, kg, sk in CONFIGS:
+                    if bm == 128 and (Cout if op == 'fwd' else Cin) < 128:
+                        continue
+                    check(lib.vc_tune_igemm_override(bm, kg, sk))
+                    try:
+                        u, _ = time_call(f, kind, args.reps)
+                    except Exception as e:               # a configuration the launch refuses
+                        continue
+                    res.append((u, bm, kg, sk))
+                check(lib.vc_tune_igemm_override(0, 0, 0))
+                res.sort()
+                line += ' | best ' + '  '.join('%dx%d/%d %.1f' % (bm, kg, sk, u) for u, bm, kg, sk in res[:4])
+                # key: (a_trans, M, Ptot per class is geometry dependent) -> record the forward shape key; dgrad classes differ
+                if res:
+                    table.append((nm, op, res[0], us))
+            print(line, flush=True)
+            rows.append((nm, op, flops, us))
+    tot = {}
+    for nm, op, fl, us in rows:
+        t = tot.setdefault(op, [0.0, 0.0]); t[0] += fl; t[1] += us
+    for op, (fl, us) in tot.items():
+        print('sum %-5s %7.1f GFLOP %8.1f us  %6.1f TF' % (op, fl / 1e9, us, fl / us / 1e6))
+    if args.emit and table:
+        with open(args.emit, 'w') as f:
+            for nm, op, (u, bm, kg, sk), auto in table:
+                f.write('// %s %s: best %dx%d split %d %.1f us (auto %.1f us)\n' % (nm, op, bm, kg, sk, u, auto))
+
+
+if __name__ == '__main__':
+    main()

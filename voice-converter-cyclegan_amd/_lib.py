@@ -37,6 +37,7 @@ SIGNATURES = [
     ('vc_crc32c', C.c_uint32, [vp, C.c_uint64, C.c_uint32]),
     ('vc_set_math_mode', i32, [i32]),
     ('vc_get_math_mode', i32, []),
+    ('vc_tune_igemm_override', i32, [i32, i32, i32]),
     ('vc_prof_enable', i32, [i32]),
     ('vc_prof_collect', i32, [i32, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_double)]),
     ('vc_prof_records', i32, [i32, C.POINTER(C.c_double), C.POINTER(C.c_double), i32]),
@@ -55,7 +56,10 @@ SIGNATURES = [
     ('vc_l2_loss', i32, [vp, vp, i64, vp, vp, vp]),
     ('vc_adam_tf_update', i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp]),
     ('vc_plan_create', i32, [i32, i32, C.POINTER(vp)]),
+    ('vc_plan_create_inference', i32, [i32, i32, C.POINTER(vp)]),
     ('vc_plan_destroy', None, [vp]),
+    ('vc_plan_set_math_mode', i32, [vp, i32]),
+    ('vc_plan_get_math_mode', i32, [vp]),
     ('vc_generator_save_floats', i64, [vp, i32]),
     ('vc_discriminator_save_floats', i64, [vp, i32]),
     ('vc_scratch_floats', i64, [vp, i32]),
@@ -73,6 +77,12 @@ SIGNATURES = [
     ('vc_step_num_g_buckets', i32, [vp]),
     ('vc_step_g_bucket', i32, [vp, i32, C.POINTER(i64), C.POINTER(i64)]),
     ('vc_step_wait_g_bucket', i32, [vp, i32, vp]),
+    ('vc_comm_unique_id', i32, [vp]),
+    ('vc_comm_init', i32, [i32, i32, vp, C.POINTER(vp)]),
+    ('vc_comm_destroy', i32, [vp]),
+    ('vc_comm_world', i32, [vp]),
+    ('vc_allreduce_f32', i32, [vp, vp, i64, vp]),
+    ('vc_step_exchange_and_update', i32, [vp, vp, vp, vp, vp, vp, f32, f32, f32, f32, f32, vp]),
 ]
 for _n, _r, _a in SIGNATURES:
     _f = getattr(lib, _n)          # AttributeError here == header/library mismatch

@@ -1,31 +1,56 @@
 """Builds libvcgan_hip.so (hand-written HIP for gfx950) in-tree with hipcc.
 
-No torch.utils.cpp_extension (it would hipify); plain `hipcc -shared -fPIC`.
+No torch.utils.cpp_extension (it would hipify); plain `hipcc -c` per translation unit (in parallel) and one
+`hipcc -shared` link.  Objects live in csrc/build/ (git-ignored), the library next to the sources.
 """
 import os
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
+OBJ = os.path.join(CSRC, 'build')
 LIB = os.path.join(CSRC, 'libvcgan_hip.so')
-SOURCES = ['vc_kernels.hip', 'vc_api.hip']
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++20', '-munsafe-fp-atomics', '-shared', '-fPIC',
+SOURCES = ['vc_conv_igemm.hip', 'vc_conv_wgrad.hip', 'vc_conv_small.hip', 'vc_elementwise.hip', 'vc_api.hip', 'vc_comm.hip']
+HEADERS = ['vc_internal.h', 'vc_device_util.h', 'vc_tuned_igemm.h', os.path.join('..', '..', 'include', 'vc_cyclegan.h')]
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++20', '-munsafe-fp-atomics', '-fPIC',
          '-Wall', '-Wextra', '-Wno-unused-parameter']
 
 
+def _mtime(p):
+    return os.path.getmtime(p) if os.path.exists(p) else 0.0
+
+
+def _stale(target, deps):
+    t = _mtime(target)
+    return t == 0.0 or any(_mtime(d) > t for d in deps)
+
+
 def needs_build():
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    deps = SOURCES + ['vc_internal.h', os.path.join('..', '..', 'include', 'vc_cyclegan.h')]
-    return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in deps)
+    deps = [os.path.join(CSRC, d) for d in SOURCES + HEADERS]
+    return _stale(LIB, deps)
 
 
 def build(force=False, verbose=True):
     if not force and not needs_build():
         return LIB
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    cmd = [hipcc] + FLAGS + os.environ.get('VC_EXTRA_FLAGS', '').split() + ['-o', LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    os.makedirs(OBJ, exist_ok=True)
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS]
+    extra = os.environ.get('VC_EXTRA_FLAGS', '').split()
+
+    def compile_one(src):
+        obj = os.path.join(OBJ, src.replace('.hip', '.o'))
+        if force or extra or _stale(obj, [os.path.join(CSRC, src)] + hdrs):
+            cmd = [hipcc] + FLAGS + extra + ['-c', os.path.join(CSRC, src), '-o', obj]
+            if verbose:
+                print('[vcgan] ' + ' '.join(cmd), flush=True)
+            subprocess.check_call(cmd, cwd=CSRC)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs + ['-ldl']
     if verbose:
         print('[vcgan] ' + ' '.join(cmd), flush=True)
     subprocess.check_call(cmd, cwd=CSRC)

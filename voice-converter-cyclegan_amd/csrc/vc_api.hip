@@ -72,186 +72,249 @@ static Geom make_geom(int Cin, int H, int W, int Cout, int kh, int kw, int sh, i
 }
 
 // ------------------------------------------------------------------------------------
-// K tables (device resident, cached per geometry)
+// K tables (device resident, cached per geometry, reference-counted by the plans that use them)
+//
+// A table lists the GEMM-K rows of one convolution (forward / filter gradient) or of one stride-parity class of its
+// input gradient, tap by tap; every tap is padded to a multiple of 32 rows, so a 32-row chunk never straddles taps
+// (vc_internal.h: IgemmArgs).  Padding rows: tap bit 0 for their run of 4 (the gathered operand reads 0), weight
+// offset 0 (any finite weight), a_off -1 (no filter-gradient row).
 // ------------------------------------------------------------------------------------
 struct HostRow { int c, dh, dw, a_off, tap; };
-struct Table { KEntry* dev = nullptr; XEntry* xe = nullptr; Tap* taps = nullptr; unsigned* atab = nullptr;
-               int ntaps = 0, rows = 0, valid = 0; };
+struct Table { KEntry* dev = nullptr; int* xsoff = nullptr; unsigned* rtap = nullptr; unsigned* aoff = nullptr; Tap* taps = nullptr;
+               int ntaps = 0, rows = 0, valid = 0, xbias = 0, refs = 0; };
+typedef std::array<int, 14> TabKey;
 static std::mutex g_tab_mu;
-static std::map<std::array<int, 14>, Table> g_tabs;
+static std::map<TabKey, Table> g_tabs;
 
 template <class T> static int to_device(const std::vector<T>& h, T** d) {
     VC_HIP(hipMalloc((void**)d, h.size() * sizeof(T)));
     VC_HIP(hipMemcpy(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
     return 0;
 }
-// xH, xW: dims of the tensor the K rows gather from (forward: the input; input-gradient: dY)
-static int upload_table(const std::vector<HostRow>& rows, const std::vector<Tap>& taps, int pad_to, int xH, int xW, Table* t) {
+static void free_table(Table& t) {
+    (void)hipFree(t.dev); (void)hipFree(t.xsoff); (void)hipFree(t.rtap); (void)hipFree(t.aoff); (void)hipFree(t.taps);
+    t = Table{};
+}
+// rows_per_tap[t] consecutive entries of `rows` belong to tap t.  xH, xW: dims of the tensor the K rows gather from
+// (forward: the input; input gradient: dY).
+static int upload_table(const std::vector<HostRow>& rows, const std::vector<int>& rows_per_tap, const std::vector<Tap>& taps,
+                        int xH, int xW, Table* t) {
     if (taps.size() > 32) { vc_set_error("conv kernel has %d taps; at most 32 supported", (int)taps.size()); return VC_E_ARG; }
-    std::vector<KEntry> ke; std::vector<XEntry> xe; std::vector<unsigned> at;
-    for (const HostRow& r : rows) {
-        ke.push_back(KEntry{r.c, r.dh, r.dw, r.a_off});
-        const long soff = ((long)r.c * xH * xW + (long)r.dh * xW + r.dw) * 4;
-        if (soff > 0x7fffffffL || soff < -0x7fffffffL || (long)r.a_off * 4 > 0x7fffffffL) {
-            vc_set_error("tensor too large for 32-bit byte offsets"); return VC_E_ARG; }
-        xe.push_back(XEntry{(int)soff, 1u << r.tap});
-        at.push_back((unsigned)r.a_off * 4u);
+    long min_soff = 0;
+    for (const HostRow& r : rows) min_soff = std::min(min_soff, ((long)r.c * xH * xW + (long)r.dh * xW + r.dw) * 4);
+    const long xbias = -min_soff;
+    std::vector<KEntry> ke; std::vector<int> xs; std::vector<unsigned> rt, ao;
+    size_t at = 0;
+    for (size_t tp = 0; tp < rows_per_tap.size(); ++tp) {
+        const int n = rows_per_tap[tp];
+        if (n % 4) { vc_set_error("conv: channel count %d is not a multiple of 4", n); return VC_E_ARG; }
+        const HostRow& r0 = rows[at];
+        const long soff0 = ((long)r0.c * xH * xW + (long)r0.dh * xW + r0.dw) * 4 + xbias;
+        for (int k = 0; k < n; ++k) {
+            const HostRow& r = rows[at + k];
+            const long soff = ((long)r.c * xH * xW + (long)r.dh * xW + r.dw) * 4 + xbias;
+            if (soff > 0x7fffff00L || (long)r.a_off * 4 > 0x7fffff00L) { vc_set_error("tensor too large for 32-bit byte offsets"); return VC_E_ARG; }
+            ke.push_back(KEntry{r.c, r.dh, r.dw, r.a_off}); xs.push_back((int)soff); ao.push_back((unsigned)r.a_off * 4u);
+            if (k % 4 == 0) rt.push_back(1u << r.tap);
+        }
+        for (int k = n; k % VC_KC; ++k) {          // pad the tap to whole chunks: addressable (row 0 of the tap), never contributing
+            ke.push_back(KEntry{r0.c, r0.dh, r0.dw, -1}); xs.push_back((int)soff0); ao.push_back(0u);
+            if (k % 4 == 0) rt.push_back(0u);
+        }
+        at += n;
     }
-    t->valid = (int)rows.size();
-    while (ke.size() % pad_to || ke.empty()) { ke.push_back(KEntry{0, 0, 0, -1}); xe.push_back(XEntry{0, 0u}); at.push_back(0x80000000u); }
-    t->rows = (int)ke.size(); t->ntaps = (int)taps.size();
-    // 3 extra padding chunks: the igemm loader runs ahead of the K range without branching
-    for (int i = 0; i < 192; ++i) { ke.push_back(KEntry{0, 0, 0, -1}); xe.push_back(XEntry{0, 0u}); at.push_back(0x80000000u); }
-    VC_CHECK(to_device(ke, &t->dev)); VC_CHECK(to_device(xe, &t->xe)); VC_CHECK(to_device(at, &t->atab));
+    t->valid = (int)rows.size(); t->ntaps = (int)taps.size(); t->xbias = (int)xbias;
+    auto pad_chunk = [&]() { for (int k = 0; k < VC_KC; ++k) { ke.push_back(KEntry{0, 0, 0, -1}); xs.push_back((int)xbias); ao.push_back(0u); if (k % 4 == 0) rt.push_back(0u); } };
+    while (ke.size() % 64 || ke.empty()) pad_chunk();          // the filter-gradient kernel walks 64-row tiles
+    t->rows = (int)ke.size();
+    for (int i = 0; i < 4; ++i) pad_chunk();                   // the loaders run ahead of the K range without branching
+    VC_CHECK(to_device(ke, &t->dev)); VC_CHECK(to_device(xs, &t->xsoff)); VC_CHECK(to_device(rt, &t->rtap)); VC_CHECK(to_device(ao, &t->aoff));
     std::vector<Tap> tp = taps; if (tp.empty()) tp.push_back(Tap{0, 0});
     VC_CHECK(to_device(tp, &t->taps));
     return 0;
 }
+static TabKey fwd_key(const Geom& g) { return TabKey{0, g.Cin, g.Cout, g.kh, g.kw, g.sh, g.sw, g.pt, g.pl, 0, 0, g.H, g.W, 0}; }
+static TabKey dgrad_key(const Geom& g, int ph, int pw) { return TabKey{1, g.Cin, g.Cout, g.kh, g.kw, g.sh, g.sw, g.pt, g.pl, ph, pw, g.OH, g.OW, 0}; }
 // forward / wgrad table: row kk = ((i*kw + j)*Cin + ci), tap = i*kw + j
-static int get_fwd_table(const Geom& g, Table* out) {
-    std::array<int, 14> key{0, g.Cin, g.Cout, g.kh, g.kw, g.sh, g.sw, g.pt, g.pl, 0, 0, g.H, g.W, 0};
+static int get_fwd_table(const Geom& g, Table* out, std::vector<TabKey>* owner = nullptr) {
+    const TabKey key = fwd_key(g);
     std::lock_guard<std::mutex> l(g_tab_mu);
     auto it = g_tabs.find(key);
-    if (it != g_tabs.end()) { *out = it->second; return 0; }
-    std::vector<HostRow> rows; std::vector<Tap> taps;
-    for (int i = 0; i < g.kh; ++i) for (int j = 0; j < g.kw; ++j) {
-        taps.push_back(Tap{i - g.pt, j - g.pl});
-        for (int ci = 0; ci < g.Cin; ++ci)
-            rows.push_back(HostRow{ci, i - g.pt, j - g.pl, ((i * g.kw + j) * g.Cin + ci) * g.Cout, i * g.kw + j});
+    if (it == g_tabs.end()) {
+        std::vector<HostRow> rows; std::vector<Tap> taps; std::vector<int> rpt;
+        for (int i = 0; i < g.kh; ++i) for (int j = 0; j < g.kw; ++j) {
+            taps.push_back(Tap{i - g.pt, j - g.pl}); rpt.push_back(g.Cin);
+            for (int ci = 0; ci < g.Cin; ++ci)
+                rows.push_back(HostRow{ci, i - g.pt, j - g.pl, ((i * g.kw + j) * g.Cin + ci) * g.Cout, i * g.kw + j});
+        }
+        Table t; VC_CHECK(upload_table(rows, rpt, taps, g.H, g.W, &t));
+        it = g_tabs.emplace(key, t).first;
     }
-    Table t; VC_CHECK(upload_table(rows, taps, 64, g.H, g.W, &t));
-    g_tabs[key] = t; *out = t;
+    if (owner) { ++it->second.refs; owner->push_back(key); }
+    *out = it->second;
     return 0;
 }
 // input-gradient table of parity class (ph, pw): rows (tap in class, co), gathered tensor = dY [Cout][OH][OW]
-static int get_dgrad_table(const Geom& g, int ph, int pw, Table* out) {
-    std::array<int, 14> key{1, g.Cin, g.Cout, g.kh, g.kw, g.sh, g.sw, g.pt, g.pl, ph, pw, g.OH, g.OW, 0};
+static int get_dgrad_table(const Geom& g, int ph, int pw, Table* out, std::vector<TabKey>* owner = nullptr) {
+    const TabKey key = dgrad_key(g, ph, pw);
     std::lock_guard<std::mutex> l(g_tab_mu);
     auto it = g_tabs.find(key);
-    if (it != g_tabs.end()) { *out = it->second; return 0; }
-    std::vector<HostRow> rows; std::vector<Tap> taps;
-    for (int i = 0; i < g.kh; ++i) {
-        const int nh = ph + g.pt - i;
-        if (((nh % g.sh) + g.sh) % g.sh) continue;
-        for (int j = 0; j < g.kw; ++j) {
-            const int nw = pw + g.pl - j;
-            if (((nw % g.sw) + g.sw) % g.sw) continue;
-            const int dh = nh / g.sh, dw = nw / g.sw;   // exact
-            const int tap = (int)taps.size();
-            taps.push_back(Tap{dh, dw});
-            for (int co = 0; co < g.Cout; ++co)
-                rows.push_back(HostRow{co, dh, dw, ((i * g.kw + j) * g.Cin) * g.Cout + co, tap});
+    if (it == g_tabs.end()) {
+        std::vector<HostRow> rows; std::vector<Tap> taps; std::vector<int> rpt;
+        for (int i = 0; i < g.kh; ++i) {
+            const int nh = ph + g.pt - i;
+            if (((nh % g.sh) + g.sh) % g.sh) continue;
+            for (int j = 0; j < g.kw; ++j) {
+                const int nw = pw + g.pl - j;
+                if (((nw % g.sw) + g.sw) % g.sw) continue;
+                const int dh = nh / g.sh, dw = nw / g.sw;   // exact
+                const int tap = (int)taps.size();
+                taps.push_back(Tap{dh, dw}); rpt.push_back(g.Cout);
+                for (int co = 0; co < g.Cout; ++co)
+                    rows.push_back(HostRow{co, dh, dw, ((i * g.kw + j) * g.Cin) * g.Cout + co, tap});
+            }
         }
+        Table t; VC_CHECK(upload_table(rows, rpt, taps, g.OH, g.OW, &t));
+        it = g_tabs.emplace(key, t).first;
     }
-    Table t; VC_CHECK(upload_table(rows, taps, 64, g.OH, g.OW, &t));
-    g_tabs[key] = t; *out = t;
+    if (owner) { ++it->second.refs; owner->push_back(key); }
+    *out = it->second;
     return 0;
 }
+// a plan gives its tables back; the last owner frees them (hipFree waits for the device, so no launch still reads them)
+static void release_tables(std::vector<TabKey>& keys) {
+    std::lock_guard<std::mutex> l(g_tab_mu);
+    for (const TabKey& k : keys) {
+        auto it = g_tabs.find(k);
+        if (it != g_tabs.end() && --it->second.refs <= 0) { free_table(it->second); g_tabs.erase(it); }
+    }
+    keys.clear();
+}
+
+// arithmetic of the MFMA kernels for calls that carry no plan (operator level): per calling thread
+static thread_local int t_math = VC_MATH_FP32;
+extern "C" int vc_set_math_mode(int mode) {
+    if (mode < VC_MATH_FP32 || mode > VC_MATH_BF16X3) { vc_set_error("vc_set_math_mode: mode %d (0 fp32, 1 bf16, 2 bf16x3)", mode); return VC_E_ARG; }
+    t_math = mode;
+    return 0;
+}
+extern "C" int vc_get_math_mode(void) { return t_math; }
 
 // ------------------------------------------------------------------------------------
 // conv operators
 // ------------------------------------------------------------------------------------
-static int igemm_run(IgemmArgs& a, bool a_trans, float* y_zero_base, long y_zero_gs, long y_zero_elems,
-                     hipStream_t s, double flops, bool* zeroed, bool prezeroed = false) {
-    igemm_config(a);
-    if (prezeroed) *zeroed = true;        // the caller zeroed the destination as part of a batched zero launch
-    if (a.splitk > 1 && !a.accumulate) {
-        // atomics need a zeroed destination; parity classes of one dgrad share the tensor -> zero once
-        if (!*zeroed) {
-            for (int g = 0; g < a.groups; ++g)
-                VC_HIP(hipMemsetAsync(y_zero_base + (long)g * y_zero_gs, 0, y_zero_elems * sizeof(float), s));
-            *zeroed = true;
-        }
-        a.accumulate = 1;
-    }
-    return launch_igemm(a, a_trans, s, flops);
-}
+static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
-// Cin = 1 with at most 9 taps (the discriminator's h1 layer) goes to the vector-ALU kernels; VC_C1_PATH=0 keeps it on MFMA
-static bool c1_path(const Geom& g) {
-    static const bool on = [] { const char* v = getenv("VC_C1_PATH"); return !v || atoi(v) != 0; }();
-    return on && g.Cin == 1 && g.kh * g.kw <= 9;
-}
-// 1-D, stride 1, 24 input channels, 15 taps (the generator's h1 layer): weight-stationary kernel; VC_WSCONV=0 keeps the igemm
+// Cin = 1 with at most 9 taps (the discriminator's h1 layer) goes to the vector-ALU kernels
+static bool c1_path(const Geom& g) { return g.Cin == 1 && g.kh * g.kw <= 9; }
+// 1-D, stride 1, 24 input channels, 15 taps (the generator's h1 layer at 24 MCEPs): weight-stationary kernel
 static bool wsconv_path(const Geom& g) {
-    static const bool on = [] { const char* v = getenv("VC_WSCONV"); return !v || atoi(v) != 0; }();
-    return on && g.H == 1 && g.kh == 1 && g.sh == 1 && g.sw == 1 && g.Cin == 24 && g.kw == 15 && g.W % 4 == 0;   // 16-byte output stores
+    return g.H == 1 && g.kh == 1 && g.sh == 1 && g.sw == 1 && g.Cin == 24 && g.kw == 15 && g.W % 4 == 0;   // 16-byte output stores
 }
-static C1Args c1_args(const Geom& g, int G, int B) {
+static C1Args c1_args(const Geom& g, int G, int B, int math) {
     C1Args c{};
     c.B = B; c.H = g.H; c.W = g.W; c.Cout = g.Cout; c.kh = g.kh; c.kw = g.kw; c.sh = g.sh; c.sw = g.sw;
-    c.OH = g.OH; c.OW = g.OW; c.pt = g.pt; c.pl = g.pl; c.G = G; c.math = vc_math_mode();
+    c.OH = g.OH; c.OW = g.OW; c.pt = g.pt; c.pl = g.pl; c.G = G; c.math = math;
     return c;
+}
+static int check_conv_geom(const Geom& g, int B) {
+    VC_ARG(g.Cout % 4 == 0, "conv: Cout must be a multiple of 4");
+    VC_ARG(c1_path(g) || g.Cin % 4 == 0, "conv: Cin must be a multiple of 4 (or 1 with at most 9 taps)");
+    VC_ARG((long)B * g.Cin * g.H * g.W * 4 < 0xfff00000L && (long)B * g.Cout * g.OH * g.OW * 4 < 0xfff00000L,
+           "conv: a tensor of one group exceeds 4 GiB (32-bit buffer offsets)");
+    VC_ARG((long)B * g.OH * g.OW < (1L << 24) && (long)B * g.H * g.W < (1L << 24), "conv: more than 2^24 pixels per group");
+    return 0;
+}
+static void fill_pixel_grid(IgemmArgs& a, int B, int NPB, int OWc) {
+    a.NPB = NPB; a.OWc = OWc; a.Ptot = B * NPB; a.inv_npb = 1.0f / (float)NPB; a.inv_ow = 1.0f / (float)OWc;
+}
+static void set_vec4(IgemmArgs& a) {
+    a.vec4 = a.so_w == 1 && a.OWc % 4 == 0 && a.o_w0 % 4 == 0 && a.yW % 4 == 0 && a.yHW % 4 == 0 && a.y_bs % 4 == 0 &&
+             a.y_gs % 4 == 0 && aligned16(a.Y) && (!a.addend || (aligned16(a.addend) && a.add_gs % 4 == 0));
 }
 
 // query != nullptr: do not launch, only report whether the launch would use split-K atomics (needs a zeroed y)
 static int conv_fwd(const float* x, long x_gs, const float* w, long w_gs, const float* bias, long b_gs,
-                    float* y, long y_gs, int G, int B, const Geom& g, hipStream_t s,
+                    float* y, long y_gs, int G, int B, const Geom& g, int math, hipStream_t s,
                     bool prezeroed = false, bool* query = nullptr) {
+    VC_CHECK(check_conv_geom(g, B));
     if (c1_path(g)) {      // Cin = 1 (D.h1): vector-ALU kernel, plain stores, never needs a zeroed destination
         if (query) { *query = false; return 0; }
-        C1Args c = c1_args(g, G, B); c.x = x; c.x_gs = x_gs; c.w = w; c.w_gs = w_gs; c.bias = bias; c.b_gs = b_gs; c.y = y; c.y_gs = y_gs;
+        C1Args c = c1_args(g, G, B, math); c.x = x; c.x_gs = x_gs; c.w = w; c.w_gs = w_gs; c.bias = bias; c.b_gs = b_gs; c.y = y; c.y_gs = y_gs;
         return launch_c1_fwd(c, s);
     }
     if (wsconv_path(g)) {  // few input channels, 1-D, stride 1 (G.h1): weight-stationary kernel, plain stores
         if (query) { *query = false; return 0; }
         WsConvArgs c{}; c.x = x; c.w = w; c.bias = bias; c.y = y; c.x_gs = x_gs; c.w_gs = w_gs; c.b_gs = b_gs; c.y_gs = y_gs;
         c.B = B; c.T = g.W; c.Cout = g.Cout; c.G = G;
-        const int r = launch_wsconv1d(c, g.Cin, g.kw, s, 2.0 * G * B * g.W * (double)g.Cout * g.kw * g.Cin);
+        const int r = launch_wsconv1d(c, g.Cin, g.kw, math, s, 2.0 * G * B * g.W * (double)g.Cout * g.kw * g.Cin);
         if (r != -2) return r;
     }
     Table t; VC_CHECK(get_fwd_table(g, &t));
     IgemmArgs a{};
     a.A = w; a.X = x; a.Y = y; a.bias = bias; a.addend = nullptr;
-    a.xtab = t.xe; a.taps = t.taps; a.ntaps = t.ntaps; a.atab = nullptr;
-    a.a_ks_bytes = (unsigned)g.Cout * 4u;
-    VC_ARG((long)B * g.Cin * g.H * g.W * 4 < 0xffffff00L, "conv: input tensor of one group exceeds 4 GiB");
-    a.x_bytes = (unsigned)((long)B * g.Cin * g.H * g.W * 4); a.a_bytes = (unsigned)((long)t.valid * g.Cout * 4);
+    a.xsoff = t.xsoff; a.rtap = t.rtap; a.aoff = t.aoff; a.taps = t.taps; a.ntaps = t.ntaps; a.xbias = t.xbias;
+    // buffer sizes for the hardware range check: measured on gfx950, the check covers VGPR offset + SGPR offset, so the
+    // gathered tensor's size includes the table bias that rides in every SGPR offset
+    a.x_bytes = (unsigned)((long)B * g.Cin * g.H * g.W * 4 + t.xbias); a.a_bytes = (unsigned)std::min<long>((long)t.valid * g.Cout * 4, 0xffffff00L);
     a.a_gs = w_gs; a.x_gs = x_gs; a.y_gs = y_gs; a.bias_gs = b_gs; a.add_gs = 0;
     a.x_bs = (long)g.Cin * g.H * g.W; a.y_bs = (long)g.Cout * g.OH * g.OW;
     a.krows = t.rows; a.M = g.Cout; a.a_ms = 1;
     a.Hl = g.H; a.Wl = g.W; a.xHW = g.H * g.W; a.xW = g.W; a.si = g.sh; a.sj = g.sw;
-    a.NPB = g.OH * g.OW; a.OWc = g.OW; a.Ptot = B * a.NPB;
+    fill_pixel_grid(a, B, g.OH * g.OW, g.OW);
     a.yHW = g.OH * g.OW; a.yW = g.OW; a.so_h = 1; a.so_w = 1; a.o_h0 = 0; a.o_w0 = 0;
-    a.accumulate = 0; a.groups = G; a.kl_ok = 1;
-    bool zeroed = false;
-    const double flops = 2.0 * G * B * a.NPB * (double)g.Cout * t.valid;
-    if (query) { igemm_config(a); *query = a.splitk > 1; return 0; }
-    return igemm_run(a, false, y, y_gs, (long)B * a.y_bs, s, flops, &zeroed, prezeroed);
+    a.accumulate = 0; a.groups = G;
+    set_vec4(a);
+    igemm_config(a);
+    if (query) { *query = a.splitk > 1; return 0; }
+    if (a.splitk > 1) {          // atomics need a zeroed destination
+        if (!prezeroed)
+            for (int gi = 0; gi < G; ++gi) VC_HIP(hipMemsetAsync(y + (long)gi * y_gs, 0, (size_t)B * a.y_bs * sizeof(float), s));
+        a.accumulate = 1;
+    }
+    return launch_igemm(a, false, math, s, 2.0 * G * B * a.NPB * (double)g.Cout * t.valid);
 }
 
 static int conv_dgrad(const float* dy, long dy_gs, const float* w, long w_gs, float* dx, long dx_gs,
-                      const float* addend, long add_gs, int accumulate, int G, int B, const Geom& g, hipStream_t s,
+                      const float* addend, long add_gs, int accumulate, int G, int B, const Geom& g, int math, hipStream_t s,
                       bool prezeroed = false, bool* query = nullptr) {
-    if (c1_path(g) && !addend) {
+    VC_CHECK(check_conv_geom(g, B));
+    if (c1_path(g)) {
         if (query) { *query = false; return 0; }      // zeroes dx itself when it has to
-        C1Args c = c1_args(g, G, B); c.dy = dy; c.y_gs = dy_gs; c.w = w; c.w_gs = w_gs; c.dx = dx; c.dx_gs = dx_gs;
-        c.addend = addend; c.add_gs = add_gs;
-        return launch_c1_dgrad(c, accumulate || prezeroed, s);
+        C1Args c = c1_args(g, G, B, math); c.dy = dy; c.y_gs = dy_gs; c.w = w; c.w_gs = w_gs; c.dx = dx; c.dx_gs = dx_gs;
+        const long n = (long)B * g.H * g.W;
+        if (addend)           // the kernel scatters with atomics: seed dx with the addend first
+            for (int gi = 0; gi < G; ++gi) {
+                if (accumulate) VC_CHECK(launch_add(dx + (long)gi * dx_gs, addend + (long)gi * add_gs, n, s));
+                else VC_HIP(hipMemcpyAsync(dx + (long)gi * dx_gs, addend + (long)gi * add_gs, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, s));
+            }
+        return launch_c1_dgrad(c, accumulate || prezeroed || addend != nullptr, s);
     }
+    VC_ARG(g.Cin % 4 == 0, "conv input gradient: Cin must be a multiple of 4");
     // one launch per stride-parity class (ph, pw): inside a class the transposed conv is a dense stride-1 gather
-    std::vector<IgemmArgs> cls; std::vector<double> fl;
+    IgemmArgs cls[4]; double fl[4]; int ncls = 0;
     bool any_split = false;
     for (int ph = 0; ph < g.sh; ++ph) for (int pw = 0; pw < g.sw; ++pw) {
         const int Hc = (g.H - ph + g.sh - 1) / g.sh, Wc = (g.W - pw + g.sw - 1) / g.sw;
         if (Hc <= 0 || Wc <= 0) continue;
+        VC_ARG(ncls < 4, "conv input gradient: more than 4 stride-parity classes");
         Table t; VC_CHECK(get_dgrad_table(g, ph, pw, &t));
         IgemmArgs a{};
         a.A = w; a.X = dy; a.Y = dx; a.bias = nullptr; a.addend = addend;
-        a.xtab = t.xe; a.taps = t.taps; a.ntaps = t.ntaps; a.atab = t.atab; a.a_ks_bytes = 0;
-        VC_ARG((long)B * g.Cout * g.OH * g.OW * 4 < 0xffffff00L, "conv: dy tensor of one group exceeds 4 GiB");
-        a.x_bytes = (unsigned)((long)B * g.Cout * g.OH * g.OW * 4);
-        a.a_bytes = (unsigned)((long)g.kh * g.kw * g.Cin * g.Cout * 4);
+        a.xsoff = t.xsoff; a.rtap = t.rtap; a.aoff = t.aoff; a.taps = t.taps; a.ntaps = t.ntaps; a.xbias = t.xbias;
+        a.x_bytes = (unsigned)((long)B * g.Cout * g.OH * g.OW * 4 + t.xbias);
+        a.a_bytes = (unsigned)((long)g.kh * g.kw * g.Cin * g.Cout * 4);   // whole tensor: a 16-byte run past its end reads 0
         a.a_gs = w_gs; a.x_gs = dy_gs; a.y_gs = dx_gs; a.bias_gs = 0; a.add_gs = add_gs;
         a.x_bs = (long)g.Cout * g.OH * g.OW; a.y_bs = (long)g.Cin * g.H * g.W;
         a.krows = t.rows; a.M = g.Cin; a.a_ms = g.Cout;
         a.Hl = g.OH; a.Wl = g.OW; a.xHW = g.OH * g.OW; a.xW = g.OW; a.si = 1; a.sj = 1;
-        a.NPB = Hc * Wc; a.OWc = Wc; a.Ptot = B * a.NPB;
+        fill_pixel_grid(a, B, Hc * Wc, Wc);
         a.yHW = g.H * g.W; a.yW = g.W; a.so_h = g.sh; a.so_w = g.sw; a.o_h0 = ph; a.o_w0 = pw;
-        a.accumulate = accumulate; a.groups = G; a.kl_ok = (g.Cout % 4 == 0) ? 1 : 0;
+        a.accumulate = accumulate; a.groups = G;
+        set_vec4(a);
         igemm_config(a);
         any_split = any_split || a.splitk > 1;
-        cls.push_back(a); fl.push_back(2.0 * G * B * a.NPB * (double)g.Cin * t.valid);
+        fl[ncls] = 2.0 * G * B * a.NPB * (double)g.Cin * t.valid; cls[ncls++] = a;
     }
     if (query) { *query = any_split; return 0; }
     // the classes interleave inside dx: if ANY of them needs atomics, zero dx once up front and let all accumulate
@@ -259,39 +322,60 @@ static int conv_dgrad(const float* dy, long dy_gs, const float* w, long w_gs, fl
         if (!prezeroed)
             for (int gi = 0; gi < G; ++gi)
                 VC_HIP(hipMemsetAsync(dx + (long)gi * dx_gs, 0, (size_t)B * g.Cin * g.H * g.W * sizeof(float), s));
-        for (auto& a : cls) a.accumulate = 1;
+        for (int i = 0; i < ncls; ++i) cls[i].accumulate = 1;
     }
-    // short-K parity classes go out as ONE launch (each alone underfills the chip: G.d1 63->50 us, D.d1 221->190 us);
-    // long-K ones (D.d3: 384/768 chunks) are L2-heavy and measured faster back to back (563 vs 674 us)
-    int max_chunks = 0; for (auto& a : cls) max_chunks = std::max(max_chunks, a.krows / a.kc);
-    if (cls.size() > 1 && max_chunks <= 128) {
-        double fsum = 0; for (double f : fl) fsum += f;
-        return launch_igemm_multi(cls.data(), (int)cls.size(), true, s, fsum);
+    // short-K parity classes go out as ONE launch (each alone underfills the chip); long-K ones (D.d3: 288 chunks) are
+    // L2-heavy and measured faster back to back
+    int max_chunks = 0; bool same = true;
+    for (int i = 0; i < ncls; ++i) {
+        max_chunks = std::max(max_chunks, cls[i].krows / VC_KC);
+        same = same && cls[i].bm == cls[0].bm && cls[i].kg == cls[0].kg;
     }
-    for (size_t i = 0; i < cls.size(); ++i) VC_CHECK(launch_igemm(cls[i], true, s, fl[i]));
+    if (ncls > 1 && max_chunks <= 128 && same) {
+        double fsum = 0; for (int i = 0; i < ncls; ++i) fsum += fl[i];
+        return launch_igemm_multi(cls, ncls, true, math, s, fsum);
+    }
+    for (int i = 0; i < ncls; ++i) VC_CHECK(launch_igemm(cls[i], true, math, s, fl[i]));
     return 0;
 }
 
-static int conv_wgrad(const float* x, long x_gs, const float* dy, long dy_gs, float* dw, long dw_gs,
-                      int G, int B, const Geom& g, hipStream_t s, bool first_touch = false) {
+// One application of a layer as seen by the filter gradient: its input, the gradient of its raw output, its batch.
+struct WgradApp { const float* x; long x_gs; const float* dy; long dy_gs; int B; };
+// dW (+)= sum over the applications; store: dW holds nothing yet (plain stores when the launch does not split K)
+// query != nullptr: only report whether the launch would accumulate with atomics (needs a zeroed dW)
+static int conv_wgrad(const WgradApp* apps, int napps, float* dw, long dw_gs, int G, const Geom& g, int math, hipStream_t s,
+                      bool store, bool* query = nullptr) {
     if (c1_path(g)) {
-        C1Args c = c1_args(g, G, B); c.x = x; c.x_gs = x_gs; c.dy = dy; c.y_gs = dy_gs; c.dw = dw; c.dw_gs = dw_gs;
-        return launch_c1_wgrad(c, s);
+        if (query) { *query = true; return 0; }
+        for (int k = 0; k < napps; ++k) {
+            VC_CHECK(check_conv_geom(g, apps[k].B));
+            C1Args c = c1_args(g, G, apps[k].B, math); c.x = apps[k].x; c.x_gs = apps[k].x_gs; c.dy = apps[k].dy; c.y_gs = apps[k].dy_gs;
+            c.dw = dw; c.dw_gs = dw_gs;
+            VC_CHECK(launch_c1_wgrad(c, s));
+        }
+        return 0;
     }
+    VC_ARG(napps >= 1 && napps <= 2, "conv filter gradient: 1 or 2 applications per launch");
     Table t; VC_CHECK(get_fwd_table(g, &t));
     WgradArgs a{};
-    a.X = x; a.dY = dy; a.dW = dw; a.ktab = t.dev;
-    a.x_gs = x_gs; a.dy_gs = dy_gs; a.dw_gs = dw_gs;
+    a.dW = dw; a.ktab = t.dev; a.xsoff = t.xsoff; a.xbias = t.xbias; a.dw_gs = dw_gs;
     a.x_bs = (long)g.Cin * g.H * g.W; a.dy_bs = (long)g.Cout * g.OH * g.OW;
     a.N = g.Cout; a.Hl = g.H; a.Wl = g.W; a.xHW = g.H * g.W; a.xW = g.W; a.si = g.sh; a.sj = g.sw;
-    a.NPB = g.OH * g.OW; a.OWc = g.OW; a.Ptot = B * a.NPB; a.nchunks = (a.Ptot + 31) / 32;
-    a.ktiles = t.rows / 64; a.groups = G;
-    VC_ARG((long)B * a.x_bs * 4 < 0xffffff00L && (long)B * a.dy_bs * 4 < 0xffffff00L, "conv: tensor of one group exceeds 4 GiB");
-    a.x_bytes = (unsigned)((long)B * a.x_bs * 4); a.dy_bytes = (unsigned)((long)B * a.dy_bs * 4);
-    a.inv_ow = 1.0f / (float)g.OW;
-    a.first_touch = first_touch ? 1 : 0;
-    const double flops = 2.0 * G * B * a.NPB * (double)g.Cout * t.valid;
-    return launch_wgrad(a, s, flops);
+    a.NPB = g.OH * g.OW; a.OWc = g.OW; a.inv_ow = 1.0f / (float)g.OW; a.inv_npb = 1.0f / (float)a.NPB;
+    a.ktiles = t.rows / 64; a.groups = G; a.nseg = napps; a.nchunks = 0;
+    double flops = 0;
+    for (int k = 0; k < napps; ++k) {
+        VC_CHECK(check_conv_geom(g, apps[k].B));
+        WgradSeg& sg = a.seg[k];
+        sg.X = apps[k].x; sg.dY = apps[k].dy; sg.x_gs = apps[k].x_gs; sg.dy_gs = apps[k].dy_gs;
+        sg.x_bytes = (unsigned)((long)apps[k].B * a.x_bs * 4 + t.xbias); sg.dy_bytes = (unsigned)((long)apps[k].B * a.dy_bs * 4);
+        sg.Ptot = apps[k].B * a.NPB; sg.nchunks = (sg.Ptot + VC_KC - 1) / VC_KC;
+        a.nchunks += sg.nchunks;
+        flops += 2.0 * G * apps[k].B * a.NPB * (double)g.Cout * t.valid;
+    }
+    a.store = store ? 1 : 0;
+    if (query) { *query = !store || wgrad_splitk(a) > 1; return 0; }
+    return launch_wgrad(a, math, s, flops);
 }
 
 extern "C" int vc_conv2d_fwd(const float* x, int64_t x_gs, const float* w, int64_t w_gs,
@@ -300,7 +384,7 @@ extern "C" int vc_conv2d_fwd(const float* x, int64_t x_gs, const float* w, int64
                              int kh, int kw, int sh, int sw, void* stream) {
     VC_ARG(x && w && y && G > 0 && B > 0 && Cin > 0 && H > 0 && W > 0 && Cout > 0, "vc_conv2d_fwd: bad args");
     VC_ARG(Cout % 4 == 0, "vc_conv2d_fwd: Cout must be a multiple of 4");
-    return conv_fwd(x, x_gs, w, w_gs, bias, b_gs, y, y_gs, G, B, make_geom(Cin, H, W, Cout, kh, kw, sh, sw), (hipStream_t)stream);
+    return conv_fwd(x, x_gs, w, w_gs, bias, b_gs, y, y_gs, G, B, make_geom(Cin, H, W, Cout, kh, kw, sh, sw), t_math, (hipStream_t)stream);
 }
 extern "C" int vc_conv2d_dgrad(const float* dy, int64_t dy_gs, const float* w, int64_t w_gs,
                                float* dx, int64_t dx_gs, const float* addend, int64_t add_gs, int accumulate,
@@ -308,13 +392,14 @@ extern "C" int vc_conv2d_dgrad(const float* dy, int64_t dy_gs, const float* w, i
                                int kh, int kw, int sh, int sw, void* stream) {
     VC_ARG(dy && w && dx && G > 0 && B > 0, "vc_conv2d_dgrad: bad args");
     return conv_dgrad(dy, dy_gs, w, w_gs, dx, dx_gs, addend, add_gs, accumulate, G, B,
-                      make_geom(Cin, H, W, Cout, kh, kw, sh, sw), (hipStream_t)stream);
+                      make_geom(Cin, H, W, Cout, kh, kw, sh, sw), t_math, (hipStream_t)stream);
 }
 extern "C" int vc_conv2d_wgrad(const float* x, int64_t x_gs, const float* dy, int64_t dy_gs,
                                float* dw, int64_t dw_gs, int G, int B, int Cin, int H, int W, int Cout,
                                int kh, int kw, int sh, int sw, void* stream) {
     VC_ARG(x && dy && dw && G > 0 && B > 0, "vc_conv2d_wgrad: bad args");
-    return conv_wgrad(x, x_gs, dy, dy_gs, dw, dw_gs, G, B, make_geom(Cin, H, W, Cout, kh, kw, sh, sw), (hipStream_t)stream);
+    const WgradApp app{x, x_gs, dy, dy_gs, B};
+    return conv_wgrad(&app, 1, dw, dw_gs, G, make_geom(Cin, H, W, Cout, kh, kw, sh, sw), t_math, (hipStream_t)stream, /*store=*/false);
 }
 extern "C" int vc_bias_grad(const float* dy, int64_t dy_gs, float* db, int64_t db_gs,
                             int G, int B, int C, int L, void* stream) {
@@ -502,7 +587,9 @@ struct vc_plan {
     NetDesc G, D;
     std::vector<LayerGeo> gg, dg;
     int d_hw;                     // discriminator output pixels per sample
-    long g_scr, d_scr;            // per-sample scratch unit
+    int math = VC_MATH_FP32;      // arithmetic of the MFMA kernels for every launch made through this plan
+    bool inference = false;       // generator-forward tables only
+    std::vector<TabKey> tables;   // geometry tables this plan holds a reference on
     hipEvent_t d_ready = nullptr;
     // side stream for the chains of the step that do not depend on each other (fork / join with events)
     hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -537,23 +624,29 @@ static void plan_geos(const NetDesc& n, int C0, int H0, int W0, std::vector<Laye
     }
 }
 
-extern "C" int vc_plan_create(int num_features, int n_frames, vc_plan** out) {
+static int plan_create(int num_features, int n_frames, bool inference, vc_plan** out) {
     VC_ARG(out, "vc_plan_create: out is NULL");
     VC_ARG(num_features > 0 && num_features % 4 == 0, "vc_plan_create: num_features must be a positive multiple of 4");
     VC_ARG(n_frames > 0 && n_frames % 4 == 0, "vc_plan_create: n_frames must be a positive multiple of 4 (preprocess.py:146-156)");
     vc_plan* p = new vc_plan();
-    p->F = num_features; p->T = n_frames;
+    p->F = num_features; p->T = n_frames; p->inference = inference; p->math = t_math;
     p->G = make_generator(num_features); p->D = make_discriminator();
     plan_geos(p->G, num_features, 1, n_frames, p->gg);
     plan_geos(p->D, 1, num_features, n_frames, p->dg);
     p->d_hw = p->dg.back().g.OH * p->dg.back().g.OW;
-    long m = 0; for (auto& l : p->gg) m = std::max(m, l.raw_ps); p->g_scr = m;
-    m = 0; for (auto& l : p->dg) m = std::max(m, l.raw_ps); p->d_scr = m;
-    // build every geometry table now so steady-state calls never allocate
-    for (auto* v : {&p->gg, &p->dg}) for (auto& l : *v) {
-        Table t; int r = get_fwd_table(l.g, &t); if (r) { delete p; return r; }
-        for (int ph = 0; ph < l.g.sh; ++ph) for (int pw = 0; pw < l.g.sw; ++pw) { r = get_dgrad_table(l.g, ph, pw, &t); if (r) { delete p; return r; } }
+    // build every geometry table now so steady-state calls never allocate (an inference plan: generator forward only)
+    int r = 0;
+    for (auto* v : {&p->gg, &p->dg}) {
+        if (inference && v == &p->dg) break;
+        for (auto& l : *v) {
+            if (c1_path(l.g)) continue;
+            Table t;
+            if (!(wsconv_path(l.g) && inference)) r = r ? r : get_fwd_table(l.g, &t, &p->tables);
+            if (inference) continue;
+            for (int ph = 0; ph < l.g.sh && !r; ++ph) for (int pw = 0; pw < l.g.sw && !r; ++pw) r = get_dgrad_table(l.g, ph, pw, &t, &p->tables);
+        }
     }
+    if (r) { release_tables(p->tables); delete p; return r; }
     hipError_t e = hipEventCreateWithFlags(&p->d_ready, hipEventDisableTiming);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming);
@@ -564,14 +657,15 @@ extern "C" int vc_plan_create(int num_features, int n_frames, vc_plan** out) {
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->wstream_d, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_wjoin_d, hipEventDisableTiming);
     for (int k = 0; k < 8 && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&p->ev_layer_d[k], hipEventDisableTiming);
-    { const char* v = getenv("VC_STEP_STREAMS"); if (v) p->use_side = atoi(v) > 1; }
     for (int k = 0; k < vc_plan::kBuckets && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&p->g_ready[k], hipEventDisableTiming);
     for (int k = 0; k < vc_plan::kBuckets && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&p->g_free[k], hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&p->d_free, hipEventDisableTiming);
-    if (e != hipSuccess) { vc_set_error("hipEventCreate failed: %s", hipGetErrorString(e)); delete p; return (int)e; }
+    if (e != hipSuccess) { vc_set_error("hipEventCreate failed: %s", hipGetErrorString(e)); vc_plan_destroy(p); return (int)e; }
     *out = p;
     return 0;
 }
+extern "C" int vc_plan_create(int num_features, int n_frames, vc_plan** out) { return plan_create(num_features, n_frames, false, out); }
+extern "C" int vc_plan_create_inference(int num_features, int n_frames, vc_plan** out) { return plan_create(num_features, n_frames, true, out); }
 extern "C" void vc_plan_destroy(vc_plan* p) {
     if (!p) return;
     if (p->d_ready) (void)hipEventDestroy(p->d_ready);
@@ -587,13 +681,21 @@ extern "C" void vc_plan_destroy(vc_plan* p) {
     for (hipEvent_t ev : p->g_ready) if (ev) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : p->g_free) if (ev) (void)hipEventDestroy(ev);
     if (p->d_free) (void)hipEventDestroy(p->d_free);
+    release_tables(p->tables);
     delete p;
 }
+extern "C" int vc_plan_set_math_mode(vc_plan* p, int mode) {
+    VC_ARG(p, "vc_plan_set_math_mode: bad plan");
+    VC_ARG(mode >= VC_MATH_FP32 && mode <= VC_MATH_BF16X3, "vc_plan_set_math_mode: mode %d (0 fp32, 1 bf16, 2 bf16x3)", mode);
+    p->math = mode;
+    return 0;
+}
+extern "C" int vc_plan_get_math_mode(const vc_plan* p) { return p ? p->math : VC_E_STATE; }
 
 static long align64(long x) { return (x + 63) & ~63L; }
 // save map: for every layer raw output, activation, stats -- offsets (floats) inside one group's save area
 struct SaveMap { std::vector<long> raw, act, st; long total; };
-static SaveMap save_map(const NetDesc& n, const std::vector<LayerGeo>& geo, int B, bool has_head) {
+static SaveMap save_map(const NetDesc& n, const std::vector<LayerGeo>& geo, int B) {
     SaveMap m; long o = 0;
     for (size_t i = 0; i < n.layers.size(); ++i) {
         const Layer& L = n.layers[i];
@@ -604,42 +706,52 @@ static SaveMap save_map(const NetDesc& n, const std::vector<LayerGeo>& geo, int 
         if (L.mode == M_GATED_IN) o = align64(o + (long)B * 2 * L.C * 2);
         else if (L.mode == M_IN_RES) o = align64(o + (long)B * L.C * 2);
     }
-    (void)has_head;
     m.total = o;
     return m;
 }
-extern "C" int64_t vc_generator_save_floats(const vc_plan* p, int B) { return p ? save_map(p->G, p->gg, B, false).total : 0; }
-extern "C" int64_t vc_discriminator_save_floats(const vc_plan* p, int B) { return p ? save_map(p->D, p->dg, B, true).total : 0; }
+extern "C" int64_t vc_generator_save_floats(const vc_plan* p, int B) { return p ? save_map(p->G, p->gg, B).total : 0; }
+extern "C" int64_t vc_discriminator_save_floats(const vc_plan* p, int B) { return p ? save_map(p->D, p->dg, B).total : 0; }
 // backward scratch of one group: for every layer i [dY_i: gradient w.r.t. its raw conv output][dA_i: gradient w.r.t. its
 // activation].  Per-layer buffers (not a rotating pair) so a filter gradient on the side stream can still read dY_i
 // while the chain has moved on.
-static long scratch_floats_net(const std::vector<LayerGeo>& geo, long raw_max, int B) {
-    (void)raw_max;
+static long scratch_floats_net(const std::vector<LayerGeo>& geo, int B) {
     long o = 0;
     for (const LayerGeo& l : geo) o += align64(l.raw_ps * B) + align64(l.act_ps * B);
     return o;
 }
 extern "C" int64_t vc_scratch_floats(const vc_plan* p, int B) {
     if (!p) return 0;
-    return std::max(scratch_floats_net(p->gg, p->g_scr, B), scratch_floats_net(p->dg, p->d_scr, B));
+    return std::max(scratch_floats_net(p->gg, B), scratch_floats_net(p->dg, B));
 }
 extern "C" int vc_discriminator_out_elems(const vc_plan* p) { return p ? p->d_hw : 0; }
 
 // ------------------------------------------------------------------------------------
 // forward / backward schedules (shared by generator and discriminator)
 // ------------------------------------------------------------------------------------
+// An earlier application of the same network whose filter gradients were deferred (the cycle hop): the first-hop
+// backward reduces both applications into dW with ONE launch per layer (WgradArgs segments).
+struct DeferredApp { const float* x; long x_gs; const float* save; long save_gs; const SaveMap* sm;
+                     const float* scratch; long scr_gs; const float* dtop; long dtop_gs; int B; };
+enum { W_NONE = 0, W_SELF = 1 };
 struct NetCtx {
     const NetDesc* n; const std::vector<LayerGeo>* geo;
     const float* params; long par_gs;
     float* dparams; long dpar_gs;          // may be null
     float* save; long save_gs; SaveMap sm; // layout batch = Bl
-    int G, B, Bl;
+    int G, B, Bl, math;
     hipStream_t s;
     hipStream_t ws = nullptr; const hipEvent_t* ev_layer = nullptr; hipEvent_t ev_wjoin = nullptr;   // wgrad stream (null: same stream)
-    bool wgrad_first = false;              // this backward is the first contribution of the step to dparams' conv kernels
+    int wmode = W_SELF;                    // W_NONE: leave the conv filter gradients to a later application (DeferredApp)
+    bool wgrad_store = false;              // this backward's filter gradients are the step's only contribution to dparams' conv kernels
+    const DeferredApp* deferred = nullptr; // reduce this earlier application in the same launches
     const int* ev_first = nullptr; const hipEvent_t* ev = nullptr; int n_ev = 0;   // record ev[k] once layer ev_first[k] is done (backward)
     const hipEvent_t* ev_free = nullptr;                                            // ... and ev_free[k] after its input gradient is issued
 };
+// scratch map of one group: dY[i], dA[i] per layer (dA[i] = gradient w.r.t. the activation (output) of layer i)
+static void scratch_map(const std::vector<LayerGeo>& geo, int B, long* dY, long* dA) {
+    long o = 0;
+    for (size_t i = 0; i < geo.size(); ++i) { dY[i] = o; o += align64(geo[i].raw_ps * B); dA[i] = o; o += align64(geo[i].act_ps * B); }
+}
 
 static int net_forward(NetCtx& c, const float* x, long x_gs, float* y_plain, long y_plain_gs) {
     // one launch zeroes every raw conv output of this pass whose convolution will reduce over split-K with atomics
@@ -649,7 +761,7 @@ static int net_forward(NetCtx& c, const float* x, long x_gs, float* y_plain, lon
             const Layer& L = c.n->layers[i];
             if (L.mode == M_PLAIN) continue;
             bool split = false;
-            VC_CHECK(conv_fwd(nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0, c.G, c.B, (*c.geo)[i].g, c.s, false, &split));
+            VC_CHECK(conv_fwd(nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0, c.G, c.B, (*c.geo)[i].g, c.math, c.s, false, &split));
             if (split) for (int g = 0; g < c.G; ++g) zl.push_back({c.save + c.sm.raw[i] + (long)g * c.save_gs, (*c.geo)[i].raw_ps * c.B});
         }
         if (!zl.empty()) VC_CHECK(launch_zero_list(zl, c.s));
@@ -661,7 +773,7 @@ static int net_forward(NetCtx& c, const float* x, long x_gs, float* y_plain, lon
         float* raw = (L.mode == M_PLAIN) ? y_plain : c.save + c.sm.raw[i];
         const long raw_gs = (L.mode == M_PLAIN) ? y_plain_gs : c.save_gs;
         if (L.mode == M_GATED_IN && i + 1 < c.n->layers.size() && c.n->layers[i + 1].mode == M_IN_RES) { blk_in = in; blk_in_gs = in_gs; }
-        VC_CHECK(conv_fwd(in, in_gs, c.params + L.w, c.par_gs, c.params + L.b, c.par_gs, raw, raw_gs, c.G, c.B, lg.g, c.s,
+        VC_CHECK(conv_fwd(in, in_gs, c.params + L.w, c.par_gs, c.params + L.b, c.par_gs, raw, raw_gs, c.G, c.B, lg.g, c.math, c.s,
                           /*prezeroed=*/L.mode != M_PLAIN));
         if (L.mode == M_PLAIN) break;
         NormArgs a{};
@@ -682,21 +794,21 @@ static int net_forward(NetCtx& c, const float* x, long x_gs, float* y_plain, lon
 // dtop: gradient w.r.t. the network's last activation (for the generator: d o1 output, i.e. dy of the
 // plain layer; for the discriminator: gradient w.r.t. the last GLU output, produced by the head).
 static int net_backward(NetCtx& c, const float* x, long x_gs, const float* dtop, long dtop_gs,
-                        float* dx, long dx_gs, int dx_acc, float* scratch, long scr_gs, long raw_max) {
+                        float* dx, long dx_gs, int dx_acc, float* scratch, long scr_gs) {
     const int nl = (int)c.n->layers.size();
-    (void)raw_max;
-    // scratch map of one group: dY[i], dA[i] per layer (dA[i] = gradient w.r.t. the activation (output) of layer i)
-    std::vector<float*> dYb(nl), dA(nl);
-    { long o = 0; for (int i = 0; i < nl; ++i) { dYb[i] = scratch + o; o += align64((*c.geo)[i].raw_ps * c.B);
-                                                   dA[i] = scratch + o; o += align64((*c.geo)[i].act_ps * c.B); } }
+    VC_ARG(nl <= 24, "net_backward: more than 24 layers");
+    long dYo[24], dAo[24];
+    scratch_map(*c.geo, c.B, dYo, dAo);
+    long dYd[24], dAd[24];
+    if (c.deferred) scratch_map(*c.geo, c.deferred->B, dYd, dAd);
     hipStream_t ws = c.ws ? c.ws : c.s;       // the plan sizes its event pools for its own networks (18 / 4 layers)
     // one launch zeroes every dA that a split-K input-gradient will accumulate into
     {
         std::vector<std::pair<float*, long>> zl;
         for (int i = 1; i < nl; ++i) {
             bool split = false;
-            VC_CHECK(conv_dgrad(nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, c.G, c.B, (*c.geo)[i].g, c.s, false, &split));
-            if (split) for (int g = 0; g < c.G; ++g) zl.push_back({dA[i - 1] + (long)g * scr_gs, (*c.geo)[i - 1].act_ps * c.B});
+            VC_CHECK(conv_dgrad(nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, c.G, c.B, (*c.geo)[i].g, c.math, c.s, false, &split));
+            if (split) for (int g = 0; g < c.G; ++g) zl.push_back({scratch + dAo[i - 1] + (long)g * scr_gs, (*c.geo)[i - 1].act_ps * c.B});
         }
         if (!zl.empty()) VC_CHECK(launch_zero_list(zl, c.s));
     }
@@ -717,7 +829,7 @@ static int net_backward(NetCtx& c, const float* x, long x_gs, const float* dtop,
             if (L.mode == M_IN_RES) { skip = dcur; skip_gs = dcur_gs; }
             NormArgs a{};
             a.y = c.save + c.sm.raw[i]; a.y_gs = c.save_gs; a.dout = dcur; a.do_gs = dcur_gs;
-            a.dy = dYb[i]; a.dy_gs = scr_gs;
+            a.dy = scratch + dYo[i]; a.dy_gs = scr_gs;
             a.G = c.G; a.B = c.B; a.C = L.C; a.ps = L.ps; a.L = lg.g.OH * lg.g.OW * (L.ps ? 2 : 1);
             if (L.mode != M_GATED) {
                 a.gamma = c.params + L.gamma; a.beta = c.params + L.beta; a.par_gs = c.par_gs;
@@ -726,23 +838,32 @@ static int net_backward(NetCtx& c, const float* x, long x_gs, const float* dtop,
             }
             if (c.dparams) { a.dbias = c.dparams + L.b; a.dbias_gs = c.dpar_gs; }
             VC_CHECK(launch_norm_bwd(L.mode, a, c.s));
-            dyp = dYb[i]; dy_gs = scr_gs;
-            if (c.dparams && ws != c.s) { VC_HIP(hipEventRecord(c.ev_layer[i], c.s)); VC_HIP(hipStreamWaitEvent(ws, c.ev_layer[i], 0)); }
+            dyp = scratch + dYo[i]; dy_gs = scr_gs;
+            if (c.dparams && c.wmode != W_NONE && ws != c.s) { VC_HIP(hipEventRecord(c.ev_layer[i], c.s)); VC_HIP(hipStreamWaitEvent(ws, c.ev_layer[i], 0)); }
         }
-        if (c.dparams) VC_CHECK(conv_wgrad(in, in_gs, dyp, dy_gs, c.dparams + L.w, c.dpar_gs, c.G, c.B, lg.g, ws, c.wgrad_first));
+        if (c.dparams && c.wmode != W_NONE) {
+            WgradApp apps[2]; int na = 0;
+            if (c.deferred) {
+                const DeferredApp& d = *c.deferred;
+                apps[na++] = WgradApp{i == 0 ? d.x : d.save + d.sm->act[i - 1], i == 0 ? d.x_gs : d.save_gs,
+                                      L.mode == M_PLAIN ? d.dtop : d.scratch + dYd[i], L.mode == M_PLAIN ? d.dtop_gs : d.scr_gs, d.B};
+            }
+            apps[na++] = WgradApp{in, in_gs, dyp, dy_gs, c.B};
+            VC_CHECK(conv_wgrad(apps, na, c.dparams + L.w, c.dpar_gs, c.G, lg.g, c.math, ws, c.wgrad_store));
+        }
         for (int k = 0; k < c.n_ev; ++k) if (c.ev_first[k] == i) VC_HIP(hipEventRecord(c.ev[k], ws));
         if (i == 0) {
-            if (dx) VC_CHECK(conv_dgrad(dyp, dy_gs, c.params + L.w, c.par_gs, dx, dx_gs, nullptr, 0, dx_acc, c.G, c.B, lg.g, c.s));
+            if (dx) VC_CHECK(conv_dgrad(dyp, dy_gs, c.params + L.w, c.par_gs, dx, dx_gs, nullptr, 0, dx_acc, c.G, c.B, lg.g, c.math, c.s));
             for (int k = 0; k < c.n_ev; ++k) if (c.ev_free && c.ev_first[k] == i) VC_HIP(hipEventRecord(c.ev_free[k], c.s));
             break;        // falls through to the join below
         }
         // gradient w.r.t. this layer's input = activation of layer i-1; the head of a residual block adds the skip
         const bool block_head = (L.mode == M_GATED_IN && i + 1 < nl && c.n->layers[i + 1].mode == M_IN_RES);
-        VC_CHECK(conv_dgrad(dyp, dy_gs, c.params + L.w, c.par_gs, dA[i - 1], scr_gs,
-                            block_head ? skip : nullptr, block_head ? skip_gs : 0, 0, c.G, c.B, lg.g, c.s, /*prezeroed=*/true));
+        VC_CHECK(conv_dgrad(dyp, dy_gs, c.params + L.w, c.par_gs, scratch + dAo[i - 1], scr_gs,
+                            block_head ? skip : nullptr, block_head ? skip_gs : 0, 0, c.G, c.B, lg.g, c.math, c.s, /*prezeroed=*/true));
         if (block_head) skip = nullptr;
         for (int k = 0; k < c.n_ev; ++k) if (c.ev_free && c.ev_first[k] == i) VC_HIP(hipEventRecord(c.ev_free[k], c.s));
-        dcur = dA[i - 1]; dcur_gs = scr_gs;
+        dcur = scratch + dAo[i - 1]; dcur_gs = scr_gs;
     }
     if (ws != c.s) { VC_HIP(hipEventRecord(c.ev_wjoin, ws)); VC_HIP(hipStreamWaitEvent(c.s, c.ev_wjoin, 0)); }   // join
     return 0;
@@ -752,14 +873,14 @@ static NetCtx gen_ctx(const vc_plan* p, const float* params, long par_gs, float*
                       float* save, int G, int B, int Bl, hipStream_t s) {
     NetCtx c{};
     c.n = &p->G; c.geo = &p->gg; c.params = params; c.par_gs = par_gs; c.dparams = dparams; c.dpar_gs = dpar_gs;
-    c.sm = save_map(p->G, p->gg, Bl, false); c.save = save; c.save_gs = c.sm.total; c.G = G; c.B = B; c.Bl = Bl; c.s = s;
+    c.sm = save_map(p->G, p->gg, Bl); c.save = save; c.save_gs = c.sm.total; c.G = G; c.B = B; c.Bl = Bl; c.s = s; c.math = p->math;
     return c;
 }
 static NetCtx disc_ctx(const vc_plan* p, const float* params, long par_gs, float* dparams, long dpar_gs,
                        float* save, int G, int B, int Bl, hipStream_t s) {
     NetCtx c{};
     c.n = &p->D; c.geo = &p->dg; c.params = params; c.par_gs = par_gs; c.dparams = dparams; c.dpar_gs = dpar_gs;
-    c.sm = save_map(p->D, p->dg, Bl, true); c.save = save; c.save_gs = c.sm.total; c.G = G; c.B = B; c.Bl = Bl; c.s = s;
+    c.sm = save_map(p->D, p->dg, Bl); c.save = save; c.save_gs = c.sm.total; c.G = G; c.B = B; c.Bl = Bl; c.s = s; c.math = p->math;
     return c;
 }
 
@@ -768,18 +889,21 @@ static int gen_forward(const vc_plan* p, const float* params, long par_gs, const
     NetCtx c = gen_ctx(p, params, par_gs, nullptr, 0, save, G, B, B, s);
     return net_forward(c, x, x_gs, y, y_gs);
 }
+struct BwdOpts { bool record_buckets = false, wgrad_store = false; int wmode = W_SELF; const DeferredApp* deferred = nullptr; };
 static int gen_backward(const vc_plan* p, const float* params, long par_gs, const float* x, long x_gs,
                         const float* dy, long dy_gs, float* save, int Bl, float* dparams, long dpar_gs,
-                        float* dx, long dx_gs, int dx_acc, float* scratch, int G, int B, hipStream_t s, bool record_buckets = false,
-                        bool wgrad_first = false) {
+                        float* dx, long dx_gs, int dx_acc, float* scratch, long scr_gs, int G, int B, hipStream_t s,
+                        const BwdOpts& o = BwdOpts()) {
+    VC_ARG(!p->inference, "this plan was created for inference only (vc_plan_create_inference)");
     NetCtx c = gen_ctx(p, params, par_gs, dparams, dpar_gs, save, G, B, Bl, s);
-    c.wgrad_first = wgrad_first;
-    if (p->use_side && dparams) { c.ws = p->wstream; c.ev_layer = p->ev_layer; c.ev_wjoin = p->ev_wjoin; }
-    if (record_buckets) { c.ev_first = p->bucket_first; c.ev = p->g_ready; c.ev_free = p->g_free; c.n_ev = vc_plan::kBuckets; }
-    return net_backward(c, x, x_gs, dy, dy_gs, dx, dx_gs, dx_acc, scratch, vc_scratch_floats(p, B), p->g_scr);
+    c.wgrad_store = o.wgrad_store; c.wmode = o.wmode; c.deferred = o.deferred;
+    if (p->use_side && dparams && o.wmode != W_NONE) { c.ws = p->wstream; c.ev_layer = p->ev_layer; c.ev_wjoin = p->ev_wjoin; }
+    if (o.record_buckets) { c.ev_first = p->bucket_first; c.ev = p->g_ready; c.ev_free = p->g_free; c.n_ev = vc_plan::kBuckets; }
+    return net_backward(c, x, x_gs, dy, dy_gs, dx, dx_gs, dx_acc, scratch, scr_gs);
 }
 static int disc_forward(const vc_plan* p, const float* params, long par_gs, const float* x, long x_gs,
                         float* o, long o_gs, float* save, int G, int B, hipStream_t s) {
+    VC_ARG(!p->inference, "this plan was created for inference only (vc_plan_create_inference)");
     NetCtx c = disc_ctx(p, params, par_gs, nullptr, 0, save, G, B, B, s);
     VC_CHECK(net_forward(c, x, x_gs, nullptr, 0));
     const int last = (int)p->D.layers.size() - 1;
@@ -790,21 +914,20 @@ static int disc_forward(const vc_plan* p, const float* params, long par_gs, cons
 static int disc_backward(const vc_plan* p, const float* params, long par_gs, const float* x, long x_gs,
                          const float* o, long o_gs, const float* dout, long do_gs, float* save, int Bl,
                          float* dparams, long dpar_gs, float* dx, long dx_gs, int dx_acc,
-                         float* scratch, int G, int B, hipStream_t s, bool wgrad_first = false) {
+                         float* scratch, long scr_gs, int G, int B, hipStream_t s, bool wgrad_store = false) {
+    VC_ARG(!p->inference, "this plan was created for inference only (vc_plan_create_inference)");
     NetCtx c = disc_ctx(p, params, par_gs, dparams, dpar_gs, save, G, B, Bl, s);
-    c.wgrad_first = wgrad_first;
+    c.wgrad_store = wgrad_store;
     if (p->use_side && dparams) { c.ws = p->wstream_d; c.ev_layer = p->ev_layer_d; c.ev_wjoin = p->ev_wjoin_d; }
     const int last = (int)p->D.layers.size() - 1;
-    const long scr_gs = vc_scratch_floats(p, B);
     // the head's input gradient goes where net_backward's scratch map puts dA[last]
-    long off = 0;
-    for (int i = 0; i < last; ++i) off += align64(p->dg[i].raw_ps * B) + align64(p->dg[i].act_ps * B);
-    off += align64(p->dg[last].raw_ps * B);
-    float* dtop = scratch + off;
+    long dYo[24], dAo[24];
+    scratch_map(p->dg, B, dYo, dAo);
+    float* dtop = scratch + dAo[last];
     VC_CHECK(launch_head_bwd(save + c.sm.act[last], c.save_gs, params + p->D.head_w, par_gs, o, o_gs, dout, do_gs,
                              dtop, scr_gs, dparams ? dparams + p->D.head_w : nullptr,
                              dparams ? dparams + p->D.head_b : nullptr, dpar_gs, G, B, p->D.head_c, p->d_hw, s));
-    return net_backward(c, x, x_gs, dtop, scr_gs, dx, dx_gs, dx_acc, scratch, scr_gs, p->d_scr);
+    return net_backward(c, x, x_gs, dtop, scr_gs, dx, dx_gs, dx_acc, scratch, scr_gs);
 }
 
 extern "C" int vc_generator_forward(const vc_plan* p, const float* params, int64_t par_gs,
@@ -820,7 +943,7 @@ extern "C" int vc_generator_backward(const vc_plan* p, const float* params, int6
                                      float* scratch, int G, int B, void* stream) {
     VC_ARG(p && params && x && dy && save && scratch && G > 0 && B > 0, "vc_generator_backward: bad args");
     return gen_backward(p, params, par_gs, x, x_gs, dy, dy_gs, const_cast<float*>(save), B, dparams, dpar_gs,
-                        dx, dx_gs, dx_accumulate, scratch, G, B, (hipStream_t)stream);
+                        dx, dx_gs, dx_accumulate, scratch, vc_scratch_floats(p, B), G, B, (hipStream_t)stream);
 }
 extern "C" int vc_discriminator_forward(const vc_plan* p, const float* params, int64_t par_gs,
                                         const float* x, int64_t x_gs, float* o, int64_t o_gs,
@@ -836,7 +959,7 @@ extern "C" int vc_discriminator_backward(const vc_plan* p, const float* params, 
     VC_ARG(p && params && x && dout && save && scratch && G > 0 && B > 0, "vc_discriminator_backward: bad args");
     // the sigmoid outputs are recomputed from the saved last activation (cheap) into the tail of scratch
     hipStream_t s = (hipStream_t)stream;
-    SaveMap sm = save_map(p->D, p->dg, B, true);
+    SaveMap sm = save_map(p->D, p->dg, B);
     const int last = (int)p->D.layers.size() - 1;
     // the dY region of the scratch is free until the first norm backward writes it; o only has to survive the head
     // kernels (stream-ordered)
@@ -845,7 +968,7 @@ extern "C" int vc_discriminator_backward(const vc_plan* p, const float* params, 
     VC_CHECK(launch_head_fwd(save + sm.act[last], sm.total, params + p->D.head_w, params + p->D.head_b, par_gs,
                              o, o_gs, G, B, p->D.head_c, p->d_hw, s));
     return disc_backward(p, params, par_gs, x, x_gs, o, o_gs, dout, do_gs, const_cast<float*>(save), B, dparams, dpar_gs,
-                         dx, dx_gs, dx_accumulate, scratch, G, B, s);
+                         dx, dx_gs, dx_accumulate, scratch, vc_scratch_floats(p, B), G, B, s);
 }
 
 // ------------------------------------------------------------------------------------
@@ -857,8 +980,8 @@ extern "C" int64_t vc_flat_offset(const vc_plan* p, int net) {
     switch (net) { case 0: return 0; case 1: return p->G.total; case 2: return 2 * p->G.total; case 3: return 2 * p->G.total + p->D.total; }
     return -1;
 }
-struct StepMap { long X1, O1, CY, DX, DO, dO1, dCY, dDO_D, dDO_G, S1, S2, SD, SCR, SCR2, ACC, total;
-                 long ft2, ft1, hw2, hw1, s1_gs, s2_gs, sd_gs, scr_gs; };
+struct StepMap { long X1, O1, CY, DX, DO, dO1, dCY, dDO_D, dDO_G, S1, S2, SD, SCR, SCRC, SCR2, ACC, total;
+                 long ft2, ft1, hw2, hw1, s1_gs, s2_gs, sd_gs, scr_gs, scrc_gs; };
 static StepMap step_map(const vc_plan* p, int B) {
     StepMap m{}; long o = 0;
     const long FT = (long)p->F * p->T;
@@ -870,6 +993,8 @@ static StepMap step_map(const vc_plan* p, int B) {
     m.s2_gs = vc_generator_save_floats(p, B);     m.S2 = take(m.s2_gs);
     m.sd_gs = vc_discriminator_save_floats(p, 2 * B); m.SD = take(m.sd_gs);
     m.scr_gs = vc_scratch_floats(p, 2 * B); m.SCR = take(m.scr_gs);   // backward calls with batch B use a smaller group stride inside it
+    m.scrc_gs = scratch_floats_net(p->gg, B); m.SCRC = take(m.scrc_gs);   // cycle-hop backward: its dY buffers stay live until the
+                                                                          // first-hop backward has reduced them into the filter gradients
     m.SCR2 = take(m.scr_gs);                      // scratch of the discriminator_loss backward (runs on the side stream)
     m.ACC = o; o += 64;
     m.total = o;
@@ -877,12 +1002,42 @@ static StepMap step_map(const vc_plan* p, int B) {
 }
 extern "C" int64_t vc_step_workspace_floats(const vc_plan* p, int B) { return p ? step_map(p, B).total : 0; }
 
+// Gradient ranges that are accumulated with atomics during the step (conv biases, instance-norm gamma/beta, the dense
+// head, the Cin = 1 kernel, filter gradients whose launch splits K) -- together with the padding between tensors --
+// are zeroed by ONE multi-buffer launch.  Every other filter gradient is written with plain stores by its single
+// (two-application) launch, so the 479 MB gradient memset of a naive step is not needed.
+static int zero_step_grads(const vc_plan* p, float* grads, int B, int Bbwd, hipStream_t s) {
+    std::vector<std::pair<float*, long>> zl;
+    const long PG = p->G.total, PD = p->D.total;
+    for (int net = 0; net < 4; ++net) {
+        const bool gen = net < 2;
+        const NetDesc& n = gen ? p->G : p->D;
+        const std::vector<LayerGeo>& geo = gen ? p->gg : p->dg;
+        float* base = grads + (gen ? net * PG : 2 * PG + (net - 2) * PD);
+        for (size_t i = 0; i < n.layers.size(); ++i) {
+            const Layer& L = n.layers[i];
+            const long next_w = (i + 1 < n.layers.size()) ? n.layers[i + 1].w : (n.head_w >= 0 ? n.head_w : n.total);
+            long lo = L.b;
+            // does the filter gradient of this layer accumulate?  (same decision conv_wgrad will take)
+            WgradApp apps[2] = {{nullptr, 0, nullptr, 0, gen ? B : 2 * B}, {nullptr, 0, nullptr, 0, Bbwd}};
+            bool acc = true;
+            VC_CHECK(conv_wgrad(apps, gen ? 2 : 1, nullptr, 0, 2, geo[i].g, p->math, s, /*store=*/true, &acc));
+            if (acc) lo = L.w;
+            zl.push_back({base + lo, next_w - lo});
+        }
+        if (n.head_w >= 0) zl.push_back({base + n.head_w, n.total - n.head_w});
+    }
+    return launch_zero_list(zl, s);
+}
+
 extern "C" int vc_cyclegan_step_grads(const vc_plan* p, const float* params, float* grads,
                                       const float* A, const float* Bm, int batch,
                                       float lambda_cycle, float lambda_identity,
                                       float* losses, float* gen_A, float* gen_B,
                                       float* ws, int64_t ws_floats, void* stream) {
     VC_ARG(p && params && grads && A && Bm && losses && ws && batch > 0, "vc_cyclegan_step_grads: bad args");
+    VC_ARG(!p->inference, "this plan was created for inference only (vc_plan_create_inference)");
+    VC_ARG(aligned16(grads) && aligned16(ws), "vc_cyclegan_step_grads: grads and workspace must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     const int B = batch;
     const StepMap m = step_map(p, B);
@@ -895,15 +1050,19 @@ extern "C" int vc_cyclegan_step_grads(const vc_plan* p, const float* params, flo
     float *dO1 = ws + m.dO1, *dCY = ws + m.dCY, *dDO_D = ws + m.dDO_D, *dDO_G = ws + m.dDO_G;
     const long X1g = gs(m.ft2), O1g = gs(m.ft2), CYg = gs(m.ft1), DXg = gs(m.ft2), DOg = gs(m.hw2);
     const long dO1g = gs(m.ft2), dCYg = gs(m.ft1), dDDg = gs(m.hw2), dDGg = gs(m.hw1);
-    float *S1 = ws + m.S1, *S2 = ws + m.S2, *SD = ws + m.SD, *SCR = ws + m.SCR;
+    float *S1 = ws + m.S1, *S2 = ws + m.S2, *SD = ws + m.SD, *SCR = ws + m.SCR, *SCRC = ws + m.SCRC;
+    const long scr_gs = align64(m.scr_gs), scrc_gs = align64(m.scrc_gs);
     // the save/scratch areas were sized with take(): group stride = align64(size)
     // (save_map totals are already multiples of 64, so align64 is the identity there)
+    // With lambda_identity == 0 (train.py:98-99 after 10 000 iterations) the identity half carries an exactly-zero
+    // seed gradient: only the generation half (the first B samples of every saved tensor) is propagated.
+    const int Bbwd = (lambda_identity == 0.0f) ? B : 2 * B;
 
     hipStream_t s2 = p->use_side ? p->side : s;
-    // 0. zero the flat gradient on the side stream, under the first-hop forward (nothing touches it before step 7;
-    //    the fork/join pairs below order it before every consumer)
+    // 0. zero the accumulated parts of the flat gradient on the side stream, under the first-hop forward (nothing touches
+    //    them before step 7; the fork/join pairs below order it before every consumer)
     if (s2 != s) { VC_HIP(hipEventRecord(p->ev_fork, s)); VC_HIP(hipStreamWaitEvent(s2, p->ev_fork, 0)); }
-    VC_HIP(hipMemsetAsync(grads, 0, (size_t)vc_flat_param_floats(p) * sizeof(float), s2));
+    VC_CHECK(zero_step_grads(p, grads, B, Bbwd, s2));
     // 1. first-hop inputs: g0 = A2B on [A;B], g1 = B2A on [B;A]   (model.py:44,51 / 47,50)
     VC_HIP(hipMemcpyAsync(X1, A, FTb, hipMemcpyDeviceToDevice, s));
     VC_HIP(hipMemcpyAsync(X1 + ft1, Bm, FTb, hipMemcpyDeviceToDevice, s));
@@ -914,7 +1073,6 @@ extern "C" int vc_cyclegan_step_grads(const vc_plan* p, const float* params, flo
     // Two pairs of chains are independent and run side by side (main stream s / side stream s2, fork+join by events):
     //   forward : [3. cycle hop G forward]            ||  [4-5. D inputs + D forward]
     //   backward: [8-10. generator_loss backward]     ||  [7. discriminator_loss backward]
-    // (s2 is declared before step 1: the gradient zeroing already runs there)
     auto fork = [&]() -> int { if (s2 != s) { VC_HIP(hipEventRecord(p->ev_fork, s)); VC_HIP(hipStreamWaitEvent(s2, p->ev_fork, 0)); } return 0; };
     auto join = [&]() -> int { if (s2 != s) { VC_HIP(hipEventRecord(p->ev_join, s2)); VC_HIP(hipStreamWaitEvent(s, p->ev_join, 0)); } return 0; };
     VC_CHECK(fork());
@@ -941,22 +1099,24 @@ extern "C" int vc_cyclegan_step_grads(const vc_plan* p, const float* params, flo
     VC_CHECK(fork());
     // 7. discriminator_loss backward over [fake; real] -> D gradients (model.py:94,107)   [side stream, own scratch]
     VC_CHECK(disc_backward(p, params + 2 * PG, PD, DX, DXg, DO, DOg, dDO_D, dDDg, SD, 2 * B,
-                           grads + 2 * PG, PD, nullptr, 0, 0, ws + m.SCR2, 2, 2 * B, s2, /*wgrad_first=*/true));
+                           grads + 2 * PG, PD, nullptr, 0, 0, ws + m.SCR2, scr_gs, 2, 2 * B, s2, /*wgrad_store=*/true));
     VC_HIP(hipEventRecord(p->d_ready, s2));
     // 8. adversarial generator terms: gradient through D's inputs only (var_list = generator_vars, model.py:95,108)
     //    g0 = D_A -> d gen_A = dO1[g1][0:B]; g1 = D_B -> d gen_B = dO1[g0][0:B]
     VC_CHECK(disc_backward(p, params + 2 * PG, PD, DX, DXg, DO, DOg, dDO_G, dDGg, SD, 2 * B,
-                           nullptr, 0, dO1 + dO1g, -dO1g, 0, SCR, 2, B, s));
+                           nullptr, 0, dO1 + dO1g, -dO1g, 0, SCR, scr_gs, 2, B, s));
     VC_HIP(hipEventRecord(p->d_free, s));     // last read of the discriminator weights in this step
-    // 9. cycle hop backward: g0 = A2B on gen_A -> adds into d gen_A; g1 = B2A on gen_B -> d gen_B
+    // 9. cycle hop backward: g0 = A2B on gen_A -> adds into d gen_A; g1 = B2A on gen_B -> d gen_B.  Its filter
+    //    gradients are NOT launched here: step 10 reduces both applications of every layer in one launch.
+    BwdOpts oc; oc.wmode = W_NONE;
     VC_CHECK(gen_backward(p, params, PG, O1 + O1g, -O1g, dCY, dCYg, S2, B, grads, PG,
-                          dO1 + dO1g, -dO1g, 1, SCR, 2, B, s, false, /*wgrad_first=*/true));
-    // 10. first-hop backward over [generation; identity]
-    //     With lambda_identity == 0 (train.py:98-99 after 10 000 iterations) the identity half carries an exactly-zero
-    //     seed gradient: only the generation half (the first B samples of every saved tensor) is propagated.
-    const int Bbwd = (lambda_identity == 0.0f) ? B : 2 * B;
+                          dO1 + dO1g, -dO1g, 1, SCRC, scrc_gs, 2, B, s, oc));
+    // 10. first-hop backward over [generation; identity] (+ the deferred cycle-hop filter gradients)
+    const SaveMap sm2 = save_map(p->G, p->gg, B);
+    const DeferredApp cyc{O1 + O1g, -O1g, S2, sm2.total, &sm2, SCRC, scrc_gs, dCY, dCYg, B};
+    BwdOpts o1; o1.record_buckets = true; o1.wgrad_store = true; o1.deferred = &cyc;
     VC_CHECK(gen_backward(p, params, PG, X1, X1g, dO1, dO1g, S1, 2 * B, grads, PG,
-                          nullptr, 0, 0, SCR, 2, Bbwd, s, /*record_buckets=*/true));
+                          nullptr, 0, 0, SCR, scr_gs, 2, Bbwd, s, o1));
     VC_CHECK(join());      // the caller's next work on `stream` (Adam) sees the discriminator gradients
     return 0;
 }

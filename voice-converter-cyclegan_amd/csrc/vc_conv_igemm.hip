@@ -1,0 +1,379 @@
+// vc_conv_igemm.hip -- table-driven implicit GEMM on v_mfma_f32_32x32x2_f32 (exact fp32, k-ordered fma chain).
+// Serves tf.layers.conv1d/conv2d forward (reference module.py:32-40, 54-62) and their input gradients (autodiff of
+// model.py:107-108), 1-D and 2-D, TF-SAME asymmetric padding, every stride-parity class of a transposed convolution.
+//
+//   D[m][n] = sum_k A[k][m] * Xg[k][n],  m = output channel, n = launch pixel (time-contiguous), K = (tap, channel).
+//
+// Workgroup = KG K-groups x (BM/32 x 2) waves; a K group multiplies its own K range into a BM x 64 tile (every wave owns
+// one 32x32 MFMA tile), the groups' partial tiles are summed through LDS in the epilogue (split-K inside the workgroup:
+// no atomics, no zero-filled destination, 16-byte stores).  LDS tiles are k-contiguous ([row][32 + 4]): a lane fetches
+// its 16 k values of a chunk with 4 ds_read_b128 per operand (k = 8q + 4h .. + 3; MFMA step 4q + e pairs k = 8q + e in
+// lanes 0-31 with k = 8q + 4 + e in lanes 32-63, the same for A and B).
+//
+// What the K loop costs besides its 16 MFMAs decides this kernel (an f32-input MFMA runs on the vector ALU's own FMA
+// lanes: nothing co-issues with it, every other instruction is pipe time).  So the loader carries no address arithmetic:
+//   * every 32-row chunk lies inside ONE filter tap (tables pad taps to 32 rows) and a lane loads aligned runs of 4 rows,
+//     so the bounds check is one AND per run: the VGPR offset of a run's loads is the lane's pixel offset, or VC_OOB
+//     (hardware range check -> 0) when the tap leaves the image for that pixel or the run is table padding;
+//   * the K row's offset rides in the buffer load's SGPR offset, fetched from scalar-cache tables one chunk ahead;
+//   * loader instructions are issued one slice behind every MFMA (sched_barrier-pinned), global loads two chunks ahead.
+#include "vc_internal.h"
+#include <algorithm>
+#include <type_traits>
+#include <utility>
+
+typedef const __attribute__((address_space(4))) int* c_int_p;
+typedef const __attribute__((address_space(4))) unsigned* c_uint_p;
+typedef const __attribute__((address_space(4))) Tap* c_tap_p;
+
+template <int BM, bool AT, int KG, int MATH>
+__global__ __launch_bounds__(64 * (BM / 32) * 2 * KG, (64 * (BM / 32) * 2 * KG >= 1024) ? 4 : 2) void igemm_kernel(const IgemmMulti mm) {
+    const IgemmArgs& p = mm.c[blockIdx.y];                    // blockIdx.y: which fused launch (parity class)
+    if (blockIdx.x >= (unsigned)(p.mtiles * p.ntiles) || blockIdx.z >= (unsigned)(p.groups * p.splitk)) return;
+    constexpr int BN = 64, KC = VC_KC, LDK = KC + 4;
+    constexpr int WMG = BM / 32, WNG = 2, GT = 64 * WMG * WNG, NT = GT * KG;   // GT: threads of one K group
+    constexpr int ASZ = BM * LDK, XSZ = BN * LDK, REG = 2 * (ASZ + XSZ);       // floats of one K group's LDS region
+    constexpr int LDY = BN + 4;
+    static_assert(BM * LDY <= REG, "the epilogue stages a group's tile inside its own region");
+    __shared__ __attribute__((aligned(16))) float smem[KG * REG];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int kg = __builtin_amdgcn_readfirstlane(tid / GT);
+    const int gtid = tid % GT, gw = __builtin_amdgcn_readfirstlane(gtid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm = gw / WNG, wn = gw % WNG;
+    float* As = smem + kg * REG;
+    float* Xs = As + 2 * ASZ;
+
+    // XCD-aware tile order (speed only; any order is correct): block b runs on XCD b % 8 with a private L2.  Walk the
+    // tiles m-major (all pixel tiles of one weight slab are consecutive) and give every XCD one CONTIGUOUS range of that
+    // walk, so a weight slab is fetched into as few L2s as possible.
+    int mt, nt;
+    {
+        const int total = p.mtiles * p.ntiles, per = total >> 3, tile = blockIdx.x;
+        const int idx = (tile < (per << 3)) ? (tile & 7) * per + (tile >> 3) : tile;   // the last total % 8 tiles keep their place
+        mt = idx / p.ntiles; nt = idx - mt * p.ntiles;
+    }
+    // K range: split-K parts across workgroups (blockIdx.z) times K groups inside the workgroup; every part runs `cps`
+    // chunks (an even count: the loop body is a pair of chunks with static register sets and no exit in between), parts
+    // that reach past the table multiply its all-zero padding chunk.
+    const int g = blockIdx.z / p.splitk, sp = blockIdx.z - g * p.splitk;
+    const int nchunks = p.krows / KC;
+    const int parts = p.splitk * KG;
+    const int cps = (((nchunks + parts - 1) / parts) + 1) & ~1;
+    if (sp * KG * cps >= nchunks) return;                     // whole workgroup beyond the K range (uniform)
+    const int c0 = (sp * KG + kg) * cps;
+
+    // ---- gathered-operand loader: a lane owns pixel n = lane of the tile and XL consecutive K rows of every chunk
+    constexpr int XL = (KC * BN) / GT;                        // 4 (8-wave group) or 8 (4-wave group)
+    static_assert(XL % 4 == 0, "whole 16-byte k runs per thread");
+    const int xrow0 = gw * XL;
+    unsigned xoffb = 0, tapmask = 0;
+    {
+        const int P = nt * BN + lane;
+        const bool pv = P < p.Ptot;
+        int xb = 0, xi = 0, xj = 0;
+        if (pv) { int r; xb = fast_divmod(P, p.NPB, p.inv_npb, &r); xi = fast_divmod(r, p.OWc, p.inv_ow, &xj); }
+        const int li0 = xi * p.si, lj0 = xj * p.sj;
+        xoffb = (unsigned)(((long)xb * p.x_bs + (long)li0 * p.xW + lj0) * 4);
+        c_tap_p taps = (c_tap_p)p.taps;
+        for (int t = 0; t < p.ntaps; ++t) {
+            const int dh = taps[t].dh, dw = taps[t].dw;
+            const bool ok = pv && (unsigned)(li0 + dh) < (unsigned)p.Hl && (unsigned)(lj0 + dw) < (unsigned)p.Wl;
+            tapmask |= (unsigned)ok << t;
+        }
+    }
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((const char*)(p.X + (long)g * p.x_gs) - p.xbias), 0, (int)p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ars =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (long)g * p.a_gs), 0, (int)p.a_bytes, 0x00020000);
+    c_int_p xsoff = (c_int_p)p.xsoff;
+    c_uint_p rtap = (c_uint_p)p.rtap;
+    c_uint_p aoff = (c_uint_p)p.aoff;
+
+    // ---- weight loader.  Rows m >= M are clamped to row M-1 (loaded, multiplied, never stored): no out-of-range reads.
+    //  plain : thread = (m = gtid % BM, k quad gtid / BM + q * QPP): 4 loads of 4 B (rows 4*quad .. +3, lanes along m:
+    //          coalesced), one 16-B LDS store.  The quad is wave-uniform, so the 4 row offsets are one scalar load.
+    //  transp: thread = (k quad gtid % 8, m = gtid / 8 + q * MPP): one 16-B load along k (a chunk's 32 rows are contiguous
+    //          in the weight tensor: same tap, consecutive channels), one 16-B LDS store.  A run that reaches past the last
+    //          channel of a row (taps padded to 32 rows) reads the next row's weights (finite; their X operand is 0), past
+    //          the end of the tensor 0 (hardware range check).
+    constexpr int QPP = GT / BM, NQ = (KC / 4) / QPP;         // plain: quads per pass, passes
+    constexpr int MPP = GT / 8, NMP = BM / MPP;               // transposed: m rows per pass, passes
+    const int am = AT ? gtid / 8 : gtid % BM;
+    const int aq = AT ? gtid % 8 : __builtin_amdgcn_readfirstlane(gtid / BM);
+    unsigned avoff[AT ? NMP : 1];
+    if constexpr (AT) {
+#pragma unroll
+        for (int q = 0; q < NMP; ++q) avoff[q] = (unsigned)(min(mt * BM + am + q * MPP, p.M - 1) * p.a_ms) * 4u + (unsigned)aq * 16u;
+    } else {
+        avoff[0] = (unsigned)min(mt * BM + am, p.M - 1) * 4u;
+    }
+
+    constexpr int NAL = AT ? NMP : NQ * 4, NAS = AT ? NMP : NQ;
+    float xr[2][XL];                 // two register sets: global loads run two chunks ahead of the multiply
+    float at[2][AT ? 1 : NQ * 4];
+    f32x4 af[2][AT ? NMP : 1];
+    int xs[XL];                      // scalar-cache table entries of the chunk the NEXT load() fetches
+    unsigned as[NAL];
+    unsigned tb[XL / 4];
+    // table reads: one byte offset per chunk (scalar), constant displacements per entry -> s_load with immediate offsets
+    typedef const __attribute__((address_space(4))) char* c_char_p;
+    auto fetch_tab = [&](int c) {
+        const unsigned cb = (unsigned)min(c, nchunks) * (unsigned)(KC * 4);   // chunks past the table: its all-zero padding chunk
+#pragma unroll
+        for (int q = 0; q < XL; ++q) xs[q] = *(c_int_p)((c_char_p)xsoff + (cb + (unsigned)(xrow0 + q) * 4u));
+#pragma unroll
+        for (int q = 0; q < XL / 4; ++q) tb[q] = *(c_uint_p)((c_char_p)rtap + ((cb >> 2) + (unsigned)(xrow0 + 4 * q)));
+        if constexpr (AT) {
+#pragma unroll
+            for (int q = 0; q < NAL; ++q) as[q] = *(c_uint_p)((c_char_p)aoff + cb);
+        } else {
+#pragma unroll
+            for (int q = 0; q < NAL; ++q) as[q] = *(c_uint_p)((c_char_p)aoff + (cb + (unsigned)(4 * (aq + (q >> 2) * QPP) + (q & 3)) * 4u));
+        }
+    };
+
+    constexpr int NACC = 2;          // two accumulator banks: the dependency distance of the accumulate chain is two MFMAs
+    f32x16 accb[NACC];
+#pragma unroll
+    for (int bk = 0; bk < NACC; ++bk)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accb[bk][r] = 0.f;
+
+    // loader items: [X loads | A loads | X stores | A stores]
+    constexpr int NLOAD = XL + NAL, NSTORE = XL / 4 + NAS, NITEMS = NLOAD + NSTORE;
+    unsigned vx = VC_OOB;
+    auto item = [&](auto IC, auto SLC, auto SSC, int sbuf) {
+        constexpr int I = decltype(IC)::value, SL = decltype(SLC)::value, SS = decltype(SSC)::value;
+        if constexpr (I < XL) {
+            if constexpr (I % 4 == 0) vx = (tapmask & tb[I / 4]) ? xoffb : VC_OOB;
+            xr[SL][I] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, vx, xs[I], 0));
+        } else if constexpr (I < NLOAD) {
+            constexpr int q = I - XL;
+            if constexpr (AT)
+                af[SL][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ars, avoff[q], as[q], 0));
+            else
+                at[SL][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ars, avoff[0], as[q], 0));
+        } else if constexpr (I < NLOAD + XL / 4) {
+            constexpr int q = I - NLOAD;
+            f32x4 v = {xr[SS][4 * q], xr[SS][4 * q + 1], xr[SS][4 * q + 2], xr[SS][4 * q + 3]};
+            *reinterpret_cast<f32x4*>(Xs + sbuf * XSZ + lane * LDK + xrow0 + 4 * q) = v;
+        } else {
+            constexpr int q = I - NLOAD - XL / 4;
+            if constexpr (AT) *reinterpret_cast<f32x4*>(As + sbuf * ASZ + (am + q * MPP) * LDK + aq * 4) = af[SS][q];
+            else {
+                f32x4 v = {at[SS][4 * q], at[SS][4 * q + 1], at[SS][4 * q + 2], at[SS][4 * q + 3]};
+                *reinterpret_cast<f32x4*>(As + sbuf * ASZ + am * LDK + (aq + q * QPP) * 4) = v;
+            }
+        }
+    };
+    // items [I0, I0+N) -- expanded at compile time so every register index stays static
+    auto items = [&](auto I0C, auto CNT, auto SLC, auto SSC, int sbuf) {
+        constexpr int I0 = decltype(I0C)::value, N = decltype(CNT)::value;
+        [&]<int... Ix>(std::integer_sequence<int, Ix...>) {
+            ((I0 + Ix < NITEMS ? item(std::integral_constant<int, (I0 + Ix < NITEMS ? I0 + Ix : 0)>{}, SLC, SSC, sbuf)
+                               : (void)0), ...);
+        }(std::make_integer_sequence<int, N>{});
+    };
+    // One K chunk: 16 MFMA slots on LDS[buf]; behind every slot one slice of the loader: global loads of chunk `cl` into
+    // register set SL, LDS stores of set SS into LDS[buf^1].
+    constexpr int NSLOT = KC / 2;
+    constexpr int IPS = (NITEMS + NSLOT - 1) / NSLOT;
+    auto chunk = [&](auto SLC, auto SSC, int buf, int cl) {
+        const f32x4* asp = reinterpret_cast<const f32x4*>(As + buf * ASZ + (wm * 32 + l31) * LDK + 4 * h);
+        const f32x4* xsp = reinterpret_cast<const f32x4*>(Xs + buf * XSZ + (wn * 32 + l31) * LDK + 4 * h);
+        f32x4 a4[4], b4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { a4[q] = asp[2 * q]; b4[q] = xsp[2 * q]; }
+        __builtin_amdgcn_sched_barrier(0);
+        auto slot = [&](auto SC) {
+            constexpr int sidx = decltype(SC)::value;
+            if constexpr (MATH == VC_MATH_FP32) {
+                accb[sidx % NACC] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[sidx / 4][sidx % 4], b4[sidx / 4][sidx % 4], accb[sidx % NACC], 0, 0, 0);
+            } else if constexpr ((sidx & 7) == 7) {
+                // bf16 modes: the 8 k-steps just passed (the SAME k set for A and B in either lane half) become one 32x32x16 MFMA
+                constexpr int q0 = (sidx >> 3) * 2, bank = (sidx >> 3) % NACC;
+                bf16x8 ah, al, bh, bl;
+                float va[8], vb[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { va[e] = a4[q0 + e / 4][e % 4]; vb[e] = b4[q0 + e / 4][e % 4]; }
+                to_frag<MATH>(va, ah, al); to_frag<MATH>(vb, bh, bl);
+                if constexpr (MATH == VC_MATH_BF16X3) {
+                    accb[bank] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, accb[bank], 0, 0, 0);
+                    accb[bank] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, accb[bank], 0, 0, 0);
+                }
+                accb[bank] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, accb[bank], 0, 0, 0);
+            }
+            items(std::integral_constant<int, sidx * IPS>{}, std::integral_constant<int, IPS>{}, SLC, SSC, buf ^ 1);
+            if constexpr (sidx * IPS < NLOAD && (sidx + 1) * IPS >= NLOAD) fetch_tab(cl + 1);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        [&]<int... Sx>(std::integer_sequence<int, Sx...>) { (slot(std::integral_constant<int, Sx>{}), ...); }
+            (std::make_integer_sequence<int, NSLOT>{});
+    };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    using ZERO = std::integral_constant<int, 0>;
+    using LD0 = std::integral_constant<int, NLOAD>;
+    using ST0 = std::integral_constant<int, NSTORE>;
+
+    // the loader never branches: it runs up to 3 chunks past the part's range (LDS it then fills is never read)
+    fetch_tab(c0);
+    items(ZERO{}, LD0{}, S0{}, S0{}, 0);
+    fetch_tab(c0 + 1);
+    items(ZERO{}, LD0{}, S1{}, S1{}, 0);
+    fetch_tab(c0 + 2);
+    items(LD0{}, ST0{}, S0{}, S0{}, 0);
+    __syncthreads();
+    for (int c = 0; c < cps; c += 2) {
+        chunk(S0{}, S1{}, 0, c0 + c + 2);   // multiply LDS[0] = chunk c; load c+2 -> set 0; store set 1 (c+1) -> LDS[1]
+        __syncthreads();
+        chunk(S1{}, S0{}, 1, c0 + c + 3);
+        __syncthreads();
+    }
+
+    // ---- epilogue: every K group parks its tile in its own LDS region; all threads then sum the groups, add
+    //      bias (+ addend) and store 4 consecutive pixels per lane (16 bytes when they are contiguous in the output).
+    {
+        const f32x16 acc = accb[0] + accb[1];
+        float* Ys = smem + kg * REG;          // the tile loop ended on a barrier: the region is free
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            Ys[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * LDY + wn * 32 + l31] = acc[r];
+    }
+    __syncthreads();
+    const bool atomic = p.splitk > 1 || p.accumulate;
+    const bool first = sp == 0;
+    float* Yg = p.Y + (long)g * p.y_gs;
+    const float* Bg = (p.bias && first) ? p.bias + (long)g * p.bias_gs : nullptr;
+    const float* Dg = (p.addend && first) ? p.addend + (long)g * p.add_gs : nullptr;
+    constexpr int NV = (BM * BN / 4 + NT - 1) / NT;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int idx = tid + i * NT, ml = idx >> 4, n4 = (idx & 15) * 4;
+        const int m = mt * BM + ml, P0 = nt * BN + n4;
+        if ((BM * BN / 4) % NT != 0 && ml >= BM) break;
+        if (m >= p.M || P0 >= p.Ptot) continue;
+        f32x4 v = *reinterpret_cast<const f32x4*>(smem + ml * LDY + n4);
+#pragma unroll
+        for (int k2 = 1; k2 < KG; ++k2) v += *reinterpret_cast<const f32x4*>(smem + k2 * REG + ml * LDY + n4);
+        if (Bg) v += Bg[m];
+        if (p.vec4) {
+            int r0, j; const int b = fast_divmod(P0, p.NPB, p.inv_npb, &r0); const int ii = fast_divmod(r0, p.OWc, p.inv_ow, &j);
+            const long o = (long)b * p.y_bs + (long)m * p.yHW + (long)(ii * p.so_h + p.o_h0) * p.yW + j + p.o_w0;
+            if (Dg) v += *reinterpret_cast<const f32x4*>(Dg + o);
+            if (atomic) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) atomicAdd(Yg + o + e, v[e]);
+            } else *reinterpret_cast<f32x4*>(Yg + o) = v;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int Pn = P0 + e;
+                if (Pn < p.Ptot) {
+                    int r0, j; const int b = fast_divmod(Pn, p.NPB, p.inv_npb, &r0); const int ii = fast_divmod(r0, p.OWc, p.inv_ow, &j);
+                    const long o = (long)b * p.y_bs + (long)m * p.yHW + (long)(ii * p.so_h + p.o_h0) * p.yW + (j * p.so_w + p.o_w0);
+                    float val = v[e];
+                    if (Dg) val += Dg[o];
+                    if (atomic) atomicAdd(Yg + o, val); else Yg[o] = val;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Tile / K-group / split-K choice.  A workgroup costs its K chunks plus a fixed prologue + epilogue (`ovh` chunks); a
+// launch runs in ceil(workgroups / resident workgroups) rounds.  K groups inside the workgroup are free of atomics and
+// of the zero-fill launch, so they are preferred over split-K across workgroups at equal cost.
+// ------------------------------------------------------------------------------------------------------------------
+static const int kCUs = 256;
+static int resident_per_cu(int bm, int kg) {            // LDS: 55 KB (128 rows) / 37 KB (64 rows) per K group, 160 KB per CU; 32 waves per CU
+    const int waves = (bm / 32) * 2 * kg;
+    const int by_lds = 160 / ((bm == 128 ? 55 : 37) * kg), by_waves = 32 / waves;
+    return std::max(1, std::min(std::min(by_lds, by_waves), bm == 128 ? 2 : 4));
+}
+// tools/tune_igemm.py: force one configuration for every following launch of the process (0 = automatic)
+static int g_force_bm = 0, g_force_kg = 0, g_force_sk = 0;
+extern "C" int vc_tune_igemm_override(int bm, int kg, int splitk) {
+    const bool ok = (bm == 0 && kg == 0 && splitk == 0) ||
+                    ((bm == 64 || bm == 128) && (kg == 1 || kg == 2 || (kg == 4 && bm == 64)) && splitk >= 1 && splitk <= 64);
+    if (!ok) { vc_set_error("vc_tune_igemm_override: tile %d, K groups %d, split-K %d is not a built configuration", bm, kg, splitk); return -1; }
+    g_force_bm = bm; g_force_kg = kg; g_force_sk = splitk;
+    return 0;
+}
+// measured choices (tools/tune_igemm.py on MI355X), keyed by the launch shape; everything else goes by the cost model
+struct TunedCfg { int at, M, Ptot, krows, groups, bm, kg, sk; };
+#include "vc_tuned_igemm.h"
+
+void igemm_config(IgemmArgs& a) {
+    const int nchunks = a.krows / VC_KC;
+    a.mtiles = 0;
+    if (g_force_bm) { a.bm = g_force_bm; a.kg = g_force_kg; a.splitk = std::min(g_force_sk, std::max(1, nchunks / (2 * a.kg))); }
+    else {
+        const int at = a.a_ms != 1 ? 1 : 0;
+        for (const TunedCfg& t : kTunedIgemm)
+            if (t.at == at && t.M == a.M && t.Ptot == a.Ptot && t.krows == a.krows && t.groups == a.groups) { a.bm = t.bm; a.kg = t.kg; a.splitk = t.sk; a.mtiles = 1; break; }
+    }
+    if (g_force_bm || a.mtiles) { a.mtiles = (a.M + a.bm - 1) / a.bm; a.ntiles = (a.Ptot + 63) / 64; return; }
+    // Cost model, in units of one wave's chunk time: a workgroup runs `cps` chunks at a pace set by the waves that share
+    // its SIMDs (T), plus a fixed prologue + epilogue; workgroups beyond what is resident run in further rounds.
+    double best = 1e30;
+    for (int bm : {128, 64}) {
+        if (bm == 128 && a.M < 512) continue;              // narrow outputs stay on 64-row tiles (measured)
+        const long tiles = (long)((a.M + bm - 1) / bm) * ((a.Ptot + 63) / 64) * a.groups;
+        for (int kg : {1, 2, 4}) {
+            if (bm == 128 && kg == 4) continue;
+            for (int sk = 1; sk <= 16; sk *= 2) {
+                const int parts = kg * sk;
+                const int cps = (((nchunks + parts - 1) / parts) + 1) & ~1;
+                if (parts > 1 && cps * (parts - 1) >= nchunks) continue;      // a part with no work
+                const long wgs = tiles * sk;
+                const double w_wg = (bm / 32) * 2 * kg / 4.0;                  // waves per SIMD of one workgroup
+                const long n_cu = (wgs + kCUs - 1) / kCUs;
+                const long conc = std::min<long>(resident_per_cu(bm, kg), n_cu);
+                const double rounds = (double)((n_cu + conc - 1) / conc);
+                const double T = 0.25 + 0.8 * (double)conc * w_wg;
+                const double ovh = 4.0 + (kg > 1 ? 1.0 : 0.0) + (sk > 1 ? 2.5 : 0.0);    // + LDS reduction; + atomics and the zero-fill
+                const double c = rounds * (cps * T * (bm == 64 ? 1.12 : 1.0) + ovh) * (1.0 + 0.01 * sk);
+                if (c < best) { best = c; a.bm = bm; a.kg = kg; a.splitk = sk; }
+            }
+        }
+    }
+    a.mtiles = (a.M + a.bm - 1) / a.bm; a.ntiles = (a.Ptot + 63) / 64;
+}
+
+int launch_igemm_multi(const IgemmArgs* cls, int n, bool a_trans, int math, hipStream_t s, double flops) {
+    if (n < 1 || n > 4) { vc_set_error("launch_igemm_multi: 1..4 launches can be fused"); return -1; }
+    IgemmMulti m{}; m.n = n;
+    int tiles = 0, z = 0;
+    for (int i = 0; i < n; ++i) {
+        const IgemmArgs& a = cls[i];
+        if (a.splitk > 1 && !a.accumulate) { vc_set_error("launch_igemm: split-K requires accumulate semantics"); return -1; }
+        if (a.bm != cls[0].bm || a.kg != cls[0].kg || a.groups != cls[0].groups) { vc_set_error("launch_igemm_multi: mixed tile configurations"); return -1; }
+        m.c[i] = a; tiles = std::max(tiles, a.mtiles * a.ntiles); z = std::max(z, a.groups * a.splitk);
+    }
+    const int bm = cls[0].bm, kg = cls[0].kg;
+    dim3 grid(tiles, n, z), block(64 * (bm / 32) * 2 * kg);
+    ProfScope ps(0, flops, s);
+#define VC_IG(BM, KG, MATH) { if (a_trans) igemm_kernel<BM, true, KG, MATH><<<grid, block, 0, s>>>(m); \
+                              else igemm_kernel<BM, false, KG, MATH><<<grid, block, 0, s>>>(m); }
+#define VC_IG_MATH(MATH) \
+    switch (bm * 8 + kg) { \
+        case 128 * 8 + 1: VC_IG(128, 1, MATH) break; \
+        case 128 * 8 + 2: VC_IG(128, 2, MATH) break; \
+        case 64 * 8 + 1: VC_IG(64, 1, MATH) break; \
+        case 64 * 8 + 2: VC_IG(64, 2, MATH) break; \
+        case 64 * 8 + 4: VC_IG(64, 4, MATH) break; \
+        default: vc_set_error("launch_igemm: tile %d x K groups %d is not built", bm, kg); return -1; \
+    }
+    if (math == VC_MATH_BF16) VC_IG_MATH(VC_MATH_BF16)
+    else if (math == VC_MATH_BF16X3) VC_IG_MATH(VC_MATH_BF16X3)
+    else VC_IG_MATH(VC_MATH_FP32)
+#undef VC_IG_MATH
+#undef VC_IG
+    VC_HIP(hipGetLastError());
+    return 0;
+}
+int launch_igemm(const IgemmArgs& a, bool a_trans, int math, hipStream_t s, double flops) { return launch_igemm_multi(&a, 1, a_trans, math, s, flops); }

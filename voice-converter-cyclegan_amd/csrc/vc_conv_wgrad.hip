@@ -1,0 +1,248 @@
+// vc_conv_wgrad.hip -- filter gradient of tf.layers.conv1d/conv2d (autodiff of reference model.py:107-108 through
+// module.py:32-40, 54-62) on v_mfma_f32_32x32x2_f32:
+//
+//   dW[kk][co] = sum over (segment, sample, pixel) of Xg[kk][P] * dY[co][P]
+//
+// rows = K rows of the forward table (64 per tile: two 32-row chunks, each inside ONE filter tap), cols = Cout (BN per
+// tile), reduction = pixels in chunks of 32.  A *segment* is one application of the layer: the generator's weights are
+// used twice per step (first hop on 2B samples, cycle hop on B samples, model.py:44-51, `reuse=True`), and both
+// applications reduce into the same dW, so they are ONE launch over the concatenated pixel axis -- one write of dW,
+// no atomics, no zero-filled destination.
+//
+// Loader without address arithmetic: a lane owns pixel (lane & 31) of the chunk and the row pairs 2*(wave + 4q) + (lane >> 5):
+// the pair base rides in the buffer load's SGPR offset (loop-invariant), the lane's pixel offset (+ one channel for the
+// upper lane half) in the VGPR offset, VC_OOB where the tap leaves the image for that pixel (hardware range check -> 0).
+#include "vc_internal.h"
+#include <algorithm>
+#include <type_traits>
+#include <utility>
+
+typedef const __attribute__((address_space(4))) int* c_int_p;
+
+template <int BN, int MATH>
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs p) {
+    // LDS tiles are [row][pixel] with a 36-float row stride: the loader writes whole pixel runs (conflict-free), and a
+    // lane reads its 16 k values (pixels 16h..16h+15 of its row; MFMA step u pairs pixels u and 16+u) as 4 ds_read_b128
+    constexpr int BM = 64, KC = VC_KC, LDT = KC + 4;
+    constexpr int WN = BN / 2, NJ = WN / 32;
+    constexpr int ASZ = BM * LDT, BSZ = BN * LDT;
+    constexpr int LDY = BN + 4;
+    static_assert(BM * LDY <= 2 * (ASZ + BSZ), "epilogue staging fits the tile buffers");
+    __shared__ __attribute__((aligned(16))) float smem[2 * (ASZ + BSZ)];
+    float* As = smem;
+    float* Bs = smem + 2 * ASZ;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int nt = blockIdx.x % p.ntiles, kt = blockIdx.x / p.ntiles;
+    const int g = blockIdx.z / p.splitk, sp = blockIdx.z - g * p.splitk;
+    // every split-K part runs `cps` chunks (an even count: the loop body is a pair of chunks with static register sets);
+    // chunks past the last segment load zeros
+    const int cps = (((p.nchunks + p.splitk - 1) / p.splitk) + 1) & ~1;
+    const int c0 = sp * cps;
+    if (c0 >= p.nchunks) return;
+
+    // ---- loop invariants of the K rows and columns this wave loads
+    const KEntry e0 = p.ktab[kt * BM], e1 = p.ktab[kt * BM + 32];          // the two taps of this k-tile (wave-uniform)
+    const int dh0 = e0.a_off >= 0 ? e0.dh : 0x4000, dw0 = e0.dw;           // padding chunk: dh = 16384 always fails the bounds check
+    const int dh1 = e1.a_off >= 0 ? e1.dh : 0x4000, dw1 = e1.dw;
+    c_int_p xso = (c_int_p)p.xsoff;
+    const int xbias = p.xbias;
+    int xs[8];                                                             // SGPR offsets of the 8 row pairs (rows 2*(wid+4q), +1 in the upper lane half)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) xs[q] = xso[kt * BM + 2 * (wid + 4 * q)];
+    constexpr int NY = BN / 8;
+    int ys[NY];                                                            // same for the dY rows (columns co of the tile); rows >= N clamp to the last pair
+#pragma unroll
+    for (int q = 0; q < NY; ++q) ys[q] = min(nt * BN + 2 * (wid + 4 * q), p.N - 2) * p.NPB * 4;
+    const unsigned xhalf = (unsigned)h * (unsigned)p.xHW * 4u, yhalf = (unsigned)h * (unsigned)p.NPB * 4u;
+
+    // ---- segment / pixel cursor of the LOADER (runs two chunks ahead of the multiply)
+    int lc = c0;                                         // chunk (of the concatenated axis) the next load() fetches
+    int seg = (p.nseg > 1 && lc >= p.seg[0].nchunks) ? 1 : 0;
+    int segbase = seg ? p.seg[0].nchunks : 0, segend = seg ? p.nchunks : p.seg[0].nchunks, segP = p.seg[seg].Ptot;
+    __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((const char*)(p.seg[seg].X + (long)g * p.seg[seg].x_gs) - xbias), 0, (int)p.seg[seg].x_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.seg[seg].dY + (long)g * p.seg[seg].dy_gs), 0, (int)p.seg[seg].dy_bytes, 0x00020000);
+    int pP = (lc - segbase) * KC + l31;                  // pixel of this lane inside the segment
+    int pr, pb = fast_divmod(pP, p.NPB, p.inv_npb, &pr);
+
+    f32x16 acc[NJ];
+#pragma unroll
+    for (int nj = 0; nj < NJ; ++nj)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nj][r] = 0.f;
+
+    // Loader cut into items [pixel decode + X loads | dY loads | X stores | dY stores]; one slice runs in the shadow
+    // of every MFMA group.  Two register sets: loads run two chunks ahead.
+    constexpr int NLOAD = 8 + NY, NITEMS = 2 * NLOAD;
+    float xr[2][8], dr[2][NY];
+    unsigned vx0 = VC_OOB, vx1 = VC_OOB, vy = VC_OOB;
+    auto decode = [&]() {
+        if (lc == segend && seg + 1 < p.nseg) {          // uniform: the loader crosses into the next segment
+            seg = 1; segbase = segend; segend = p.nchunks; segP = p.seg[1].Ptot;
+            xrs = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)((const char*)(p.seg[1].X + (long)g * p.seg[1].x_gs) - xbias), 0, (int)p.seg[1].x_bytes, 0x00020000);
+            yrs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.seg[1].dY + (long)g * p.seg[1].dy_gs), 0, (int)p.seg[1].dy_bytes, 0x00020000);
+            pP = l31; pb = fast_divmod(pP, p.NPB, p.inv_npb, &pr);
+        }
+        const bool pv = pP < segP && lc < segend;        // chunks past the last segment (loader run-ahead) load zeros
+        int j; const int i = fast_divmod(pr, p.OWc, p.inv_ow, &j);
+        const int li0 = i * p.si, lj0 = j * p.sj;
+        const unsigned xoffb = (unsigned)(((long)pb * p.x_bs + (long)li0 * p.xW + lj0) * 4) + xhalf;
+        const bool ok0 = pv & ((unsigned)(li0 + dh0) < (unsigned)p.Hl) & ((unsigned)(lj0 + dw0) < (unsigned)p.Wl);
+        const bool ok1 = pv & ((unsigned)(li0 + dh1) < (unsigned)p.Hl) & ((unsigned)(lj0 + dw1) < (unsigned)p.Wl);
+        vx0 = ok0 ? xoffb : VC_OOB; vx1 = ok1 ? xoffb : VC_OOB;
+        vy = pv ? (unsigned)(((long)pb * p.dy_bs + pr) * 4) + yhalf : VC_OOB;
+        ++lc; pP += KC;
+        if (p.NPB >= KC) { pr += KC; const bool w = pr >= p.NPB; pr = w ? pr - p.NPB : pr; pb += (int)w; }   // at most one wrap
+        else pb = fast_divmod(pP, p.NPB, p.inv_npb, &pr);                                                  // tiny images (uniform branch)
+    };
+    auto item = [&](auto IC, auto SLC, auto SSC, int sbuf) {
+        constexpr int I = decltype(IC)::value, SL = decltype(SLC)::value, SS = decltype(SSC)::value;
+        if constexpr (I < 8) {
+            if constexpr (I == 0) decode();
+            xr[SL][I] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, I < 4 ? vx0 : vx1, xs[I], 0));
+        } else if constexpr (I < NLOAD) {
+            constexpr int q = I - 8;
+            dr[SL][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yrs, vy, ys[q], 0));
+        } else if constexpr (I < NLOAD + 8) {
+            constexpr int q = I - NLOAD;
+            As[sbuf * ASZ + (2 * (wid + 4 * q) + h) * LDT + l31] = xr[SS][q];
+        } else {
+            constexpr int q = I - NLOAD - 8;
+            Bs[sbuf * BSZ + (2 * (wid + 4 * q) + h) * LDT + l31] = dr[SS][q];
+        }
+    };
+    auto items = [&](auto I0C, auto CNT, auto SLC, auto SSC, int sbuf) {
+        constexpr int I0 = decltype(I0C)::value, N = decltype(CNT)::value;
+        [&]<int... Ix>(std::integer_sequence<int, Ix...>) {
+            ((I0 + Ix < NITEMS ? item(std::integral_constant<int, (I0 + Ix < NITEMS ? I0 + Ix : 0)>{}, SLC, SSC, sbuf)
+                               : (void)0), ...);
+        }(std::make_integer_sequence<int, N>{});
+    };
+    constexpr int NSLOT = KC / 2;
+    constexpr int IPS = (NITEMS + NSLOT - 1) / NSLOT;
+    auto chunk = [&](auto SLC, auto SSC, int buf) {
+        const f32x4* as = reinterpret_cast<const f32x4*>(As + buf * ASZ + (wm * 32 + l31) * LDT + 16 * h);
+        const f32x4* bs = reinterpret_cast<const f32x4*>(Bs + buf * BSZ + (wn * WN + l31) * LDT + 16 * h);
+        f32x4 a4[4], b4[NJ][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            a4[j] = as[j];
+#pragma unroll
+            for (int nj = 0; nj < NJ; ++nj) b4[nj][j] = bs[nj * 32 * LDT / 4 + j];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        auto slot = [&](auto SC) {
+            constexpr int u = decltype(SC)::value;      // MFMA step u multiplies pixels u (lanes 0-31) and 16+u (lanes 32-63)
+            if constexpr (MATH == VC_MATH_FP32) {
+#pragma unroll
+                for (int nj = 0; nj < NJ; ++nj)
+                    acc[nj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[u / 4][u % 4], b4[nj][u / 4][u % 4], acc[nj], 0, 0, 0);
+            } else if constexpr ((u & 7) == 7) {
+                // bf16 modes: pixels 16h + 8*(u/8) .. +7 of this lane's row (same set for X and dY) -> one 32x32x16 MFMA
+                constexpr int j0 = (u >> 3) * 2;
+                bf16x8 ah, al, bh, bl;
+                {
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = a4[j0 + e / 4][e % 4];
+                    to_frag<MATH>(v, ah, al);
+                }
+#pragma unroll
+                for (int nj = 0; nj < NJ; ++nj) {
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = b4[nj][j0 + e / 4][e % 4];
+                    to_frag<MATH>(v, bh, bl);
+                    if constexpr (MATH == VC_MATH_BF16X3) {
+                        acc[nj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[nj], 0, 0, 0);
+                        acc[nj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[nj], 0, 0, 0);
+                    }
+                    acc[nj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[nj], 0, 0, 0);
+                }
+            }
+            items(std::integral_constant<int, u * IPS>{}, std::integral_constant<int, IPS>{}, SLC, SSC, buf ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        [&]<int... Sx>(std::integer_sequence<int, Sx...>) { (slot(std::integral_constant<int, Sx>{}), ...); }
+            (std::make_integer_sequence<int, NSLOT>{});
+    };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    using ZERO = std::integral_constant<int, 0>;
+    using LD0 = std::integral_constant<int, NLOAD>;
+    // the loader never branches on the range: it runs up to 3 chunks past the part -- inside the range of the NEXT split
+    // that data is real but lands in LDS that is never multiplied; past the last segment it is zeros
+    items(ZERO{}, LD0{}, S0{}, S0{}, 0);        // chunk c0   -> set 0
+    items(ZERO{}, LD0{}, S1{}, S1{}, 0);        // chunk c0+1 -> set 1
+    items(LD0{}, LD0{}, S0{}, S0{}, 0);         // set 0 -> LDS[0]
+    __syncthreads();
+    for (int c = 0; c < cps; c += 2) {
+        chunk(S0{}, S1{}, 0);                   // multiply chunk c, load c+2 -> set 0, store set 1 (c+1) -> LDS[1]
+        __syncthreads();
+        chunk(S1{}, S0{}, 1);                   // multiply chunk c+1, load c+3 -> set 1, store set 0 (c+2) -> LDS[0]
+        __syncthreads();
+    }
+
+    // ---- epilogue through LDS: a lane stores 4 consecutive Cout values of one K row (16 bytes).  Plain stores when this
+    //      launch is the only contribution of the step to dW, fire-and-forget fp32 atomics otherwise.
+    float* Ys = smem;
+#pragma unroll
+    for (int nj = 0; nj < NJ; ++nj)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            Ys[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * LDY + wn * WN + nj * 32 + l31] = acc[nj][r];
+    __syncthreads();
+    float* Wg = p.dW + (long)g * p.dw_gs;
+    constexpr int NV = BM * BN / 4 / 256;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int idx = tid + i * 256, ml = idx / (BN / 4), n4 = (idx % (BN / 4)) * 4;
+        const int aoff = p.ktab[kt * BM + ml].a_off, co = nt * BN + n4;
+        if (aoff < 0 || co >= p.N) continue;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(Ys + ml * LDY + n4);
+        if (p.store) *reinterpret_cast<f32x4*>(Wg + aoff + co) = v;          // Cout % 4 == 0: whole runs are in range and aligned
+        else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) atomicAdd(Wg + aoff + co + e, v[e]);
+        }
+    }
+}
+
+// split-K factor: as for the implicit GEMM, least rounds * (chunks per split + fixed cost); 512 workgroups are resident
+int wgrad_splitk(const WgradArgs& a) {
+    const int BN = (a.N >= 128) ? 128 : 64;
+    const long tiles = (long)a.ktiles * ((a.N + BN - 1) / BN) * a.groups;
+    if (tiles >= 512) return 1;
+    int best = 1; double bestc = 1e30;
+    for (int sk = 1; sk <= 16; sk *= 2) {
+        if (sk > 1 && a.nchunks / sk < 2) break;
+        const double rounds = (double)((tiles * sk + 511) / 512);
+        const double c = rounds * ((a.nchunks + sk - 1) / sk + 6.0 + (sk > 1 ? 2.0 : 0.0));
+        if (c < bestc * 0.97) { best = sk; bestc = c; }
+    }
+    return best;
+}
+
+int launch_wgrad(const WgradArgs& a0, int math, hipStream_t s, double flops) {
+    WgradArgs a = a0;
+    const int BN = (a.N >= 128) ? 128 : 64;
+    a.ntiles = (a.N + BN - 1) / BN;
+    a.splitk = wgrad_splitk(a);
+    if (a.splitk > 1) a.store = 0;
+    dim3 grid(a.ktiles * a.ntiles, 1, a.groups * a.splitk), block(256);
+    ProfScope ps(1, flops, s);
+#define VC_WGRAD_MATH(MATH) { if (BN == 128) wgrad_kernel<128, MATH><<<grid, block, 0, s>>>(a); \
+                              else wgrad_kernel<64, MATH><<<grid, block, 0, s>>>(a); }
+    if (math == VC_MATH_BF16) VC_WGRAD_MATH(VC_MATH_BF16)
+    else if (math == VC_MATH_BF16X3) VC_WGRAD_MATH(VC_MATH_BF16X3)
+    else VC_WGRAD_MATH(VC_MATH_FP32)
+#undef VC_WGRAD_MATH
+    VC_HIP(hipGetLastError());
+    return 0;
+}

@@ -1,0 +1,689 @@
+// vc_elementwise.hip -- the non-GEMM kernels of the CycleGAN-VC hot path (all HBM- or latency-bound):
+//  norm_*_kernel   : instance_norm_layer + gated_linear_layer (+ pixel_shuffler, + residual add),
+//                    DPP / wavefront-shuffle reductions (reference module.py:3-20,81,135-146)
+//  head_*          : tf.layers.dense(1, sigmoid) (module.py:211)
+//  loss_kernel     : utils.py:6-12 + loss algebra model.py:57-90, fused with the seed gradients
+//  adam_kernel     : ApplyAdam (model.py:107-108)
+//  crop_batch      : preprocess.sample_train_data's crop (preprocess.py:226-233)
+#include "vc_internal.h"
+#include "vc_device_util.h"
+#include <algorithm>
+#include <mutex>
+#include <vector>
+
+// =====================================================================================
+// instance norm / GLU / pixel shuffle / residual, one (g,b,c) row per LPR lanes,
+// whole row in registers, wavefront shuffles for the per-channel reductions.
+// =====================================================================================
+#define IN_EPS 1e-6f
+
+// sum over the LPR (32 or 64) consecutive lanes that share one (sample, channel) row; every lane gets the total.
+// Rows of 16 on DPP, the last one or two steps through ds_bpermute (was 5-6 bpermutes per sum: the norm kernels are
+// latency-bound and issue 4-8 of these per thread).
+template <int LPR> __device__ __forceinline__ float group_sum(float v) {
+    static_assert(LPR == 32 || LPR == 64, "a row group is 32 or 64 lanes");
+    v = row16_sum(v);
+#pragma unroll
+    for (int o = 16; o < LPR; o <<= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// float offset of logical element (branch br, channel c, position l) of sample b in the raw conv output
+template <int NB> __device__ __forceinline__ long yoff(const NormArgs& p, int b, int br, int c, int l) {
+    if (p.ps) {
+        const int T = p.L >> 1;
+        return ((long)b * (NB * 2 * p.C) + br * 2 * p.C + (l & 1) * p.C + c) * T + (l >> 1);
+    }
+    return ((long)b * (NB * p.C) + br * p.C + c) * p.L + l;
+}
+
+template <int MODE, int LPR, int NE>
+__global__ __launch_bounds__(256) void norm_fwd_kernel(const NormArgs p) {
+    constexpr int NB = (MODE == 2) ? 1 : 2;
+    const int unit = blockIdx.x * (256 / LPR) + threadIdx.x / LPR;
+    const int sub = threadIdx.x % LPR;
+    const int total = p.G * p.B * p.C;
+    if (unit >= total) return;
+    const int g = unit / (p.B * p.C); const int rem = unit - g * (p.B * p.C);
+    const int b = rem / p.C, c = rem - b * p.C;
+    const float* y = p.y + (long)g * p.y_gs;
+    float* out = p.out + (long)g * p.out_gs + ((long)b * p.C + c) * p.L;
+    const float invL = 1.f / (float)p.L;
+
+    float v[NE], gt[NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+        const int l = sub + e * LPR;
+        const bool ok = l < p.L;
+        v[e] = ok ? y[yoff<NB>(p, b, 0, c, l)] : 0.f;
+        if (NB == 2) gt[e] = ok ? y[yoff<NB>(p, b, 1, c, l)] : 0.f;
+    }
+    if (MODE == 1) {
+#pragma unroll
+        for (int e = 0; e < NE; ++e) { const int l = sub + e * LPR; if (l < p.L) out[l] = v[e] * sigmoidf_(gt[e]); }
+        return;
+    }
+    const float* gam = p.gamma + (long)g * p.par_gs;
+    const float* bet = p.beta + (long)g * p.par_gs;
+    float* st = p.stats + (long)g * p.st_gs + ((long)b * NB * p.C) * 2;
+
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) s += v[e];
+    const float mu = group_sum<LPR>(s) * invL;
+    float q = 0.f;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) { const float d = (sub + e * LPR < p.L) ? v[e] - mu : 0.f; q += d * d; }
+    const float rs = rsqrtf(group_sum<LPR>(q) * invL + IN_EPS);
+    const float ga = gam[c], be = bet[c];
+    if (sub == 0) { st[2 * c] = mu; st[2 * c + 1] = rs; }
+
+    if (MODE == 2) {
+        const float* res = p.res + (long)g * p.res_gs + ((long)b * p.C + c) * p.L;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const int l = sub + e * LPR;
+            if (l < p.L) out[l] = res[l] + ((v[e] - mu) * rs * ga + be);
+        }
+        return;
+    }
+    float s2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) s2 += gt[e];
+    const float mu2 = group_sum<LPR>(s2) * invL;
+    float q2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) { const float d = (sub + e * LPR < p.L) ? gt[e] - mu2 : 0.f; q2 += d * d; }
+    const float rs2 = rsqrtf(group_sum<LPR>(q2) * invL + IN_EPS);
+    const float ga2 = gam[p.C + c], be2 = bet[p.C + c];
+    if (sub == 0) { st[2 * (p.C + c)] = mu2; st[2 * (p.C + c) + 1] = rs2; }
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+        const int l = sub + e * LPR;
+        if (l < p.L) out[l] = ((v[e] - mu) * rs * ga + be) * sigmoidf_((gt[e] - mu2) * rs2 * ga2 + be2);
+    }
+}
+
+template <int MODE, int LPR, int NE>
+__global__ __launch_bounds__(256) void norm_bwd_kernel(const NormArgs p) {
+    constexpr int NB = (MODE == 2) ? 1 : 2;
+    const int unit = blockIdx.x * (256 / LPR) + threadIdx.x / LPR;
+    const int sub = threadIdx.x % LPR;
+    const int total = p.G * p.B * p.C;
+    if (unit >= total) return;
+    const int g = unit / (p.B * p.C); const int rem = unit - g * (p.B * p.C);
+    const int b = rem / p.C, c = rem - b * p.C;
+    const float* y = p.y + (long)g * p.y_gs;
+    float* dy = p.dy + (long)g * p.dy_gs;
+    const float* dout = p.dout + (long)g * p.do_gs + ((long)b * p.C + c) * p.L;
+    const float invL = 1.f / (float)p.L;
+    const bool odd = sub & 1;   // LPR is even: every element this lane owns has parity sub&1
+
+    float v[NE], gt[NE], dO[NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+        const int l = sub + e * LPR;
+        const bool ok = l < p.L;
+        v[e] = ok ? y[yoff<NB>(p, b, 0, c, l)] : 0.f;
+        if (NB == 2) gt[e] = ok ? y[yoff<NB>(p, b, 1, c, l)] : 0.f;
+        dO[e] = ok ? dout[l] : 0.f;
+    }
+    float* dbias = p.dbias ? p.dbias + (long)g * p.dbias_gs : nullptr;
+    // conv channels whose bias gradient this row contributes to
+    const int cb0 = p.ps ? c : c;                       // branch 0, even l (or all l)
+    const int cstride_par = p.ps ? p.C : 0;             // odd l -> +C when shuffled
+    const int brstride = p.ps ? 2 * p.C : p.C;          // branch 1 offset in conv channels
+
+    if (MODE == 1) {
+        float sv = 0.f, sg = 0.f;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const int l = sub + e * LPR;
+            const float s = sigmoidf_(gt[e]);
+            const float dv = dO[e] * s, dg = dO[e] * v[e] * s * (1.f - s);
+            if (l < p.L) { dy[yoff<NB>(p, b, 0, c, l)] = dv; dy[yoff<NB>(p, b, 1, c, l)] = dg; }
+            sv += dv; sg += dg;
+        }
+        if (dbias) {
+            sv = group_sum<LPR>(sv); sg = group_sum<LPR>(sg);
+            if (sub == 0) { atomicAdd(dbias + c, sv); atomicAdd(dbias + p.C + c, sg); }
+        }
+        return;
+    }
+    const float* gam = p.gamma + (long)g * p.par_gs;
+    const float* bet = p.beta + (long)g * p.par_gs;
+    const float* st = p.stats_in + (long)g * p.st_gs + ((long)b * NB * p.C) * 2;
+    float* dgam = p.dgamma ? p.dgamma + (long)g * p.dpar_gs : nullptr;
+    float* dbet = p.dbeta ? p.dbeta + (long)g * p.dpar_gs : nullptr;
+    const float mu = st[2 * c], rs = st[2 * c + 1], ga = gam[c], be = bet[c];
+
+    if (MODE == 2) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) { const float xh = (v[e] - mu) * rs; s1 += dO[e]; s2 += dO[e] * xh; }
+        s1 = group_sum<LPR>(s1); s2 = group_sum<LPR>(s2);
+        float sb = 0.f;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const int l = sub + e * LPR;
+            const float xh = (v[e] - mu) * rs;
+            const float d = ga * rs * (dO[e] - s1 * invL - xh * s2 * invL);
+            if (l < p.L) { dy[yoff<NB>(p, b, 0, c, l)] = d; sb += d; }
+        }
+        sb = group_sum<LPR>(sb);
+        if (sub == 0) {
+            if (dgam) { atomicAdd(dgam + c, s2); atomicAdd(dbet + c, s1); }
+            if (dbias) atomicAdd(dbias + c, sb);
+        }
+        return;
+    }
+    const float mu2 = st[2 * (p.C + c)], rs2 = st[2 * (p.C + c) + 1], ga2 = gam[p.C + c], be2 = bet[p.C + c];
+    float s1v = 0.f, s2v = 0.f, s1g = 0.f, s2g = 0.f;
+    float dnv[NE], dng[NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+        const float xv = (v[e] - mu) * rs, xg = (gt[e] - mu2) * rs2;
+        const float nv = ga * xv + be, ng = ga2 * xg + be2;
+        const float s = sigmoidf_(ng);
+        dnv[e] = dO[e] * s; dng[e] = dO[e] * nv * s * (1.f - s);
+        s1v += dnv[e]; s2v += dnv[e] * xv; s1g += dng[e]; s2g += dng[e] * xg;
+    }
+    s1v = group_sum<LPR>(s1v); s2v = group_sum<LPR>(s2v);
+    s1g = group_sum<LPR>(s1g); s2g = group_sum<LPR>(s2g);
+    float sbv = 0.f, sbg = 0.f;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+        const int l = sub + e * LPR;
+        const float xv = (v[e] - mu) * rs, xg = (gt[e] - mu2) * rs2;
+        const float dv = ga * rs * (dnv[e] - s1v * invL - xv * s2v * invL);
+        const float dg = ga2 * rs2 * (dng[e] - s1g * invL - xg * s2g * invL);
+        if (l < p.L) { dy[yoff<NB>(p, b, 0, c, l)] = dv; dy[yoff<NB>(p, b, 1, c, l)] = dg; sbv += dv; sbg += dg; }
+    }
+    if (dbias) {
+        // conv-channel sums; with pixel shuffle even/odd positions belong to different conv channels
+        float ev = group_sum<LPR>((p.ps && odd) ? 0.f : sbv), eg = group_sum<LPR>((p.ps && odd) ? 0.f : sbg);
+        float ov = 0.f, og = 0.f;
+        if (p.ps) { ov = group_sum<LPR>(odd ? sbv : 0.f); og = group_sum<LPR>(odd ? sbg : 0.f); }
+        if (sub == 0) {
+            atomicAdd(dbias + cb0, ev); atomicAdd(dbias + brstride + cb0, eg);
+            if (p.ps) { atomicAdd(dbias + cstride_par + cb0, ov); atomicAdd(dbias + brstride + cstride_par + cb0, og); }
+        }
+    }
+    if (sub == 0 && dgam) {
+        atomicAdd(dgam + c, s2v); atomicAdd(dbet + c, s1v);
+        atomicAdd(dgam + p.C + c, s2g); atomicAdd(dbet + p.C + c, s1g);
+    }
+}
+
+// ---- streaming variants for rows longer than 2048 (36x256 discriminator, long utterances): one 256-thread block
+// per (g, b, c) row, the row is re-read from L2 for each pass instead of living in registers.
+__device__ __forceinline__ float block_sum_256s(float v, float* red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void norm_fwd_stream_kernel(const NormArgs p) {
+    constexpr int NB = (MODE == 2) ? 1 : 2;
+    __shared__ float red[4];
+    const int unit = blockIdx.x;
+    const int g = unit / (p.B * p.C); const int rem = unit - g * (p.B * p.C);
+    const int b = rem / p.C, c = rem - b * p.C;
+    const float* y = p.y + (long)g * p.y_gs;
+    float* out = p.out + (long)g * p.out_gs + ((long)b * p.C + c) * p.L;
+    const float invL = 1.f / (float)p.L;
+    if (MODE == 1) {
+        for (int l = threadIdx.x; l < p.L; l += 256) out[l] = y[yoff<NB>(p, b, 0, c, l)] * sigmoidf_(y[yoff<NB>(p, b, 1, c, l)]);
+        return;
+    }
+    const float* gam = p.gamma + (long)g * p.par_gs;
+    const float* bet = p.beta + (long)g * p.par_gs;
+    float* st = p.stats + (long)g * p.st_gs + ((long)b * NB * p.C) * 2;
+    float mu[NB], rs[NB];
+#pragma unroll
+    for (int br = 0; br < NB; ++br) {
+        float s = 0.f;
+        for (int l = threadIdx.x; l < p.L; l += 256) s += y[yoff<NB>(p, b, br, c, l)];
+        mu[br] = block_sum_256s(s, red) * invL;
+        float q = 0.f;
+        for (int l = threadIdx.x; l < p.L; l += 256) { const float d = y[yoff<NB>(p, b, br, c, l)] - mu[br]; q += d * d; }
+        rs[br] = rsqrtf(block_sum_256s(q, red) * invL + IN_EPS);
+        if (threadIdx.x == 0) { st[2 * (br * p.C + c)] = mu[br]; st[2 * (br * p.C + c) + 1] = rs[br]; }
+    }
+    const float ga = gam[c], be = bet[c];
+    if (MODE == 2) {
+        const float* res = p.res + (long)g * p.res_gs + ((long)b * p.C + c) * p.L;
+        for (int l = threadIdx.x; l < p.L; l += 256) out[l] = res[l] + ((y[yoff<NB>(p, b, 0, c, l)] - mu[0]) * rs[0] * ga + be);
+    } else {
+        const float ga2 = gam[p.C + c], be2 = bet[p.C + c];
+        for (int l = threadIdx.x; l < p.L; l += 256)
+            out[l] = ((y[yoff<NB>(p, b, 0, c, l)] - mu[0]) * rs[0] * ga + be) *
+                     sigmoidf_((y[yoff<NB>(p, b, NB - 1, c, l)] - mu[NB - 1]) * rs[NB - 1] * ga2 + be2);
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void norm_bwd_stream_kernel(const NormArgs p) {
+    constexpr int NB = (MODE == 2) ? 1 : 2;
+    __shared__ float red[4];
+    const int unit = blockIdx.x;
+    const int g = unit / (p.B * p.C); const int rem = unit - g * (p.B * p.C);
+    const int b = rem / p.C, c = rem - b * p.C;
+    const float* y = p.y + (long)g * p.y_gs;
+    float* dy = p.dy + (long)g * p.dy_gs;
+    const float* dout = p.dout + (long)g * p.do_gs + ((long)b * p.C + c) * p.L;
+    const float invL = 1.f / (float)p.L;
+    float* dbias = p.dbias ? p.dbias + (long)g * p.dbias_gs : nullptr;
+    const int cstride_par = p.ps ? p.C : 0, brstride = p.ps ? 2 * p.C : p.C;
+    // conv-channel bias sums: [branch][parity]; without pixel shuffle only parity 0 is used
+    float sb[NB][2];
+#pragma unroll
+    for (int br = 0; br < NB; ++br) sb[br][0] = sb[br][1] = 0.f;
+    if (MODE == 1) {
+        for (int l = threadIdx.x; l < p.L; l += 256) {
+            const float v = y[yoff<NB>(p, b, 0, c, l)], s = sigmoidf_(y[yoff<NB>(p, b, 1, c, l)]);
+            const float dv = dout[l] * s, dg = dout[l] * v * s * (1.f - s);
+            dy[yoff<NB>(p, b, 0, c, l)] = dv; dy[yoff<NB>(p, b, 1, c, l)] = dg;
+            sb[0][0] += dv; sb[NB - 1][0] += (NB == 2) ? dg : 0.f;
+        }
+    } else {
+        const float* gam = p.gamma + (long)g * p.par_gs;
+        const float* bet = p.beta + (long)g * p.par_gs;
+        const float* st = p.stats_in + (long)g * p.st_gs + ((long)b * NB * p.C) * 2;
+        float* dgam = p.dgamma ? p.dgamma + (long)g * p.dpar_gs : nullptr;
+        float* dbet = p.dbeta ? p.dbeta + (long)g * p.dpar_gs : nullptr;
+        float mu[NB], rs[NB], ga[NB], be[NB], s1[NB], s2[NB];
+#pragma unroll
+        for (int br = 0; br < NB; ++br) {
+            mu[br] = st[2 * (br * p.C + c)]; rs[br] = st[2 * (br * p.C + c) + 1];
+            ga[br] = gam[br * p.C + c]; be[br] = bet[br * p.C + c]; s1[br] = s2[br] = 0.f;
+        }
+        auto dn = [&](int l, float* d) {     // gradient w.r.t. the normalised value(s) at position l
+            const float dO = dout[l];
+            if (MODE == 2) { d[0] = dO; return; }
+            const float nv = ga[0] * (y[yoff<NB>(p, b, 0, c, l)] - mu[0]) * rs[0] + be[0];
+            const float ng = ga[NB - 1] * (y[yoff<NB>(p, b, NB - 1, c, l)] - mu[NB - 1]) * rs[NB - 1] + be[NB - 1];
+            const float s = sigmoidf_(ng);
+            d[0] = dO * s; d[NB - 1] = dO * nv * s * (1.f - s);
+        };
+        for (int l = threadIdx.x; l < p.L; l += 256) {
+            float d[NB]; dn(l, d);
+#pragma unroll
+            for (int br = 0; br < NB; ++br) { s1[br] += d[br]; s2[br] += d[br] * (y[yoff<NB>(p, b, br, c, l)] - mu[br]) * rs[br]; }
+        }
+#pragma unroll
+        for (int br = 0; br < NB; ++br) { s1[br] = block_sum_256s(s1[br], red); s2[br] = block_sum_256s(s2[br], red); }
+        for (int l = threadIdx.x; l < p.L; l += 256) {
+            float d[NB]; dn(l, d);
+#pragma unroll
+            for (int br = 0; br < NB; ++br) {
+                const float xh = (y[yoff<NB>(p, b, br, c, l)] - mu[br]) * rs[br];
+                const float v = ga[br] * rs[br] * (d[br] - s1[br] * invL - xh * s2[br] * invL);
+                dy[yoff<NB>(p, b, br, c, l)] = v;
+                sb[br][p.ps ? (l & 1) : 0] += v;
+            }
+        }
+        if (threadIdx.x == 0 && dgam) {
+#pragma unroll
+            for (int br = 0; br < NB; ++br) { atomicAdd(dgam + br * p.C + c, s2[br]); atomicAdd(dbet + br * p.C + c, s1[br]); }
+        }
+    }
+    if (dbias) {
+#pragma unroll
+        for (int br = 0; br < NB; ++br) {
+            const float e = block_sum_256s(sb[br][0], red), o = block_sum_256s(sb[br][1], red);
+            if (threadIdx.x == 0) {
+                atomicAdd(dbias + br * brstride + c, e);
+                if (p.ps) atomicAdd(dbias + br * brstride + cstride_par + c, o);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void bias_grad_kernel(const float* dy, long dy_gs, float* db, long db_gs,
+                                                        int B, int C, int L) {
+    __shared__ float red[4];
+    const int c = blockIdx.x, g = blockIdx.y;
+    const float* d = dy + (long)g * dy_gs;
+    float s = 0.f;
+    const int n = B * L;
+    for (int i = threadIdx.x; i < n; i += 256) { const int b = i / L, l = i - b * L; s += d[((long)b * C + c) * L + l]; }
+    s = block_sum_256(s, red);
+    if (threadIdx.x == 0) atomicAdd(db + (long)g * db_gs + c, s);
+}
+
+__global__ __launch_bounds__(256) void head_fwd_kernel(const float* x, long x_gs, const float* w, const float* bias,
+                                                       long par_gs, float* o, long o_gs, int C, int HW) {
+    __shared__ float red[4][64];
+    const int g = blockIdx.z, b = blockIdx.y;
+    const int px = blockIdx.x * 64 + (threadIdx.x & 63), cq = threadIdx.x >> 6;
+    const float* xb = x + (long)g * x_gs + (long)b * C * HW;
+    const float* wg = w + (long)g * par_gs;
+    float s = 0.f;
+    if (px < HW) for (int c = cq; c < C; c += 4) s += xb[(long)c * HW + px] * wg[c];
+    red[cq][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (cq == 0 && px < HW) {
+        const float z = red[0][px & 63] + red[1][px & 63] + red[2][px & 63] + red[3][px & 63] + bias[(long)g * par_gs];
+        o[(long)g * o_gs + (long)b * HW + px] = sigmoidf_(z);
+    }
+}
+
+// dx[b][c][p] = dz[b][p] * w[c], dz = dout*o*(1-o)
+__global__ __launch_bounds__(256) void head_bwd_dx_kernel(const float* w, long par_gs, const float* o, long o_gs,
+                                                          const float* dout, long do_gs, float* dx, long dx_gs, int B, int C, int HW) {
+    const int g = blockIdx.y;
+    const long n = (long)B * C * HW;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int pxl = (int)(i % HW); const long bc = i / HW; const int c = (int)(bc % C); const int b = (int)(bc / C);
+        const float ov = o[(long)g * o_gs + (long)b * HW + pxl];
+        const float dz = dout[(long)g * do_gs + (long)b * HW + pxl] * ov * (1.f - ov);
+        dx[(long)g * dx_gs + i] = dz * w[(long)g * par_gs + c];
+    }
+}
+// one wave per channel: dw[c] += sum_{b,p} dz*x ; the wave of channel 0 also does db
+__global__ __launch_bounds__(256) void head_bwd_dw_kernel(const float* x, long x_gs, const float* o, long o_gs, const float* dout,
+                                                          long do_gs, float* dw, float* db, long dpar_gs, int B, int C, int HW) {
+    const int g = blockIdx.y;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (c >= C) return;
+    const int n = B * HW;
+    float s = 0.f, sb = 0.f;
+    for (int i = lane; i < n; i += 64) {
+        const int b = i / HW, pxl = i - b * HW;
+        const float ov = o[(long)g * o_gs + i];
+        const float dz = dout[(long)g * do_gs + i] * ov * (1.f - ov);
+        s += dz * x[(long)g * x_gs + ((long)b * C + c) * HW + pxl];
+        sb += dz;
+    }
+    s = wave_sum(s);
+    if (lane == 0) atomicAdd(dw + (long)g * dpar_gs + c, s);
+    if (c == 0) { sb = wave_sum(sb); if (lane == 0) atomicAdd(db + (long)g * dpar_gs, sb); }
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
+                                                   const float* __restrict__ g, long n4, long n, float alpha,
+                                                   float b1, float b2, float eps, float gs) {
+    const float omb1 = 1.f - b1, omb2 = 1.f - b2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        float4 P = reinterpret_cast<float4*>(p)[i], M = reinterpret_cast<float4*>(m)[i], V = reinterpret_cast<float4*>(v)[i];
+        float4 G = reinterpret_cast<const float4*>(g)[i];
+#define VC_ADAM1(x) { const float gg = G.x * gs; M.x += (gg - M.x) * omb1; V.x += (gg * gg - V.x) * omb2; \
+                      P.x -= (M.x * alpha) / (sqrtf(V.x) + eps); }
+        VC_ADAM1(x) VC_ADAM1(y) VC_ADAM1(z) VC_ADAM1(w)
+        reinterpret_cast<float4*>(p)[i] = P; reinterpret_cast<float4*>(m)[i] = M; reinterpret_cast<float4*>(v)[i] = V;
+    }
+    if (blockIdx.x == 0) {
+        for (long i = n4 * 4 + threadIdx.x; i < n; i += 256) {
+            const float gg = g[i] * gs;
+            float mm = m[i], vv = v[i];
+            mm += (gg - mm) * omb1; vv += (gg * gg - vv) * omb2;
+            p[i] -= (mm * alpha) / (sqrtf(vv) + eps);
+            m[i] = mm; v[i] = vv;
+        }
+    }
+}
+
+__device__ __forceinline__ float signf_(float x) { return (float)((x > 0.f) - (x < 0.f)); }
+
+// utils.py:6-12 + model.py:57-90, plus the gradients of every mean w.r.t. its input.
+__global__ __launch_bounds__(256) void loss_kernel(const LossArgs a) {
+    __shared__ float red[4];
+    float s[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) s[k] = 0.f;
+    const long n1 = (long)a.B * a.FT, n2 = (long)a.B * a.HW;
+    const float inv1 = 1.f / (float)n1, inv2 = 1.f / (float)n2;
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n1; i += stride) {
+        const float A = a.A[i], Bm = a.Bm[i];
+        const float cycB = a.cyc[i], cycA = a.cyc[a.cyc_gs + i];
+        const float idB = a.out1[n1 + i], idA = a.out1[a.out1_gs + n1 + i];
+        s[0] += fabsf(A - cycA); s[1] += fabsf(Bm - cycB); s[2] += fabsf(A - idA); s[3] += fabsf(Bm - idB);
+        a.d_cyc[i] = a.lambda_cycle * signf_(cycB - Bm) * inv1;
+        a.d_cyc[a.d_cyc_gs + i] = a.lambda_cycle * signf_(cycA - A) * inv1;
+        a.d_out1[n1 + i] = a.lambda_identity * signf_(idB - Bm) * inv1;
+        a.d_out1[a.d_out1_gs + n1 + i] = a.lambda_identity * signf_(idA - A) * inv1;
+    }
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n2; i += stride) {
+        const float dAf = a.dout[i], dAr = a.dout[n2 + i];
+        const float dBf = a.dout[a.dout_gs + i], dBr = a.dout[a.dout_gs + n2 + i];
+        s[4] += (1.f - dBf) * (1.f - dBf); s[5] += (1.f - dAf) * (1.f - dAf);
+        s[6] += (1.f - dAr) * (1.f - dAr); s[7] += dAf * dAf;
+        s[8] += (1.f - dBr) * (1.f - dBr); s[9] += dBf * dBf;
+        a.d_dout_G[i] = -2.f * (1.f - dAf) * inv2;
+        a.d_dout_G[a.d_dout_G_gs + i] = -2.f * (1.f - dBf) * inv2;
+        a.d_dout_D[i] = dAf * inv2;                 a.d_dout_D[n2 + i] = -(1.f - dAr) * inv2;
+        a.d_dout_D[a.d_dout_D_gs + i] = dBf * inv2; a.d_dout_D[a.d_dout_D_gs + n2 + i] = -(1.f - dBr) * inv2;
+    }
+#pragma unroll
+    for (int k = 0; k < 10; ++k) {
+        const float t = block_sum_256(s[k], red);
+        if (threadIdx.x == 0) atomicAdd(a.acc + k, t);
+    }
+}
+__global__ void loss_finalize_kernel(const float* acc, float* L, float n1, float n2, float lc, float li) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const float cyc = acc[0] / n1 + acc[1] / n1;
+        const float idl = acc[2] / n1 + acc[3] / n1;
+        const float gA2B = acc[4] / n2, gB2A = acc[5] / n2;
+        const float dA = (acc[6] / n2 + acc[7] / n2) * 0.5f, dB = (acc[8] / n2 + acc[9] / n2) * 0.5f;
+        L[0] = cyc; L[1] = idl; L[2] = gA2B; L[3] = gB2A;
+        L[4] = gA2B + gB2A + lc * cyc + li * idl;
+        L[5] = dA; L[6] = dB; L[7] = dA + dB;
+    }
+}
+
+// sample_train_data's crop (preprocess.py:226-233): out[n][f][t] = src[off[n] + f*len[n] + start[n] + t]
+__global__ __launch_bounds__(256) void crop_batch_kernel(const float* src, const long* off, const int* len, const int* start,
+                                                         float* out, int F, int n_frames) {
+    const int n = blockIdx.y;
+    const float* s = src + off[n] + start[n];
+    const int L = len[n], tot = F * n_frames;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < tot; i += gridDim.x * 256) {
+        const int f = i / n_frames, t = i - f * n_frames;
+        out[(long)n * tot + i] = s[(long)f * L + t];
+    }
+}
+int launch_crop_batch(const float* src, const long* off, const int* len, const int* start, float* out,
+                      int N, int F, int n_frames, hipStream_t s) {
+    int bx = (F * n_frames + 255) / 256; if (bx > 64) bx = 64;
+    crop_batch_kernel<<<dim3(bx, N), 256, 0, s>>>(src, off, len, start, out, F, n_frames);
+    VC_HIP(hipGetLastError());
+    return 0;
+}
+
+// utils.l1_loss / utils.l2_loss (utils.py:6-12) as stand-alone ops for the plug-in path:
+// loss = mean(|y - y_hat|) or mean((y - y_hat)^2); d_yhat = d loss / d y_hat.
+__global__ __launch_bounds__(256) void mean_loss_kernel(const float* y, const float* yh, long n, int squared,
+                                                        float* loss, float* d_yhat) {
+    __shared__ float red[4];
+    float s = 0.f;
+    const float inv = 1.f / (float)n;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float d = y[i] - yh[i];
+        if (squared) { s += d * d; if (d_yhat) d_yhat[i] = -2.f * d * inv; }
+        else { s += fabsf(d); if (d_yhat) d_yhat[i] = -signf_(d) * inv; }
+    }
+    s = block_sum_256(s, red);
+    if (threadIdx.x == 0) atomicAdd(loss, s * inv);
+}
+
+// =====================================================================================
+// launchers
+// =====================================================================================
+// ---- opt-in per-launch timing of the MFMA kernels (bench.py roofline leg): HIP events on the launch's own stream
+namespace {
+struct ProfRec { hipEvent_t a, b; double flops; int kind; };
+std::mutex g_prof_mu;
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof;
+}  // namespace
+ProfScope::ProfScope(int kind_, double flops_, hipStream_t st) : on(g_prof_on), a(nullptr), b(nullptr), flops(flops_), kind(kind_), s(st) {
+    if (on) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, s); }
+}
+ProfScope::~ProfScope() {
+    if (on) { (void)hipEventRecord(b, s); std::lock_guard<std::mutex> l(g_prof_mu); g_prof.push_back(ProfRec{a, b, flops, kind}); }
+}
+
+extern "C" int vc_prof_enable(int on) {
+    std::lock_guard<std::mutex> l(g_prof_mu);
+    for (auto& r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    g_prof.clear();
+    g_prof_on = on != 0;
+    return 0;
+}
+extern "C" int vc_prof_collect(int kind, double* ms, long long* launches, double* flops) {
+    std::lock_guard<std::mutex> l(g_prof_mu);
+    double t = 0, f = 0; long long n = 0;
+    for (auto& r : g_prof) {
+        if (r.kind != kind) continue;
+        VC_HIP(hipEventSynchronize(r.b));
+        float e = 0; VC_HIP(hipEventElapsedTime(&e, r.a, r.b));
+        t += e; f += r.flops; ++n;
+    }
+    if (ms) *ms = t; if (launches) *launches = n; if (flops) *flops = f;
+    return 0;
+}
+
+// one launch zeroes a whole list of buffers (split-K destinations of a network pass)
+struct ZeroList { float* p[48]; long n[48]; int count; };
+__global__ __launch_bounds__(256) void zero_list_kernel(const ZeroList z) {
+    float* p = z.p[blockIdx.y]; const long n = z.n[blockIdx.y];
+    const long n4 = n >> 2;
+    f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) reinterpret_cast<f32x4*>(p)[i] = zero;
+    if (blockIdx.x == 0) for (long i = n4 * 4 + threadIdx.x; i < n; i += 256) p[i] = 0.f;
+}
+__global__ __launch_bounds__(256) void add_kernel(float* __restrict__ dst, const float* __restrict__ src, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) dst[i] += src[i];
+}
+int launch_add(float* dst, const float* src, long n, hipStream_t s) {
+    long blocks = (n + 255) / 256; if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
+    add_kernel<<<dim3((unsigned)blocks), 256, 0, s>>>(dst, src, n);
+    VC_HIP(hipGetLastError());
+    return 0;
+}
+int launch_zero_list(const std::vector<std::pair<float*, long>>& bufs, hipStream_t s) {
+    for (size_t i0 = 0; i0 < bufs.size(); i0 += 48) {
+        ZeroList z{}; long mx = 0;
+        z.count = (int)std::min<size_t>(48, bufs.size() - i0);
+        for (int i = 0; i < z.count; ++i) {
+            z.p[i] = bufs[i0 + i].first; z.n[i] = bufs[i0 + i].second; mx = std::max(mx, z.n[i]);
+            if ((uintptr_t)z.p[i] % 16) { vc_set_error("zero list: buffer not 16-byte aligned"); return -1; }
+        }
+        long bx = (mx / 4 + 255) / 256; if (bx > 256) bx = 256; if (bx < 1) bx = 1;
+        zero_list_kernel<<<dim3((unsigned)bx, z.count), 256, 0, s>>>(z);
+    }
+    VC_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int vc_prof_records(int kind, double* ms, double* flops, int max_n) {
+    std::lock_guard<std::mutex> l(g_prof_mu);
+    int n = 0;
+    for (auto& r : g_prof) {
+        if (r.kind != kind) continue;
+        if (n < max_n) {
+            VC_HIP(hipEventSynchronize(r.b));
+            float e = 0; VC_HIP(hipEventElapsedTime(&e, r.a, r.b));
+            ms[n] = e; flops[n] = r.flops;
+        }
+        ++n;
+    }
+    return n;
+}
+
+template <int MODE, bool FWD>
+static int norm_dispatch(const NormArgs& a, hipStream_t s) {
+    const int units = a.G * a.B * a.C;
+    dim3 block(256);
+#define VC_NORM_CASE(LPR, NE) { dim3 grid((units + (256 / LPR) - 1) / (256 / LPR)); \
+        if (FWD) norm_fwd_kernel<MODE, LPR, NE><<<grid, block, 0, s>>>(a); \
+        else     norm_bwd_kernel<MODE, LPR, NE><<<grid, block, 0, s>>>(a); }
+    if (a.L <= 32) VC_NORM_CASE(32, 1)
+    else if (a.L <= 64) VC_NORM_CASE(64, 1)
+    else if (a.L <= 128) VC_NORM_CASE(64, 2)
+    else if (a.L <= 256) VC_NORM_CASE(64, 4)
+    else if (a.L <= 512) VC_NORM_CASE(64, 8)
+    else if (a.L <= 1024) VC_NORM_CASE(64, 16)
+    else if (a.L <= 2048) VC_NORM_CASE(64, 32)
+    else {   // streaming: one block per row
+        if (FWD) norm_fwd_stream_kernel<MODE><<<dim3(units), block, 0, s>>>(a);
+        else     norm_bwd_stream_kernel<MODE><<<dim3(units), block, 0, s>>>(a);
+    }
+#undef VC_NORM_CASE
+    VC_HIP(hipGetLastError());
+    return 0;
+}
+int launch_norm_fwd(int mode, const NormArgs& a, hipStream_t s) {
+    if (a.ps && (a.L & 1)) { vc_set_error("pixel shuffle needs even L"); return -1; }
+    switch (mode) {
+        case 0: return norm_dispatch<0, true>(a, s);
+        case 1: return norm_dispatch<1, true>(a, s);
+        case 2: return norm_dispatch<2, true>(a, s);
+    }
+    vc_set_error("bad norm mode %d", mode); return -1;
+}
+int launch_norm_bwd(int mode, const NormArgs& a, hipStream_t s) {
+    if (a.ps && (a.L & 1)) { vc_set_error("pixel shuffle needs even L"); return -1; }
+    switch (mode) {
+        case 0: return norm_dispatch<0, false>(a, s);
+        case 1: return norm_dispatch<1, false>(a, s);
+        case 2: return norm_dispatch<2, false>(a, s);
+    }
+    vc_set_error("bad norm mode %d", mode); return -1;
+}
+
+int launch_bias_grad(const float* dy, long dy_gs, float* db, long db_gs, int G, int B, int C, int L, hipStream_t s) {
+    bias_grad_kernel<<<dim3(C, G), 256, 0, s>>>(dy, dy_gs, db, db_gs, B, C, L);
+    VC_HIP(hipGetLastError());
+    return 0;
+}
+int launch_head_fwd(const float* x, long x_gs, const float* w, const float* b, long par_gs,
+                    float* o, long o_gs, int G, int B, int C, int HW, hipStream_t s) {
+    head_fwd_kernel<<<dim3((HW + 63) / 64, B, G), 256, 0, s>>>(x, x_gs, w, b, par_gs, o, o_gs, C, HW);
+    VC_HIP(hipGetLastError());
+    return 0;
+}
+int launch_head_bwd(const float* x, long x_gs, const float* w, long par_gs, const float* o, long o_gs,
+                    const float* dout, long do_gs, float* dx, long dx_gs, float* dw, float* db,
+                    long dpar_gs, int G, int B, int C, int HW, hipStream_t s) {
+    if (dx) {
+        const long n = (long)B * C * HW;
+        const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+        head_bwd_dx_kernel<<<dim3(blocks, G), 256, 0, s>>>(w, par_gs, o, o_gs, dout, do_gs, dx, dx_gs, B, C, HW);
+    }
+    if (dw) head_bwd_dw_kernel<<<dim3((C + 3) / 4, G), 256, 0, s>>>(x, x_gs, o, o_gs, dout, do_gs, dw, db, dpar_gs, B, C, HW);
+    VC_HIP(hipGetLastError());
+    return 0;
+}
+int launch_adam(float* p, float* m, float* v, const float* g, long n, float alpha, float b1,
+                float b2, float eps, float gscale, hipStream_t s) {
+    const long n4 = n / 4;
+    long blocks = (n4 + 255) / 256; if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
+    adam_kernel<<<dim3((unsigned)blocks), 256, 0, s>>>(p, m, v, g, n4, n, alpha, b1, b2, eps, gscale);
+    VC_HIP(hipGetLastError());
+    return 0;
+}
+int launch_mean_loss(const float* y, const float* yh, long n, int squared, float* loss, float* d_yhat, hipStream_t s) {
+    VC_HIP(hipMemsetAsync(loss, 0, sizeof(float), s));
+    long blocks = (n + 255) / 256; if (blocks > 1024) blocks = 1024; if (blocks < 1) blocks = 1;
+    mean_loss_kernel<<<dim3((unsigned)blocks), 256, 0, s>>>(y, yh, n, squared, loss, d_yhat);
+    VC_HIP(hipGetLastError());
+    return 0;
+}
+int launch_loss(const LossArgs& a, hipStream_t s) {
+    VC_HIP(hipMemsetAsync(a.acc, 0, 10 * sizeof(float), s));
+    const long n1 = (long)a.B * a.FT;
+    long blocks = (n1 + 255) / 256; if (blocks > 1024) blocks = 1024; if (blocks < 1) blocks = 1;
+    loss_kernel<<<dim3((unsigned)blocks), 256, 0, s>>>(a);
+    loss_finalize_kernel<<<1, 64, 0, s>>>(a.acc, a.losses, (float)n1, (float)((long)a.B * a.HW),
+                                          a.lambda_cycle, a.lambda_identity);
+    VC_HIP(hipGetLastError());
+    return 0;
+}

@@ -1,78 +1,113 @@
-// Internal launch descriptors shared by vc_kernels.hip (device code + launchers)
-// and vc_api.hip (host orchestration + C-ABI).  gfx950 only.
+// Internal launch descriptors shared by the device TUs (vc_conv_igemm.hip, vc_conv_wgrad.hip, vc_conv_small.hip,
+// vc_elementwise.hip) and the host orchestration (vc_api.hip, vc_comm.cpp).  gfx950 only.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <utility>
+#include <vector>
 
-// One entry per GEMM-K row of an implicit-GEMM convolution.
+// Arithmetic of the MFMA kernels (vc_plan_set_math_mode / vc_set_math_mode):
+//   0  fp32   v_mfma_f32_32x32x2_f32, exact fp32 products (default; the parity configuration)
+//   1  bf16   operands rounded to bf16 (RNE) on their way into v_mfma_f32_32x32x16_bf16, fp32 accumulate
+//   2  bf16x3 every operand split x = hi + lo (two bf16), products hi*hi + hi*lo + lo*hi: ~2^-16 relative per product
+#define VC_MATH_FP32 0
+#define VC_MATH_BF16 1
+#define VC_MATH_BF16X3 2
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// 8 k-values of one operand row -> one bf16 MFMA fragment (and the residual fragment for the split mode)
+template <int MATH> __device__ __forceinline__ void to_frag(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        hi[e] = (__bf16)v[e];
+        if constexpr (MATH == VC_MATH_BF16X3) lo[e] = (__bf16)(v[e] - (float)hi[e]);
+    }
+}
+
+// x / d and x % d for 0 <= x < 2^24 with inv = 1.0f / d: float estimate plus one correction step (a 32-bit integer
+// division costs ~40 instructions on gfx950; this is 8).
+__device__ __forceinline__ int fast_divmod(int x, int d, float inv, int* rem) {
+    int q = (int)((float)x * inv);
+    int r = x - q * d;
+    if (r < 0) { --q; r += d; }
+    if (r >= d) { ++q; r -= d; }
+    *rem = r;
+    return q;
+}
+
+// One entry per GEMM-K row of an implicit-GEMM convolution (filter-gradient kernel).
 //   c     : channel of the gathered tensor this K row reads
 //   dh,dw : offset (in gathered-tensor pixels) added to the launch pixel (i*si, j*sj)
 //   a_off : float offset of this K row inside the weight tensor, -1 = padding row
 struct __attribute__((aligned(16))) KEntry { int c, dh, dw, a_off; };
-
-// Y[g][b][m][P(i,j)] (+)= sum_kk A[a_off(kk) + m*a_ms] * X[g][b][c(kk)][i*si+dh(kk)][j*sj+dw(kk)]
-// Gather-table entry of one GEMM-K row, read through the scalar cache:
-//   soff   : byte offset (c*xHW + dh*xW + dw)*4 added to the lane's pixel byte offset
-//   tapbit : 1 << tap index; 0 marks a padding row.  A lane keeps a bitmask of the taps that fall inside the
-//            gathered tensor for ITS pixel, so the per-element bounds check is one AND.
-struct __attribute__((aligned(8))) XEntry { int soff; unsigned tapbit; };
 struct Tap { int dh, dw; };
 #define VC_OOB 0xffffffffu     // buffer-load offset beyond num_records: the hardware returns 0
+#define VC_KC 32               // K rows per chunk; every chunk of a table lies inside ONE filter tap (taps are padded to 32 rows)
 
 // Y[g][b][m][P(i,j)] (+)= sum_kk A[a_off(kk) + m*a_ms] * X[g][b][c(kk)][i*si+dh(kk)][j*sj+dw(kk)]
+// The K rows are described by three scalar-cache tables (structure of arrays, one scalar load serves 4-8 rows):
+//   xsoff[kk] : byte offset (c*xHW + dh*xW + dw)*4 + xbias of the row inside the gathered tensor, >= 0.  It travels in the
+//               buffer load's SGPR offset (excluded from the hardware range check); the lane's own pixel offset travels
+//               in the VGPR offset, which is VC_OOB when the chunk's tap falls outside the tensor for that pixel.
+//   rtap[kk/4]: 1 << tap of the aligned run of 4 rows (0 = padding run; runs never straddle taps or padding)
+//   aoff[kk]  : byte offset of the row inside the weight tensor (padding rows: 0 -- any finite value, their X is 0)
 struct IgemmArgs {
     const float* A; const float* X; float* Y; const float* bias; const float* addend;
-    const XEntry* xtab;                           // nchunks*32 entries
+    const int* xsoff; const unsigned* rtap; const unsigned* aoff;
     const Tap* taps; int ntaps;                   // <= 32 taps
-    const unsigned* atab;                         // transposed-A mode: byte offset of each K row (0x80000000 = padding)
-    unsigned a_ks_bytes;                          // plain-A mode: byte stride between K rows
+    int xbias;                                    // bytes the X base pointer is moved down so that every xsoff >= 0
     unsigned x_bytes, a_bytes;                    // buffer sizes (per group) for the hardware range check
     long a_gs, x_gs, y_gs, bias_gs, add_gs;      // signed group strides (floats)
     long x_bs, y_bs;                              // batch strides (floats)
-    int krows;                                    // K rows of the table (padded to a multiple of 64)
-    int kc;                                       // K chunk chosen by igemm_config (32 or 64)
+    int krows;                                    // K rows of the table (a multiple of 32)
     int M, a_ms;                                  // output rows, stride of m in A
     int Hl, Wl;                                   // bounds of the gathered tensor
     int xHW, xW;                                  // channel / row stride of the gathered tensor
     int si, sj;                                   // pixel stride launch grid -> gathered tensor
     int NPB, OWc, Ptot;                           // launch pixel grid: per sample, width, total
+    float inv_npb, inv_ow;                        // 1/NPB, 1/OWc (fast_divmod)
     int yHW, yW;                                  // channel / row stride of the output tensor
     int so_h, so_w, o_h0, o_w0;                   // launch pixel -> output pixel
-    int splitk, accumulate, mtiles, ntiles, groups, big;
-    int kl_ok;                                    // the k-contiguous-LDS kernel may serve this launch (transposed A: K rows come in aligned runs of 4)
+    int vec4;                                     // 4 consecutive launch pixels are 16 contiguous, aligned output bytes
+    int splitk, accumulate, mtiles, ntiles, groups;
+    int bm, kg;                                   // tile rows (64 / 128) and K groups inside a workgroup (1, 2, 4)
 };
 
 // Up to 4 launches of the same tile configuration fused into one grid (blockIdx.y): the stride-parity classes of an
 // input gradient, which individually underfill the chip.
 struct IgemmMulti { IgemmArgs c[4]; int n; };
 
-// dW[a_off(kk) + co] += sum_{b,i,j} X[g][b][c(kk)][i*si+dh][j*sj+dw] * dY[g][b][co][i][j]
+// dW[a_off(kk) + co] (+)= sum over segments, samples and pixels of X[g][b][c(kk)][i*si+dh][j*sj+dw] * dY[g][b][co][i][j].
+// A segment is one application of the layer (the generator runs twice per step on different batches, model.py:44-51);
+// both reduce into the same filter gradient, so they go out as ONE launch whose reduction axis is their concatenation.
+struct WgradSeg { const float* X; const float* dY; long x_gs, dy_gs; unsigned x_bytes, dy_bytes; int Ptot, nchunks; };
 struct WgradArgs {
-    const float* X; const float* dY; float* dW; const KEntry* ktab;
-    long x_gs, dy_gs, dw_gs; long x_bs, dy_bs;
-    unsigned x_bytes, dy_bytes;
-    float inv_ow;                                 // 1/OWc for the pixel decode
+    WgradSeg seg[2]; int nseg;
+    float* dW; const KEntry* ktab; const int* xsoff; int xbias; long dw_gs; long x_bs, dy_bs;   // xsoff / xbias: as IgemmArgs (forward table)
+    float inv_ow, inv_npb;
     int N;                                        // Cout
     int Hl, Wl, xHW, xW, si, sj;
-    int NPB, OWc, Ptot;
-    int nchunks;                                  // ceil(Ptot/32)
+    int NPB, OWc;
+    int nchunks;                                  // all segments
     int splitk, ktiles, ntiles, groups;
-    int first_touch;                              // dW holds no earlier contribution (it is zero): store instead of add
+    int store;                                    // dW holds no earlier contribution and split-K is 1: plain stores
 };
 
 // Single-input-channel convolution (the discriminator's first layer, module.py:201-202: Cin = 1, 3x3 -> K = 9): a
 // bandwidth job, done on the vector ALU instead of padding K = 9 up to an MFMA tile.  kh*kw <= 9.
 struct C1Args {
     const float* x; const float* w; const float* bias; const float* addend; const float* dy;
-    float* y; float* dx; float* dw;
-    long x_gs, w_gs, b_gs, y_gs, dx_gs, add_gs, dw_gs;     // signed group strides (floats); y_gs also strides dy
+    float* y; float* dx; float* dw; float* db;
+    long x_gs, w_gs, b_gs, y_gs, dx_gs, add_gs, dw_gs, db_gs;     // signed group strides (floats); y_gs also strides dy
     int B, H, W, Cout, kh, kw, sh, sw, OH, OW, pt, pl, G;
     int math;                                               // VC_MATH_*: bf16 mode rounds both operands like the MFMA kernels do
 };
 int launch_c1_fwd(const C1Args& a, hipStream_t s);
 int launch_c1_dgrad(const C1Args& a, int accumulate, hipStream_t s);   // dx (+)= ...; atomics into dx (zeroed here unless accumulate)
 int launch_c1_wgrad(const C1Args& a, hipStream_t s);                   // dw += ... (atomics)
-int vc_math_mode();
 
 // Weight-stationary 1-D convolution forward for few input channels (the generator's h1 layer, module.py:161-162:
 // 24 -> 2x128 channels, k = 15, stride 1): K = Cin*k = 360 is too short a loop for the tiled implicit GEMM (12 chunks
@@ -83,7 +118,7 @@ struct WsConvArgs {
     long x_gs, w_gs, b_gs, y_gs;          // signed group strides (floats)
     int B, T, Cout, G;
 };
-int launch_wsconv1d(const WsConvArgs& a, int cin, int kw, hipStream_t s, double flops);   // returns -2 when the geometry is not built
+int launch_wsconv1d(const WsConvArgs& a, int cin, int kw, int math, hipStream_t s, double flops);   // returns -2 when the geometry is not built
 
 struct NormArgs {
     const float* y; const float* res; const float* gamma; const float* beta;
@@ -93,13 +128,14 @@ struct NormArgs {
     int G, B, C, L, ps;
 };
 
-void igemm_config(IgemmArgs& a);   // picks tile size + split-K, fills mtiles/ntiles/splitk/big
-int launch_igemm(const IgemmArgs& a, bool a_trans, hipStream_t s, double flops);
-int launch_igemm_multi(const IgemmArgs* cls, int n, bool a_trans, hipStream_t s, double flops);   // all configured alike
-int launch_wgrad(const WgradArgs& a, hipStream_t s, double flops);
-#include <utility>
-#include <vector>
+// picks tile rows, K groups and split-K for a launch (fills bm/kg/splitk/mtiles/ntiles)
+void igemm_config(IgemmArgs& a);
+int launch_igemm(const IgemmArgs& a, bool a_trans, int math, hipStream_t s, double flops);
+int launch_igemm_multi(const IgemmArgs* cls, int n, bool a_trans, int math, hipStream_t s, double flops);   // all configured alike
+int wgrad_splitk(const WgradArgs& a);            // the split-K factor launch_wgrad will use (1 = plain stores possible)
+int launch_wgrad(const WgradArgs& a, int math, hipStream_t s, double flops);
 int launch_zero_list(const std::vector<std::pair<float*, long>>& bufs, hipStream_t s);
+int launch_add(float* dst, const float* src, long n, hipStream_t s);   // dst += src
 int launch_norm_fwd(int mode, const NormArgs& a, hipStream_t s);
 int launch_norm_bwd(int mode, const NormArgs& a, hipStream_t s);
 int launch_bias_grad(const float* dy, long dy_gs, float* db, long db_gs, int G, int B, int C, int L, hipStream_t s);
@@ -128,6 +164,13 @@ int launch_loss(const LossArgs& a, hipStream_t s);
 int launch_crop_batch(const float* src, const long* off, const int* len, const int* start, float* out,
                       int N, int F, int n_frames, hipStream_t s);
 int launch_mean_loss(const float* y, const float* yh, long n, int squared, float* loss, float* d_yhat, hipStream_t s);
+
+// per-launch timing records (vc_prof_*): kind 0 igemm, 1 wgrad, 2 wsconv
+struct ProfScope {
+    bool on; hipEvent_t a, b; double flops; int kind; hipStream_t s;
+    ProfScope(int kind, double flops, hipStream_t st);
+    ~ProfScope();
+};
 
 void vc_set_error(const char* fmt, ...);
 #define VC_HIP(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { \

@@ -5,9 +5,11 @@ It is the object behind `model.CycleGAN` (reference: model.py:9-150): one engine
 one reference `tf.Session` with its four variable scopes `generator_A2B`,
 `generator_B2A`, `discriminator_A`, `discriminator_B` (model.py:44-54).
 
-torch is used for device memory, streams and torch.distributed only; every
-arithmetic op of the step runs in libvcgan_hip.so.  There is no CPU fallback.
+torch is used for device memory, streams and (to bootstrap the native RCCL communicator, and as the
+exchange on non-RCCL backends) torch.distributed; every arithmetic op of the step runs in
+libvcgan_hip.so.  There is no CPU fallback.
 """
+import collections
 import ctypes as C
 
 import numpy as np
@@ -21,25 +23,57 @@ ADAM_BETA1, ADAM_BETA2, ADAM_EPS = 0.5, 0.999, 1e-8      # model.py:107-108 + TF
 SCOPES = ('generator_A2B', 'generator_B2A', 'discriminator_A', 'discriminator_B')
 LOSS_NAMES = ('cycle_loss', 'identity_loss', 'generator_loss_A2B', 'generator_loss_B2A', 'generator_loss',
               'discriminator_loss_A', 'discriminator_loss_B', 'discriminator_loss')   # model.py:155-167
+MATH_MODES = {'fp32': 0, 'bf16': 1, 'bf16x3': 2}
+
+
+def set_default_math(mode):
+    """Arithmetic of the operator-level calls of THIS thread (vc_conv2d_*, which carry no plan) and the initial mode of
+    plans it creates afterwards (vc_set_math_mode).  Engines set the mode of their own plans: CycleGANEngine.set_math."""
+    check(lib.vc_set_math_mode(MATH_MODES[mode]), 'vc_set_math_mode')
 
 
 class GradSync:
-    """Data-parallel gradient exchange: one SUM all-reduce per flat segment, the 1/world
-    factor is folded into the Adam kernel (grad_scale).  Works on any backend (RCCL on
-    GPUs via backend 'nccl'; gloo in the CPU tests)."""
+    """Data-parallel gradient exchange: one SUM all-reduce per flat segment, the 1/world factor folded into the Adam
+    kernel (grad_scale).  On the 'nccl' backend the collective itself is issued by libvcgan_hip.so on its own RCCL
+    communicator (vc_comm_init; torch.distributed only carries the 128-byte unique id to the other ranks); on any other
+    backend (gloo in the CPU / shared-GPU tests) torch.distributed does the all-reduce."""
 
-    def __init__(self, group=None, enabled=True):
+    def __init__(self, group=None, enabled=True, device=None):
         import torch.distributed as dist
         self.dist = dist
         self.group = group
-        self.world = dist.get_world_size(group) if enabled and dist.is_available() and dist.is_initialized() else 1
+        on = enabled and dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if on else 1
+        self.rank = dist.get_rank(group) if on else 0
+        self.comm = None                       # native RCCL communicator (vc_comm*)
+        if self.world > 1 and device is not None and dist.get_backend(group) == 'nccl':
+            ident = (C.c_ubyte * 128)()
+            if self.rank == 0:
+                check(lib.vc_comm_unique_id(ident), 'vc_comm_unique_id')
+            box = [bytes(ident)]
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            ident = (C.c_ubyte * 128).from_buffer_copy(box[0])
+            torch.cuda.set_device(device)
+            h = _lib.vp()
+            check(lib.vc_comm_init(self.rank, self.world, ident, C.byref(h)), 'vc_comm_init')
+            self.comm = h
+            assert lib.vc_comm_world(h) == self.world
+
+    def close(self):
+        if self.comm is not None:
+            lib.vc_comm_destroy(self.comm)
+            self.comm = None
 
     @property
     def scale(self):
         return 1.0 / self.world
 
-    def all_reduce(self, t, async_op=False):
+    def all_reduce(self, t, async_op=False, stream=None):
         if self.world == 1:
+            return None
+        if self.comm is not None and t.is_cuda and t.dtype == torch.float32:
+            s = stream if stream is not None else _lib.vp(torch.cuda.current_stream(t.device).cuda_stream)
+            check(lib.vc_allreduce_f32(self.comm, ptr(t), t.numel(), s), 'vc_allreduce_f32')
             return None
         return self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group, async_op=async_op)
 
@@ -47,8 +81,42 @@ class GradSync:
         if self.world > 1:
             self.dist.broadcast(t, src=src, group=self.group)
 
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier(group=self.group)
+
+
+class PlanCache:
+    """LRU of native plans keyed by n_frames.  CycleGAN.test sees a new utterance length on almost every call
+    (train.py:132, convert.py:46); evicted plans are destroyed (streams, events, geometry tables)."""
+
+    def __init__(self, create, capacity):
+        self.create, self.capacity, self.plans = create, capacity, collections.OrderedDict()
+
+    def get(self, T):
+        p = self.plans.get(T)
+        if p is not None:
+            self.plans.move_to_end(T)
+            return p
+        while len(self.plans) >= self.capacity:
+            torch.cuda.synchronize()           # nothing in flight may still use the plan's streams / tables
+            _, old = self.plans.popitem(last=False)
+            lib.vc_plan_destroy(old)
+        p = self.plans[T] = self.create(T)
+        return p
+
+    def values(self):
+        return self.plans.values()
+
+    def clear(self):
+        for p in self.plans.values():
+            lib.vc_plan_destroy(p)
+        self.plans.clear()
+
 
 class CycleGANEngine:
+    MATH_MODES = MATH_MODES
+
     def __init__(self, num_features=24, device='cuda:0', seed=None, group=None, data_parallel=True):
         if not torch.cuda.is_available():
             raise RuntimeError('CycleGANEngine needs an MI355X: the hot path is HIP-only (no CPU fallback)')
@@ -66,15 +134,31 @@ class CycleGANEngine:
         self.m = torch.zeros(self.n_flat, device=self.device)
         self.v = torch.zeros(self.n_flat, device=self.device)
         self.losses = torch.zeros(8, device=self.device)
-        self._plans, self._ws = {}, None
+        self._math = 'fp32'
         self._overlap = True
-        self.sync = GradSync(group, enabled=data_parallel)
+        self._plans = PlanCache(lambda T: self._new_plan(T, False), 4)
+        self._infer_plans = PlanCache(lambda T: self._new_plan(T, True), 8)
+        self._ws = None
+        self.sync = GradSync(group, enabled=data_parallel, device=self.device)
         self._comm_stream = torch.cuda.Stream(device=self.device)      # gradient exchange + Adam, beside the backward
         # tf.train.AdamOptimizer keeps beta1_power/beta2_power as fp32 variables (one pair per optimizer)
         self.b1p = [np.float32(ADAM_BETA1), np.float32(ADAM_BETA1)]
         self.b2p = [np.float32(ADAM_BETA2), np.float32(ADAM_BETA2)]
         self.init_parameters(np.random.default_rng(seed))
         self.sync.broadcast(self.params, 0)       # identical replicas
+
+    def close(self):
+        """release the native plans (streams, events, geometry tables) and the RCCL communicator"""
+        torch.cuda.synchronize()
+        self._plans.clear()
+        self._infer_plans.clear()
+        self.sync.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     # ------------------------------------------------------------------ parameters
     def init_parameters(self, rng):
@@ -104,16 +188,18 @@ class CycleGANEngine:
         return self._unpack(self.grads)
 
     # ------------------------------------------------------------------ plans / workspace
+    def _new_plan(self, T, inference):
+        h = _lib.vp()
+        create = lib.vc_plan_create_inference if inference else lib.vc_plan_create
+        check(create(self.F, int(T), C.byref(h)), 'vc_plan_create')
+        assert lib.vc_flat_param_floats(h) == self.n_flat
+        check(lib.vc_plan_set_math_mode(h, MATH_MODES[self._math]), 'vc_plan_set_math_mode')
+        if not self._overlap:
+            lib.vc_plan_set_overlap(h, 0)
+        return h
+
     def plan(self, T):
-        p = self._plans.get(T)
-        if p is None:
-            h = _lib.vp()
-            check(lib.vc_plan_create(self.F, int(T), C.byref(h)), 'vc_plan_create')
-            assert lib.vc_flat_param_floats(h) == self.n_flat
-            if not self._overlap:
-                lib.vc_plan_set_overlap(h, 0)
-            self._plans[T] = p = h
-        return p
+        return self._plans.get(int(T))
 
     def set_overlap(self, enabled):
         """run the step's independent chains on two streams (default) or serialised (for per-kernel timing)"""
@@ -121,19 +207,18 @@ class CycleGANEngine:
         for h in self._plans.values():
             lib.vc_plan_set_overlap(h, int(self._overlap))
 
-    MATH_MODES = {'fp32': 0, 'bf16': 1, 'bf16x3': 2}
+    def set_math(self, mode):
+        """Arithmetic of the conv kernels of THIS engine's plans (vc_plan_set_math_mode): 'fp32' (default, the reference's
+        precision), 'bf16' (bf16 MFMA operands, fp32 accumulate / storage / statistics; BASELINE config 3) or 'bf16x3'."""
+        if mode not in MATH_MODES:
+            raise ValueError('math mode must be one of %s' % sorted(MATH_MODES))
+        self._math = mode
+        for cache in (self._plans, self._infer_plans):
+            for h in cache.values():
+                check(lib.vc_plan_set_math_mode(h, MATH_MODES[mode]), 'vc_plan_set_math_mode')
 
-    @staticmethod
-    def set_math(mode):
-        """Arithmetic of the conv kernels, process-wide (vc_set_math_mode): 'fp32' (default, the reference's precision),
-        'bf16' (bf16 MFMA operands, fp32 accumulate / storage / statistics; BASELINE config 3) or 'bf16x3'."""
-        if mode not in CycleGANEngine.MATH_MODES:
-            raise ValueError('math mode must be one of %s' % sorted(CycleGANEngine.MATH_MODES))
-        check(lib.vc_set_math_mode(CycleGANEngine.MATH_MODES[mode]), 'vc_set_math_mode')
-
-    @staticmethod
-    def get_math():
-        return {v: k for k, v in CycleGANEngine.MATH_MODES.items()}[lib.vc_get_math_mode()]
+    def get_math(self):
+        return self._math
 
     def _workspace(self, n):
         if self._ws is None or self._ws.numel() < n:
@@ -168,6 +253,11 @@ class CycleGANEngine:
         one = np.float32(1)
         return float(np.float32(lr) * np.sqrt(one - self.b2p[k]) / (one - self.b1p[k]))
 
+    def _advance_beta_powers(self):
+        for k in range(2):
+            self.b1p[k] = np.float32(self.b1p[k] * np.float32(ADAM_BETA1))
+            self.b2p[k] = np.float32(self.b2p[k] * np.float32(ADAM_BETA2))
+
     def apply_adam(self, generator_learning_rate, discriminator_learning_rate):
         """ApplyAdam over both optimizers' variable lists (model.py:107-108)."""
         s, gs = self._stream(), float(self.sync.scale)
@@ -176,8 +266,7 @@ class CycleGANEngine:
             check(lib.vc_adam_tf_update(ptr(self.params[lo:hi]), ptr(self.m[lo:hi]), ptr(self.v[lo:hi]),
                                         ptr(self.grads[lo:hi]), hi - lo, self._alpha(lr, k),
                                         ADAM_BETA1, ADAM_BETA2, ADAM_EPS, gs, s), 'vc_adam_tf_update')
-            self.b1p[k] = np.float32(self.b1p[k] * np.float32(ADAM_BETA1))
-            self.b2p[k] = np.float32(self.b2p[k] * np.float32(ADAM_BETA2))
+        self._advance_beta_powers()
 
     def grad_segments(self, plan):
         """[(kind, index, [(lo, hi), ...])] in the order the segments become final inside step_grads:
@@ -191,53 +280,46 @@ class CycleGANEngine:
         return segs
 
     def exchange_grads(self, plan):
-        """The one gradient exchange of the step (SUM all-reduce of the flat fp32 gradient), issued as segments in
-        the order they become final so that all but the last small bucket rides under the remaining backward:
-        the native schedule records a HIP event per segment, the comm stream waits on it, RCCL runs beside compute."""
+        """The one gradient exchange of the step (SUM all-reduce of the flat fp32 gradient) on the caller's stream, as
+        segments in the order they become final.  Used with set_overlap(False) (per-kernel timing, debugging)."""
         if self.sync.world == 1:
             return
-        main = torch.cuda.current_stream(self.device)
-        works = []
-        with torch.cuda.stream(self._comm_stream):
-            cs = _lib.vp(self._comm_stream.cuda_stream)
-            for kind, k, ranges in self.grad_segments(plan):
-                if kind == 'd':
-                    check(lib.vc_step_wait_d_grads(plan, cs), 'vc_step_wait_d_grads')
-                else:
-                    check(lib.vc_step_wait_g_bucket(plan, k, cs), 'vc_step_wait_g_bucket')
-                for lo, hi in ranges:
-                    works.append(self.sync.all_reduce(self.grads[lo:hi], async_op=True))
-        for w in works:
-            w.wait()
-        main.wait_stream(self._comm_stream)
+        for kind, k, ranges in self.grad_segments(plan):
+            for lo, hi in ranges:
+                self.sync.all_reduce(self.grads[lo:hi])
 
     def exchange_and_update(self, plan, generator_learning_rate, discriminator_learning_rate):
-        """Gradient exchange (data parallel) + ApplyAdam, segment by segment on the side stream, each as soon as the
-        native schedule says the segment's gradients are final AND its weights are no longer read (vc_step_wait_*):
-        the discriminator half rides under the whole generator backward, generator buckets under the rest of it.
-        Adam is HBM-bound (28 B/param), the backward MFMA-bound, so they share the chip well; only the last small
-        bucket (h1, d1, d2) is exposed.  Arithmetic is identical to exchange_grads() + apply_adam()."""
+        """Gradient exchange (data parallel) + ApplyAdam, segment by segment on the update stream, each as soon as the
+        native schedule says the segment's gradients are final AND its weights are no longer read: the discriminator half
+        rides under the whole generator backward, generator buckets under the rest of it.  Adam is HBM-bound
+        (28 B/param), the backward MFMA-bound, so they share the chip well; only the last small bucket (h1, d1, d2) is
+        exposed.  Arithmetic is identical to exchange_grads() + apply_adam().
+        RCCL backend (or a single GPU): ONE native call, vc_step_exchange_and_update, which issues ncclAllReduce per
+        segment on the update stream.  Any other backend: the same loop here, with torch.distributed as the collective."""
         main = torch.cuda.current_stream(self.device)
-        side, gs = self._comm_stream, float(self.sync.scale)
+        side = self._comm_stream
         alphas = (self._alpha(generator_learning_rate, 0), self._alpha(discriminator_learning_rate, 1))
-        with torch.cuda.stream(side):
-            cs = _lib.vp(side.cuda_stream)
-            for kind, k, ranges in self.grad_segments(plan):
-                if kind == 'd':
-                    check(lib.vc_step_wait_d_grads(plan, cs), 'vc_step_wait_d_grads')
-                else:
-                    check(lib.vc_step_wait_g_bucket(plan, k, cs), 'vc_step_wait_g_bucket')
-                if self.sync.world > 1:
+        cs = _lib.vp(side.cuda_stream)
+        if self.sync.world == 1 or self.sync.comm is not None:
+            check(lib.vc_step_exchange_and_update(plan, self.sync.comm, ptr(self.params), ptr(self.grads), ptr(self.m),
+                                                  ptr(self.v), alphas[0], alphas[1], ADAM_BETA1, ADAM_BETA2, ADAM_EPS, cs),
+                  'vc_step_exchange_and_update')
+        else:
+            gs = float(self.sync.scale)
+            with torch.cuda.stream(side):
+                for kind, k, ranges in self.grad_segments(plan):
+                    if kind == 'd':
+                        check(lib.vc_step_wait_d_grads(plan, cs), 'vc_step_wait_d_grads')
+                    else:
+                        check(lib.vc_step_wait_g_bucket(plan, k, cs), 'vc_step_wait_g_bucket')
                     for w in [self.sync.all_reduce(self.grads[lo:hi], async_op=True) for lo, hi in ranges]:
                         w.wait()                     # makes the side stream wait for the collective
-                for lo, hi in ranges:
-                    check(lib.vc_adam_tf_update(ptr(self.params[lo:hi]), ptr(self.m[lo:hi]), ptr(self.v[lo:hi]),
-                                                ptr(self.grads[lo:hi]), hi - lo, alphas[1 if kind == 'd' else 0],
-                                                ADAM_BETA1, ADAM_BETA2, ADAM_EPS, gs, cs), 'vc_adam_tf_update')
+                    for lo, hi in ranges:
+                        check(lib.vc_adam_tf_update(ptr(self.params[lo:hi]), ptr(self.m[lo:hi]), ptr(self.v[lo:hi]),
+                                                    ptr(self.grads[lo:hi]), hi - lo, alphas[1 if kind == 'd' else 0],
+                                                    ADAM_BETA1, ADAM_BETA2, ADAM_EPS, gs, cs), 'vc_adam_tf_update')
         main.wait_stream(side)
-        for k in range(2):
-            self.b1p[k] = np.float32(self.b1p[k] * np.float32(ADAM_BETA1))
-            self.b2p[k] = np.float32(self.b2p[k] * np.float32(ADAM_BETA2))
+        self._advance_beta_powers()
 
     def train_step(self, A, Bm, lambda_cycle, lambda_identity, generator_learning_rate,
                    discriminator_learning_rate, sync=True, gen_A=None, gen_B=None):
@@ -268,7 +350,7 @@ class CycleGANEngine:
         x = self._to_dev(inputs)
         assert x.dim() == 3 and x.shape[1] == self.F, x.shape
         B, _, T = x.shape
-        p = self.plan(T)
+        p = self._infer_plans.get(int(T))
         save = self._workspace(lib.vc_generator_save_floats(p, B))
         y = torch.empty_like(x)
         check(lib.vc_generator_forward(p, ptr(self.params[off:]), 0, ptr(x), 0, ptr(y), 0, ptr(save), 1, B,

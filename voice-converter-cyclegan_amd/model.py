@@ -8,6 +8,7 @@ the step runs as ONE fused native schedule (vc_cyclegan_step_grads); with user-s
 callables (the reference's injection seam, model.py:9,14-15) the same loss algebra
 (model.py:44-90) is composed from the callables on the autograd tape.
 """
+import atexit
 import os
 import time
 from datetime import datetime
@@ -33,9 +34,10 @@ class ScalarWriter:
         train_log/*.csv, so train_log/plot.py reads them unchanged)
     under log_dir."""
 
-    def __init__(self, log_dir, flush_every=200):
-        self.log_dir, self.flush_every, self.rows, self.n = log_dir, flush_every, {}, 0
-        self.events, self.pending = None, []
+    def __init__(self, log_dir, flush_every=200, flush_secs=120.0):
+        self.log_dir, self.flush_every, self.flush_secs, self.rows, self.n = log_dir, flush_every, flush_secs, {}, 0
+        self.events, self.pending, self.last_flush = None, [], time.time()
+        atexit.register(self.close)            # tf.summary.FileWriter flushes on a timer and at close; so do we
 
     def add(self, group, tag, step, value):
         now = time.time()
@@ -45,10 +47,17 @@ class ScalarWriter:
         else:
             self.pending.append((group, step, now, {'%s/%s' % (group, tag): value}))
         self.n += 1
-        if self.n >= self.flush_every:
+        if self.n >= self.flush_every or now - self.last_flush >= self.flush_secs:
             self.flush()
 
+    def close(self):
+        self.flush()
+        if self.events is not None:
+            self.events.close()
+            self.events = None
+
     def flush(self):
+        self.last_flush = time.time()
         if not self.n:
             return
         os.makedirs(self.log_dir, exist_ok=True)
@@ -86,11 +95,14 @@ class CycleGAN(object):
         self.build_model()
         self.optimizer_initializer()
 
+        # Under the data-parallel launch (one process per GPU, the reference's train.py unchanged on every rank) only
+        # rank 0 touches the file system: checkpoints, event files and CSVs have ONE writer.
+        self._io_rank = self.engine.sync.rank == 0
         if self.mode == 'train':
             self.train_step = 0
             now = datetime.now()
             self.log_dir = os.path.join(log_dir, now.strftime('%Y%m%d-%H%M%S'))
-            self.writer = ScalarWriter(self.log_dir)
+            self.writer = ScalarWriter(self.log_dir) if self._io_rank else None
             self.generator_summaries, self.discriminator_summaries = self.summary()
 
     # ------------------------------------------------------------------ model.py:32-100
@@ -127,10 +139,11 @@ class CycleGAN(object):
                                               generator_learning_rate, discriminator_learning_rate)
             generator_loss, discriminator_loss = scal['generator_loss'], scal['discriminator_loss']
         if self.mode == 'train':
-            for tag in G_SUMMARIES:
-                self.writer.add('generator_summaries', tag, self.train_step, scal[tag])
-            for tag in D_SUMMARIES:
-                self.writer.add('discriminator_summaries', tag, self.train_step, scal[tag])
+            if self.writer is not None:
+                for tag in G_SUMMARIES:
+                    self.writer.add('generator_summaries', tag, self.train_step, scal[tag])
+                for tag in D_SUMMARIES:
+                    self.writer.add('discriminator_summaries', tag, self.train_step, scal[tag])
             self.train_step += 1
         return np.float32(generator_loss), np.float32(discriminator_loss)
 
@@ -187,9 +200,12 @@ class CycleGAN(object):
     def save(self, directory, filename):
         """tf.train.Saver().save over ALL global variables: weights, Adam slots, beta powers (model.py:21).
         One .npz keyed by the TF variable names (`<var>`, `<var>/Adam`, `<var>/Adam_1`, `beta{1,2}_power{,_1}`)."""
-        if not os.path.exists(directory):
-            os.makedirs(directory)
         eng = self.engine
+        path = os.path.join(directory, filename)
+        if not self._io_rank:                  # replicas are identical: rank 0 writes, everybody leaves together
+            eng.sync.barrier()
+            return path
+        os.makedirs(directory, exist_ok=True)
         out = {}
         out.update(eng.tf_variables())
         out.update({k + '/Adam': v for k, v in eng._unpack(eng.m).items()})
@@ -197,14 +213,16 @@ class CycleGAN(object):
         # optimizer creation order in model.py:107-108: discriminator first, then generator
         out['beta1_power'], out['beta2_power'] = eng.b1p[1], eng.b2p[1]
         out['beta1_power_1'], out['beta2_power_1'] = eng.b1p[0], eng.b2p[0]
-        path = os.path.join(directory, filename)
-        with open(path + '.npz', 'wb') as f:
+        tmp = path + '.npz.tmp'
+        with open(tmp, 'wb') as f:
             np.savez(f, **out)
+        os.replace(tmp, path + '.npz')         # a reader never sees a half-written checkpoint
         if self.save_tf_checkpoint:
             # the files tf.train.Saver writes (minus the .meta graph): `<path>.index`, `<path>.data-00000-of-00001`, `checkpoint`
             tfio.write_tf_checkpoint(path, out)
-        if self.mode == 'train':
+        if self.mode == 'train' and self.writer is not None:
             self.writer.flush()
+        eng.sync.barrier()
         return path
 
     def load(self, filepath):
@@ -221,6 +239,16 @@ class CycleGAN(object):
             raise IOError('no checkpoint at %s(.npz|.index)' % filepath)
         eng.load_tf_variables(d)
         if self.mode != 'train' or not any(k.endswith('/Adam') for k in d):
+            return
+        need = ['beta1_power', 'beta2_power', 'beta1_power_1', 'beta2_power_1']
+        for i, sc in enumerate(SCOPES):
+            for r in eng._layout(i).recs:
+                need += [sc + '/' + r['name'] + '/Adam', sc + '/' + r['name'] + '/Adam_1']
+        missing = [k for k in need if k not in d]
+        if missing:
+            import warnings
+            warnings.warn('checkpoint %s has optimizer slots but lacks %d of them (first: %s): restoring the weights only'
+                          % (filepath, len(missing), missing[0]))
             return
         blocks_m, blocks_v = [], []
         for i, s in enumerate(SCOPES):
