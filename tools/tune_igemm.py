@@ -44,6 +44,31 @@ def time_call(f, kind, reps):
     return 1e3 * ms.value / reps, int(n.value // reps)      # us per call, launches per call
 
 
+def _same(n, k, s):
+    out = -(-n // s); total = max((out - 1) * s + k - n, 0)
+    return out, total // 2
+
+
+def _pad_rows(ntaps, per_tap):
+    rows = ntaps * (-(-per_tap // 32) * 32)
+    return -(-rows // 64) * 64
+
+
+def launch_keys(op, Cin, H, W, Cout, kh, kw, sh, sw, Bs):
+    """(a_trans, M, Ptot, krows) of every implicit-GEMM launch the op makes (vc_api.hip: conv_fwd / conv_dgrad)"""
+    OH, pt = _same(H, kh, sh); OW, pl = _same(W, kw, sw)
+    if op == 'fwd':
+        return [(0, Cout, Bs * OH * OW, _pad_rows(kh * kw, Cin))]
+    keys = []
+    for ph in range(sh):
+        for pw in range(sw):
+            Hc, Wc = -(-(H - ph) // sh), -(-(W - pw) // sw)
+            nt = sum(1 for i in range(kh) for j in range(kw) if (ph + pt - i) % sh == 0 and (pw + pl - j) % sw == 0)
+            if Hc > 0 and Wc > 0 and nt:
+                keys.append((1, Cin, Bs * Hc * Wc, _pad_rows(nt, Cout)))
+    return keys
+
+
 def shapes(B):
     out = []
     for nm, g in G_LAYERS.items():
@@ -101,7 +126,7 @@ def main():
                 line += ' | best ' + '  '.join('%dx%d/%d %.1f' % (bm, kg, sk, u) for u, bm, kg, sk in res[:4])
                 # key: (a_trans, M, Ptot per class is geometry dependent) -> record the forward shape key; dgrad classes differ
                 if res:
-                    table.append((nm, op, res[0], us))
+                    table.append((nm, op, res[0], us, launch_keys(op, Cin, H, W, Cout, kh, kw, sh, sw, Bs)))
             print(line, flush=True)
             rows.append((nm, op, flops, us))
     tot = {}
@@ -111,8 +136,10 @@ def main():
         print('sum %-5s %7.1f GFLOP %8.1f us  %6.1f TF' % (op, fl / 1e9, us, fl / us / 1e6))
     if args.emit and table:
         with open(args.emit, 'w') as f:
-            for nm, op, (u, bm, kg, sk), auto in table:
-                f.write('// %s %s: best %dx%d split %d %.1f us (auto %.1f us)\n' % (nm, op, bm, kg, sk, u, auto))
+            for nm, op, (u, bm, kg, sk), auto, keys in table:
+                f.write('    // %s %s: %.1f us (cost model: %.1f us)\n' % (nm, op, u, auto))
+                for at, M, P, kr in keys:
+                    f.write('    {%d, %d, %d, %d, 2, %d, %d, %d},\n' % (at, M, P, kr, bm, kg, sk))
 
 
 if __name__ == '__main__':

@@ -248,37 +248,44 @@ __global__ __launch_bounds__(64 * (BM / 32) * 2 * KG, (64 * (BM / 32) * 2 * KG >
     float* Yg = p.Y + (long)g * p.y_gs;
     const float* Bg = (p.bias && first) ? p.bias + (long)g * p.bias_gs : nullptr;
     const float* Dg = (p.addend && first) ? p.addend + (long)g * p.add_gs : nullptr;
-    constexpr int NV = (BM * BN / 4 + NT - 1) / NT;
+    if (p.vec4 && !atomic) {
+        // plain stores, 4 consecutive pixels (16 contiguous bytes) per lane: a wave instruction writes 4 rows x 256 B
+        constexpr int NV = BM * BN / 4 / NT;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int idx = tid + i * NT, ml = idx >> 4, n4 = (idx & 15) * 4;
-        const int m = mt * BM + ml, P0 = nt * BN + n4;
-        if ((BM * BN / 4) % NT != 0 && ml >= BM) break;
-        if (m >= p.M || P0 >= p.Ptot) continue;
-        f32x4 v = *reinterpret_cast<const f32x4*>(smem + ml * LDY + n4);
+        for (int i = 0; i < NV; ++i) {
+            const int idx = tid + i * NT, ml = idx >> 4, n4 = (idx & 15) * 4;
+            const int m = mt * BM + ml, P0 = nt * BN + n4;
+            if (m >= p.M || P0 >= p.Ptot) continue;
+            f32x4 v = *reinterpret_cast<const f32x4*>(smem + ml * LDY + n4);
 #pragma unroll
-        for (int k2 = 1; k2 < KG; ++k2) v += *reinterpret_cast<const f32x4*>(smem + k2 * REG + ml * LDY + n4);
-        if (Bg) v += Bg[m];
-        if (p.vec4) {
+            for (int k2 = 1; k2 < KG; ++k2) v += *reinterpret_cast<const f32x4*>(smem + k2 * REG + ml * LDY + n4);
+            if (Bg) v += Bg[m];
             int r0, j; const int b = fast_divmod(P0, p.NPB, p.inv_npb, &r0); const int ii = fast_divmod(r0, p.OWc, p.inv_ow, &j);
             const long o = (long)b * p.y_bs + (long)m * p.yHW + (long)(ii * p.so_h + p.o_h0) * p.yW + j + p.o_w0;
             if (Dg) v += *reinterpret_cast<const f32x4*>(Dg + o);
-            if (atomic) {
+            *reinterpret_cast<f32x4*>(Yg + o) = v;
+        }
+    } else {
+        // one pixel per lane, lanes along the pixels of one output row: atomics (split-K across workgroups, accumulate)
+        // and strided stores (stride-parity classes of an input gradient) touch whole 256-byte runs per instruction
+        constexpr int NE = BM * BN / NT;
+        const int n = tid & 63, Pn = nt * BN + n;
+        long obase = 0;
+        if (Pn < p.Ptot) {
+            int r0, j; const int b = fast_divmod(Pn, p.NPB, p.inv_npb, &r0); const int ii = fast_divmod(r0, p.OWc, p.inv_ow, &j);
+            obase = (long)b * p.y_bs + (long)(ii * p.so_h + p.o_h0) * p.yW + (j * p.so_w + p.o_w0);
+        }
+#pragma unroll 4
+        for (int i = 0; i < NE; ++i) {
+            const int ml = (tid >> 6) + i * (NT / 64), m = mt * BM + ml;
+            if (m >= p.M || Pn >= p.Ptot) continue;
+            float v = smem[ml * LDY + n];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) atomicAdd(Yg + o + e, v[e]);
-            } else *reinterpret_cast<f32x4*>(Yg + o) = v;
-        } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int Pn = P0 + e;
-                if (Pn < p.Ptot) {
-                    int r0, j; const int b = fast_divmod(Pn, p.NPB, p.inv_npb, &r0); const int ii = fast_divmod(r0, p.OWc, p.inv_ow, &j);
-                    const long o = (long)b * p.y_bs + (long)m * p.yHW + (long)(ii * p.so_h + p.o_h0) * p.yW + (j * p.so_w + p.o_w0);
-                    float val = v[e];
-                    if (Dg) val += Dg[o];
-                    if (atomic) atomicAdd(Yg + o, val); else Yg[o] = val;
-                }
-            }
+            for (int k2 = 1; k2 < KG; ++k2) v += smem[k2 * REG + ml * LDY + n];
+            if (Bg) v += Bg[m];
+            const long o = obase + (long)m * p.yHW;
+            if (Dg) v += Dg[o];
+            if (atomic) atomicAdd(Yg + o, v); else Yg[o] = v;
         }
     }
 }
@@ -317,11 +324,16 @@ void igemm_config(IgemmArgs& a) {
             if (t.at == at && t.M == a.M && t.Ptot == a.Ptot && t.krows == a.krows && t.groups == a.groups) { a.bm = t.bm; a.kg = t.kg; a.splitk = t.sk; a.mtiles = 1; break; }
     }
     if (g_force_bm || a.mtiles) { a.mtiles = (a.M + a.bm - 1) / a.bm; a.ntiles = (a.Ptot + 63) / 64; return; }
-    // Cost model, in units of one wave's chunk time: a workgroup runs `cps` chunks at a pace set by the waves that share
-    // its SIMDs (T), plus a fixed prologue + epilogue; workgroups beyond what is resident run in further rounds.
+    // Cost model in microseconds, fitted to the sweep of tools/tune_igemm.py (profiles/r02_tune_sweep_b8.txt): a workgroup
+    // runs `cps` chunks at a pace set by the k waves that share its SIMDs (0.2 + 0.62 k us per chunk: a lone wave
+    // exposes its LDS and barrier latency, four saturate the MFMA pipe at ~65 %), plus a fixed prologue + epilogue;
+    // workgroups beyond what is resident run in further rounds; split-K across workgroups pays for its fp32 atomics
+    // (~0.4 TB/s of read-modify-write) and the zero-fill.  64-row tiles win everywhere at batch <= 16 (two K groups
+    // share nothing but the epilogue, so they cost no more loader work than two workgroups would).
     double best = 1e30;
-    for (int bm : {128, 64}) {
-        if (bm == 128 && a.M < 512) continue;              // narrow outputs stay on 64-row tiles (measured)
+    const double out_bytes = 4.0 * a.M * (double)a.Ptot * a.groups;
+    for (int bm : {64, 128}) {
+        if (bm == 128 && a.M < 512) continue;
         const long tiles = (long)((a.M + bm - 1) / bm) * ((a.Ptot + 63) / 64) * a.groups;
         for (int kg : {1, 2, 4}) {
             if (bm == 128 && kg == 4) continue;
@@ -334,9 +346,8 @@ void igemm_config(IgemmArgs& a) {
                 const long n_cu = (wgs + kCUs - 1) / kCUs;
                 const long conc = std::min<long>(resident_per_cu(bm, kg), n_cu);
                 const double rounds = (double)((n_cu + conc - 1) / conc);
-                const double T = 0.25 + 0.8 * (double)conc * w_wg;
-                const double ovh = 4.0 + (kg > 1 ? 1.0 : 0.0) + (sk > 1 ? 2.5 : 0.0);    // + LDS reduction; + atomics and the zero-fill
-                const double c = rounds * (cps * T * (bm == 64 ? 1.12 : 1.0) + ovh) * (1.0 + 0.01 * sk);
+                const double t_chunk = (0.2 + 0.62 * (double)conc * w_wg) * (bm == 128 ? 1.05 : 1.0);
+                const double c = 5.0 + rounds * (cps * t_chunk + 1.0) + (sk > 1 ? 6.0 + out_bytes * sk / 0.4e6 : 0.0);
                 if (c < best) { best = c; a.bm = bm; a.kg = kg; a.splitk = sk; }
             }
         }
