@@ -19,30 +19,33 @@
 
 typedef const __attribute__((address_space(4))) int* c_int_p;
 
-template <int BN, int MATH>
-__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs p) {
+template <int BN, int KG, int MATH>
+__global__ __launch_bounds__(256 * KG, KG == 4 ? 4 : 2) void wgrad_kernel(const WgradArgs p) {
     // LDS tiles are [row][pixel] with a 36-float row stride: the loader writes whole pixel runs (conflict-free), and a
     // lane reads its 16 k values (pixels 16h..16h+15 of its row; MFMA step u pairs pixels u and 16+u) as 4 ds_read_b128
     constexpr int BM = 64, KC = VC_KC, LDT = KC + 4;
     constexpr int WN = BN / 2, NJ = WN / 32;
     constexpr int ASZ = BM * LDT, BSZ = BN * LDT;
-    constexpr int LDY = BN + 4;
-    static_assert(BM * LDY <= 2 * (ASZ + BSZ), "epilogue staging fits the tile buffers");
-    __shared__ __attribute__((aligned(16))) float smem[2 * (ASZ + BSZ)];
-    float* As = smem;
-    float* Bs = smem + 2 * ASZ;
-
+    constexpr int LDY = BN + 4, REG = 2 * (ASZ + BSZ), NT = 256 * KG;
+    static_assert(BM * LDY <= REG, "epilogue staging fits the tile buffers");
+    // KG K groups of 4 waves, each with its own pair of tile buffers and its own range of the pixel axis; their partial
+    // tiles are summed through LDS in the epilogue (split-K inside the workgroup: no atomics)
+    __shared__ __attribute__((aligned(16))) float smem[KG * REG];
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kg = __builtin_amdgcn_readfirstlane(tid >> 8);
+    float* As = smem + kg * REG;
+    float* Bs = As + 2 * ASZ;
+    const int wid = __builtin_amdgcn_readfirstlane((tid >> 6) & 3);
     const int l31 = lane & 31, h = lane >> 5;
     const int wm = wid >> 1, wn = wid & 1;
     const int nt = blockIdx.x % p.ntiles, kt = blockIdx.x / p.ntiles;
     const int g = blockIdx.z / p.splitk, sp = blockIdx.z - g * p.splitk;
     // every split-K part runs `cps` chunks (an even count: the loop body is a pair of chunks with static register sets);
     // chunks past the last segment load zeros
-    const int cps = (((p.nchunks + p.splitk - 1) / p.splitk) + 1) & ~1;
-    const int c0 = sp * cps;
-    if (c0 >= p.nchunks) return;
+    const int parts = p.splitk * KG;
+    const int cps = (((p.nchunks + parts - 1) / parts) + 1) & ~1;
+    if (sp * KG * cps >= p.nchunks) return;               // whole workgroup beyond the pixel axis (uniform)
+    const int c0 = (sp * KG + kg) * cps;
 
     // ---- loop invariants of the K rows and columns this wave loads
     const KEntry e0 = p.ktab[kt * BM], e1 = p.ktab[kt * BM + 32];          // the two taps of this k-tile (wave-uniform)
@@ -189,60 +192,99 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs p) {
         __syncthreads();
     }
 
-    // ---- epilogue through LDS: a lane stores 4 consecutive Cout values of one K row (16 bytes).  Plain stores when this
-    //      launch is the only contribution of the step to dW, fire-and-forget fp32 atomics otherwise.
-    float* Ys = smem;
+    // ---- epilogue through LDS: every K group parks its tile; all threads sum the groups.  Plain 16-byte stores (4
+    //      consecutive Cout values of one K row per lane) when this launch is the only contribution of the step to dW,
+    //      fire-and-forget fp32 atomics (one value per lane, lanes along Cout) otherwise.
+    {
+        float* Ys = smem + kg * REG;
 #pragma unroll
-    for (int nj = 0; nj < NJ; ++nj)
+        for (int nj = 0; nj < NJ; ++nj)
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-            Ys[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * LDY + wn * WN + nj * 32 + l31] = acc[nj][r];
+            for (int r = 0; r < 16; ++r)
+                Ys[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * LDY + wn * WN + nj * 32 + l31] = acc[nj][r];
+    }
     __syncthreads();
     float* Wg = p.dW + (long)g * p.dw_gs;
-    constexpr int NV = BM * BN / 4 / 256;
+    if (p.store) {
+        constexpr int NV = BM * BN / 4 / NT;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int idx = tid + i * 256, ml = idx / (BN / 4), n4 = (idx % (BN / 4)) * 4;
-        const int aoff = p.ktab[kt * BM + ml].a_off, co = nt * BN + n4;
-        if (aoff < 0 || co >= p.N) continue;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(Ys + ml * LDY + n4);
-        if (p.store) *reinterpret_cast<f32x4*>(Wg + aoff + co) = v;          // Cout % 4 == 0: whole runs are in range and aligned
-        else {
+        for (int i = 0; i < NV; ++i) {
+            const int idx = tid + i * NT, ml = idx / (BN / 4), n4 = (idx % (BN / 4)) * 4;
+            const int aoff = p.ktab[kt * BM + ml].a_off, co = nt * BN + n4;
+            if (aoff < 0 || co >= p.N) continue;
+            f32x4 v = *reinterpret_cast<const f32x4*>(smem + ml * LDY + n4);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) atomicAdd(Wg + aoff + co + e, v[e]);
+            for (int k2 = 1; k2 < KG; ++k2) v += *reinterpret_cast<const f32x4*>(smem + k2 * REG + ml * LDY + n4);
+            *reinterpret_cast<f32x4*>(Wg + aoff + co) = v;          // Cout % 4 == 0: whole runs are in range and aligned
+        }
+    } else {
+        constexpr int NE = BM * BN / NT;
+#pragma unroll 4
+        for (int i = 0; i < NE; ++i) {
+            const int idx = tid + i * NT, ml = idx / BN, n = idx % BN;
+            const int aoff = p.ktab[kt * BM + ml].a_off, co = nt * BN + n;
+            if (aoff < 0 || co >= p.N) continue;
+            float v = smem[ml * LDY + n];
+#pragma unroll
+            for (int k2 = 1; k2 < KG; ++k2) v += smem[k2 * REG + ml * LDY + n];
+            atomicAdd(Wg + aoff + co, v);
         }
     }
 }
 
-// split-K factor: as for the implicit GEMM, least rounds * (chunks per split + fixed cost); 512 workgroups are resident
-int wgrad_splitk(const WgradArgs& a) {
-    const int BN = (a.N >= 128) ? 128 : 64;
-    const long tiles = (long)a.ktiles * ((a.N + BN - 1) / BN) * a.groups;
-    if (tiles >= 512) return 1;
-    int best = 1; double bestc = 1e30;
-    for (int sk = 1; sk <= 16; sk *= 2) {
-        if (sk > 1 && a.nchunks / sk < 2) break;
-        const double rounds = (double)((tiles * sk + 511) / 512);
-        const double c = rounds * ((a.nchunks + sk - 1) / sk + 6.0 + (sk > 1 ? 2.0 : 0.0));
-        if (c < bestc * 0.97) { best = sk; bestc = c; }
+// Tile width (Cout columns), K groups and split-K: the cost model of igemm_config (vc_conv_igemm.hip) with this kernel's
+// chunk (32 pixels x (64 + BN) rows; 32 or 16 MFMAs per wave).  us per chunk of one wave among k on its SIMD.
+struct WgradCfg { int bn, kg, sk; };
+static WgradCfg wgrad_config(const WgradArgs& a) {
+    WgradCfg best{128, 1, 1}; double bestc = 1e30;
+    const double out_bytes = 4.0 * 64.0 * a.ktiles * (double)a.N * a.groups;
+    for (int bn : {128, 64}) {
+        if (bn == 128 && a.N < 128) continue;
+        const long tiles = (long)a.ktiles * ((a.N + bn - 1) / bn) * a.groups;
+        for (int kg : {1, 2, 4}) {
+            if (bn == 128 && kg == 4) continue;                              // LDS: 55 KB per group
+            for (int sk = 1; sk <= 16; sk *= 2) {
+                const int parts = kg * sk;
+                const int cps = (((a.nchunks + parts - 1) / parts) + 1) & ~1;
+                if (parts > 1 && cps * (parts - 1) >= a.nchunks) continue;   // a part with no work
+                const long wgs = tiles * sk;
+                const int res = bn == 128 ? (kg == 1 ? 2 : 1) : (kg == 1 ? 4 : kg == 2 ? 2 : 1);
+                const long n_cu = (wgs + 255) / 256;
+                const long conc = std::min<long>(res, n_cu);
+                const double rounds = (double)((n_cu + conc - 1) / conc);
+                const double k = (double)conc * kg;                          // waves per SIMD
+                const double t_chunk = bn == 128 ? 0.3 + 1.25 * k : 0.25 + 0.72 * k;
+                const double c = 5.0 + rounds * (cps * t_chunk + 1.5) + ((sk > 1 || !a.store) ? 6.0 + out_bytes * sk / 0.4e6 : 0.0);
+                if (c < bestc) { bestc = c; best = WgradCfg{bn, kg, sk}; }
+            }
+        }
     }
     return best;
 }
+int wgrad_splitk(const WgradArgs& a) { return wgrad_config(a).sk; }
 
 int launch_wgrad(const WgradArgs& a0, int math, hipStream_t s, double flops) {
     WgradArgs a = a0;
-    const int BN = (a.N >= 128) ? 128 : 64;
-    a.ntiles = (a.N + BN - 1) / BN;
-    a.splitk = wgrad_splitk(a);
+    const WgradCfg c = wgrad_config(a);
+    a.ntiles = (a.N + c.bn - 1) / c.bn;
+    a.splitk = c.sk;
     if (a.splitk > 1) a.store = 0;
-    dim3 grid(a.ktiles * a.ntiles, 1, a.groups * a.splitk), block(256);
+    dim3 grid(a.ktiles * a.ntiles, 1, a.groups * a.splitk), block(256 * c.kg);
     ProfScope ps(1, flops, s);
-#define VC_WGRAD_MATH(MATH) { if (BN == 128) wgrad_kernel<128, MATH><<<grid, block, 0, s>>>(a); \
-                              else wgrad_kernel<64, MATH><<<grid, block, 0, s>>>(a); }
+#define VC_WG(BN, KG, MATH) wgrad_kernel<BN, KG, MATH><<<grid, block, 0, s>>>(a);
+#define VC_WGRAD_MATH(MATH) \
+    switch (c.bn * 8 + c.kg) { \
+        case 128 * 8 + 1: VC_WG(128, 1, MATH) break; \
+        case 128 * 8 + 2: VC_WG(128, 2, MATH) break; \
+        case 64 * 8 + 1: VC_WG(64, 1, MATH) break; \
+        case 64 * 8 + 2: VC_WG(64, 2, MATH) break; \
+        default: VC_WG(64, 4, MATH) break; \
+    }
     if (math == VC_MATH_BF16) VC_WGRAD_MATH(VC_MATH_BF16)
     else if (math == VC_MATH_BF16X3) VC_WGRAD_MATH(VC_MATH_BF16X3)
     else VC_WGRAD_MATH(VC_MATH_FP32)
 #undef VC_WGRAD_MATH
+#undef VC_WG
     VC_HIP(hipGetLastError());
     return 0;
 }
