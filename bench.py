@@ -10,7 +10,8 @@ model.py:110-125): forward of the 6 generator + 6 discriminator applications,
 fused cycle/identity/LSGAN losses, every gradient, the gradient all-reduce (N>1)
 and both Adam updates, on one synthetic [B, 24, 128] minibatch per domain that is
 already resident in HBM.  Workload = BASELINE.json configs[1]: fp32, batch 8 per GPU.
-Weak scaling: every rank runs batch 8, ranks all-reduce the 479 MB fp32 gradient.
+Default: weak scaling, every rank runs batch 8, ranks all-reduce the 479 MB fp32 gradient (native RCCL communicator).
+--global-batch G: strong scaling (BASELINE configs[3]: --global-batch 256), every rank runs G / N samples.
 
 Prints ONE JSON line on rank 0 (see --help of the driver contract in the task):
   value          whole-job frames/s = n_gpus * B * n_frames * K / max-over-ranks time
@@ -36,8 +37,16 @@ MATH_TEXT = {'fp32': 'fp32', 'bf16': 'bf16 MFMA operands (fp32 accumulate, fp32 
 HBM_PEAK_GBS = 8000.0
 
 
-def cpu_baseline(n_steps=4):
-    """oracle/cyclegan_oracle.py on the host cores: B=1, 24x128 (BASELINE configs[0]), 1 warm-up + n timed."""
+def _blas_threads():
+    try:
+        from threadpoolctl import threadpool_info
+        return ', '.join('%s x%d' % (i.get('internal_api', '?'), i.get('num_threads', 0)) for i in threadpool_info()) or 'none'
+    except Exception:
+        return 'unknown'
+
+
+def cpu_baseline(n_steps=10):
+    """oracle/cyclegan_oracle.py on the host cores: B=1, 24x128 (BASELINE configs[0]: 10 steps), 1 warm-up + n timed."""
     import numpy as np
     from oracle import cyclegan_oracle as O
     P = O.init_params(seed=42)
@@ -52,7 +61,18 @@ def cpu_baseline(n_steps=4):
     med = float(np.median(ts))
     return dict(value=128.0 / med, unit='frames/s', cores=os.cpu_count(), kind='port',
                 sample='numpy oracle (oracle/cyclegan_oracle.py), B=1 x 24x128, 1 warm-up + %d timed full '
-                       'train steps, median %.2f s/step; TF1 reference not runnable (no tensorflow)' % (n_steps, med))
+                       'train steps, median %.2f s/step; the GEMMs run in numpy\'s BLAS (%s), the rest single-threaded; '
+                       'TF1 reference not runnable (no tensorflow)' % (n_steps, med, _blas_threads()))
+
+
+def _pmc_traffic(B, F, T, world, math):
+    """HBM-side bytes per igemm launch from the committed PMC summary of the same configuration (None if not profiled)"""
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')) as f:
+            d = json.load(f)
+        return d.get('%s_b%d_%dx%d' % (math, B, F, T)) if world == 1 else None
+    except Exception:
+        return None
 
 
 def named_kernel_h1(lib, dev, B=256, reps=20, peak=FP32_MFMA_PEAK_TFLOPS, math='fp32'):
@@ -61,6 +81,7 @@ def named_kernel_h1(lib, dev, B=256, reps=20, peak=FP32_MFMA_PEAK_TFLOPS, math='
     import numpy as np
     import torch
     from voice_converter_cyclegan_amd._lib import ptr, check, vp
+    from voice_converter_cyclegan_amd.engine import CycleGANEngine
     x = torch.randn((1, B, 24, 1, 128), device=dev)
     w = torch.randn((1, 1, 15, 24, 256), device=dev) * 0.05
     b = torch.zeros((1, 256), device=dev)
@@ -70,7 +91,7 @@ def named_kernel_h1(lib, dev, B=256, reps=20, peak=FP32_MFMA_PEAK_TFLOPS, math='
     for _ in range(3):
         call()
     torch.cuda.synchronize()
-    lib.vc_prof_enable(1)
+    CycleGANEngine.profiling(True)
     for _ in range(reps):
         call()
     torch.cuda.synchronize()
@@ -78,16 +99,19 @@ def named_kernel_h1(lib, dev, B=256, reps=20, peak=FP32_MFMA_PEAK_TFLOPS, math='
     lib.vc_prof_collect(2, C.byref(ms), C.byref(n), C.byref(fl))      # wsconv1d_kernel ...
     if n.value == 0:
         lib.vc_prof_collect(0, C.byref(ms), C.byref(n), C.byref(fl))  # ... or the tiled igemm when VC_WSCONV=0
-    lib.vc_prof_enable(0)
+    CycleGANEngine.profiling(False)
     t = ms.value * 1e-3 / max(n.value, 1)
-    nbytes = B * (24 * 128 + 256 * 128) * 4 + (15 * 24 * 256 + 256) * 4
+    moved = B * (24 * 128 + 256 * 128) * 4 + (15 * 24 * 256 + 256) * 4        # what this kernel reads + writes (value and gate unfused)
+    algo = B * (24 * 128 + 128 * 128) * 4 + (15 * 24 * 256 + 256) * 4         # fused GLU output, 20.29 MB at B=256
     flops = 2.0 * B * 128 * 256 * 15 * 24
     return {'kernel': 'wsconv1d_kernel (weight-stationary): G.h1 gated conv1d forward, B=%d' % B, 'us': t * 1e6,
-            'hbm': {'achieved_GBs': nbytes / t / 1e9, 'peak_GBs': HBM_PEAK_GBS, 'frac': nbytes / t / 1e9 / HBM_PEAK_GBS},
+            'hbm': {'achieved_GBs': algo / t / 1e9, 'peak_GBs': HBM_PEAK_GBS, 'frac': algo / t / 1e9 / HBM_PEAK_GBS,
+                    'algorithmic_bytes': algo, 'bytes_moved': moved, 'frac_on_bytes_moved': moved / t / 1e9 / HBM_PEAK_GBS},
             'mfma': {'achieved_TFLOPs': flops / t / 1e12, 'peak_TFLOPs': peak, 'frac': flops / t / 1e12 / peak},
-            'note': ('exact-fp32 MFMA makes this kernel FLOP-bound: at fp32 peak it takes 38.4 us vs 2.5 us of HBM time'
-                     if math == 'fp32' else 'bf16 MFMA operands, fp32 tensors in HBM (value and gate written unfused: 36.7 MB, '
-                     'vs the 20.3 MB of a GLU-fused output that hbm.frac is priced on)')}
+            'note': ('hbm.frac is priced on the algorithmic 20.29 MB of SURVEY 8d (GLU-fused output); the kernel itself still '
+                     'writes value and gate separately (bytes_moved).  ' +
+                     ('Exact-fp32 MFMA makes it FLOP-bound: 38.4 us at the fp32 peak vs 2.5 us of HBM time.' if math == 'fp32'
+                      else 'bf16 MFMA operands, fp32 tensors in HBM.'))}
 
 
 def main():
@@ -96,11 +120,14 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=8, help='per-GPU minibatch (BASELINE configs[1])')
+    ap.add_argument('--global-batch', type=int, default=0,
+                    help='strong scaling: total minibatch split over the ranks (BASELINE configs[3]: 256); overrides --batch')
     ap.add_argument('--frames', type=int, default=128)
     ap.add_argument('--features', type=int, default=24)
     ap.add_argument('--math', choices=['fp32', 'bf16', 'bf16x3'], default='fp32',
                     help='arithmetic of the conv kernels; fp32 (default) is the reference precision and the headline, '
                          'bf16 is BASELINE configs[2] (bf16 MFMA operands, fp32 accumulate/storage/statistics)')
+    ap.add_argument('--graph', action='store_true', help='replay the step as one hipGraph (vc_train_step_graph) instead of launching it')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--serial', action='store_true',
@@ -135,8 +162,14 @@ def main():
     eng = CycleGANEngine(num_features=args.features, device=dev, seed=42)
     if args.serial:
         eng.set_overlap(False)
+    if args.graph:
+        eng.use_graph = True
     eng.set_math(args.math)
     peak = {'fp32': FP32_MFMA_PEAK_TFLOPS, 'bf16': BF16_MFMA_PEAK_TFLOPS, 'bf16x3': BF16_MFMA_PEAK_TFLOPS / 3}[args.math]
+    if args.global_batch:
+        if args.global_batch % world:
+            sys.exit('--global-batch must be a multiple of the number of GPUs')
+        args.batch = args.global_batch // world
     B, F, T = args.batch, args.features, args.frames
     rng = np.random.default_rng(1234 + rank)
     A = torch.from_numpy(rng.standard_normal((B, F, T)).astype(np.float32)).to(dev)
@@ -170,15 +203,21 @@ def main():
             'metric': 'MCEP frames/sec per train step (G+D fwd/bwd)',
             'value': frames / dt, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': {'fp32': 'f32'}.get(args.math, args.math), 'data': 'synthetic',
+            'scaling': 'strong' if args.global_batch else 'weak', 'vs_baseline': None, 'dtype': {'fp32': 'f32'}.get(args.math, args.math), 'data': 'synthetic',
             'config': {'workload': 'BASELINE configs[%d]: full CycleGAN-VC train step (2G+2D fwd/bwd + losses + '
                                    'TF-Adam), %s, batch %d per GPU, %dx%d MCEP, random-init weights'
                                    % (1 if args.math == 'fp32' else 2, MATH_TEXT[args.math], B, F, T),
                        'global_batch': world * B, 'frames_per_step_per_domain': world * B * T,
                        'parallelism': 'dp%d' % world,
-                       'gflop_per_step': 91.41 * world * B if (F, T) == (24, 128) else None},
-            'step_flop_frac_of_fp32_peak': (91.41e9 * B / (dt / args.steps)) / (FP32_MFMA_PEAK_TFLOPS * 1e12)
-            if (F, T) == (24, 128) else None,
+                       'launch': 'one hipGraph replay per step (vc_train_step_graph)' if (eng.use_graph and world == 1 and not args.serial)
+                       else 'launch by launch',
+                       'gradient_exchange': ('native RCCL communicator (vc_comm_init / vc_step_exchange_and_update), %d ranks'
+                                             % lib.vc_comm_world(eng.sync.comm)) if eng.sync.comm is not None
+                       else ('none (single GPU)' if world == 1 else 'torch.distributed'),
+                       # the reference graph is 91.41 GFLOP per sample; the fused step legitimately skips the two
+                       # D(fake) forwards of the D sub-step (D weights are unchanged by the G update, model.py:112-119) and the
+                       # input gradients nobody consumes: what it EXECUTES is filled in below from the per-launch records
+                       'reference_graph_gflop_per_step': 91.41 * world * B if (F, T) == (24, 128) else None},
         }
 
     # ---- roofline leg: the same steps again with HIP events around every implicit-GEMM launch
@@ -190,17 +229,17 @@ def main():
         for _ in range(2):
             eng.train_step(A, Bm, *hp, sync=False)
         torch.cuda.synchronize()
-        lib.vc_prof_enable(1)
+        CycleGANEngine.profiling(True)
         n_prof = 3
         for _ in range(n_prof):
             eng.train_step(A, Bm, *hp, sync=False)
         torch.cuda.synchronize()
         stats = {}
-        for kind, name in ((0, 'igemm_kl_kernel (conv fwd + dgrad, every Cin > 1 layer)'), (1, 'wgrad_kernel')):
+        for kind, name in ((0, 'igemm_kernel (conv fwd + dgrad, every Cin > 1 layer)'), (1, 'wgrad_kernel'), (2, 'wsconv1d_kernel')):
             ms, n, fl = C.c_double(0), C.c_longlong(0), C.c_double(0)
             lib.vc_prof_collect(kind, C.byref(ms), C.byref(n), C.byref(fl))
             stats[kind] = (name, ms.value, n.value, fl.value)
-        lib.vc_prof_enable(0)
+        CycleGANEngine.profiling(False)
         eng.set_overlap(not args.serial)
         if rank == 0:
             name, ms, n, fl = stats[0]
@@ -210,8 +249,9 @@ def main():
                 'frac': ach / peak,
                 # HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
                 # (profiles/r01_pmc_hbm_traffic_b8.txt; FETCH_SIZE doubled per MI355X_MICROARCH.md, L3 hits included)
-                'traffic': 110.41e6 if (B, F, T, world, args.math) == (8, 24, 128, 1, 'fp32') else None,
-                'traffic_unit': 'bytes/launch (offline PMC pass, upper bound: Infinity-Cache hits counted)',
+                'traffic': _pmc_traffic(B, F, T, world, args.math),
+                'traffic_unit': 'bytes/launch (offline rocprofv3 PMC passes of this command, profiles/r02_pmc_traffic.json; '
+                                'FETCH_SIZE doubled per MI355X_MICROARCH.md; upper bound: Infinity-Cache hits counted)',
                 'kernel': name, 'launches_per_step': n // n_prof,
                 'condition': 'step chains serialised on one stream (no co-running launches); see --serial',
                 'avg_launch_us': 1e3 * ms / max(n, 1), 'algorithmic_gflop_per_step': fl / n_prof / 1e9,
@@ -222,6 +262,12 @@ def main():
             out['roofline_wgrad'] = {'bound': 'mfma', 'achieved': ach, 'peak': peak,
                                      'unit': 'TFLOP/s', 'frac': ach / peak, 'kernel': name,
                                      'launches_per_step': n // n_prof, 'kernel_ms_per_step': ms / n_prof}
+            # FLOPs the step executes: every MFMA launch carries its algorithmic FLOPs; the Cin = 1 layer (D.h1, vector ALU)
+            # is added analytically: forward over 2B samples per D, filter gradient over 2B, input gradient over B
+            c1 = 2.0 * 9 * 256 * (F * (T // 2)) * 2 * (2 * B + 2 * B + B)      # 9 taps x 256 filters x F x T/2 pixels, 2 discriminators
+            executed = (stats[0][3] + stats[1][3] + stats[2][3]) / n_prof + c1
+            out['config']['executed_gflop_per_step'] = world * executed / 1e9
+            out['step_flop_frac_of_fp32_peak'] = executed / (out['ms_per_step'] * 1e-3) / (FP32_MFMA_PEAK_TFLOPS * 1e12)
 
     # ---- the kernel the north_star names: gated-conv1d forward (G.h1: 24 -> 2x128, k=15) at B=256
     if rank == 0 and not args.no_roofline:

@@ -248,6 +248,19 @@ int vc_step_num_g_buckets(const vc_plan* p);
 int vc_step_g_bucket(const vc_plan* p, int k, int64_t* lo, int64_t* hi);
 int vc_step_wait_g_bucket(const vc_plan* p, int k, void* other_stream);
 
+/* The WHOLE train step (model.py:110-125: vc_cyclegan_step_grads + both ApplyAdam updates, single GPU) as one hipGraph
+ * replay.  The reference trains at mini_batch_size = 1 (train.py:16), where the step is ~330 small launches and the host
+ * is the bottleneck.  The first call with a given (batch, lambda_identity == 0, buffer set) captures and instantiates the
+ * graph (cached in the plan, at most 8); later calls write {lambda_cycle, lambda_identity, alpha_g, alpha_d} to a device
+ * buffer and replay.  Work is ordered after what `stream` holds at the call and `stream` waits for it.  All buffers as in
+ * vc_cyclegan_step_grads / vc_adam_tf_update; they must stay alive (and at the same addresses) between replays. */
+int vc_train_step_graph(vc_plan* p, float* params, float* grads, float* m, float* v,
+                        const float* A, const float* B, int batch,
+                        float lambda_cycle, float lambda_identity, float alpha_g, float alpha_d,
+                        float beta1, float beta2, float eps,
+                        float* losses, float* gen_A, float* gen_B,
+                        float* workspace, int64_t workspace_floats, void* stream);
+
 /* ---- data parallel: the step's one gradient exchange (the reference itself is single-process, model.py:22) ----
  * One process per GPU, replicas identical, global batch split contiguously over the ranks.  RCCL is bound at run time
  * (dlopen librccl.so.1); single-GPU users never need it. */

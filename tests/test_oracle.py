@@ -188,6 +188,38 @@ def test_golden_full_fp32_step0():
     assert np.abs(orc.last_fakes[0] - z['gen_A']).max() < 1e-4 * np.abs(z['gen_A']).max()
 
 
+@pytest.mark.timeout(600)
+@pytest.mark.skipif(not os.path.exists(os.path.join(GOLD, 'golden_tf_f32.npz')),
+                    reason='no TensorFlow-made fixture: run tests/golden/make_tf_golden.py under TensorFlow 1.x (parity unpinned until then)')
+def test_oracle_against_tensorflow_reference():
+    """THE pin: the oracle against numbers produced by the reference graph itself under TensorFlow 1.x
+    (tests/golden/make_tf_golden.py; same schema as golden_full_f32.npz).  1e-3, the north_star tolerance."""
+    z = np.load(os.path.join(GOLD, 'golden_tf_f32.npz'))
+    P = O.init_params(seed=42, randomize_affine=True)
+    A, B = O.synthetic_batch(1, 24, 128)
+    orc = O.CycleGANOracle({k: v.copy() for k, v in P.items()})
+    keys = ('cycle_loss', 'identity_loss', 'generator_loss_A2B', 'generator_loss_B2A', 'generator_loss',
+            'discriminator_loss_A', 'discriminator_loss_B', 'discriminator_loss')
+    for step in range(3):
+        orc.train(A, B, 10.0, 5.0, 2e-4, 1e-4)
+        got = np.array([orc.last[k] for k in keys])
+        ref = z['step%d/losses' % step]
+        assert np.abs(got - ref).max() <= 1e-3 * np.abs(ref).max(), (step, got, ref)
+        if step == 0:
+            assert np.abs(orc.last_fakes[0] - z['gen_A']).max() < 1e-3 * np.abs(z['gen_A']).max()
+            assert np.abs(orc.last_fakes[1] - z['gen_B']).max() < 1e-3 * np.abs(z['gen_B']).max()
+            G = dict(orc.last_grads[0]); G.update(orc.last_grads[1])
+            for i, n in enumerate(z['grad_names']):
+                n = str(n)
+                l2 = float(np.linalg.norm(G[n].astype(np.float64)))
+                if z['grad_l2'][i] > 1e-6 * max(z['grad_l2']):      # conv biases under an instance norm: exactly-zero gradient
+                    assert abs(l2 - z['grad_l2'][i]) <= 1e-3 * z['grad_l2'][i], (n, l2, float(z['grad_l2'][i]))
+                    assert abs(_probe(G[n], i) - z['grad_proj'][i]) <= 3e-3 * z['grad_l2'][i], n
+    for i, n in enumerate(z['grad_names']):                          # parameters after three TF-Adam steps
+        n = str(n)
+        assert abs(np.linalg.norm(orc.P[n].astype(np.float64)) - z['param_l2'][i]) <= 1e-4 * z['param_l2'][i] + 1e-6, n
+
+
 def test_bf16_operand_rounding_is_round_to_nearest_even():
     """oracle.round_bf16 (the BASELINE config-3 operand rounding) against torch's float32 -> bfloat16 cast."""
     import torch

@@ -17,7 +17,8 @@ IN_BIAS_SUFFIX = ('_h1_conv/bias', '_h1_gates/bias', '_h2_conv/bias')   # conv b
 
 
 L1_GAP_MIN = 5e-5
-BF16_GAP_MIN = 2e-3      # bf16 mode: the two sides' forwards differ by ~1e-3 (neighbouring-bf16 roundings); ties must be farther away
+BF16_GAP_MIN = 3e-4      # bf16 mode: the two sides' forwards differ by ~2e-4 rms (neighbouring-bf16 roundings); ties must be farther away
+                         # (a seed with no |difference| below 3e-4 among 6144 elements turns up every ~5 candidates)
 
 
 def _setup(B, T=128, F=24, seed=11, lambda_identity=5.0, gap=True, rounding=None):
@@ -297,6 +298,32 @@ def test_against_committed_golden_vectors(built_lib):
         # a random projection of an n-vector has magnitude ~ its L2 norm; 1e-3 rel-L2 agreement bounds the difference
         # of the projections by ~1e-3 * L2 (3 sigma: 3e-3)
         assert abs(proj - z['grad_proj'][i]) <= 3e-3 * z['grad_l2'][i], (n, proj, float(z['grad_proj'][i]))
+
+
+def test_graph_step_equals_launch_by_launch(built_lib):
+    """vc_train_step_graph (one hipGraph replay per step, the default on a single GPU) against the same step issued launch by
+    launch: losses, generations and the parameters after four steps whose hyper-parameters change from step to step --
+    the learning rates and lambda_cycle travel through the device buffer, lambda_identity -> 0 (train.py:98-99) switches
+    to a second captured schedule."""
+    from tests import gpu_util as U
+    O, P, A, Bm, eng_g = _setup(2, gap=False)
+    from voice_converter_cyclegan_amd.engine import CycleGANEngine
+    eng_e = CycleGANEngine(24, device='cuda:0'); eng_e.load_tf_variables(P); eng_e.use_graph = False
+    eng_g.use_graph = True       # opt-in: on ROCm 7.2 the replay is slower than launching (DESIGN.md), so it is off by default
+    sched = [(10.0, 5.0, 2e-4, 1e-4), (10.0, 5.0, 1.5e-4, 0.5e-4), (8.0, 0.0, 2e-4, 1e-4), (10.0, 0.0, 1e-4, 1e-4), (10.0, 5.0, 2e-4, 1e-4)]
+    rng = np.random.default_rng(3)
+    gA = torch.empty((2, 24, 128), device=U.DEV); gB = torch.empty_like(gA); hA = torch.empty_like(gA); hB = torch.empty_like(gA)
+    for step, hp in enumerate(sched):
+        a = rng.standard_normal((2, 24, 128)).astype(np.float32); b = rng.standard_normal((2, 24, 128)).astype(np.float32)
+        g1, d1 = eng_g.train_step(a, b, *hp, gen_A=gA, gen_B=gB)
+        g2, d2 = eng_e.train_step(a, b, *hp, gen_A=hA, gen_B=hB)
+        # not bitwise: bias / gamma / beta gradients are summed with fp32 atomics, and Adam's first steps turn a ~0 gradient's
+        # sign into a +-lr move of that weight
+        assert abs(g1 - g2) <= 1e-4 * abs(g2) and abs(d1 - d2) <= 1e-4 * max(1.0, abs(d2)), (step, g1, g2, d1, d2)
+        assert U.rel_err(gA.cpu().numpy(), hA.cpu().numpy()) < 1e-4 and U.rel_err(gB.cpu().numpy(), hB.cpu().numpy()) < 1e-4
+    e = float((eng_g.params - eng_e.params).double().norm() / eng_e.params.double().norm())
+    assert e < 1e-4, 'parameters after %d steps differ: rel-L2 %g' % (len(sched), e)
+    assert eng_g.b1p == eng_e.b1p and eng_g.b2p == eng_e.b2p
 
 
 def test_zero_lambda_identity_schedule(built_lib):

@@ -13,7 +13,7 @@ for a in sys.argv[2:]:
 rng = np.random.default_rng(0)
 A = torch.from_numpy(rng.standard_normal((B, 24, 128)).astype(np.float32)).cuda(); Bm = torch.from_numpy(rng.standard_normal((B, 24, 128)).astype(np.float32)).cuda()
 for _ in range(3): eng.train_step(A, Bm, 10., 5., 2e-4, 1e-4, sync=False)
-torch.cuda.synchronize(); lib.vc_prof_enable(1)
+torch.cuda.synchronize(); CycleGANEngine.profiling(True)
 eng.train_step(A, Bm, 10., 5., 2e-4, 1e-4, sync=False); torch.cuda.synchronize()
 for kind, nm in ((0, 'igemm'), (1, 'wgrad')):
     ms = (C.c_double * 512)(); fl = (C.c_double * 512)()
@@ -26,4 +26,4 @@ for kind, nm in ((0, 'igemm'), (1, 'wgrad')):
     for l_, t, f, i in lost[:int(os.environ.get('TOPN', '22'))]:
         print('   #%3d  %7.1f us  %7.2f GFLOP  %5.1f TF   lost vs 100TF: %6.1f us' % (i, t, f, f / t * 1e3 if t else 0, l_))
     print('   total lost vs 100 TF: %.2f ms' % (sum(x[0] for x in lost) / 1e3))
-lib.vc_prof_enable(0)
+CycleGANEngine.profiling(False)

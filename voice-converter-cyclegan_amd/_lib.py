@@ -77,6 +77,7 @@ SIGNATURES = [
     ('vc_step_num_g_buckets', i32, [vp]),
     ('vc_step_g_bucket', i32, [vp, i32, C.POINTER(i64), C.POINTER(i64)]),
     ('vc_step_wait_g_bucket', i32, [vp, i32, vp]),
+    ('vc_train_step_graph', i32, [vp, vp, vp, vp, vp, vp, vp, i32, f32, f32, f32, f32, f32, f32, f32, vp, vp, vp, vp, i64, vp]),
     ('vc_comm_unique_id', i32, [vp]),
     ('vc_comm_init', i32, [i32, i32, vp, C.POINTER(vp)]),
     ('vc_comm_destroy', i32, [vp]),

@@ -596,7 +596,7 @@ struct vc_plan {
     // filter gradients are leaves of the backward chain: they run on their own stream behind one event per layer
     hipStream_t wstream = nullptr; hipEvent_t ev_layer[24] = {}; hipEvent_t ev_wjoin = nullptr;
     hipStream_t wstream_d = nullptr; hipEvent_t ev_layer_d[8] = {}; hipEvent_t ev_wjoin_d = nullptr;   // same for the discriminator chain
-    int use_side = 1;
+    int use_side = 7;             // bit 0: independent chains on the side stream; bit 1 / 2: generator / discriminator filter gradients on their own streams
     // generator gradient buckets: layers [first, last] of each generator become final (in reverse layer order) during
     // the last backward of the step; an event per bucket lets the caller overlap their all-reduce with the rest of it
     static constexpr int kBuckets = 4;
@@ -606,6 +606,12 @@ struct vc_plan {
     // the main stream, the filter gradients on the wgrad stream): after both, the caller may update them in place
     hipEvent_t g_free[kBuckets] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t d_free = nullptr;                          // last read of the discriminator weights (generator_loss path)
+    // captured train steps (vc_train_step_graph): one executable graph per (batch, schedule, buffer set)
+    struct StepGraph { std::array<const void*, 12> key; hipGraph_t graph; hipGraphExec_t exec; };
+    std::vector<StepGraph> graphs;
+    hipStream_t gstream = nullptr, ustream = nullptr;     // capture / replay stream, update (exchange + Adam) stream
+    hipEvent_t ev_gin = nullptr, ev_gout = nullptr, ev_ujoin = nullptr;
+    float* hp_dev = nullptr;                              // {lambda_cycle, lambda_identity, alpha_g, alpha_d} of the step being replayed
 };
 
 static void plan_geos(const NetDesc& n, int C0, int H0, int W0, std::vector<LayerGeo>& out) {
@@ -660,6 +666,12 @@ static int plan_create(int num_features, int n_frames, bool inference, vc_plan**
     for (int k = 0; k < vc_plan::kBuckets && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&p->g_ready[k], hipEventDisableTiming);
     for (int k = 0; k < vc_plan::kBuckets && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&p->g_free[k], hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&p->d_free, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->gstream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->ustream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_gin, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_gout, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_ujoin, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipMalloc((void**)&p->hp_dev, 4 * sizeof(float));
     if (e != hipSuccess) { vc_set_error("hipEventCreate failed: %s", hipGetErrorString(e)); vc_plan_destroy(p); return (int)e; }
     *out = p;
     return 0;
@@ -681,6 +693,13 @@ extern "C" void vc_plan_destroy(vc_plan* p) {
     for (hipEvent_t ev : p->g_ready) if (ev) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : p->g_free) if (ev) (void)hipEventDestroy(ev);
     if (p->d_free) (void)hipEventDestroy(p->d_free);
+    for (auto& g : p->graphs) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); }
+    if (p->gstream) (void)hipStreamDestroy(p->gstream);
+    if (p->ustream) (void)hipStreamDestroy(p->ustream);
+    if (p->ev_gin) (void)hipEventDestroy(p->ev_gin);
+    if (p->ev_gout) (void)hipEventDestroy(p->ev_gout);
+    if (p->ev_ujoin) (void)hipEventDestroy(p->ev_ujoin);
+    if (p->hp_dev) (void)hipFree(p->hp_dev);
     release_tables(p->tables);
     delete p;
 }
@@ -897,7 +916,7 @@ static int gen_backward(const vc_plan* p, const float* params, long par_gs, cons
     VC_ARG(!p->inference, "this plan was created for inference only (vc_plan_create_inference)");
     NetCtx c = gen_ctx(p, params, par_gs, dparams, dpar_gs, save, G, B, Bl, s);
     c.wgrad_store = o.wgrad_store; c.wmode = o.wmode; c.deferred = o.deferred;
-    if (p->use_side && dparams && o.wmode != W_NONE) { c.ws = p->wstream; c.ev_layer = p->ev_layer; c.ev_wjoin = p->ev_wjoin; }
+    if ((p->use_side & 2) && dparams && o.wmode != W_NONE) { c.ws = p->wstream; c.ev_layer = p->ev_layer; c.ev_wjoin = p->ev_wjoin; }
     if (o.record_buckets) { c.ev_first = p->bucket_first; c.ev = p->g_ready; c.ev_free = p->g_free; c.n_ev = vc_plan::kBuckets; }
     return net_backward(c, x, x_gs, dy, dy_gs, dx, dx_gs, dx_acc, scratch, scr_gs);
 }
@@ -918,7 +937,7 @@ static int disc_backward(const vc_plan* p, const float* params, long par_gs, con
     VC_ARG(!p->inference, "this plan was created for inference only (vc_plan_create_inference)");
     NetCtx c = disc_ctx(p, params, par_gs, dparams, dpar_gs, save, G, B, Bl, s);
     c.wgrad_store = wgrad_store;
-    if (p->use_side && dparams) { c.ws = p->wstream_d; c.ev_layer = p->ev_layer_d; c.ev_wjoin = p->ev_wjoin_d; }
+    if ((p->use_side & 4) && dparams) { c.ws = p->wstream_d; c.ev_layer = p->ev_layer_d; c.ev_wjoin = p->ev_wjoin_d; }
     const int last = (int)p->D.layers.size() - 1;
     // the head's input gradient goes where net_backward's scratch map puts dA[last]
     long dYo[24], dAo[24];
@@ -1030,11 +1049,13 @@ static int zero_step_grads(const vc_plan* p, float* grads, int B, int Bbwd, hipS
     return launch_zero_list(zl, s);
 }
 
-extern "C" int vc_cyclegan_step_grads(const vc_plan* p, const float* params, float* grads,
-                                      const float* A, const float* Bm, int batch,
-                                      float lambda_cycle, float lambda_identity,
-                                      float* losses, float* gen_A, float* gen_B,
-                                      float* ws, int64_t ws_floats, void* stream) {
+// hp != nullptr: lambda_cycle / lambda_identity are read from hp[0..1] on the device (a captured step is replayed with new
+// values); the host copies still decide the schedule (lambda_identity == 0 skips the identity half).
+static int step_grads_impl(const vc_plan* p, const float* params, float* grads,
+                           const float* A, const float* Bm, int batch,
+                           float lambda_cycle, float lambda_identity, const float* hp,
+                           float* losses, float* gen_A, float* gen_B,
+                           float* ws, int64_t ws_floats, void* stream) {
     VC_ARG(p && params && grads && A && Bm && losses && ws && batch > 0, "vc_cyclegan_step_grads: bad args");
     VC_ARG(!p->inference, "this plan was created for inference only (vc_plan_create_inference)");
     VC_ARG(aligned16(grads) && aligned16(ws), "vc_cyclegan_step_grads: grads and workspace must be 16-byte aligned");
@@ -1058,16 +1079,18 @@ extern "C" int vc_cyclegan_step_grads(const vc_plan* p, const float* params, flo
     // seed gradient: only the generation half (the first B samples of every saved tensor) is propagated.
     const int Bbwd = (lambda_identity == 0.0f) ? B : 2 * B;
 
-    hipStream_t s2 = p->use_side ? p->side : s;
-    // 0. zero the accumulated parts of the flat gradient on the side stream, under the first-hop forward (nothing touches
-    //    them before step 7; the fork/join pairs below order it before every consumer)
-    if (s2 != s) { VC_HIP(hipEventRecord(p->ev_fork, s)); VC_HIP(hipStreamWaitEvent(s2, p->ev_fork, 0)); }
-    VC_CHECK(zero_step_grads(p, grads, B, Bbwd, s2));
+    hipStream_t s2 = (p->use_side & 1) ? p->side : s;
     // 1. first-hop inputs: g0 = A2B on [A;B], g1 = B2A on [B;A]   (model.py:44,51 / 47,50)
     VC_HIP(hipMemcpyAsync(X1, A, FTb, hipMemcpyDeviceToDevice, s));
     VC_HIP(hipMemcpyAsync(X1 + ft1, Bm, FTb, hipMemcpyDeviceToDevice, s));
     VC_HIP(hipMemcpyAsync(X1 + X1g, Bm, FTb, hipMemcpyDeviceToDevice, s));
     VC_HIP(hipMemcpyAsync(X1 + X1g + ft1, A, FTb, hipMemcpyDeviceToDevice, s));
+    // 0. zero the accumulated parts of the flat gradient on the side stream, under the first-hop forward (nothing touches
+    //    them before step 7; the fork/join pairs below order it before every consumer).  The fork comes AFTER the first
+    //    work on `stream`: under hipGraph capture, an event recorded on a stream that has captured nothing yet does not
+    //    pull the waiting stream into the capture (ROCm 7.2; the replayed graph then crashes at hipStreamEndCapture).
+    if (s2 != s) { VC_HIP(hipEventRecord(p->ev_fork, s)); VC_HIP(hipStreamWaitEvent(s2, p->ev_fork, 0)); }
+    VC_CHECK(zero_step_grads(p, grads, B, Bbwd, s2));
     // 2. O1[g0] = [gen_B; id_B], O1[g1] = [gen_A; id_A]
     VC_CHECK(gen_forward(p, params, PG, X1, X1g, O1, O1g, S1, 2, 2 * B, s));
     // Two pairs of chains are independent and run side by side (main stream s / side stream s2, fork+join by events):
@@ -1094,7 +1117,7 @@ extern "C" int vc_cyclegan_step_grads(const vc_plan* p, const float* params, flo
     la.d_out1 = dO1; la.d_out1_gs = dO1g; la.d_cyc = dCY; la.d_cyc_gs = dCYg;
     la.d_dout_D = dDO_D; la.d_dout_D_gs = dDDg; la.d_dout_G = dDO_G; la.d_dout_G_gs = dDGg;
     la.acc = ws + m.ACC; la.losses = losses; la.B = B; la.FT = p->F * p->T; la.HW = p->d_hw;
-    la.lambda_cycle = lambda_cycle; la.lambda_identity = lambda_identity;
+    la.lambda_cycle = lambda_cycle; la.lambda_identity = lambda_identity; la.hp = hp;
     VC_CHECK(launch_loss(la, s));
     VC_CHECK(fork());
     // 7. discriminator_loss backward over [fake; real] -> D gradients (model.py:94,107)   [side stream, own scratch]
@@ -1121,9 +1144,74 @@ extern "C" int vc_cyclegan_step_grads(const vc_plan* p, const float* params, flo
     return 0;
 }
 
+extern "C" int vc_cyclegan_step_grads(const vc_plan* p, const float* params, float* grads,
+                                      const float* A, const float* Bm, int batch,
+                                      float lambda_cycle, float lambda_identity,
+                                      float* losses, float* gen_A, float* gen_B,
+                                      float* ws, int64_t ws_floats, void* stream) {
+    return step_grads_impl(p, params, grads, A, Bm, batch, lambda_cycle, lambda_identity, nullptr, losses, gen_A, gen_B, ws, ws_floats, stream);
+}
+
+// Gradient exchange + ApplyAdam per segment (see vc_step_exchange_and_update in vc_comm.hip); hp: step sizes from device memory
+int step_update_impl(const vc_plan* p, const vc_comm* comm, float* params, float* grads, float* m, float* v,
+                     float alpha_g, float alpha_d, const float* hp, float beta1, float beta2, float eps, hipStream_t us);
+
+// The whole train step (model.py:110-125: forward, every gradient, both ApplyAdam updates) as ONE hipGraph launch.
+// The reference trains at mini_batch_size = 1 (train.py:16), where a step is ~330 small launches and the host is the
+// bottleneck; the captured graph replays them with one call.  Values that change from step to step (lambda_cycle,
+// lambda_identity, both Adam step sizes) live in a 4-float device buffer written just before the replay; what changes the
+// SCHEDULE (batch, lambda_identity == 0, any pointer) selects a different cached graph.  Single GPU (no collective).
+extern "C" int vc_train_step_graph(vc_plan* p, float* params, float* grads, float* m, float* v,
+                                   const float* A, const float* Bm, int batch,
+                                   float lambda_cycle, float lambda_identity, float alpha_g, float alpha_d,
+                                   float beta1, float beta2, float eps,
+                                   float* losses, float* gen_A, float* gen_B,
+                                   float* ws, int64_t ws_floats, void* stream) {
+    VC_ARG(p && params && grads && m && v && A && Bm && losses && ws && batch > 0, "vc_train_step_graph: bad args");
+    VC_ARG(!p->inference, "this plan was created for inference only (vc_plan_create_inference)");
+    hipStream_t user = (hipStream_t)stream;
+    const std::array<const void*, 12> key{params, grads, m, v, A, Bm, losses, gen_A, gen_B, ws,
+                                          (const void*)(intptr_t)(batch * 16 + (lambda_identity == 0.0f ? 1 : 0) * 8 + (p->use_side & 7)),
+                                          (const void*)(intptr_t)p->math};
+    vc_plan::StepGraph* sg = nullptr;
+    for (auto& g : p->graphs) if (g.key == key) { sg = &g; break; }
+    if (!sg) {
+        // ROCm 7.2: a stream forked from an already-forked stream (the discriminator's filter-gradient stream hangs off
+        // the side stream) crashes hipStreamEndCapture; the captured schedule keeps those launches on the side stream
+        const int overlap = p->use_side;
+        p->use_side &= ~4;
+        VC_HIP(hipStreamBeginCapture(p->gstream, hipStreamCaptureModeThreadLocal));
+        int r = step_grads_impl(p, params, grads, A, Bm, batch, lambda_cycle, lambda_identity, p->hp_dev, losses, gen_A, gen_B,
+                                ws, ws_floats, p->gstream);
+        if (!r) r = step_update_impl(p, nullptr, params, grads, m, v, 0.f, 0.f, p->hp_dev, beta1, beta2, eps, p->ustream);
+        if (!r) { hipError_t e = hipEventRecord(p->ev_ujoin, p->ustream); if (e == hipSuccess) e = hipStreamWaitEvent(p->gstream, p->ev_ujoin, 0); r = (int)e; }
+        hipGraph_t graph = nullptr;
+        const hipError_t ec = hipStreamEndCapture(p->gstream, &graph);
+        p->use_side = overlap;
+        if (r) { if (graph) (void)hipGraphDestroy(graph); return r; }
+        VC_HIP(ec);
+        hipGraphExec_t exec = nullptr;
+        VC_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        if (p->graphs.size() >= 8) {            // few schedules exist in practice (lambda_identity on / off); bound the cache
+            (void)hipGraphExecDestroy(p->graphs.front().exec); (void)hipGraphDestroy(p->graphs.front().graph);
+            p->graphs.erase(p->graphs.begin());
+        }
+        p->graphs.push_back(vc_plan::StepGraph{key, graph, exec});
+        sg = &p->graphs.back();
+    }
+    // order: caller's stream -> graph stream -> caller's stream
+    VC_HIP(hipEventRecord(p->ev_gin, user));
+    VC_HIP(hipStreamWaitEvent(p->gstream, p->ev_gin, 0));
+    VC_CHECK(launch_set4(p->hp_dev, lambda_cycle, lambda_identity, alpha_g, alpha_d, p->gstream));
+    VC_HIP(hipGraphLaunch(sg->exec, p->gstream));
+    VC_HIP(hipEventRecord(p->ev_gout, p->gstream));
+    VC_HIP(hipStreamWaitEvent(user, p->ev_gout, 0));
+    return 0;
+}
+
 extern "C" int vc_plan_set_overlap(vc_plan* p, int enabled) {
     VC_ARG(p, "vc_plan_set_overlap: bad plan");
-    p->use_side = enabled != 0;
+    p->use_side = enabled == 1 ? 7 : ((enabled >> 3) & 7);   // 0 / 1: the documented switch; 8 * bits selects single mechanisms (debugging)
     return 0;
 }
 extern "C" int vc_step_num_g_buckets(const vc_plan* p) { return p ? vc_plan::kBuckets : 0; }

@@ -101,21 +101,21 @@ extern "C" int vc_allreduce_f32(const vc_comm* c, float* buf, int64_t n, void* s
 // final before the generator backward starts), then the generator buckets in reverse layer order.  Each segment is
 // all-reduced (SUM over the ranks of `comm`; comm == NULL: single GPU, no collective) and then updated in place with the
 // 1/world factor folded into Adam.  All but the last small bucket ride under the rest of the backward.
-extern "C" int vc_step_exchange_and_update(const vc_plan* p, const vc_comm* comm, float* params, float* grads, float* m, float* v,
-                                           float alpha_g, float alpha_d, float beta1, float beta2, float eps, void* update_stream) {
+int step_update_impl(const vc_plan* p, const vc_comm* comm, float* params, float* grads, float* m, float* v,
+                     float alpha_g, float alpha_d, const float* hp, float beta1, float beta2, float eps, hipStream_t us) {
     VC_ARG(p && params && grads && m && v, "vc_step_exchange_and_update: bad args");
-    hipStream_t us = (hipStream_t)update_stream;
     const Rccl* R = (comm && comm->world > 1) ? rccl() : nullptr;
     VC_ARG(!(comm && comm->world > 1) || R, "RCCL not loaded");
     const float gscale = comm ? 1.0f / (float)comm->world : 1.0f;
     const int64_t g0 = vc_flat_offset(p, 0), g1 = vc_flat_offset(p, 1), d0 = vc_flat_offset(p, 2), total = vc_flat_param_floats(p);
-    auto seg = [&](int64_t lo, int64_t hi, float alpha) -> int {
-        return launch_adam(params + lo, m + lo, v + lo, grads + lo, hi - lo, alpha, beta1, beta2, eps, gscale, us);
+    auto seg = [&](int64_t lo, int64_t hi, bool disc) -> int {        // hp: {.., .., alpha_g, alpha_d} on the device (captured steps)
+        return launch_adam(params + lo, m + lo, v + lo, grads + lo, hi - lo, disc ? alpha_d : alpha_g, beta1, beta2, eps, gscale, us,
+                           hp ? hp + (disc ? 3 : 2) : nullptr);
     };
     // discriminator half: one contiguous range
     { int r = vc_step_wait_d_grads(p, us); if (r) return r; }
     if (R) VC_RCCL(R->AllReduce(grads + d0, grads + d0, (size_t)(total - d0), kFloat32, kSum, comm->comm, us));
-    { int r = seg(d0, total, alpha_d); if (r) return r; }
+    { int r = seg(d0, total, true); if (r) return r; }
     // generator buckets: the same layer range of both generators, one collective group
     for (int k = 0; k < vc_step_num_g_buckets(p); ++k) {
         int64_t lo = 0, hi = 0;
@@ -127,8 +127,12 @@ extern "C" int vc_step_exchange_and_update(const vc_plan* p, const vc_comm* comm
             VC_RCCL(R->AllReduce(grads + g1 + lo, grads + g1 + lo, (size_t)(hi - lo), kFloat32, kSum, comm->comm, us));
             VC_RCCL(R->GroupEnd());
         }
-        { int r = seg(g0 + lo, g0 + hi, alpha_g); if (r) return r; }
-        { int r = seg(g1 + lo, g1 + hi, alpha_g); if (r) return r; }
+        { int r = seg(g0 + lo, g0 + hi, false); if (r) return r; }
+        { int r = seg(g1 + lo, g1 + hi, false); if (r) return r; }
     }
     return 0;
+}
+extern "C" int vc_step_exchange_and_update(const vc_plan* p, const vc_comm* comm, float* params, float* grads, float* m, float* v,
+                                           float alpha_g, float alpha_d, float beta1, float beta2, float eps, void* update_stream) {
+    return step_update_impl(p, comm, params, grads, m, v, alpha_g, alpha_d, nullptr, beta1, beta2, eps, (hipStream_t)update_stream);
 }

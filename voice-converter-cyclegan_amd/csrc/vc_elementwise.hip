@@ -406,8 +406,9 @@ __global__ __launch_bounds__(256) void head_bwd_dw_kernel(const float* x, long x
 }
 
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
-                                                   const float* __restrict__ g, long n4, long n, float alpha,
-                                                   float b1, float b2, float eps, float gs) {
+                                                   const float* __restrict__ g, long n4, long n, float alpha_arg,
+                                                   float b1, float b2, float eps, float gs, const float* __restrict__ alpha_dev) {
+    const float alpha = alpha_dev ? *alpha_dev : alpha_arg;      // captured steps (hipGraph) read the step size from device memory
     const float omb1 = 1.f - b1, omb2 = 1.f - b2;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
         float4 P = reinterpret_cast<float4*>(p)[i], M = reinterpret_cast<float4*>(m)[i], V = reinterpret_cast<float4*>(v)[i];
@@ -438,16 +439,17 @@ __global__ __launch_bounds__(256) void loss_kernel(const LossArgs a) {
     for (int k = 0; k < 10; ++k) s[k] = 0.f;
     const long n1 = (long)a.B * a.FT, n2 = (long)a.B * a.HW;
     const float inv1 = 1.f / (float)n1, inv2 = 1.f / (float)n2;
+    const float lambda_cycle = a.hp ? a.hp[0] : a.lambda_cycle, lambda_identity = a.hp ? a.hp[1] : a.lambda_identity;
     const long stride = (long)gridDim.x * 256;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n1; i += stride) {
         const float A = a.A[i], Bm = a.Bm[i];
         const float cycB = a.cyc[i], cycA = a.cyc[a.cyc_gs + i];
         const float idB = a.out1[n1 + i], idA = a.out1[a.out1_gs + n1 + i];
         s[0] += fabsf(A - cycA); s[1] += fabsf(Bm - cycB); s[2] += fabsf(A - idA); s[3] += fabsf(Bm - idB);
-        a.d_cyc[i] = a.lambda_cycle * signf_(cycB - Bm) * inv1;
-        a.d_cyc[a.d_cyc_gs + i] = a.lambda_cycle * signf_(cycA - A) * inv1;
-        a.d_out1[n1 + i] = a.lambda_identity * signf_(idB - Bm) * inv1;
-        a.d_out1[a.d_out1_gs + n1 + i] = a.lambda_identity * signf_(idA - A) * inv1;
+        a.d_cyc[i] = lambda_cycle * signf_(cycB - Bm) * inv1;
+        a.d_cyc[a.d_cyc_gs + i] = lambda_cycle * signf_(cycA - A) * inv1;
+        a.d_out1[n1 + i] = lambda_identity * signf_(idB - Bm) * inv1;
+        a.d_out1[a.d_out1_gs + n1 + i] = lambda_identity * signf_(idA - A) * inv1;
     }
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n2; i += stride) {
         const float dAf = a.dout[i], dAr = a.dout[n2 + i];
@@ -466,8 +468,9 @@ __global__ __launch_bounds__(256) void loss_kernel(const LossArgs a) {
         if (threadIdx.x == 0) atomicAdd(a.acc + k, t);
     }
 }
-__global__ void loss_finalize_kernel(const float* acc, float* L, float n1, float n2, float lc, float li) {
+__global__ void loss_finalize_kernel(const float* acc, float* L, float n1, float n2, float lc, float li, const float* hp) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
+        if (hp) { lc = hp[0]; li = hp[1]; }
         const float cyc = acc[0] / n1 + acc[1] / n1;
         const float idl = acc[2] / n1 + acc[3] / n1;
         const float gA2B = acc[4] / n2, gB2A = acc[5] / n2;
@@ -568,6 +571,12 @@ int launch_add(float* dst, const float* src, long n, hipStream_t s) {
     VC_HIP(hipGetLastError());
     return 0;
 }
+__global__ void set4_kernel(float* dst, float a, float b, float c, float d) { dst[0] = a; dst[1] = b; dst[2] = c; dst[3] = d; }
+int launch_set4(float* dst, float a, float b, float c, float d, hipStream_t s) {
+    set4_kernel<<<1, 1, 0, s>>>(dst, a, b, c, d);
+    VC_HIP(hipGetLastError());
+    return 0;
+}
 int launch_zero_list(const std::vector<std::pair<float*, long>>& bufs, hipStream_t s) {
     for (size_t i0 = 0; i0 < bufs.size(); i0 += 48) {
         ZeroList z{}; long mx = 0;
@@ -663,10 +672,10 @@ int launch_head_bwd(const float* x, long x_gs, const float* w, long par_gs, cons
     return 0;
 }
 int launch_adam(float* p, float* m, float* v, const float* g, long n, float alpha, float b1,
-                float b2, float eps, float gscale, hipStream_t s) {
+                float b2, float eps, float gscale, hipStream_t s, const float* alpha_dev) {
     const long n4 = n / 4;
     long blocks = (n4 + 255) / 256; if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
-    adam_kernel<<<dim3((unsigned)blocks), 256, 0, s>>>(p, m, v, g, n4, n, alpha, b1, b2, eps, gscale);
+    adam_kernel<<<dim3((unsigned)blocks), 256, 0, s>>>(p, m, v, g, n4, n, alpha, b1, b2, eps, gscale, alpha_dev);
     VC_HIP(hipGetLastError());
     return 0;
 }
@@ -683,7 +692,7 @@ int launch_loss(const LossArgs& a, hipStream_t s) {
     long blocks = (n1 + 255) / 256; if (blocks > 1024) blocks = 1024; if (blocks < 1) blocks = 1;
     loss_kernel<<<dim3((unsigned)blocks), 256, 0, s>>>(a);
     loss_finalize_kernel<<<1, 64, 0, s>>>(a.acc, a.losses, (float)n1, (float)((long)a.B * a.HW),
-                                          a.lambda_cycle, a.lambda_identity);
+                                          a.lambda_cycle, a.lambda_identity, a.hp);
     VC_HIP(hipGetLastError());
     return 0;
 }

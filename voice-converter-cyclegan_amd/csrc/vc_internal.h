@@ -145,7 +145,8 @@ int launch_head_bwd(const float* x, long x_gs, const float* w, long par_gs, cons
                     const float* dout, long do_gs, float* dx, long dx_gs, float* dw, float* db,
                     long dpar_gs, int G, int B, int C, int HW, hipStream_t s);
 int launch_adam(float* p, float* m, float* v, const float* g, long n, float alpha, float b1,
-                float b2, float eps, float gscale, hipStream_t s);
+                float b2, float eps, float gscale, hipStream_t s, const float* alpha_dev = nullptr);   // alpha_dev: read the step size from device memory
+int launch_set4(float* dst, float a, float b, float c, float d, hipStream_t s);
 
 struct LossArgs {
     const float* A; const float* Bm;      // real [B][F][T]
@@ -159,6 +160,7 @@ struct LossArgs {
     float* acc;                           // 10 fp32 partial sums (zeroed by the launcher)
     float* losses;                        // 8 scalars
     int B, FT, HW; float lambda_cycle, lambda_identity;
+    const float* hp;                      // non-null: {lambda_cycle, lambda_identity} are read from device memory (captured steps)
 };
 int launch_loss(const LossArgs& a, hipStream_t s);
 int launch_crop_batch(const float* src, const long* off, const int* len, const int* start, float* out,

@@ -136,6 +136,10 @@ class CycleGANEngine:
         self.losses = torch.zeros(8, device=self.device)
         self._math = 'fp32'
         self._overlap = True
+        # single GPU: replay the whole step as one hipGraph (vc_train_step_graph).  Off by default: measured on ROCm 7.2 the
+        # replay is SLOWER than launching the step's ~330 kernels on its five streams (B=1 3.49 vs 3.21 ms, B=8 8.06 vs 7.67)
+        self.use_graph = False
+        self._gbuf = {}                # (B, T) -> persistent input / output staging of the captured step
         self._plans = PlanCache(lambda T: self._new_plan(T, False), 4)
         self._infer_plans = PlanCache(lambda T: self._new_plan(T, True), 8)
         self._ws = None
@@ -249,6 +253,17 @@ class CycleGANEngine:
         self._keep = (A, Bm)     # keep inputs alive until the stream has consumed them
         return p
 
+    _prof_on = False
+
+    @classmethod
+    def profiling(cls, on):
+        """per-launch HIP-event timing of the MFMA kernels (vc_prof_enable); captured steps are bypassed while it is on"""
+        cls._prof_on = bool(on)
+        lib.vc_prof_enable(int(bool(on)))
+
+    def _profiling(self):
+        return CycleGANEngine._prof_on
+
     def _alpha(self, lr, k):
         one = np.float32(1)
         return float(np.float32(lr) * np.sqrt(one - self.b2p[k]) / (one - self.b1p[k]))
@@ -321,16 +336,43 @@ class CycleGANEngine:
         main.wait_stream(side)
         self._advance_beta_powers()
 
+    def _graph_step(self, A, Bm, lambda_cycle, lambda_identity, lr_g, lr_d, gen_A, gen_B):
+        """the whole step as ONE hipGraph replay (vc_train_step_graph): inputs are staged into persistent buffers (a
+        captured graph holds addresses), the scalars that change per step travel through a device buffer"""
+        A, Bm = self._to_dev(A), self._to_dev(Bm)
+        assert A.shape == Bm.shape and A.dim() == 3 and A.shape[1] == self.F, (A.shape, Bm.shape)
+        B, _, T = A.shape
+        p = self.plan(T)
+        buf = self._gbuf.get((B, T))
+        if buf is None:
+            mk = lambda: torch.empty((B, self.F, T), device=self.device)
+            buf = self._gbuf[(B, T)] = (mk(), mk(), mk(), mk())
+        sA, sB, oA, oB = buf
+        sA.copy_(A); sB.copy_(Bm)
+        ws = self._workspace(lib.vc_step_workspace_floats(p, B))
+        check(lib.vc_train_step_graph(p, ptr(self.params), ptr(self.grads), ptr(self.m), ptr(self.v), ptr(sA), ptr(sB), B,
+                                      float(lambda_cycle), float(lambda_identity), self._alpha(lr_g, 0), self._alpha(lr_d, 1),
+                                      ADAM_BETA1, ADAM_BETA2, ADAM_EPS, ptr(self.losses), ptr(oA), ptr(oB),
+                                      ptr(ws), ws.numel(), self._stream()), 'vc_train_step_graph')
+        if gen_A is not None:
+            gen_A.copy_(oA)
+        if gen_B is not None:
+            gen_B.copy_(oB)
+        self._advance_beta_powers()
+
     def train_step(self, A, Bm, lambda_cycle, lambda_identity, generator_learning_rate,
                    discriminator_learning_rate, sync=True, gen_A=None, gen_B=None):
         """model.CycleGAN.train (model.py:110-125): returns (generator_loss, discriminator_loss).
         sync=False returns the 8-element device tensor of losses without a host round trip."""
-        p = self.step_grads(A, Bm, lambda_cycle, lambda_identity, gen_A, gen_B)
-        if self._overlap:
-            self.exchange_and_update(p, generator_learning_rate, discriminator_learning_rate)
-        else:                                        # everything on the caller's stream (per-kernel timing, debugging)
-            self.exchange_grads(p)
-            self.apply_adam(generator_learning_rate, discriminator_learning_rate)
+        if self.use_graph and self._overlap and self.sync.world == 1 and not self._profiling():
+            self._graph_step(A, Bm, lambda_cycle, lambda_identity, generator_learning_rate, discriminator_learning_rate, gen_A, gen_B)
+        else:
+            p = self.step_grads(A, Bm, lambda_cycle, lambda_identity, gen_A, gen_B)
+            if self._overlap:
+                self.exchange_and_update(p, generator_learning_rate, discriminator_learning_rate)
+            else:                                        # everything on the caller's stream (per-kernel timing, debugging)
+                self.exchange_grads(p)
+                self.apply_adam(generator_learning_rate, discriminator_learning_rate)
         if not sync:
             return self.losses
         l = self.losses.cpu().numpy()
