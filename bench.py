@@ -76,42 +76,43 @@ def _pmc_traffic(B, F, T, world, math):
 
 
 def named_kernel_h1(lib, dev, B=256, reps=20, peak=FP32_MFMA_PEAK_TFLOPS, math='fp32'):
-    """G.h1 value+gate convolution forward (module.py:161-162) at B=256: SURVEY 8d's named target.
-    algorithmic bytes 20.29 MB, algorithmic FLOPs 6.04 G; exact fp32 caps the HBM fraction at ~6.6 %."""
+    """The north star's named kernel: the generator's gated conv1d block (module.py:161-163: h1 value + gate convolutions +
+    GLU) forward at B=256, as ONE kernel (vc_gated_conv1d_glu_fwd).  SURVEY 8d: algorithmic bytes 20.29 MB (frames in,
+    GLU output out, weights once), algorithmic FLOPs 6.04 G; exact fp32 caps the HBM fraction at ~6.6 %."""
     import numpy as np
     import torch
     from voice_converter_cyclegan_amd._lib import ptr, check, vp
     from voice_converter_cyclegan_amd.engine import CycleGANEngine
-    x = torch.randn((1, B, 24, 1, 128), device=dev)
-    w = torch.randn((1, 1, 15, 24, 256), device=dev) * 0.05
-    b = torch.zeros((1, 256), device=dev)
-    y = torch.empty((1, B, 256, 1, 128), device=dev)
+    x = torch.randn((1, B, 24, 128), device=dev)
+    w = torch.randn((1, 15, 24, 256), device=dev) * 0.05
+    b = torch.randn((1, 256), device=dev) * 0.1
+    y = torch.empty((1, B, 128, 128), device=dev)
     s = vp(torch.cuda.current_stream().cuda_stream)
-    call = lambda: check(lib.vc_conv2d_fwd(ptr(x), 0, ptr(w), 0, ptr(b), 0, ptr(y), 0, 1, B, 24, 1, 128, 256, 1, 15, 1, 1, s))
-    for _ in range(3):
-        call()
-    torch.cuda.synchronize()
-    CycleGANEngine.profiling(True)
-    for _ in range(reps):
-        call()
-    torch.cuda.synchronize()
-    ms, n, fl = C.c_double(0), C.c_longlong(0), C.c_double(0)
-    lib.vc_prof_collect(2, C.byref(ms), C.byref(n), C.byref(fl))      # wsconv1d_kernel ...
-    if n.value == 0:
-        lib.vc_prof_collect(0, C.byref(ms), C.byref(n), C.byref(fl))  # ... or the tiled igemm when VC_WSCONV=0
-    CycleGANEngine.profiling(False)
+    check(lib.vc_set_math_mode({'fp32': 0, 'bf16': 1}[math]))
+    wsp = torch.empty(lib.vc_gated_conv1d_glu_workspace_floats(1, 256), device=dev)
+    call = lambda: check(lib.vc_gated_conv1d_glu_fwd(ptr(x), 0, ptr(w), 0, ptr(b), 0, ptr(y), 0, 1, B, 24, 128, 256, 15, ptr(wsp), wsp.numel(), s))
+    try:
+        for _ in range(3):
+            call()
+        torch.cuda.synchronize()
+        CycleGANEngine.profiling(True)
+        for _ in range(reps):
+            call()
+        torch.cuda.synchronize()
+        ms, n, fl = C.c_double(0), C.c_longlong(0), C.c_double(0)
+        lib.vc_prof_collect(2, C.byref(ms), C.byref(n), C.byref(fl))
+        CycleGANEngine.profiling(False)
+    finally:
+        check(lib.vc_set_math_mode(0))
     t = ms.value * 1e-3 / max(n.value, 1)
-    moved = B * (24 * 128 + 256 * 128) * 4 + (15 * 24 * 256 + 256) * 4        # what this kernel reads + writes (value and gate unfused)
-    algo = B * (24 * 128 + 128 * 128) * 4 + (15 * 24 * 256 + 256) * 4         # SURVEY 8d: fused GLU output, 20.29 MB at B=256
+    algo = B * (24 * 128 + 128 * 128) * 4 + (15 * 24 * 256 + 256) * 4         # SURVEY 8d: 20.29 MB at B=256; also what the kernel moves
     flops = 2.0 * B * 128 * 256 * 15 * 24
-    return {'kernel': 'wsconv1d_kernel (weight-stationary): G.h1 gated conv1d forward, B=%d' % B, 'us': t * 1e6,
-            'hbm': {'achieved_GBs': algo / t / 1e9, 'peak_GBs': HBM_PEAK_GBS, 'frac': algo / t / 1e9 / HBM_PEAK_GBS,
-                    'algorithmic_bytes': algo, 'bytes_moved': moved, 'frac_on_bytes_moved': moved / t / 1e9 / HBM_PEAK_GBS},
+    return {'kernel': 'gated_conv1d_glu_kernel: G.h1 value + gate conv1d + GLU forward in one kernel, B=%d, %s' % (B, math),
+            'us': t * 1e6, 'algorithmic_bytes': algo,
+            'hbm': {'achieved_GBs': algo / t / 1e9, 'peak_GBs': HBM_PEAK_GBS, 'frac': algo / t / 1e9 / HBM_PEAK_GBS},
             'mfma': {'achieved_TFLOPs': flops / t / 1e12, 'peak_TFLOPs': peak, 'frac': flops / t / 1e12 / peak},
-            'note': ('hbm.frac is priced on the algorithmic 20.29 MB of SURVEY 8d (GLU-fused output); the kernel itself still '
-                     'writes value and gate separately (bytes_moved).  ' +
-                     ('Exact-fp32 MFMA makes it FLOP-bound: 38.4 us at the fp32 peak vs 2.5 us of HBM time.' if math == 'fp32'
-                      else 'bf16 MFMA operands, fp32 tensors in HBM.'))}
+            'note': ('exact-fp32 MFMA makes this kernel FLOP-bound: 38.4 us at the fp32 peak vs 2.5 us of HBM time' if math == 'fp32'
+                     else 'bf16 MFMA operands (rounded once on their way into LDS), fp32 tensors in HBM, fp32 accumulate')}
 
 
 def main():
@@ -271,12 +272,10 @@ def main():
 
     # ---- the kernel the north_star names: gated-conv1d forward (G.h1: 24 -> 2x128, k=15) at B=256
     if rank == 0 and not args.no_roofline:
-        out['named_kernel'] = named_kernel_h1(lib, dev, peak=peak, math=args.math)
-        if args.math == 'fp32':      # the same kernel with bf16 MFMA operands (BASELINE configs[2] arithmetic), for the HBM-roofline view
-            eng.set_math('bf16')
-            r = named_kernel_h1(lib, dev, peak=BF16_MFMA_PEAK_TFLOPS, math='bf16')
-            eng.set_math('fp32')
-            out['named_kernel']['bf16_mode'] = {'us': r['us'], 'hbm_frac': r['hbm']['frac'], 'achieved_TFLOPs': r['mfma']['achieved_TFLOPs']}
+        out['named_kernel'] = named_kernel_h1(lib, dev, peak=FP32_MFMA_PEAK_TFLOPS, math='fp32')
+        # the same kernel with bf16 MFMA operands (BASELINE configs[2] arithmetic): the HBM-roofline view the north star asks for
+        r = named_kernel_h1(lib, dev, peak=BF16_MFMA_PEAK_TFLOPS, math='bf16')
+        out['named_kernel']['bf16_mode'] = {'us': r['us'], 'hbm_frac': r['hbm']['frac'], 'achieved_TFLOPs': r['mfma']['achieved_TFLOPs']}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline()

@@ -105,6 +105,19 @@ int vc_conv2d_wgrad(const float* x, int64_t x_gs, const float* dy, int64_t dy_gs
                     float* dw, int64_t dw_gs,
                     int G, int B, int Cin, int H, int W, int Cout,
                     int kh, int kw, int sh, int sw, void* stream);
+/* The generator's first block in ONE kernel (module.py:161-163: h1 = conv1d, h1_gates = conv1d, h1_glu = gated_linear_layer,
+ * no instance norm): out [G][B][Cout2/2][T] = (conv_v(x) + b_v) * sigmoid(conv_g(x) + b_g), stride 1, SAME.  w [k][Cin][Cout2]
+ * with the value filters in [0, Cout2/2) and the gate filters in [Cout2/2, Cout2), bias likewise.  Neither raw convolution
+ * is written: HBM sees the frames once and the activation once (the north-star kernel; inference plans use it, the train
+ * step keeps value and gate for the backward).  Built for Cin = 24, k = 15 (24 MCEPs), Cout2 % 64 == 0, T % 4 == 0.
+ * Math mode of the calling thread: fp32 (exact) or bf16 (operands rounded once, when the filters are packed / the frames
+ * staged).  workspace (vc_gated_conv1d_glu_workspace_floats floats, 16-byte aligned) receives the filters re-laid-out as
+ * the kernel's LDS image; it is rebuilt by a small launch on every call. */
+int64_t vc_gated_conv1d_glu_workspace_floats(int G, int Cout2);
+int vc_gated_conv1d_glu_fwd(const float* x, int64_t x_gs, const float* w, int64_t w_gs,
+                            const float* bias, int64_t b_gs, float* out, int64_t out_gs,
+                            int G, int B, int Cin, int T, int Cout2, int k,
+                            float* workspace, int64_t workspace_floats, void* stream);
 /* BiasAddGrad: db[c] += sum_{b,l} dy[g][b][c][l]  (dy [G][B][C][L]). */
 int vc_bias_grad(const float* dy, int64_t dy_gs, float* db, int64_t db_gs,
                  int G, int B, int C, int L, void* stream);

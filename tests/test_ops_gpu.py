@@ -158,6 +158,41 @@ def _conv_check(case):
     assert e < TOL, 'wgrad accumulate rel err %g' % e
 
 
+@pytest.mark.parametrize('mode', ['fp32', 'bf16'])
+@pytest.mark.parametrize('B,T', [(2, 128), (256, 128), (3, 132), (8, 2048), (1, 4)])
+def test_gated_conv1d_glu_fused(built_lib, B, T, mode):
+    """vc_gated_conv1d_glu_fwd: the generator's h1 block (module.py:161-163) in one kernel, against conv1d + conv1d +
+    gated_linear_layer of the oracle.  (256, 128) is the shape bench.py times as the north-star kernel; (8, 2048) an
+    inference batch; T = 132 / 4: ragged last tile, tile smaller than the kernel."""
+    from tests import gpu_util as U
+    from voice_converter_cyclegan_amd._lib import lib, ptr, check
+    O = _oracle()
+    rng = np.random.default_rng(B * 7 + T)
+    G, C = 2, 128
+    x = rng.standard_normal((G, B, T, 24)).astype(np.float32)
+    w = (rng.standard_normal((G, 15, 24, 2 * C)) / np.sqrt(360)).astype(np.float32)
+    b = rng.uniform(-0.5, 0.5, (G, 2 * C)).astype(np.float32)
+    check(lib.vc_set_math_mode({'fp32': 0, 'bf16': 1}[mode]))
+    O.set_operand_rounding('bf16' if mode == 'bf16' else None)
+    try:
+        ref = []
+        for g in range(G):
+            v, _ = O.conv1d_fwd(x[g], w[g][:, :, :C], b[g][:C], 1)
+            gt, _ = O.conv1d_fwd(x[g], w[g][:, :, C:], b[g][C:], 1)
+            ref.append(np.transpose(O.glu_fwd(v, gt)[0], (0, 2, 1)))
+        x_d = U.dev(np.ascontiguousarray(np.transpose(x, (0, 1, 3, 2))))
+        w_d, b_d = U.dev(w), U.dev(b)
+        out = torch.full((G, B, C, T), float('nan'), device=U.DEV)
+        wsp = torch.empty(lib.vc_gated_conv1d_glu_workspace_floats(G, 2 * C), device=U.DEV)
+        check(lib.vc_gated_conv1d_glu_fwd(ptr(x_d), x_d[0].numel(), ptr(w_d), w_d[0].numel(), ptr(b_d), 2 * C,
+                                          ptr(out), out[0].numel(), G, B, 24, T, 2 * C, 15, ptr(wsp), wsp.numel(), U.stream()))
+        e = U.rel_err(out.cpu().numpy(), np.stack(ref))
+    finally:
+        O.set_operand_rounding(None)
+        check(lib.vc_set_math_mode(0))
+    assert e < (TOL if mode == 'fp32' else 2e-4), 'rel err %g' % e
+
+
 def test_conv_group_stride_negative(built_lib):
     """group 1 placed BEFORE group 0 in memory (signed group strides)."""
     from tests import gpu_util as U

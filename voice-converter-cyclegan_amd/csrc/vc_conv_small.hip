@@ -340,3 +340,195 @@ int launch_wsconv1d(const WsConvArgs& a, int cin, int kw, int math, hipStream_t 
     VC_HIP(hipGetLastError());
     return 0;
 }
+
+// =====================================================================================
+// gated_conv1d_glu_kernel: the generator's h1 block in ONE kernel (module.py:161-163):
+//     out = (conv_value(x) + b_v) * sigmoid(conv_gate(x) + b_g)
+// value and gate filters live in one tensor w[k][2C] (filters [0,C) value, [C,2C) gate).  Weight-stationary like
+// wsconv1d_kernel: a workgroup keeps the 32 value rows AND the matching 32 gate rows of its channel slab in LDS for its
+// whole life and streams pixel tiles through them; a wave owns 32 pixels of the tile and accumulates the value tile and
+// the gate tile side by side (one B fragment feeds two MFMAs), so the GLU happens in registers and HBM sees
+// 12 KB of frames in and 64 KB of activations out per sample -- SURVEY 8d's algorithmic bytes.
+//   MATH fp32 : operands fp32 in LDS, v_mfma_f32_32x32x2_f32 (exact)            4 waves, 128-pixel tiles
+//   MATH bf16 : operands rounded to bf16 ONCE on their way into LDS (RNE),       8 waves, 256-pixel tiles
+//               fragments are plain 16-byte LDS reads into v_mfma_f32_32x32x16_bf16, fp32 accumulate
+// The window expansion is addressing: a run of R consecutive k (R = 4 fp32 / 8 bf16) is R channels of one tap, i.e.
+// contiguous bytes of Xs row (pixel + tap).
+// =====================================================================================
+template <int CIN, int KW, bool BF16>
+__global__ __launch_bounds__(BF16 ? 512 : 256, BF16 ? 2 : 1) void gated_conv1d_glu_kernel(const WsConvArgs a, const void* __restrict__ packed) {
+    typedef typename std::conditional<BF16, __bf16, float>::type T;
+    constexpr int R = BF16 ? 8 : 4;                        // k run per lane half and step
+    static_assert(CIN % R == 0 && (KW & 1), "runs of R channels inside one tap; odd kernel width");
+    constexpr int NWV = BF16 ? 8 : 4, TP = 128, NSUB = NWV / 4;   // waves, pixels per tile, tiles in flight
+    constexpr int K = CIN * KW, KR = ((K + 2 * R - 1) / (2 * R)) * (2 * R), NG = KR / (2 * R);   // steps of 2R k (one run per lane half)
+    constexpr int LDW = KR + (BF16 ? 8 : 4);               // slab row stride (elements): conflict-free 16-byte reads across 32 rows
+    constexpr int PADL = (KW - 1) / 2;
+    constexpr int XR = TP + KW + 1;                        // input positions of a tile (+ the rows the zero-weight tail runs touch)
+    constexpr int CS = BF16 ? CIN + 16 : CIN + 4;          // Xs row stride (elements): 80 B / 112 B -> conflict-free 16-byte reads across pixels
+    constexpr int NXF = (XR * CIN + 255) / 256;            // a 4-wave half of the workgroup stages its own tile
+    constexpr int LDS_S = 36;                              // per-wave 32 x 32 staging tile (row stride)
+    __shared__ __attribute__((aligned(16))) T Ws[64 * LDW];
+    __shared__ __attribute__((aligned(16))) T Xs[NSUB * XR * CS];
+    __shared__ __attribute__((aligned(16))) float Ss[NWV * 32 * LDS_S];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int sub = wid >> 2, w4 = wid & 3, stid = tid & 255;      // which of the NSUB tiles in flight this wave works on
+    const int l31 = lane & 31, h = lane >> 5;
+    const int g = blockIdx.z, slab = blockIdx.y;
+    const int C = a.Cout >> 1;
+    const int tps = (a.T + TP - 1) / TP, ntiles = a.B * tps;
+
+    float bv[16], bg[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int c = slab * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const bool ok = a.bias && c < C;
+        bv[r] = ok ? a.bias[(long)g * a.b_gs + c] : 0.f;
+        bg[r] = ok ? a.bias[(long)g * a.b_gs + C + c] : 0.f;
+    }
+    const float* xg = a.x + (long)g * a.x_gs;
+    T* Xt = Xs + sub * XR * CS;
+    float xr[NXF];
+    auto load_tile = [&](int tile) {                 // input frames t0-PADL .. of all channels -> registers (lanes along time: coalesced)
+        const bool tv = tile < ntiles;
+        const int b = tv ? tile / tps : 0, t0 = (tile - b * tps) * TP - PADL;
+        const float* xb = xg + (long)b * CIN * a.T;
+#pragma unroll
+        for (int i = 0; i < NXF; ++i) {
+            const int idx = stid + 256 * i, c = idx / XR, pos = idx - c * XR, t = t0 + pos;
+            const bool ok = tv && idx < XR * CIN && (unsigned)t < (unsigned)a.T;
+            xr[i] = xb[ok ? c * a.T + t : 0];
+            xr[i] = ok ? xr[i] : 0.f;
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < NXF; ++i) {
+            const int idx = stid + 256 * i, c = idx / XR, pos = idx - c * XR;
+            if (idx < XR * CIN) Xt[pos * CS + c] = (T)xr[i];
+        }
+    };
+    typedef typename std::conditional<BF16, bf16x8, f32x4>::type frag_t;
+    const frag_t* av = reinterpret_cast<const frag_t*>(Ws + l31 * LDW + R * h);
+    const frag_t* ag = reinterpret_cast<const frag_t*>(Ws + (32 + l31) * LDW + R * h);
+    const T* xrow = Xt + (w4 * 32 + l31) * CS;
+    float* sw = Ss + wid * 32 * LDS_S;
+
+    // persistent over the tiles: trip it handles tiles (blockIdx.x + it * gridDim.x) * NSUB + sub
+    int t0i = blockIdx.x * NSUB;
+    if (t0i < ntiles) load_tile(t0i + sub);          // the first tile's frames travel while the filter slab is copied
+    // ---- filter slab, once: rows 0-31 = value filters 32*slab.., rows 32-63 = the matching gate filters, already in the
+    //      LDS image (element type, row stride, zero tail) by pack_gated_weights_kernel: a straight 16-byte copy
+    {
+        constexpr int NV16 = 64 * LDW * (int)sizeof(T) / 16;
+        const f32x4* src = reinterpret_cast<const f32x4*>(reinterpret_cast<const T*>(packed) + ((long)g * gridDim.y + slab) * 64 * LDW);
+        f32x4* dst = reinterpret_cast<f32x4*>(Ws);
+        for (int i = tid; i < NV16; i += 64 * NWV) dst[i] = src[i];
+    }
+    for (; t0i < ntiles; t0i += gridDim.x * NSUB) {
+        const int tile = t0i + sub;
+        __syncthreads();                              // the previous tile's readers are done (first trip: orders the slab writes)
+        store_tile();
+        __syncthreads();
+        if (t0i + (int)gridDim.x * NSUB < ntiles) load_tile(t0i + gridDim.x * NSUB + sub);   // next tiles' frames are in flight during the MFMAs
+        if (tile >= ntiles) continue;                 // odd tile count: this half idles (barriers are above)
+
+        f32x16 accv[2], accg[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { accv[0][r] = accv[1][r] = 0.f; accg[0][r] = accg[1][r] = 0.f; }
+        // fragment ring RD steps deep, reads pinned ahead of the MFMAs that use them (LDS latency stays covered)
+        constexpr int RD = 3, RS = RD + 1;
+        frag_t fa[RS], fg[RS], fb[RS];
+        auto rd = [&](auto QC) {
+            constexpr int Q = decltype(QC)::value;
+            if constexpr (Q < NG) {
+                // lane half h reads run 2Q + h: tap = run / (CIN / R), channel offset (run % (CIN / R)) * R
+                constexpr int RPT = CIN / R;
+                constexpr int r0 = 2 * Q, r1 = 2 * Q + 1;
+                constexpr int o0 = (r0 / RPT) * CS + (r0 % RPT) * R, o1 = (r1 / RPT) * CS + (r1 % RPT) * R;
+                fa[Q % RS] = av[2 * Q];
+                fg[Q % RS] = ag[2 * Q];
+                fb[Q % RS] = *reinterpret_cast<const frag_t*>(xrow + (h ? o1 : o0));
+            }
+        };
+        auto mm = [&](auto QC) {
+            constexpr int Q = decltype(QC)::value;
+            const frag_t a_ = fa[Q % RS], g_ = fg[Q % RS], b_ = fb[Q % RS];
+            if constexpr (BF16) {
+                accv[Q & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_, b_, accv[Q & 1], 0, 0, 0);
+                accg[Q & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g_, b_, accg[Q & 1], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    accv[e & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_[e], b_[e], accv[e & 1], 0, 0, 0);
+                    accg[e & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(g_[e], b_[e], accg[e & 1], 0, 0, 0);
+                }
+            }
+        };
+        [&]<int... Q>(std::integer_sequence<int, Q...>) { (rd(std::integral_constant<int, Q>{}), ...); }(std::make_integer_sequence<int, RD>{});
+        [&]<int... Q>(std::integer_sequence<int, Q...>) {
+            ((rd(std::integral_constant<int, Q + RD>{}), __builtin_amdgcn_sched_barrier(0),
+              mm(std::integral_constant<int, Q>{}), __builtin_amdgcn_sched_barrier(0)), ...);
+        }(std::make_integer_sequence<int, NG>{});
+
+        // ---- epilogue in registers: + bias, GLU; through a per-wave LDS tile so that a lane stores 16 contiguous bytes
+        const f32x16 sv = accv[0] + accv[1], sg = accg[0] + accg[1];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ml = (r & 3) + 8 * (r >> 2) + 4 * h;
+            sw[ml * LDS_S + l31] = (sv[r] + bv[r]) * sigmoidf_(sg[r] + bg[r]);
+        }
+        // wave-private tile: no workgroup barrier, the LDS queue is in order within a wave
+        {
+            const int b = tile / tps, t = (tile - b * tps) * TP + w4 * 32 + (lane & 7) * 4;
+            float* y = a.y + (long)g * a.y_gs + (long)b * C * a.T + t;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ml = (lane >> 3) + 8 * i, c = slab * 32 + ml;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(sw + ml * LDS_S + (lane & 7) * 4);
+                if (c < C && t < a.T) *reinterpret_cast<f32x4*>(y + (long)c * a.T) = v;
+            }
+        }
+    }
+}
+
+// packed[g][slab][m][k] = T(w[g][k][channel(slab, m)]) in the fused kernel's LDS image: row stride LDW, rows 0-31 the value
+// filters of the slab, rows 32-63 its gate filters, k >= K zero.  Weights change once per optimizer step (or never, at
+// inference); the image is rebuilt per call here (a 3 us launch), kept out of the kernel's own time by ProfScope.
+template <int CIN, int KW, bool BF16>
+__global__ __launch_bounds__(256) void pack_gated_weights_kernel(const float* __restrict__ w, long w_gs, int Cout, void* __restrict__ packed) {
+    typedef typename std::conditional<BF16, __bf16, float>::type T;
+    constexpr int R = BF16 ? 8 : 4, K = CIN * KW, KR = ((K + 2 * R - 1) / (2 * R)) * (2 * R), LDW = KR + (BF16 ? 8 : 4);
+    const int slab = blockIdx.x, g = blockIdx.y, C = Cout >> 1;
+    T* dst = reinterpret_cast<T*>(packed) + ((long)g * gridDim.x + slab) * 64 * LDW;
+    const float* wg = w + (long)g * w_gs;
+    // lanes along the 64 rows (channels: coalesced reads), waves along k
+    const int m = threadIdx.x & 63, ch = (m < 32 ? 0 : C - 32) + slab * 32 + m;
+    const bool valid = slab * 32 + (m & 31) < C;
+    for (int k = (threadIdx.x >> 6) + 4 * blockIdx.z; k < LDW; k += 4 * gridDim.z)     // k rows spread over gridDim.z blocks: ~6 loads per thread
+        dst[m * LDW + k] = (T)((k < K && valid) ? wg[(long)k * Cout + ch] : 0.f);
+}
+
+int64_t gated_conv1d_glu_workspace_floats(int G, int cout2) {
+    const int slabs = cout2 / 64;
+    return (int64_t)G * slabs * 64 * (368 + 8);           // the larger of the two images (fp32: 64 x 364 floats; bf16: 64 x 376 halves)
+}
+
+// y [G][B][Cout/2][T] = GLU of the gated pair; returns -2 when the geometry is not built
+int launch_gated_conv1d_glu(const WsConvArgs& a, int cin, int kw, int math, float* workspace, hipStream_t s, double flops) {
+    if (cin != 24 || kw != 15 || (a.Cout & 63) || (a.T & 3)) return -2;
+    const int C = a.Cout / 2, slabs = C / 32;
+    const bool bf = math == VC_MATH_BF16;
+    const int nsub = bf ? 2 : 1, ntiles = a.B * ((a.T + 127) / 128), trips = (ntiles + nsub - 1) / nsub;
+    int parts = 256 / (slabs * a.G); if (parts < 1) parts = 1; if (parts > trips) parts = trips;       // one workgroup per CU, persistent
+    dim3 grid(parts, slabs, a.G);
+    if (bf) pack_gated_weights_kernel<24, 15, true><<<dim3(slabs, a.G, 16), 256, 0, s>>>(a.w, a.w_gs, a.Cout, workspace);
+    else pack_gated_weights_kernel<24, 15, false><<<dim3(slabs, a.G, 16), 256, 0, s>>>(a.w, a.w_gs, a.Cout, workspace);
+    ProfScope ps(2, flops, s);
+    if (bf) gated_conv1d_glu_kernel<24, 15, true><<<grid, dim3(512), 0, s>>>(a, workspace);
+    else gated_conv1d_glu_kernel<24, 15, false><<<grid, dim3(256), 0, s>>>(a, workspace);
+    VC_HIP(hipGetLastError());
+    return 0;
+}
