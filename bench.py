@@ -207,7 +207,8 @@ def main():
             'scaling': 'strong' if args.global_batch else 'weak', 'vs_baseline': None, 'dtype': {'fp32': 'f32'}.get(args.math, args.math), 'data': 'synthetic',
             'config': {'workload': 'BASELINE configs[%d]: full CycleGAN-VC train step (2G+2D fwd/bwd + losses + '
                                    'TF-Adam), %s, batch %d per GPU, %dx%d MCEP, random-init weights'
-                                   % (1 if args.math == 'fp32' else 2, MATH_TEXT[args.math], B, F, T),
+                                   % (4 if (F, T) == (36, 256) else 3 if args.global_batch else 1 if args.math == 'fp32' else 2,
+                                      MATH_TEXT[args.math], B, F, T),
                        'global_batch': world * B, 'frames_per_step_per_domain': world * B * T,
                        'parallelism': 'dp%d' % world,
                        'launch': 'one hipGraph replay per step (vc_train_step_graph)' if (eng.use_graph and world == 1 and not args.serial)

@@ -66,3 +66,59 @@ def test_two_ranks_share_one_gpu(built_lib, tmp_path):
     assert r0[1] == r1[1] and r0[2] == r1[2], 'replicas diverged after the update'
     assert abs(r0[3] - r0[5]) < 1e-3 * abs(r0[5]) and abs(r0[4] - r0[6]) < 1e-3 * max(abs(r0[6]), 1e-3)   # losses = global means
     assert r0[3] == r1[3] and r0[4] == r1[4]
+
+
+def _nccl_worker(port, outdir):
+    """the production configuration of GradSync: backend 'nccl' (= RCCL), native communicator"""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    import __graft_entry__ as ge
+    ge.build()
+    from voice_converter_cyclegan_amd.engine import CycleGANEngine, GradSync
+    from voice_converter_cyclegan_amd._lib import lib
+    s = GradSync(None, enabled=True, device=torch.device('cuda:0'))
+    np.save(os.path.join(outdir, 'nccl.npy'), np.array([s.world, 0 if s.comm is None else 1]))
+    dist.destroy_process_group()
+
+
+def test_rccl_through_the_c_abi_single_rank(built_lib, tmp_path):
+    """vc_comm_unique_id / vc_comm_init (ncclCommInitRank) / vc_allreduce_f32 (ncclAllReduce) / vc_step_exchange_and_update
+    with a communicator / vc_comm_destroy on a 1-rank RCCL communicator: the only RCCL configuration a 1-GPU box offers
+    (RCCL refuses two ranks on one device).  A SUM over one rank is the identity, so the update with the communicator must
+    equal the update without it bit for bit."""
+    import ctypes as C
+    from voice_converter_cyclegan_amd import _lib
+    from voice_converter_cyclegan_amd._lib import lib, ptr, check
+    from voice_converter_cyclegan_amd.engine import CycleGANEngine
+    ident = (C.c_ubyte * 128)()
+    check(lib.vc_comm_unique_id(ident), 'vc_comm_unique_id')
+    assert any(ident), 'ncclGetUniqueId returned zeros'
+    torch.cuda.set_device(0)
+    h = _lib.vp()
+    check(lib.vc_comm_init(0, 1, ident, C.byref(h)), 'vc_comm_init')
+    assert lib.vc_comm_world(h) == 1
+    t = torch.arange(1000, dtype=torch.float32, device='cuda:0') * 0.5
+    want = t.clone()
+    check(lib.vc_allreduce_f32(h, ptr(t), t.numel(), _lib.vp(torch.cuda.current_stream().cuda_stream)), 'vc_allreduce_f32')
+    torch.cuda.synchronize()
+    assert torch.equal(t, want)
+    # the step's exchange + update through the communicator == without it
+    rng = np.random.default_rng(5)
+    A = rng.standard_normal((2, 24, 128)).astype(np.float32); B = rng.standard_normal((2, 24, 128)).astype(np.float32)
+    res = []
+    for comm in (h, None):
+        eng = CycleGANEngine(24, device='cuda:0', seed=9, data_parallel=False)
+        eng.sync.comm = comm                      # as GradSync sets it up on the 'nccl' backend
+        eng.train_step(A, B, 10.0, 5.0, 2e-4, 1e-4)
+        torch.cuda.synchronize()
+        res.append((float(eng.params.double().sum()), float(eng.params.double().abs().sum())))
+        eng.sync.comm = None
+    assert abs(res[0][0] - res[1][0]) <= 1e-6 * abs(res[1][1]) and abs(res[0][1] - res[1][1]) <= 1e-6 * res[1][1], res
+    check(lib.vc_comm_destroy(h), 'vc_comm_destroy')
+    # GradSync on the nccl backend builds the native communicator (world 1: no collective is needed, none is created)
+    ctx = mp.get_context('spawn')
+    p = ctx.Process(target=_nccl_worker, args=(_free_port(), str(tmp_path)))
+    p.start(); p.join(300)
+    assert p.exitcode == 0
+    assert np.load(os.path.join(str(tmp_path), 'nccl.npy'))[0] == 1

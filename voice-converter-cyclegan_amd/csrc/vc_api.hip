@@ -265,7 +265,7 @@ static int conv_fwd(const float* x, long x_gs, const float* w, long w_gs, const 
     a.yHW = g.OH * g.OW; a.yW = g.OW; a.so_h = 1; a.so_w = 1; a.o_h0 = 0; a.o_w0 = 0;
     a.accumulate = 0; a.groups = G;
     set_vec4(a);
-    igemm_config(a);
+    igemm_config(a, math);
     if (query) { *query = a.splitk > 1; return 0; }
     if (a.splitk > 1) {          // atomics need a zeroed destination
         if (!prezeroed)
@@ -312,7 +312,7 @@ static int conv_dgrad(const float* dy, long dy_gs, const float* w, long w_gs, fl
         a.yHW = g.H * g.W; a.yW = g.W; a.so_h = g.sh; a.so_w = g.sw; a.o_h0 = ph; a.o_w0 = pw;
         a.accumulate = accumulate; a.groups = G;
         set_vec4(a);
-        igemm_config(a);
+        igemm_config(a, math);
         any_split = any_split || a.splitk > 1;
         fl[ncls] = 2.0 * G * B * a.NPB * (double)g.Cin * t.valid; cls[ncls++] = a;
     }

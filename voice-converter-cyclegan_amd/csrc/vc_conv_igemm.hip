@@ -314,9 +314,20 @@ extern "C" int vc_tune_igemm_override(int bm, int kg, int splitk) {
 struct TunedCfg { int at, M, Ptot, krows, groups, bm, kg, sk; };
 #include "vc_tuned_igemm.h"
 
-void igemm_config(IgemmArgs& a) {
+void igemm_config(IgemmArgs& a, int math) {
     const int nchunks = a.krows / VC_KC;
     a.mtiles = 0;
+    if (math != VC_MATH_FP32 && !g_force_bm) {
+        // bf16 operand modes: the MFMAs are 16x shorter, the launch is bound by the loader -> the tile with the least loader
+        // work per MFMA (128 rows), no K groups, split-K only to fill the chip (the round-1 rule, measured for this mode)
+        a.bm = a.M >= 512 ? 128 : 64; a.kg = 1;
+        const long tiles = (long)((a.M + a.bm - 1) / a.bm) * ((a.Ptot + 63) / 64) * a.groups;
+        int sk = 1;
+        while (tiles * sk < 512 && nchunks / (sk * 2) >= 4 && sk < 16) sk *= 2;
+        a.splitk = sk;
+        a.mtiles = (a.M + a.bm - 1) / a.bm; a.ntiles = (a.Ptot + 63) / 64;
+        return;
+    }
     if (g_force_bm) { a.bm = g_force_bm; a.kg = g_force_kg; a.splitk = std::min(g_force_sk, std::max(1, nchunks / (2 * a.kg))); }
     else {
         const int at = a.a_ms != 1 ? 1 : 0;

@@ -132,7 +132,7 @@ struct NormArgs {
 };
 
 // picks tile rows, K groups and split-K for a launch (fills bm/kg/splitk/mtiles/ntiles)
-void igemm_config(IgemmArgs& a);
+void igemm_config(IgemmArgs& a, int math);
 int launch_igemm(const IgemmArgs& a, bool a_trans, int math, hipStream_t s, double flops);
 int launch_igemm_multi(const IgemmArgs* cls, int n, bool a_trans, int math, hipStream_t s, double flops);   // all configured alike
 int wgrad_splitk(const WgradArgs& a);            // the split-K factor launch_wgrad will use (1 = plain stores possible)
