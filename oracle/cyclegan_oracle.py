@@ -511,12 +511,13 @@ def generator_losses_and_grads(P, A, Bm, lambda_cycle, lambda_identity, want_gra
     # test aid: distance of the closest L1 element to a tie.  d|x|/dx = sign(x) (S6) is discontinuous there, so an
     # implementation whose forward differs by less than fp32 rounding may legitimately take the other sign of that one
     # element; parity tests pick inputs whose gap is far above that noise (tests/test_step_gpu.py).
-    gaps = []
+    dists = []
     if lambda_cycle != 0:
-        gaps += [np.abs(cyc_A - A).min(), np.abs(cyc_B - Bm).min()]
+        dists += [np.abs(cyc_A - A).ravel(), np.abs(cyc_B - Bm).ravel()]
     if lambda_identity != 0:
-        gaps += [np.abs(id_A - A).min(), np.abs(id_B - Bm).min()]
-    generator_losses_and_grads.last_l1_gap = float(min(gaps)) if gaps else float('inf')
+        dists += [np.abs(id_A - A).ravel(), np.abs(id_B - Bm).ravel()]
+    generator_losses_and_grads.last_l1_dist = np.concatenate(dists) if dists else np.zeros(0)   # every |y_hat - y|
+    generator_losses_and_grads.last_l1_gap = float(generator_losses_and_grads.last_l1_dist.min()) if dists else float('inf')
     if not want_grads:
         return S, None, gen_A, gen_B
 
@@ -622,6 +623,7 @@ class CycleGANOracle:
         self.last_grads = (Gg, Gd)
         self.last_fakes = (gen_A, gen_B)
         self.last_l1_gap = generator_losses_and_grads.last_l1_gap
+        self.last_l1_dist = generator_losses_and_grads.last_l1_dist
         return Sg['generator_loss'], Sd['discriminator_loss']
 
     def test(self, inputs, direction):                                  # model.py:128-137

@@ -217,16 +217,24 @@ def test_train_step_losses_grads_and_updates(built_lib, B):
 
 @pytest.mark.parametrize('mode', ['bf16', 'bf16x3'])
 def test_train_step_bf16_modes(built_lib, mode):
-    """BASELINE configs[2] arithmetic (vc_set_math_mode): one whole train step at B=2.
+    """BASELINE configs[2] arithmetic (vc_plan_set_math_mode): one whole train step.
     bf16x3 : against the plain fp32 oracle: losses and generations at the fp32 tolerance 1e-3; whole-step gradients only to
              5e-2 rel-L2, because its ~1e-5 forward noise is no longer far below the L1 tie gap that _setup guarantees
              (fixed-upstream-gradient parity at 1e-3 is in test_generator_backward / test_discriminator_forward_backward).
     bf16   : against the oracle with the same bf16 operand rounding: losses 2e-3, generations 2e-2 (max-norm; measured
-             6.4e-3), whole-step gradients 5e-2 rel-L2 -- on a seed whose *bf16* oracle forward has no L1 element
-             within 2e-3 of a sign flip (the two sides' generations differ by ~1e-3, neighbouring-bf16 roundings, so
-             the fp32 tie gap of 5e-5 would not protect sign(cycle - real) of utils.l1_loss).  Gradient parity of the
-             bf16 kernels with a GIVEN upstream gradient: test_conv_bf16_modes (1e-4) and test_generator_backward /
-             test_discriminator_forward_backward [bf16] (2e-2).
+             6.4e-3).  Whole-step gradients, two runs:
+             (a) lambda_cycle = lambda_identity = 0 (LSGAN terms only, model.py:68-72 -- a smooth objective): every
+                 tensor <= 5e-2 rel-L2, the bf16 figure of VERDICT r1;
+             (b) the real lambdas (10, 5): 5e-2 PLUS a sign-flip allowance computed from the oracle's own forward.  The
+                 two sides' generations differ by ~5e-3 rms (an activation that rounds to the neighbouring bf16 on one
+                 side only is a 4e-3 relative kick that later layers spread), so sign(y_hat - y) of utils.l1_loss
+                 (utils.py:5) legitimately differs on L1 elements closer to a tie than that; with f = the fraction of
+                 the oracle's L1 elements within delta (= 3 x the measured rms forward difference) of a tie, flipped
+                 signs move the L1 seed gradient by at most 2*sqrt(f) relative (each flip is 2 units of a +-1 vector).
+                 No seed has f = 0.  Measured: (a) worst tensor 0.021; (b) f = 9.3e-3 -> bound 0.24, worst tensor
+                 (o1_conv/kernel, fed by the L1 seed directly) 0.10-0.13.
+             Gradient parity of the bf16 kernels with a GIVEN upstream gradient: test_conv_bf16_modes (1e-4) and
+             test_generator_backward / test_discriminator_forward_backward [bf16] (2e-2).
              Also bounded against the fp32 oracle: bf16 must be a faithful approximation, and must not BE fp32."""
     from tests import gpu_util as U
     B = 2 if mode == 'bf16x3' else 1      # bf16: the fewer L1 elements, the wider the best tie gap a seed offers
@@ -234,25 +242,40 @@ def test_train_step_bf16_modes(built_lib, mode):
     orc32 = O.CycleGANOracle({k: v.copy() for k, v in P.items()})
     orc32.train(A, Bm, 10.0, 5.0, 2e-4, 1e-4)
     gen_A = torch.empty((B, 24, 128), device=U.DEV); gen_B = torch.empty_like(gen_A)
-    ref, tol_l, tol_g, tol_w = orc32, TOL, TOL, 5e-2
-    with _math(mode, O, eng):
-        if mode == 'bf16':
-            ref = O.CycleGANOracle({k: v.copy() for k, v in P.items()})
-            ref.train(A, Bm, 10.0, 5.0, 2e-4, 1e-4)
-            tol_l, tol_g, tol_w = 2e-3, BF16_TOL, 5e-2
-        eng.train_step(A, Bm, 10.0, 5.0, 2e-4, 1e-4, gen_A=gen_A, gen_B=gen_B)
-        torch.cuda.synchronize()
-    for k, v in ref.last.items():
-        assert abs(eng.last_losses[k] - v) <= tol_l * max(1.0, abs(v)), (k, eng.last_losses[k], float(v))
-    eA, eB = U.rel_err(gen_A.cpu().numpy(), ref.last_fakes[0]), U.rel_err(gen_B.cpu().numpy(), ref.last_fakes[1])
-    assert eA < tol_g and eB < tol_g, (eA, eB)
-    want = dict(ref.last_grads[0]); want.update(ref.last_grads[1])
-    got = eng.tf_gradients()
-    for n, r in want.items():
-        if _is_noise_bias(n):
-            continue
-        e2 = np.linalg.norm(got[n].reshape(r.shape).astype(np.float64) - r) / (np.linalg.norm(r) + 1e-30)
-        assert e2 < tol_w, (n, float(e2))
+    lambdas = [(10.0, 5.0)] if mode == 'bf16x3' else [(0.0, 0.0), (10.0, 5.0)]
+    for lc, li in lambdas:
+        eng.load_tf_variables(P)
+        ref, tol_l, tol_g, tol_w = orc32, TOL, TOL, 5e-2
+        with _math(mode, O, eng):
+            if mode == 'bf16':
+                ref = O.CycleGANOracle({k: v.copy() for k, v in P.items()})
+                ref.train(A, Bm, lc, li, 2e-4, 1e-4)
+                tol_l, tol_g = 2e-3, BF16_TOL
+            eng.train_step(A, Bm, lc, li, 2e-4, 1e-4, gen_A=gen_A, gen_B=gen_B)
+            torch.cuda.synchronize()
+        for k, v in ref.last.items():
+            assert abs(eng.last_losses[k] - v) <= tol_l * max(1.0, abs(v)), (lc, k, eng.last_losses[k], float(v))
+        gA, gB = gen_A.cpu().numpy(), gen_B.cpu().numpy()
+        eA, eB = U.rel_err(gA, ref.last_fakes[0]), U.rel_err(gB, ref.last_fakes[1])
+        assert eA < tol_g and eB < tol_g, (lc, eA, eB)
+        if mode == 'bf16' and lc:
+            dfw = np.concatenate([(gA - ref.last_fakes[0]).ravel(), (gB - ref.last_fakes[1]).ravel()]).astype(np.float64)
+            delta = 3.0 * float(np.sqrt((dfw ** 2).mean()))
+            f = float((ref.last_l1_dist < delta).mean())
+            print('bf16 step: forward diff rms %.3g max %.3g; L1 elements within 3 rms of a tie: %.3g (within max: %.3g)'
+                  % (delta / 3, np.abs(dfw).max(), f, float((ref.last_l1_dist < np.abs(dfw).max()).mean())))
+            assert f < 1e-2, 'L1 elements within the forward noise %g of a tie: %g' % (delta, f)
+            tol_w += 2.0 * np.sqrt(f)
+        want = dict(ref.last_grads[0]); want.update(ref.last_grads[1])
+        got = eng.tf_gradients()
+        worst = 0.0
+        for n, r in want.items():
+            if _is_noise_bias(n):
+                continue
+            e2 = np.linalg.norm(got[n].reshape(r.shape).astype(np.float64) - r) / (np.linalg.norm(r) + 1e-30)
+            worst = max(worst, float(e2))
+            assert e2 < tol_w, (lc, n, float(e2), tol_w)
+        print('%s lambdas (%g, %g): worst gradient rel-L2 %.3g (bound %.3g)' % (mode, lc, li, worst, tol_w))
     if mode == 'bf16':
         e32 = U.rel_err(gen_A.cpu().numpy(), orc32.last_fakes[0])
         assert 1e-4 < e32 < 5e-2, 'bf16 generation vs the fp32 oracle: %g' % e32

@@ -1,0 +1,38 @@
+"""Timeline summary of a rocprofv3 --kernel-trace CSV of bench.py: for the last complete train steps, wall time per step,
+the union of kernel-busy time (any kernel running), the sum of kernel durations (concurrency = sum / union), idle gaps."""
+import csv
+import sys
+from collections import defaultdict
+
+rows = list(csv.DictReader(open(sys.argv[1])))
+ev = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'].split('(')[0].replace('void ', ''), r.get('Queue_Id', '?'))
+            for r in rows)
+# a step starts with the first copyBuffer burst after a loss_finalize... simpler: split at every loss_kernel (one per step)
+loss = [i for i, e in enumerate(ev) if e[2].startswith('loss_kernel')]
+if len(loss) < 4:
+    print('not enough steps'); sys.exit(0)
+steps = []
+for a, b in zip(loss[-4:-1], loss[-3:]):
+    steps.append(ev[a:b])
+for k, st in enumerate(steps):
+    t0, t1 = st[0][0], st[-1][0]
+    wall = (t1 - t0) / 1e3
+    # union of busy intervals
+    iv = sorted((s, e) for s, e, _, _ in st)
+    busy = 0; cs, ce = iv[0]
+    gaps = []
+    for s, e in iv[1:]:
+        if s > ce:
+            busy += ce - cs; gaps.append((s - ce, ce)); cs, ce = s, e
+        else:
+            ce = max(ce, e)
+    busy += ce - cs
+    tot = sum(e - s for s, e, _, _ in st)
+    print('step %d: %d kernels, wall %.1f us, busy (union) %.1f us = %.1f %%, sum of durations %.1f us, mean concurrency %.2f'
+          % (k, len(st), wall, busy / 1e3, 100 * busy / 1e3 / wall, tot / 1e3, tot / busy))
+    gaps.sort(reverse=True)
+    print('   idle gaps: %d, total %.1f us; largest: %s' % (len(gaps), sum(g for g, _ in gaps) / 1e3, ['%.1f' % (g / 1e3) for g, _ in gaps[:8]]))
+    by = defaultdict(float)
+    for s, e, n, q in st:
+        by[n.split('<')[0]] += (e - s) / 1e3
+    print('   by kernel family (us): ' + ', '.join('%s %.0f' % kv for kv in sorted(by.items(), key=lambda kv: -kv[1])[:10]))
