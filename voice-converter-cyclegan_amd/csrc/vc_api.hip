@@ -81,7 +81,10 @@ static Geom make_geom(int Cin, int H, int W, int Cout, int kh, int kw, int sh, i
 // ------------------------------------------------------------------------------------
 struct HostRow { int c, dh, dw, a_off, tap; };
 struct Table { KEntry* dev = nullptr; int* xsoff = nullptr; unsigned* rtap = nullptr; unsigned* aoff = nullptr; Tap* taps = nullptr;
-               int ntaps = 0, rows = 0, valid = 0, xbias = 0, refs = 0; };
+               int ntaps = 0, rows = 0, valid = 0, xbias = 0, refs = 0;
+               // the same K rows by octets of 8 channels, for the 16-bit data path (vc_internal.h: ConvBf16Args); koct == 0:
+               // the channel count is not a multiple of 8 and the path is not available for this geometry
+               int* oxs = nullptr; unsigned* otap = nullptr; int* wsrc = nullptr; int koct = 0, oxbias = 0; };
 typedef std::array<int, 14> TabKey;
 static std::mutex g_tab_mu;
 static std::map<TabKey, Table> g_tabs;
@@ -93,6 +96,7 @@ template <class T> static int to_device(const std::vector<T>& h, T** d) {
 }
 static void free_table(Table& t) {
     (void)hipFree(t.dev); (void)hipFree(t.xsoff); (void)hipFree(t.rtap); (void)hipFree(t.aoff); (void)hipFree(t.taps);
+    (void)hipFree(t.oxs); (void)hipFree(t.otap); (void)hipFree(t.wsrc);
     t = Table{};
 }
 // rows_per_tap[t] consecutive entries of `rows` belong to tap t.  xH, xW: dims of the tensor the K rows gather from
@@ -131,6 +135,29 @@ static int upload_table(const std::vector<HostRow>& rows, const std::vector<int>
     VC_CHECK(to_device(ke, &t->dev)); VC_CHECK(to_device(xs, &t->xsoff)); VC_CHECK(to_device(rt, &t->rtap)); VC_CHECK(to_device(ao, &t->aoff));
     std::vector<Tap> tp = taps; if (tp.empty()) tp.push_back(Tap{0, 0});
     VC_CHECK(to_device(tp, &t->taps));
+    // octet view: unit offsets inside the packed tensor [C/8][xH*xW][8] (16 bytes per unit), filter source offset per K row
+    bool oct = !rows.empty();
+    for (int n : rows_per_tap) oct = oct && n % 8 == 0;
+    if (oct) {
+        long omin = 0;
+        for (const HostRow& r : rows) omin = std::min(omin, ((long)(r.c / 8) * xH * xW + (long)r.dh * xW + r.dw) * 16);
+        std::vector<int> oxs, wsrc; std::vector<unsigned> otap;
+        for (size_t k = 0; k < rows.size(); ++k) {
+            const HostRow& r = rows[k];
+            wsrc.push_back(r.a_off);
+            if (k % 8) continue;
+            const long so = ((long)(r.c / 8) * xH * xW + (long)r.dh * xW + r.dw) * 16 - omin;
+            if (so > 0x7fffff00L) { oct = false; break; }
+            oxs.push_back((int)so); otap.push_back(1u << r.tap);
+        }
+        if (oct) {
+            auto pad_oct = [&]() { oxs.push_back((int)-omin); otap.push_back(0u); for (int e = 0; e < 8; ++e) wsrc.push_back(-1); };
+            while (oxs.size() % 8) pad_oct();
+            t->koct = (int)oxs.size(); t->oxbias = (int)-omin;
+            for (int i = 0; i < 16; ++i) pad_oct();            // the loader runs two chunks past its K range
+            VC_CHECK(to_device(oxs, &t->oxs)); VC_CHECK(to_device(otap, &t->otap)); VC_CHECK(to_device(wsrc, &t->wsrc));
+        }
+    }
     return 0;
 }
 static TabKey fwd_key(const Geom& g) { return TabKey{0, g.Cin, g.Cout, g.kh, g.kw, g.sh, g.sw, g.pt, g.pl, 0, 0, g.H, g.W, 0}; }
@@ -233,6 +260,41 @@ static void set_vec4(IgemmArgs& a) {
              a.y_gs % 4 == 0 && aligned16(a.Y) && (!a.addend || (aligned16(a.addend) && a.add_gs % 4 == 0));
 }
 
+// ------------------------------------------------------------------------------------
+// 16-bit data path of the bf16 mode: per-stream workspace for the packed operands, launch set-up
+// ------------------------------------------------------------------------------------
+// Packed operands live in a workspace owned by the stream the convolution is issued on (launches of one stream are
+// ordered, so consecutive convolutions may reuse it; concurrent chains of the step run on different streams).  It grows
+// on demand (hipFree synchronises the device, so no launch still reads the old block) and is never shrunk.
+struct PackSpace { char* p = nullptr; size_t cap = 0; };
+static std::mutex g_ws_mu;
+static std::map<hipStream_t, PackSpace> g_ws;
+static int pack_space(hipStream_t s, size_t bytes, char** out) {
+    std::lock_guard<std::mutex> l(g_ws_mu);
+    PackSpace& w = g_ws[s];
+    if (w.cap < bytes) {
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        if (s && hipStreamIsCapturing(s, &st) == hipSuccess && st != hipStreamCaptureStatusNone) {
+            vc_set_error("bf16 data path: the packed-operand workspace would have to grow during stream capture; run one eager step of this batch first");
+            return VC_E_STATE;
+        }
+        if (w.p) VC_HIP(hipFree(w.p));
+        w.p = nullptr; w.cap = 0;
+        const size_t cap = bytes + bytes / 4 + (1u << 20);
+        VC_HIP(hipMalloc((void**)&w.p, cap));
+        w.cap = cap;
+    }
+    *out = w.p;
+    return 0;
+}
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+// the path serves launches that fill its 128 x 128 tiles; everything else stays on the table-driven fp32-storage kernels
+static bool bf16_path(const Table& t, int math, int M, long Ptot) { return math == VC_MATH_BF16 && t.koct > 0 && M >= 64 && Ptot >= 64; }
+static void bf16_set_vec4(ConvBf16Args& a) {
+    a.vec4 = a.so_w == 1 && a.OWc % 4 == 0 && a.o_w0 % 4 == 0 && a.yW % 4 == 0 && a.yHW % 4 == 0 && a.y_bs % 4 == 0 &&
+             a.y_gs % 4 == 0 && aligned16(a.Y) && (!a.addend || (aligned16(a.addend) && a.add_gs % 4 == 0));
+}
+
 // query != nullptr: do not launch, only report whether the launch would use split-K atomics (needs a zeroed y)
 static int conv_fwd(const float* x, long x_gs, const float* w, long w_gs, const float* bias, long b_gs,
                     float* y, long y_gs, int G, int B, const Geom& g, int math, hipStream_t s,
@@ -251,6 +313,32 @@ static int conv_fwd(const float* x, long x_gs, const float* w, long w_gs, const 
         if (r != -2) return r;
     }
     Table t; VC_CHECK(get_fwd_table(g, &t));
+    if (bf16_path(t, math, g.Cout, (long)B * g.OH * g.OW)) {
+        ConvBf16Args a{};
+        a.Y = y; a.bias = bias; a.addend = nullptr;
+        a.xsoff = t.oxs; a.otap = t.otap; a.taps = t.taps; a.ntaps = t.ntaps; a.xbias = t.oxbias;
+        const size_t xp_g = align256((size_t)B * g.Cin * g.H * g.W * 2), ap_g = align256((size_t)g.Cout * t.koct * 16);
+        a.x_bytes = (unsigned)((long)B * g.Cin * g.H * g.W * 2 + t.oxbias); a.a_bytes = (unsigned)((long)g.Cout * t.koct * 16);
+        a.a_gs = (long)ap_g; a.x_gs = (long)xp_g; a.x_bs = (long)g.Cin * g.H * g.W * 2;
+        a.y_gs = y_gs; a.bias_gs = b_gs; a.add_gs = 0; a.y_bs = (long)g.Cout * g.OH * g.OW;
+        a.koct = t.koct; a.M = g.Cout; a.Hl = g.H; a.Wl = g.W; a.xW = g.W; a.si = g.sh; a.sj = g.sw;
+        a.NPB = g.OH * g.OW; a.OWc = g.OW; a.Ptot = B * a.NPB; a.inv_npb = 1.0f / (float)a.NPB; a.inv_ow = 1.0f / (float)g.OW;
+        a.yHW = g.OH * g.OW; a.yW = g.OW; a.so_h = 1; a.so_w = 1; a.o_h0 = 0; a.o_w0 = 0;
+        a.accumulate = 0; a.groups = G;
+        bf16_set_vec4(a);
+        conv_bf16_config(a);
+        if (query) { *query = a.splitk > 1; return 0; }
+        char* wsp; VC_CHECK(pack_space(s, (xp_g + ap_g) * G, &wsp));
+        a.X = wsp; a.A = wsp + xp_g * G;
+        VC_CHECK(launch_pack_act_bf16(x, x_gs, wsp, (long)xp_g, G, B, g.Cin, g.H * g.W, s));
+        VC_CHECK(launch_pack_filter_bf16(w, w_gs, wsp + xp_g * G, (long)ap_g, t.wsrc, 1, G, g.Cout, t.koct * 8, s));
+        if (a.splitk > 1) {
+            if (!prezeroed)
+                for (int gi = 0; gi < G; ++gi) VC_HIP(hipMemsetAsync(y + (long)gi * y_gs, 0, (size_t)B * a.y_bs * sizeof(float), s));
+            a.accumulate = 1;
+        }
+        return launch_conv_bf16(a, s, 2.0 * G * B * a.NPB * (double)g.Cout * t.valid);
+    }
     IgemmArgs a{};
     a.A = w; a.X = x; a.Y = y; a.bias = bias; a.addend = nullptr;
     a.xsoff = t.xsoff; a.rtap = t.rtap; a.aoff = t.aoff; a.taps = t.taps; a.ntaps = t.ntaps; a.xbias = t.xbias;
@@ -292,6 +380,57 @@ static int conv_dgrad(const float* dy, long dy_gs, const float* w, long w_gs, fl
     }
     VC_ARG(g.Cin % 4 == 0, "conv input gradient: Cin must be a multiple of 4");
     // one launch per stride-parity class (ph, pw): inside a class the transposed conv is a dense stride-1 gather
+    {
+        Table t0; VC_CHECK(get_dgrad_table(g, 0, 0, &t0));
+        bool native = bf16_path(t0, math, g.Cin, (long)B * ((g.H + g.sh - 1) / g.sh) * ((g.W + g.sw - 1) / g.sw));
+        for (int ph = 0; ph < g.sh && native; ++ph) for (int pw = 0; pw < g.sw && native; ++pw) {   // a class without taps: table-driven path
+            Table t; VC_CHECK(get_dgrad_table(g, ph, pw, &t));
+            native = t.koct > 0;
+        }
+        if (native) {
+            // 16-bit data path: dY is packed once, every class has its own filter image (its taps only)
+            ConvBf16Args cl[4]; double flb[4]; const int* wsrc[4]; int nc = 0; bool split = false;
+            const size_t xp_g = align256((size_t)B * g.Cout * g.OH * g.OW * 2);
+            size_t ap_off[4], ap_tot = 0;
+            for (int ph = 0; ph < g.sh; ++ph) for (int pw = 0; pw < g.sw; ++pw) {
+                const int Hc = (g.H - ph + g.sh - 1) / g.sh, Wc = (g.W - pw + g.sw - 1) / g.sw;
+                if (Hc <= 0 || Wc <= 0) continue;
+                VC_ARG(nc < 4, "conv input gradient: more than 4 stride-parity classes");
+                Table t; VC_CHECK(get_dgrad_table(g, ph, pw, &t));
+                VC_ARG(t.koct > 0, "conv input gradient: inconsistent octet tables");
+                ConvBf16Args a{};
+                a.Y = dx; a.bias = nullptr; a.addend = addend;
+                a.xsoff = t.oxs; a.otap = t.otap; a.taps = t.taps; a.ntaps = t.ntaps; a.xbias = t.oxbias;
+                a.x_bytes = (unsigned)((long)B * g.Cout * g.OH * g.OW * 2 + t.oxbias); a.a_bytes = (unsigned)((long)g.Cin * t.koct * 16);
+                a.a_gs = (long)align256((size_t)g.Cin * t.koct * 16); a.x_gs = (long)xp_g; a.x_bs = (long)g.Cout * g.OH * g.OW * 2;
+                a.y_gs = dx_gs; a.bias_gs = 0; a.add_gs = add_gs; a.y_bs = (long)g.Cin * g.H * g.W;
+                a.koct = t.koct; a.M = g.Cin; a.Hl = g.OH; a.Wl = g.OW; a.xW = g.OW; a.si = 1; a.sj = 1;
+                a.NPB = Hc * Wc; a.OWc = Wc; a.Ptot = B * a.NPB; a.inv_npb = 1.0f / (float)a.NPB; a.inv_ow = 1.0f / (float)Wc;
+                a.yHW = g.H * g.W; a.yW = g.W; a.so_h = g.sh; a.so_w = g.sw; a.o_h0 = ph; a.o_w0 = pw;
+                a.accumulate = accumulate; a.groups = G;
+                bf16_set_vec4(a);
+                conv_bf16_config(a);
+                split = split || a.splitk > 1;
+                ap_off[nc] = ap_tot; ap_tot += (size_t)a.a_gs * G;
+                wsrc[nc] = t.wsrc; flb[nc] = 2.0 * G * B * a.NPB * (double)g.Cin * t.valid; cl[nc++] = a;
+            }
+            if (query) { *query = split; return 0; }
+            char* wsp; VC_CHECK(pack_space(s, xp_g * G + ap_tot, &wsp));
+            VC_CHECK(launch_pack_act_bf16(dy, dy_gs, wsp, (long)xp_g, G, B, g.Cout, g.OH * g.OW, s));
+            if (split && !accumulate) {
+                if (!prezeroed)
+                    for (int gi = 0; gi < G; ++gi)
+                        VC_HIP(hipMemsetAsync(dx + (long)gi * dx_gs, 0, (size_t)B * g.Cin * g.H * g.W * sizeof(float), s));
+                for (int i = 0; i < nc; ++i) cl[i].accumulate = 1;
+            }
+            for (int i = 0; i < nc; ++i) {
+                cl[i].X = wsp; cl[i].A = wsp + xp_g * G + ap_off[i];
+                VC_CHECK(launch_pack_filter_bf16(w, w_gs, wsp + xp_g * G + ap_off[i], cl[i].a_gs, wsrc[i], g.Cout, G, g.Cin, cl[i].koct * 8, s));
+                VC_CHECK(launch_conv_bf16(cl[i], s, flb[i]));
+            }
+            return 0;
+        }
+    }
     IgemmArgs cls[4]; double fl[4]; int ncls = 0;
     bool any_split = false;
     for (int ph = 0; ph < g.sh; ++ph) for (int pw = 0; pw < g.sw; ++pw) {

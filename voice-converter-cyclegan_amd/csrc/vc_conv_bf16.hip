@@ -1,0 +1,275 @@
+// vc_conv_bf16.hip -- the bf16 arithmetic of BASELINE configs[2] (vc_plan_set_math_mode(VC_MATH_BF16)) as a 16-bit data
+// path: convolution forward (reference module.py:32-40, 54-62) and input gradient (autodiff of model.py:107-108) on
+// v_mfma_f32_32x32x16_bf16 with BOTH operands stored as bf16, 8 K values to a 16-byte unit, fp32 accumulate and fp32
+// output.  Same arithmetic as the operand-rounding mode of vc_conv_igemm.hip (every operand rounded to bf16 once, RNE;
+// fp32 products and sums), so the oracle's set_operand_rounding('bf16') describes it exactly.
+//
+// Layouts (built by the pack kernels below, consumed by conv_bf16_kernel):
+//   gathered operand  Xp[g][b][c/8][pixel][8]   one 16-byte unit = 8 consecutive channels of one pixel.  GEMM-K runs
+//                     (tap, channel): a K octet is ONE unit, so the loader moves 16 bytes per lane with no transposition
+//                     anywhere -- global -> LDS row [pixel][k] -> ds_read_b128 = the MFMA B fragment of that lane.
+//   filter image      Ap[g][m][k]               k-contiguous in the K order of the launch's table (padding octets 0):
+//                     forward and input gradient read it the same way, no per-row offset table, no "transposed" variant.
+//
+// Workgroup: 256 threads = 2 x 2 waves, tile 128 (m) x 128 (pixels), K chunk 64; a wave owns 64 x 64 = 2 x 2 MFMA
+// tiles (16 MFMAs of 32 cycles per chunk against 8 ds_read_b128, 8 global 16-byte loads and 8 ds_write_b128 per lane).
+// LDS rows are 144 bytes (128 + 16 padding): the b128 reads (32 rows x 2 octets per instruction) and writes are
+// conflict-free, the same pitch argument as the fp32 kernel's 36-float rows.
+#include "vc_internal.h"
+#include <algorithm>
+
+typedef const __attribute__((address_space(4))) int* c_int_p;
+typedef const __attribute__((address_space(4))) unsigned* c_uint_p;
+typedef const __attribute__((address_space(4))) Tap* c_tap_p;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+    const unsigned short a = __builtin_bit_cast(unsigned short, (__bf16)lo), b = __builtin_bit_cast(unsigned short, (__bf16)hi);
+    return (unsigned)a | ((unsigned)b << 16);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// pack kernels
+// ------------------------------------------------------------------------------------------------------------------
+// planar fp32 [g][b][C][HW] -> Xp[g][b][C/8][HW][8] bf16.  Thread = (pixel, channel octet): 8 reads 4 B (lanes along the
+// pixels: coalesced), one 16-byte store.
+__global__ __launch_bounds__(256) void pack_act_bf16_kernel(const float* __restrict__ x, long x_gs, u32x4* __restrict__ xp, long xp_gs16,
+                                                            int C8, int HW, int B) {
+    const int px = blockIdx.x * 256 + threadIdx.x;
+    if (px >= HW) return;
+    const int cb = blockIdx.y, b = blockIdx.z % B, g = blockIdx.z / B;
+    const float* src = x + (long)g * x_gs + ((long)b * C8 * 8 + (long)cb * 8) * HW + px;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = src[(long)e * HW];
+    u32x4 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+    xp[(long)g * xp_gs16 + ((long)b * C8 + cb) * HW + px] = o;
+}
+
+// filter image: Ap[g][m][k] = bf16(W[g][wsrc[k] + m * a_ms]) (0 where wsrc[k] < 0), 64 x 64 tiles through LDS.
+//   a_ms == 1 (forward: TF kernels are [tap][cin][cout], m = cout): lanes along m when reading;
+//   a_ms != 1 (input gradient: m = cin, consecutive k = consecutive cout): lanes along k when reading.
+// Writes are 16 bytes per lane, 8 lanes to a 128-byte row segment.
+__global__ __launch_bounds__(256) void pack_filter_bf16_kernel(const float* __restrict__ w, long w_gs, unsigned short* __restrict__ ap, long ap_gs,
+                                                               const int* __restrict__ wsrc, int a_ms, int M, int kp) {
+    __shared__ unsigned short tile[64][64 + 2];
+    const int k0 = blockIdx.x * 64, m0 = blockIdx.y * 64, g = blockIdx.z, tid = threadIdx.x;
+    const float* W = w + (long)g * w_gs;
+    if (a_ms == 1) {
+        const int m = tid & 63;
+#pragma unroll 4
+        for (int i = 0; i < 16; ++i) {
+            const int kk = (tid >> 6) + 4 * i, src = wsrc[k0 + kk];
+            const float v = (src >= 0 && m0 + m < M) ? W[(long)src + m0 + m] : 0.f;
+            tile[kk][m] = __builtin_bit_cast(unsigned short, (__bf16)v);
+        }
+    } else {
+        const int kk = tid & 63, src = wsrc[k0 + kk];
+#pragma unroll 4
+        for (int i = 0; i < 16; ++i) {
+            const int m = (tid >> 6) + 4 * i;
+            const float v = (src >= 0 && m0 + m < M) ? W[(long)src + (long)(m0 + m) * a_ms] : 0.f;
+            tile[kk][m] = __builtin_bit_cast(unsigned short, (__bf16)v);
+        }
+    }
+    __syncthreads();
+    const int oct = tid & 7;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = (tid >> 3) + 32 * i;
+        if (m0 + m >= M) continue;
+        unsigned q[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) q[e] = (unsigned)tile[oct * 8 + 2 * e][m] | ((unsigned)tile[oct * 8 + 2 * e + 1][m] << 16);
+        u32x4 o = {q[0], q[1], q[2], q[3]};
+        *reinterpret_cast<u32x4*>(ap + (long)g * ap_gs + (long)(m0 + m) * kp + k0 + oct * 8) = o;
+    }
+}
+
+int launch_pack_act_bf16(const float* x, long x_gs, void* xp, long xp_gs_bytes, int G, int B, int C, int HW, hipStream_t s) {
+    if (C % 8 || (long)B * G > 65535 || C / 8 > 65535) { vc_set_error("pack_act_bf16: C %% 8 != 0 or batch too large"); return -1; }
+    dim3 grid((HW + 255) / 256, C / 8, B * G);
+    pack_act_bf16_kernel<<<grid, 256, 0, s>>>(x, x_gs, (u32x4*)xp, xp_gs_bytes / 16, C / 8, HW, B);
+    VC_HIP(hipGetLastError());
+    return 0;
+}
+int launch_pack_filter_bf16(const float* w, long w_gs, void* ap, long ap_gs_bytes, const int* wsrc, int a_ms, int G, int M, int kp, hipStream_t s) {
+    dim3 grid(kp / 64, (M + 63) / 64, G);
+    pack_filter_bf16_kernel<<<grid, 256, 0, s>>>(w, w_gs, (unsigned short*)ap, ap_gs_bytes / 2, wsrc, a_ms, M, kp);
+    VC_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// the convolution
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvBf16Args p) {
+    constexpr int BM = 128, BN = 128, PITCH = 144;                 // bytes per LDS row: 8 octets + 16 padding
+    constexpr int ASZ = BM * PITCH, XSZ = BN * PITCH, STAGE = ASZ + XSZ;
+    constexpr int LDY = BN + 4;
+    static_assert(BM * LDY * 4 <= 2 * STAGE, "the epilogue stages the tile inside the operand buffers");
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm = wv >> 1, wn = wv & 1;
+
+    int mt, nt;
+    {   // XCD-aware walk, as vc_conv_igemm.hip: every XCD gets one contiguous range of the m-major tile order
+        const int total = p.mtiles * p.ntiles, per = total >> 3, tile = blockIdx.x;
+        const int idx = (tile < (per << 3)) ? (tile & 7) * per + (tile >> 3) : tile;
+        mt = idx / p.ntiles; nt = idx - mt * p.ntiles;
+    }
+    const int g = blockIdx.z / p.splitk, sp = blockIdx.z - g * p.splitk;
+    const int nchunks = p.koct >> 3;
+    const int cps = (nchunks + p.splitk - 1) / p.splitk;
+    const int c0 = sp * cps, cn = min(cps, nchunks - c0);
+    if (cn <= 0) return;
+
+    // ---- gathered operand: lane = pixel tid % 128 of the tile, octets w2 + 2 i (i = 0..3) of every chunk
+    const int w2 = __builtin_amdgcn_readfirstlane(tid >> 7);
+    const int pn = tid & 127;
+    unsigned xoffb = 0, tapmask = 0;
+    {
+        const int P = nt * BN + pn;
+        const bool pv = P < p.Ptot;
+        int xb = 0, xi = 0, xj = 0;
+        if (pv) { int r; xb = fast_divmod(P, p.NPB, p.inv_npb, &r); xi = fast_divmod(r, p.OWc, p.inv_ow, &xj); }
+        const int li0 = xi * p.si, lj0 = xj * p.sj;
+        xoffb = (unsigned)((long)xb * p.x_bs + ((long)li0 * p.xW + lj0) * 16);
+        c_tap_p taps = (c_tap_p)p.taps;
+        for (int t = 0; t < p.ntaps; ++t) {
+            const int dh = taps[t].dh, dw = taps[t].dw;
+            const bool ok = pv && (unsigned)(li0 + dh) < (unsigned)p.Hl && (unsigned)(lj0 + dw) < (unsigned)p.Wl;
+            tapmask |= (unsigned)ok << t;
+        }
+    }
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((const char*)p.X + (long)g * p.x_gs - p.xbias), 0, (int)p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ars =
+        __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.A + (long)g * p.a_gs), 0, (int)p.a_bytes, 0x00020000);
+    c_int_p xsoff = (c_int_p)p.xsoff;
+    c_uint_p otap = (c_uint_p)p.otap;
+    // ---- filter image: lane = (row tid / 8 + 32 i, octet tid % 8); rows beyond M are clamped (multiplied, never stored)
+    unsigned avoff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) avoff[i] = (unsigned)min(mt * BM + (tid >> 3) + 32 * i, p.M - 1) * (unsigned)(p.koct * 16) + (unsigned)(tid & 7) * 16u;
+
+    u32x4 xr[4], ar[4];
+    auto gload = [&](int c) {          // chunk c of the launch's K range (the tables carry 2 all-padding chunks past the end)
+        const int o0 = c * 8 + w2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int so = xsoff[o0 + 2 * i];
+            const unsigned tb = otap[o0 + 2 * i];
+            const unsigned vx = (tapmask & tb) ? xoffb : VC_OOB;
+            xr[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, vx, so, 0));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ar[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ars, avoff[i], c * 128, 0));
+    };
+    auto lstore = [&](int buf) {
+        char* As = smem + buf * STAGE; char* Xs = As + ASZ;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(Xs + pn * PITCH + (w2 + 2 * i) * 16) = xr[i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(As + ((tid >> 3) + 32 * i) * PITCH + (tid & 7) * 16) = ar[i];
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    gload(c0);
+    lstore(0);
+    gload(c0 + 1);
+    __syncthreads();
+    for (int c = 0; c < cn; ++c) {
+        const int buf = c & 1;
+        const char* As = smem + buf * STAGE + (wm * 64 + l31) * PITCH + h * 16;
+        const char* Xs = smem + buf * STAGE + ASZ + (wn * 64 + l31) * PITCH + h * 16;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(As + s * 32), a1 = *reinterpret_cast<const bf16x8*>(As + 32 * PITCH + s * 32);
+            const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(Xs + s * 32), b1 = *reinterpret_cast<const bf16x8*>(Xs + 32 * PITCH + s * 32);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        lstore(buf ^ 1);               // chunk c + 1 (its loads were issued one iteration ago); LDS[buf ^ 1] was last read in iteration c - 1
+        gload(c0 + c + 2);
+        __syncthreads();
+    }
+
+    // ---- epilogue: tile through LDS, then bias (+ addend) and 16-byte stores, or one pixel per lane for atomics /
+    //      strided parity classes (the two paths of vc_conv_igemm.hip)
+    float* Ys = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                Ys[(wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * LDY + wn * 64 + j * 32 + l31] = acc[i][j][r];
+    __syncthreads();
+    const bool atomic = p.splitk > 1 || p.accumulate;
+    const bool first = sp == 0;
+    float* Yg = p.Y + (long)g * p.y_gs;
+    const float* Bg = (p.bias && first) ? p.bias + (long)g * p.bias_gs : nullptr;
+    const float* Dg = (p.addend && first) ? p.addend + (long)g * p.add_gs : nullptr;
+    if (p.vec4 && !atomic) {
+#pragma unroll 4
+        for (int i = 0; i < BM * BN / 4 / 256; ++i) {
+            const int idx = tid + i * 256, ml = idx >> 5, n4 = (idx & 31) * 4;
+            const int m = mt * BM + ml, P0 = nt * BN + n4;
+            if (m >= p.M || P0 >= p.Ptot) continue;
+            f32x4 v = *reinterpret_cast<const f32x4*>(Ys + ml * LDY + n4);
+            if (Bg) v += Bg[m];
+            int r0, j; const int b = fast_divmod(P0, p.NPB, p.inv_npb, &r0); const int ii = fast_divmod(r0, p.OWc, p.inv_ow, &j);
+            const long o = (long)b * p.y_bs + (long)m * p.yHW + (long)(ii * p.so_h + p.o_h0) * p.yW + j + p.o_w0;
+            if (Dg) v += *reinterpret_cast<const f32x4*>(Dg + o);
+            *reinterpret_cast<f32x4*>(Yg + o) = v;
+        }
+    } else {
+        const int n = tid & 127, Pn = nt * BN + n;
+        long obase = 0;
+        if (Pn < p.Ptot) {
+            int r0, j; const int b = fast_divmod(Pn, p.NPB, p.inv_npb, &r0); const int ii = fast_divmod(r0, p.OWc, p.inv_ow, &j);
+            obase = (long)b * p.y_bs + (long)(ii * p.so_h + p.o_h0) * p.yW + (j * p.so_w + p.o_w0);
+        }
+#pragma unroll 4
+        for (int i = 0; i < BM * BN / 256; ++i) {
+            const int ml = (tid >> 7) + i * 2, m = mt * BM + ml;
+            if (m >= p.M || Pn >= p.Ptot) continue;
+            float v = Ys[ml * LDY + n];
+            if (Bg) v += Bg[m];
+            const long o = obase + (long)m * p.yHW;
+            if (Dg) v += Dg[o];
+            if (atomic) atomicAdd(Yg + o, v); else Yg[o] = v;
+        }
+    }
+}
+
+// split-K only to fill the chip (the launches this path is for, batch >= 32, rarely need it)
+void conv_bf16_config(ConvBf16Args& a) {
+    a.mtiles = (a.M + 127) / 128; a.ntiles = (a.Ptot + 127) / 128;
+    const long tiles = (long)a.mtiles * a.ntiles * a.groups;
+    const int nchunks = a.koct / 8;
+    int sk = 1;
+    while (tiles * sk < 384 && nchunks / (sk * 2) >= 4 && sk < 16) sk *= 2;
+    a.splitk = sk;
+}
+
+int launch_conv_bf16(const ConvBf16Args& a, hipStream_t s, double flops) {
+    if (a.splitk > 1 && !a.accumulate) { vc_set_error("launch_conv_bf16: split-K requires accumulate semantics"); return -1; }
+    dim3 grid(a.mtiles * a.ntiles, 1, a.groups * a.splitk);
+    ProfScope ps(0, flops, s);
+    conv_bf16_kernel<<<grid, 256, 0, s>>>(a);
+    VC_HIP(hipGetLastError());
+    return 0;
+}

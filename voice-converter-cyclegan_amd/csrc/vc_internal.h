@@ -96,6 +96,31 @@ struct WgradArgs {
     int store;                                    // dW holds no earlier contribution and split-K is 1: plain stores
 };
 
+// The 16-bit data path of the bf16 mode (vc_conv_bf16.hip): Y[g][b][m][P] (+)= sum_k Ap[g][m][k] * Xp-gather[k][P].
+//   X      packed gathered tensor  [g][b][C/8][Hl*Wl][8] bf16 (16-byte units: 8 channels of one pixel)
+//   A      packed filter image     [g][M][8*koct] bf16, k in the order of the octet table, padding octets 0
+//   xsoff  per K octet: byte offset ((c/8)*Hl*Wl + dh*xW + dw)*16 + xbias of the unit (SGPR offset of the load)
+//   otap   per K octet: 1 << tap (0 = padding octet: the load is sent out of range and returns 0)
+// Pixel grid / output fields as IgemmArgs.  Strides of A and X in BYTES, of Y / bias / addend in floats.
+struct ConvBf16Args {
+    const void* A; const void* X; float* Y; const float* bias; const float* addend;
+    const int* xsoff; const unsigned* otap; const Tap* taps; int ntaps; int xbias;
+    unsigned x_bytes, a_bytes;
+    long a_gs, x_gs, x_bs;                        // bytes
+    long y_gs, bias_gs, add_gs, y_bs;             // floats
+    int koct;                                     // K octets of the table (a multiple of 8 = whole 64-row chunks)
+    int M;
+    int Hl, Wl, xW, si, sj;
+    int NPB, OWc, Ptot; float inv_npb, inv_ow;
+    int yHW, yW, so_h, so_w, o_h0, o_w0, vec4;
+    int splitk, accumulate, mtiles, ntiles, groups;
+};
+void conv_bf16_config(ConvBf16Args& a);           // fills mtiles / ntiles / splitk
+int launch_conv_bf16(const ConvBf16Args& a, hipStream_t s, double flops);
+int launch_pack_act_bf16(const float* x, long x_gs, void* xp, long xp_gs_bytes, int G, int B, int C, int HW, hipStream_t s);
+// Ap[g][m][k] = bf16(W[g][wsrc[k] + m * a_ms]), 0 where wsrc[k] < 0; kp = 8 * koct
+int launch_pack_filter_bf16(const float* w, long w_gs, void* ap, long ap_gs_bytes, const int* wsrc, int a_ms, int G, int M, int kp, hipStream_t s);
+
 // Single-input-channel convolution (the discriminator's first layer, module.py:201-202: Cin = 1, 3x3 -> K = 9): a
 // bandwidth job, done on the vector ALU instead of padding K = 9 up to an MFMA tile.  kh*kw <= 9.
 struct C1Args {
