@@ -496,6 +496,38 @@ static int conv_wgrad(const WgradApp* apps, int napps, float* dw, long dw_gs, in
     }
     VC_ARG(napps >= 1 && napps <= 2, "conv filter gradient: 1 or 2 applications per launch");
     Table t; VC_CHECK(get_fwd_table(g, &t));
+    {
+        long ptot = 0; for (int k = 0; k < napps; ++k) ptot += (long)apps[k].B * g.OH * g.OW;
+        if (bf16_path(t, math, g.Cout, ptot) && (g.OH * g.OW) % 8 == 0) {
+            // 16-bit data path: X channel-octet packed, dY planar bf16 (one pack launch each per application)
+            WgradBf16Args a{};
+            a.dW = dw; a.dw_gs = dw_gs; a.oxs = t.oxs; a.otap = t.otap; a.wsrc = t.wsrc; a.taps = t.taps; a.xbias = t.oxbias;
+            a.x_bs = (long)g.Cin * g.H * g.W * 2; a.dy_bs = (long)g.Cout * g.OH * g.OW * 2;
+            a.koct = t.koct; a.N = g.Cout; a.Hl = g.H; a.Wl = g.W; a.xW = g.W; a.si = g.sh; a.sj = g.sw;
+            a.NPB = g.OH * g.OW; a.OWc = g.OW; a.inv_npb = 1.0f / (float)a.NPB; a.inv_ow = 1.0f / (float)g.OW;
+            a.groups = G; a.nseg = napps; a.nchunks = 0; a.store = store ? 1 : 0;
+            size_t off[2][2], tot = 0; double flops = 0;
+            for (int k = 0; k < napps; ++k) {
+                VC_CHECK(check_conv_geom(g, apps[k].B));
+                WgradBf16Seg& sg = a.seg[k];
+                sg.x_gs = (long)align256((size_t)apps[k].B * a.x_bs); sg.dy_gs = (long)align256((size_t)apps[k].B * a.dy_bs);
+                sg.x_bytes = (unsigned)((long)apps[k].B * a.x_bs + t.oxbias); sg.dy_bytes = (unsigned)((long)apps[k].B * a.dy_bs);
+                sg.Ptot = apps[k].B * a.NPB; sg.nchunks = (sg.Ptot + 63) / 64;
+                a.nchunks += sg.nchunks;
+                off[k][0] = tot; tot += (size_t)sg.x_gs * G; off[k][1] = tot; tot += (size_t)sg.dy_gs * G;
+                flops += 2.0 * G * apps[k].B * a.NPB * (double)g.Cout * t.valid;
+            }
+            wgrad_bf16_config(a);
+            if (query) { *query = !store || a.splitk > 1; return 0; }
+            char* wsp; VC_CHECK(pack_space(s, tot, &wsp));
+            for (int k = 0; k < napps; ++k) {
+                a.seg[k].X = wsp + off[k][0]; a.seg[k].dY = wsp + off[k][1];
+                VC_CHECK(launch_pack_act_bf16(apps[k].x, apps[k].x_gs, wsp + off[k][0], a.seg[k].x_gs, G, apps[k].B, g.Cin, g.H * g.W, s));
+                VC_CHECK(launch_pack_planar_bf16(apps[k].dy, apps[k].dy_gs, wsp + off[k][1], a.seg[k].dy_gs, G, (long)apps[k].B * g.Cout * a.NPB, s));
+            }
+            return launch_wgrad_bf16(a, s, flops);
+        }
+    }
     WgradArgs a{};
     a.dW = dw; a.ktab = t.dev; a.xsoff = t.xsoff; a.xbias = t.xbias; a.dw_gs = dw_gs;
     a.x_bs = (long)g.Cin * g.H * g.W; a.dy_bs = (long)g.Cout * g.OH * g.OW;
