@@ -141,11 +141,17 @@ static int upload_table(const std::vector<HostRow>& rows, const std::vector<int>
     if (oct) {
         long omin = 0;
         for (const HostRow& r : rows) omin = std::min(omin, ((long)(r.c / 8) * xH * xW + (long)r.dh * xW + r.dw) * 16);
+        // K order of this view: channel octet major, tap minor.  The taps of one channel octet read the same 16-byte
+        // units shifted by a pixel, so putting them next to each other turns kh*kw - 1 of every kh*kw fetches of the
+        // gathered tensor into cache hits (tap-major order re-streamed the whole tensor once per tap: measured 43 % L2
+        // misses, the launch bound by fabric traffic).  Any K order is correct: the filter image is built in the same one.
         std::vector<int> oxs, wsrc; std::vector<unsigned> otap;
-        for (size_t k = 0; k < rows.size(); ++k) {
+        std::vector<size_t> first;                            // first row of every octet, in tap-major table order
+        for (size_t k = 0; k < rows.size(); k += 8) first.push_back(k);
+        std::stable_sort(first.begin(), first.end(), [&](size_t a, size_t b) { return rows[a].c < rows[b].c; });
+        for (size_t k : first) {
             const HostRow& r = rows[k];
-            wsrc.push_back(r.a_off);
-            if (k % 8) continue;
+            for (int e = 0; e < 8; ++e) wsrc.push_back(rows[k + e].a_off);
             const long so = ((long)(r.c / 8) * xH * xW + (long)r.dh * xW + r.dw) * 16 - omin;
             if (so > 0x7fffff00L) { oct = false; break; }
             oxs.push_back((int)so); otap.push_back(1u << r.tap);
@@ -154,7 +160,7 @@ static int upload_table(const std::vector<HostRow>& rows, const std::vector<int>
             auto pad_oct = [&]() { oxs.push_back((int)-omin); otap.push_back(0u); for (int e = 0; e < 8; ++e) wsrc.push_back(-1); };
             while (oxs.size() % 8) pad_oct();
             t->koct = (int)oxs.size(); t->oxbias = (int)-omin;
-            for (int i = 0; i < 16; ++i) pad_oct();            // the loader runs two chunks past its K range
+            for (int i = 0; i < 40; ++i) pad_oct();            // the loaders run up to four chunks past their K range
             VC_CHECK(to_device(oxs, &t->oxs)); VC_CHECK(to_device(otap, &t->otap)); VC_CHECK(to_device(wsrc, &t->wsrc));
         }
     }
@@ -288,6 +294,15 @@ static int pack_space(hipStream_t s, size_t bytes, char** out) {
     return 0;
 }
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+// 256 zero bytes in device memory (process lifetime): where the LDS-direct copies of padding taps read
+static int zero_page(const void** out) {
+    static void* z = nullptr;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> l(mu);
+    if (!z) { VC_HIP(hipMalloc(&z, 256)); VC_HIP(hipMemset(z, 0, 256)); }
+    *out = z;
+    return 0;
+}
 // the path serves launches that fill its 128 x 128 tiles; everything else stays on the table-driven fp32-storage kernels
 static bool bf16_path(const Table& t, int math, int M, long Ptot) { return math == VC_MATH_BF16 && t.koct > 0 && M >= 64 && Ptot >= 64; }
 static void bf16_set_vec4(ConvBf16Args& a) {
@@ -298,7 +313,7 @@ static void bf16_set_vec4(ConvBf16Args& a) {
 // query != nullptr: do not launch, only report whether the launch would use split-K atomics (needs a zeroed y)
 static int conv_fwd(const float* x, long x_gs, const float* w, long w_gs, const float* bias, long b_gs,
                     float* y, long y_gs, int G, int B, const Geom& g, int math, hipStream_t s,
-                    bool prezeroed = false, bool* query = nullptr) {
+                    bool prezeroed = false, bool* query = nullptr, const char* packed_w = nullptr) {
     VC_CHECK(check_conv_geom(g, B));
     if (c1_path(g)) {      // Cin = 1 (D.h1): vector-ALU kernel, plain stores, never needs a zeroed destination
         if (query) { *query = false; return 0; }
@@ -328,10 +343,11 @@ static int conv_fwd(const float* x, long x_gs, const float* w, long w_gs, const 
         bf16_set_vec4(a);
         conv_bf16_config(a);
         if (query) { *query = a.splitk > 1; return 0; }
-        char* wsp; VC_CHECK(pack_space(s, (xp_g + ap_g) * G, &wsp));
-        a.X = wsp; a.A = wsp + xp_g * G;
+        char* wsp; VC_CHECK(pack_space(s, xp_g * G + (packed_w ? 0 : ap_g * G), &wsp));
+        VC_CHECK(zero_page(&a.zeros));
+        a.X = wsp; a.A = packed_w ? packed_w : wsp + xp_g * G;
         VC_CHECK(launch_pack_act_bf16(x, x_gs, wsp, (long)xp_g, G, B, g.Cin, g.H * g.W, s));
-        VC_CHECK(launch_pack_filter_bf16(w, w_gs, wsp + xp_g * G, (long)ap_g, t.wsrc, 1, G, g.Cout, t.koct * 8, s));
+        if (!packed_w) VC_CHECK(launch_pack_filter_bf16(w, w_gs, wsp + xp_g * G, (long)ap_g, t.wsrc, 1, G, g.Cout, t.koct * 8, s));
         if (a.splitk > 1) {
             if (!prezeroed)
                 for (int gi = 0; gi < G; ++gi) VC_HIP(hipMemsetAsync(y + (long)gi * y_gs, 0, (size_t)B * a.y_bs * sizeof(float), s));
@@ -365,7 +381,7 @@ static int conv_fwd(const float* x, long x_gs, const float* w, long w_gs, const 
 
 static int conv_dgrad(const float* dy, long dy_gs, const float* w, long w_gs, float* dx, long dx_gs,
                       const float* addend, long add_gs, int accumulate, int G, int B, const Geom& g, int math, hipStream_t s,
-                      bool prezeroed = false, bool* query = nullptr) {
+                      bool prezeroed = false, bool* query = nullptr, const char* const* packed_w = nullptr) {
     VC_CHECK(check_conv_geom(g, B));
     if (c1_path(g)) {
         if (query) { *query = false; return 0; }      // zeroes dx itself when it has to
@@ -415,7 +431,8 @@ static int conv_dgrad(const float* dy, long dy_gs, const float* w, long w_gs, fl
                 wsrc[nc] = t.wsrc; flb[nc] = 2.0 * G * B * a.NPB * (double)g.Cin * t.valid; cl[nc++] = a;
             }
             if (query) { *query = split; return 0; }
-            char* wsp; VC_CHECK(pack_space(s, xp_g * G + ap_tot, &wsp));
+            char* wsp; VC_CHECK(pack_space(s, xp_g * G + (packed_w ? 0 : ap_tot), &wsp));
+            for (int i = 0; i < nc; ++i) VC_CHECK(zero_page(&cl[i].zeros));
             VC_CHECK(launch_pack_act_bf16(dy, dy_gs, wsp, (long)xp_g, G, B, g.Cout, g.OH * g.OW, s));
             if (split && !accumulate) {
                 if (!prezeroed)
@@ -424,8 +441,8 @@ static int conv_dgrad(const float* dy, long dy_gs, const float* w, long w_gs, fl
                 for (int i = 0; i < nc; ++i) cl[i].accumulate = 1;
             }
             for (int i = 0; i < nc; ++i) {
-                cl[i].X = wsp; cl[i].A = wsp + xp_g * G + ap_off[i];
-                VC_CHECK(launch_pack_filter_bf16(w, w_gs, wsp + xp_g * G + ap_off[i], cl[i].a_gs, wsrc[i], g.Cout, G, g.Cin, cl[i].koct * 8, s));
+                cl[i].X = wsp; cl[i].A = packed_w ? packed_w[i] : wsp + xp_g * G + ap_off[i];
+                if (!packed_w) VC_CHECK(launch_pack_filter_bf16(w, w_gs, wsp + xp_g * G + ap_off[i], cl[i].a_gs, wsrc[i], g.Cout, G, g.Cin, cl[i].koct * 8, s));
                 VC_CHECK(launch_conv_bf16(cl[i], s, flb[i]));
             }
             return 0;
@@ -798,6 +815,11 @@ struct vc_plan {
     hipEvent_t ev_gin = nullptr, ev_gout = nullptr, ev_ujoin = nullptr;
     float* packed = nullptr;                              // inference plans: packed h1 filters for gated_conv1d_glu_kernel (2 groups)
     float* hp_dev = nullptr;                              // {lambda_cycle, lambda_identity, alpha_g, alpha_d} of the step being replayed
+    // bf16 data path: filter images of every layer (forward + one per input-gradient parity class), rebuilt from the
+    // fp32 weights once at the start of a train step instead of before every launch (a step uses each image 2-3 times)
+    struct LayerImages { const char* fwd = nullptr; const char* dg[4] = {nullptr, nullptr, nullptr, nullptr}; bool has_dg = false; };
+    mutable std::vector<LayerImages> img_g, img_d;
+    mutable char* img_block = nullptr;
 };
 
 static void plan_geos(const NetDesc& n, int C0, int H0, int W0, std::vector<LayerGeo>& out) {
@@ -888,6 +910,7 @@ extern "C" void vc_plan_destroy(vc_plan* p) {
     if (p->ev_ujoin) (void)hipEventDestroy(p->ev_ujoin);
     if (p->hp_dev) (void)hipFree(p->hp_dev);
     if (p->packed) (void)hipFree(p->packed);
+    if (p->img_block) (void)hipFree(p->img_block);
     release_tables(p->tables);
     delete p;
 }
@@ -949,6 +972,7 @@ struct NetCtx {
     hipStream_t s;
     hipStream_t ws = nullptr; const hipEvent_t* ev_layer = nullptr; hipEvent_t ev_wjoin = nullptr;   // wgrad stream (null: same stream)
     float* packed = nullptr;               // packed filter image of the fused gated block (plan-owned, 2 groups)
+    const std::vector<vc_plan::LayerImages>* images = nullptr;   // bf16 data path: this step's prebuilt filter images
     bool fuse_glu = false;                 // forward only: gated blocks without instance norm go out as one conv + GLU kernel
     int wmode = W_SELF;                    // W_NONE: leave the conv filter gradients to a later application (DeferredApp)
     bool wgrad_store = false;              // this backward's filter gradients are the step's only contribution to dparams' conv kernels
@@ -990,7 +1014,7 @@ static int net_forward(NetCtx& c, const float* x, long x_gs, float* y_plain, lon
             if (r != -2) { VC_CHECK(r); in = f.y; in_gs = c.save_gs; continue; }
         }
         VC_CHECK(conv_fwd(in, in_gs, c.params + L.w, c.par_gs, c.params + L.b, c.par_gs, raw, raw_gs, c.G, c.B, lg.g, c.math, c.s,
-                          /*prezeroed=*/L.mode != M_PLAIN));
+                          /*prezeroed=*/L.mode != M_PLAIN, nullptr, c.images ? (*c.images)[i].fwd : nullptr));
         if (L.mode == M_PLAIN) break;
         NormArgs a{};
         a.y = raw; a.y_gs = raw_gs; a.out = c.save + c.sm.act[i]; a.out_gs = c.save_gs;
@@ -1069,14 +1093,16 @@ static int net_backward(NetCtx& c, const float* x, long x_gs, const float* dtop,
         }
         for (int k = 0; k < c.n_ev; ++k) if (c.ev_first[k] == i) VC_HIP(hipEventRecord(c.ev[k], ws));
         if (i == 0) {
-            if (dx) VC_CHECK(conv_dgrad(dyp, dy_gs, c.params + L.w, c.par_gs, dx, dx_gs, nullptr, 0, dx_acc, c.G, c.B, lg.g, c.math, c.s));
+            if (dx) VC_CHECK(conv_dgrad(dyp, dy_gs, c.params + L.w, c.par_gs, dx, dx_gs, nullptr, 0, dx_acc, c.G, c.B, lg.g, c.math, c.s,
+                                        false, nullptr, (c.images && (*c.images)[i].has_dg) ? (*c.images)[i].dg : nullptr));
             for (int k = 0; k < c.n_ev; ++k) if (c.ev_free && c.ev_first[k] == i) VC_HIP(hipEventRecord(c.ev_free[k], c.s));
             break;        // falls through to the join below
         }
         // gradient w.r.t. this layer's input = activation of layer i-1; the head of a residual block adds the skip
         const bool block_head = (L.mode == M_GATED_IN && i + 1 < nl && c.n->layers[i + 1].mode == M_IN_RES);
         VC_CHECK(conv_dgrad(dyp, dy_gs, c.params + L.w, c.par_gs, scratch + dAo[i - 1], scr_gs,
-                            block_head ? skip : nullptr, block_head ? skip_gs : 0, 0, c.G, c.B, lg.g, c.math, c.s, /*prezeroed=*/true));
+                            block_head ? skip : nullptr, block_head ? skip_gs : 0, 0, c.G, c.B, lg.g, c.math, c.s, /*prezeroed=*/true,
+                            nullptr, (c.images && (*c.images)[i].has_dg) ? (*c.images)[i].dg : nullptr));
         if (block_head) skip = nullptr;
         for (int k = 0; k < c.n_ev; ++k) if (c.ev_free && c.ev_first[k] == i) VC_HIP(hipEventRecord(c.ev_free[k], c.s));
         dcur = scratch + dAo[i - 1]; dcur_gs = scr_gs;
@@ -1100,9 +1126,19 @@ static NetCtx disc_ctx(const vc_plan* p, const float* params, long par_gs, float
     return c;
 }
 
+// The step's prebuilt filter images (refresh_filter_images) describe `params` of the running step, two groups: only the
+// step itself hands them to its network passes (StepImages scope); operator- and network-level calls pack per launch.
+static thread_local const vc_plan* t_step_images = nullptr;
+struct StepImages { StepImages(const vc_plan* p) { t_step_images = p; } ~StepImages() { t_step_images = nullptr; } };
+static const std::vector<vc_plan::LayerImages>* step_images(const vc_plan* p, bool gen, int G) {
+    if (t_step_images != p || G != 2 || p->math != VC_MATH_BF16) return nullptr;
+    const auto& v = gen ? p->img_g : p->img_d;
+    return v.empty() ? nullptr : &v;
+}
 static int gen_forward(const vc_plan* p, const float* params, long par_gs, const float* x, long x_gs,
                        float* y, long y_gs, float* save, int G, int B, hipStream_t s) {
     NetCtx c = gen_ctx(p, params, par_gs, nullptr, 0, save, G, B, B, s);
+    c.images = step_images(p, true, G);
     c.fuse_glu = p->inference; c.packed = p->packed;
     return net_forward(c, x, x_gs, y, y_gs);
 }
@@ -1114,6 +1150,7 @@ static int gen_backward(const vc_plan* p, const float* params, long par_gs, cons
     VC_ARG(!p->inference, "this plan was created for inference only (vc_plan_create_inference)");
     NetCtx c = gen_ctx(p, params, par_gs, dparams, dpar_gs, save, G, B, Bl, s);
     c.wgrad_store = o.wgrad_store; c.wmode = o.wmode; c.deferred = o.deferred;
+    c.images = step_images(p, true, G);
     if ((p->use_side & 2) && dparams && o.wmode != W_NONE) { c.ws = p->wstream; c.ev_layer = p->ev_layer; c.ev_wjoin = p->ev_wjoin; }
     if (o.record_buckets) { c.ev_first = p->bucket_first; c.ev = p->g_ready; c.ev_free = p->g_free; c.n_ev = vc_plan::kBuckets; }
     return net_backward(c, x, x_gs, dy, dy_gs, dx, dx_gs, dx_acc, scratch, scr_gs);
@@ -1122,6 +1159,7 @@ static int disc_forward(const vc_plan* p, const float* params, long par_gs, cons
                         float* o, long o_gs, float* save, int G, int B, hipStream_t s) {
     VC_ARG(!p->inference, "this plan was created for inference only (vc_plan_create_inference)");
     NetCtx c = disc_ctx(p, params, par_gs, nullptr, 0, save, G, B, B, s);
+    c.images = step_images(p, false, G);
     VC_CHECK(net_forward(c, x, x_gs, nullptr, 0));
     const int last = (int)p->D.layers.size() - 1;
     return launch_head_fwd(save + c.sm.act[last], c.save_gs, params + p->D.head_w, params + p->D.head_b, par_gs,
@@ -1135,6 +1173,7 @@ static int disc_backward(const vc_plan* p, const float* params, long par_gs, con
     VC_ARG(!p->inference, "this plan was created for inference only (vc_plan_create_inference)");
     NetCtx c = disc_ctx(p, params, par_gs, dparams, dpar_gs, save, G, B, Bl, s);
     c.wgrad_store = wgrad_store;
+    c.images = step_images(p, false, G);
     if ((p->use_side & 4) && dparams) { c.ws = p->wstream_d; c.ev_layer = p->ev_layer_d; c.ev_wjoin = p->ev_wjoin_d; }
     const int last = (int)p->D.layers.size() - 1;
     // the head's input gradient goes where net_backward's scratch map puts dA[last]
@@ -1249,6 +1288,56 @@ static int zero_step_grads(const vc_plan* p, float* grads, int B, int Bbwd, hipS
 
 // hp != nullptr: lambda_cycle / lambda_identity are read from hp[0..1] on the device (a captured step is replayed with new
 // values); the host copies still decide the schedule (lambda_identity == 0 skips the identity half).
+// bf16 data path: build every layer's filter images from the step's fp32 weights (both generators / both discriminators
+// as the two groups of one launch).  Runs on the step's main stream before anything forks from it.
+static int refresh_filter_images(const vc_plan* p, const float* params, hipStream_t s) {
+    const long PG = p->G.total, PD = p->D.total;
+    struct Job { const float* w; long w_gs; const int* wsrc; int a_ms, M, kp; size_t off, gs; };
+    std::vector<Job> jobs; size_t tot = 256;        // offsets are never 0, so 0 / nullptr can mean 'no image'
+    const bool first = p->img_g.empty();
+    std::vector<vc_plan::LayerImages> ig(p->G.layers.size()), id(p->D.layers.size());
+    for (int net = 0; net < 2; ++net) {
+        const NetDesc& n = net ? p->D : p->G; const auto& geo = net ? p->dg : p->gg; auto& img = net ? id : ig;
+        const float* base = net ? params + 2 * PG : params; const long gs = net ? PD : PG;
+        for (size_t i = 0; i < n.layers.size(); ++i) {
+            const Geom& g = geo[i].g;
+            if (c1_path(g)) continue;
+            Table t; VC_CHECK(get_fwd_table(g, &t));
+            if (t.koct > 0 && g.Cout >= 64) {
+                const size_t a = align256((size_t)g.Cout * t.koct * 16);
+                jobs.push_back(Job{base + n.layers[i].w, gs, t.wsrc, 1, g.Cout, t.koct * 8, tot, a});
+                img[i].fwd = (const char*)tot; tot += 2 * a;
+            }
+            bool all = g.Cin >= 64; size_t off[4]; Job cj[4]; int nc = 0;
+            for (int ph = 0; ph < g.sh && all; ++ph) for (int pw = 0; pw < g.sw && all; ++pw) {
+                Table td; VC_CHECK(get_dgrad_table(g, ph, pw, &td));
+                if (td.koct <= 0) { all = false; break; }
+                const size_t a = align256((size_t)g.Cin * td.koct * 16);
+                cj[nc] = Job{base + n.layers[i].w, gs, td.wsrc, g.Cout, g.Cin, td.koct * 8, tot, a}; off[nc++] = tot; tot += 2 * a;
+            }
+            if (all && nc) { for (int k = 0; k < nc; ++k) { jobs.push_back(cj[k]); img[i].dg[k] = (const char*)off[k]; } img[i].has_dg = true; }
+            else if (nc) tot = off[0];            // give the partial reservation back
+        }
+    }
+    if (first) {
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        if (s && hipStreamIsCapturing(s, &st) == hipSuccess && st != hipStreamCaptureStatusNone) {
+            vc_set_error("bf16 data path: run one eager step before capturing (the filter images are allocated on first use)");
+            return VC_E_STATE;
+        }
+        VC_HIP(hipMalloc((void**)&p->img_block, tot + 256));
+        for (auto* v : {&ig, &id})
+            for (auto& li : *v) {
+                if (li.fwd) li.fwd = p->img_block + (size_t)li.fwd;
+                for (int k = 0; k < 4; ++k) if (li.dg[k]) li.dg[k] = p->img_block + (size_t)li.dg[k];
+            }
+        p->img_g = ig; p->img_d = id;
+    }
+    for (const Job& j : jobs)
+        VC_CHECK(launch_pack_filter_bf16(j.w, j.w_gs, p->img_block + j.off, (long)j.gs, j.wsrc, j.a_ms, 2, j.M, j.kp, s));
+    return 0;
+}
+
 static int step_grads_impl(const vc_plan* p, const float* params, float* grads,
                            const float* A, const float* Bm, int batch,
                            float lambda_cycle, float lambda_identity, const float* hp,
@@ -1278,6 +1367,8 @@ static int step_grads_impl(const vc_plan* p, const float* params, float* grads,
     const int Bbwd = (lambda_identity == 0.0f) ? B : 2 * B;
 
     hipStream_t s2 = (p->use_side & 1) ? p->side : s;
+    if (p->math == VC_MATH_BF16) VC_CHECK(refresh_filter_images(p, params, s));
+    StepImages scope(p->math == VC_MATH_BF16 ? p : nullptr);
     // 1. first-hop inputs: g0 = A2B on [A;B], g1 = B2A on [B;A]   (model.py:44,51 / 47,50)
     VC_HIP(hipMemcpyAsync(X1, A, FTb, hipMemcpyDeviceToDevice, s));
     VC_HIP(hipMemcpyAsync(X1 + ft1, Bm, FTb, hipMemcpyDeviceToDevice, s));

@@ -6,22 +6,34 @@
 //
 // Layouts (built by the pack kernels below, consumed by conv_bf16_kernel):
 //   gathered operand  Xp[g][b][c/8][pixel][8]   one 16-byte unit = 8 consecutive channels of one pixel.  GEMM-K runs
-//                     (tap, channel): a K octet is ONE unit, so the loader moves 16 bytes per lane with no transposition
-//                     anywhere -- global -> LDS row [pixel][k] -> ds_read_b128 = the MFMA B fragment of that lane.
-//   filter image      Ap[g][m][k]               k-contiguous in the K order of the launch's table (padding octets 0):
-//                     forward and input gradient read it the same way, no per-row offset table, no "transposed" variant.
+//                     (channel octet, tap): a K octet is ONE unit, so 64 consecutive pixels of an octet are 1 KB of
+//                     global memory AND the MFMA B fragments of 64 lanes.
+//   filter image      Ap[g][k/8][m][8]          the same shape with the output channel in the pixel's place, K in the order
+//                     of the launch's table (padding octets 0): forward and input gradient read it the same way.
+// Both operands therefore move global -> LDS with global_load_lds_dwordx4 (lane-linear 1 KB copies: no staging registers,
+// no ds_write pass), the LDS stage [octet][row][16 B] is read back with ds_read_b128 at consecutive 16-byte units per
+// lane (conflict-free without padding), and nothing is transposed anywhere.  Lanes of padding taps are sent out of the
+// buffer's range: the hardware returns, and copies, zeros.
 //
-// Workgroup: 256 threads = 2 x 2 waves, tile 128 (m) x 128 (pixels), K chunk 64; a wave owns 64 x 64 = 2 x 2 MFMA
-// tiles (16 MFMAs of 32 cycles per chunk against 8 ds_read_b128, 8 global 16-byte loads and 8 ds_write_b128 per lane).
-// LDS rows are 144 bytes (128 + 16 padding): the b128 reads (32 rows x 2 octets per instruction) and writes are
-// conflict-free, the same pitch argument as the fp32 kernel's 36-float rows.
+// Workgroup: 256 threads = 2 x 2 waves, tile 128 (m) x 128 (pixels), K chunk 64, two 32 KB LDS stages; a wave owns
+// 64 x 64 = 2 x 2 MFMA tiles (16 MFMAs of 32 cycles per chunk against 16 ds_read_b128 and 8 LDS-direct copies).
 #include "vc_internal.h"
 #include <algorithm>
+#include <type_traits>
 
 typedef const __attribute__((address_space(4))) int* c_int_p;
 typedef const __attribute__((address_space(4))) unsigned* c_uint_p;
 typedef const __attribute__((address_space(4))) Tap* c_tap_p;
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// 1 KB per wave, global -> LDS without registers: lane l's 16 bytes land at lds + 16 l (buffer_load_dwordx4 ... lds).
+// voff beyond the buffer's range copies zeros.  (The host pass of hipcc does not know the builtin: device pass only.)
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+__device__ __forceinline__ void lds_copy16(__amdgpu_buffer_rsrc_t rs, lds_ptr_t lds, unsigned voff, unsigned soff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, lds, 16, voff, soff, 0, 0);
+#endif
+}
 
 __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
     const unsigned short a = __builtin_bit_cast(unsigned short, (__bf16)lo), b = __builtin_bit_cast(unsigned short, (__bf16)hi);
@@ -46,10 +58,10 @@ __global__ __launch_bounds__(256) void pack_act_bf16_kernel(const float* __restr
     xp[(long)g * xp_gs16 + ((long)b * C8 + cb) * HW + px] = o;
 }
 
-// filter image: Ap[g][m][k] = bf16(W[g][wsrc[k] + m * a_ms]) (0 where wsrc[k] < 0), 64 x 64 tiles through LDS.
+// filter image: Ap[g][k/8][m][k%8] = bf16(W[g][wsrc[k] + m * a_ms]) (0 where wsrc[k] < 0), 64 x 64 tiles through LDS.
 //   a_ms == 1 (forward: TF kernels are [tap][cin][cout], m = cout): lanes along m when reading;
 //   a_ms != 1 (input gradient: m = cin, consecutive k = consecutive cout): lanes along k when reading.
-// Writes are 16 bytes per lane, 8 lanes to a 128-byte row segment.
+// Writes are 16 bytes per lane, lanes along m.
 __global__ __launch_bounds__(256) void pack_filter_bf16_kernel(const float* __restrict__ w, long w_gs, unsigned short* __restrict__ ap, long ap_gs,
                                                                const int* __restrict__ wsrc, int a_ms, int M, int kp) {
     __shared__ unsigned short tile[64][64 + 2];
@@ -73,16 +85,17 @@ __global__ __launch_bounds__(256) void pack_filter_bf16_kernel(const float* __re
         }
     }
     __syncthreads();
-    const int oct = tid & 7;
+    const int m = tid & 63;                      // lanes along m: 1 KB of one image octet per wave instruction
+    if (m0 + m < M) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int m = (tid >> 3) + 32 * i;
-        if (m0 + m >= M) continue;
-        unsigned q[4];
+        for (int i = 0; i < 2; ++i) {
+            const int oct = (tid >> 6) + 4 * i;
+            unsigned q[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) q[e] = (unsigned)tile[oct * 8 + 2 * e][m] | ((unsigned)tile[oct * 8 + 2 * e + 1][m] << 16);
-        u32x4 o = {q[0], q[1], q[2], q[3]};
-        *reinterpret_cast<u32x4*>(ap + (long)g * ap_gs + (long)(m0 + m) * kp + k0 + oct * 8) = o;
+            for (int e = 0; e < 4; ++e) q[e] = (unsigned)tile[oct * 8 + 2 * e][m] | ((unsigned)tile[oct * 8 + 2 * e + 1][m] << 16);
+            u32x4 o = {q[0], q[1], q[2], q[3]};
+            *reinterpret_cast<u32x4*>(ap + (long)g * ap_gs + ((long)(k0 / 8 + oct) * M + m0 + m) * 8) = o;
+        }
     }
 }
 
@@ -119,12 +132,12 @@ int launch_pack_filter_bf16(const float* w, long w_gs, void* ap, long ap_gs_byte
 // ------------------------------------------------------------------------------------------------------------------
 // the convolution
 // ------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvBf16Args p) {
-    constexpr int BM = 128, BN = 128, PITCH = 144;                 // bytes per LDS row: 8 octets + 16 padding
-    constexpr int ASZ = BM * PITCH, XSZ = BN * PITCH, STAGE = ASZ + XSZ;
+template <int BM, int NST> __global__ __launch_bounds__(256, NST <= 2 ? 2 : 1) void conv_bf16_kernel(const ConvBf16Args p) {
+    constexpr int BN = 128, MI = BM / 64;                 // a wave owns MI x 2 MFMA tiles: rows [wm * BM/2, +BM/2), pixels [wn * 64, +64)
+    constexpr int ASZ = 8 * BM * 16, XSZ = 8 * BN * 16, STAGE = ASZ + XSZ;      // one K chunk: [octet][row][16 B] for both operands
     constexpr int LDY = BN + 4;
-    static_assert(BM * LDY * 4 <= 2 * STAGE, "the epilogue stages the tile inside the operand buffers");
-    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+    static_assert(BM * LDY * 4 <= 3 * STAGE, "the epilogue stages the tile inside the operand buffers");
+    __shared__ __attribute__((aligned(16))) char smem[BM * LDY * 4 > NST * STAGE ? BM * LDY * 4 : NST * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, h = lane >> 5;
@@ -142,96 +155,132 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvBf16Args p)
     const int c0 = sp * cps, cn = min(cps, nchunks - c0);
     if (cn <= 0) return;
 
-    // ---- gathered operand: lane = pixel tid % 128 of the tile, octets w2 + 2 i (i = 0..3) of every chunk
-    const int w2 = __builtin_amdgcn_readfirstlane(tid >> 7);
-    const int pn = tid & 127;
-    unsigned xoffb = 0, tapmask = 0;
-    {
-        const int P = nt * BN + pn;
+    // ---- global -> LDS copies (global_load_lds_dwordx4: lane l of the instruction lands at base + 16 l, no register
+    //      staging, no ds_write): a wave moves octets 2 wv and 2 wv + 1 of every chunk, rows [0, 64) and [64, 128) of both
+    //      operands = 8 copies of 1 KB per chunk.  The lane's two pixels / two filter rows:
+    unsigned xoffb[2], tapmask[2];
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+        const int P = nt * BN + hf * 64 + lane;
         const bool pv = P < p.Ptot;
         int xb = 0, xi = 0, xj = 0;
         if (pv) { int r; xb = fast_divmod(P, p.NPB, p.inv_npb, &r); xi = fast_divmod(r, p.OWc, p.inv_ow, &xj); }
         const int li0 = xi * p.si, lj0 = xj * p.sj;
-        xoffb = (unsigned)((long)xb * p.x_bs + ((long)li0 * p.xW + lj0) * 16);
+        xoffb[hf] = (unsigned)((long)xb * p.x_bs + ((long)li0 * p.xW + lj0) * 16);
+        unsigned tm = 0;
         c_tap_p taps = (c_tap_p)p.taps;
         for (int t = 0; t < p.ntaps; ++t) {
             const int dh = taps[t].dh, dw = taps[t].dw;
             const bool ok = pv && (unsigned)(li0 + dh) < (unsigned)p.Hl && (unsigned)(lj0 + dw) < (unsigned)p.Wl;
-            tapmask |= (unsigned)ok << t;
+            tm |= (unsigned)ok << t;
         }
+        tapmask[hf] = tm;
     }
+    // buffer addressing: the lane's pixel (or VC_OOB for a padding tap: the hardware range check returns -- and copies --
+    // zeros) in the VGPR offset, the K octet in the SGPR offset; no per-copy address arithmetic on the vector ALU
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
         (void*)((const char*)p.X + (long)g * p.x_gs - p.xbias), 0, (int)p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t ars =
         __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.A + (long)g * p.a_gs), 0, (int)p.a_bytes, 0x00020000);
+    unsigned avoff[MI];         // filter image [octet][M][16 B]; rows beyond M are clamped (multiplied, never stored)
+#pragma unroll
+    for (int hf = 0; hf < MI; ++hf) avoff[hf] = (unsigned)min(mt * BM + hf * 64 + lane, p.M - 1) * 16u;
+    const unsigned a_os = (unsigned)p.M * 16u;          // bytes between consecutive octets of the image
     c_int_p xsoff = (c_int_p)p.xsoff;
     c_uint_p otap = (c_uint_p)p.otap;
-    // ---- filter image: lane = (row tid / 8 + 32 i, octet tid % 8); rows beyond M are clamped (multiplied, never stored)
-    unsigned avoff[4];
+    // table entries of the chunk the NEXT issue() copies (fetched one iteration ahead: a scalar load is a few hundred
+    // cycles, and issue() sits between the barrier and the iteration's first MFMA)
+    int tso[2]; unsigned ttb[2];
+    auto fetch_tab = [&](int c) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) avoff[i] = (unsigned)min(mt * BM + (tid >> 3) + 32 * i, p.M - 1) * (unsigned)(p.koct * 16) + (unsigned)(tid & 7) * 16u;
-
-    u32x4 xr[4], ar[4];
-    auto gload = [&](int c) {          // chunk c of the launch's K range (the tables carry 2 all-padding chunks past the end)
-        const int o0 = c * 8 + w2;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int so = xsoff[o0 + 2 * i];
-            const unsigned tb = otap[o0 + 2 * i];
-            const unsigned vx = (tapmask & tb) ? xoffb : VC_OOB;
-            xr[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, vx, so, 0));
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) ar[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ars, avoff[i], c * 128, 0));
+        for (int q = 0; q < 2; ++q) { tso[q] = xsoff[c * 8 + 2 * wv + q]; ttb[q] = otap[c * 8 + 2 * wv + q]; }
     };
-    auto lstore = [&](int buf) {
+    auto issue = [&](int c, int buf) {                  // chunk c of the K range (table entries already in tso / ttb) -> LDS stage buf
         char* As = smem + buf * STAGE; char* Xs = As + ASZ;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(Xs + pn * PITCH + (w2 + 2 * i) * 16) = xr[i];
+        for (int q = 0; q < 2; ++q) {
+            const int oq = 2 * wv + q, o = c * 8 + oq;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(As + ((tid >> 3) + 32 * i) * PITCH + (tid & 7) * 16) = ar[i];
+            for (int hf = 0; hf < 2; ++hf) {
+                lds_copy16(xrs, (lds_ptr_t)(Xs + (oq * BN + hf * 64) * 16), (tapmask[hf] & ttb[q]) ? xoffb[hf] : VC_OOB, (unsigned)tso[q]);
+                if (hf < MI) lds_copy16(ars, (lds_ptr_t)(As + (oq * BM + hf * 64) * 16), avoff[hf < MI ? hf : 0], (unsigned)o * a_os);
+            }
+        }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[MI][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    gload(c0);
-    lstore(0);
-    gload(c0 + 1);
-    __syncthreads();
+    // NST LDS stages in a ring: while chunk c is multiplied, chunks c + 1 .. c + NST - 1 are streaming in.  A chunk costs
+    // ~0.25 us of MFMA work and an L2 / HBM round trip is 0.5 - 2 us, so launches with one workgroup per CU run NST = 4
+    // (three chunks in flight); launches that fill every CU twice over run NST = 2 with two workgroups per CU.
+    // Top of an iteration: wait until THIS wave's copies of chunk c have landed (a counted vmcnt: the younger chunks stay
+    // in flight across the barrier), then the barrier tells every wave that chunk c is complete and that chunk c - 1, the
+    // previous tenant of the stage refilled next, has been multiplied.  Past the end of the K range the ring keeps
+    // copying the last chunk into stages nobody reads, so the count is the same in every iteration.
+    constexpr int GL = 4 + 2 * MI;                          // LDS-direct copies per wave and chunk
+    auto wait_landed = [&]() {
+        if constexpr (NST == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if constexpr ((NST - 2) * GL == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else if constexpr ((NST - 2) * GL == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else if constexpr ((NST - 2) * GL == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if constexpr ((NST - 2) * GL == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else static_assert(NST == 2, "add the counted wait for this ring depth");
+    };
+#pragma unroll
+    for (int k = 0; k < NST - 1; ++k) { fetch_tab(c0 + min(k, cn - 1)); issue(c0 + min(k, cn - 1), k); }
+    fetch_tab(c0 + min(NST - 1, cn - 1));
+    int st = 0;                                             // stage of chunk c
     for (int c = 0; c < cn; ++c) {
-        const int buf = c & 1;
-        const char* As = smem + buf * STAGE + (wm * 64 + l31) * PITCH + h * 16;
-        const char* Xs = smem + buf * STAGE + ASZ + (wn * 64 + l31) * PITCH + h * 16;
+        wait_landed();
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const int stn = st == 0 ? NST - 1 : st - 1;     // (c + NST - 1) % NST
+            issue(c0 + min(c + NST - 1, cn - 1), stn);
+        }
+        const char* As = smem + st * STAGE + ((wm * (BM / 2) + l31) + h * BM) * 16;
+        const char* Xs = smem + st * STAGE + ASZ + ((wn * 64 + l31) + h * BN) * 16;
+        // MFMA step s multiplies octets 2 s (lanes 0-31) and 2 s + 1 (lanes 32-63); the fragments of step s + 1 are
+        // requested before the MFMAs of step s are issued, so an LDS round trip hides behind the MFMAs
+        bf16x8 fa[2][MI], fb[2][2];
+        auto frags = [&](int s, int set) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) fa[set][i] = *reinterpret_cast<const bf16x8*>(As + s * 2 * BM * 16 + i * 32 * 16);
+            fb[set][0] = *reinterpret_cast<const bf16x8*>(Xs + s * 2 * BN * 16); fb[set][1] = *reinterpret_cast<const bf16x8*>(Xs + s * 2 * BN * 16 + 32 * 16);
+        };
+        frags(0, 0);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(As + s * 32), a1 = *reinterpret_cast<const bf16x8*>(As + 32 * PITCH + s * 32);
-            const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(Xs + s * 32), b1 = *reinterpret_cast<const bf16x8*>(Xs + 32 * PITCH + s * 32);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+            if (s < 3) frags(s + 1, (s + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);      // keep the reads of step s + 1 ahead of the MFMAs of step s
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s & 1][i], fb[s & 1][0], acc[i][0], 0, 0, 0);
+                acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s & 1][i], fb[s & 1][1], acc[i][1], 0, 0, 0);
+            }
+            if (s == 0) fetch_tab(c0 + min(c + NST, cn - 1));      // behind the first MFMAs; next used after the next barrier
+            __builtin_amdgcn_sched_barrier(0);
         }
-        lstore(buf ^ 1);               // chunk c + 1 (its loads were issued one iteration ago); LDS[buf ^ 1] was last read in iteration c - 1
-        gload(c0 + c + 2);
-        __syncthreads();
+        st = st + 1 == NST ? 0 : st + 1;
     }
+    __syncthreads();                                        // (drains the ring's trailing copies: vmcnt(0))
 
     // ---- epilogue: tile through LDS, then bias (+ addend) and 16-byte stores, or one pixel per lane for atomics /
     //      strided parity classes (the two paths of vc_conv_igemm.hip)
     float* Ys = reinterpret_cast<float*>(smem);
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                Ys[(wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * LDY + wn * 64 + j * 32 + l31] = acc[i][j][r];
+                Ys[(wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * LDY + wn * 64 + j * 32 + l31] = acc[i][j][r];
     __syncthreads();
     const bool atomic = p.splitk > 1 || p.accumulate;
     const bool first = sp == 0;
@@ -271,13 +320,24 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const ConvBf16Args p)
     }
 }
 
-// split-K only to fill the chip (the launches this path is for, batch >= 32, rarely need it)
+// Tile rows: 128, or 64 where 128-row tiles would leave the chip underfilled (M = 512 layers at batch 64: twice the
+// workgroups at 3/4 of the LDS traffic per workgroup).  Split-K across workgroups costs fp32 atomics on the whole output
+// plus its zero-fill (~1 TB/s of read-modify-write: 17 MB of output is ~20 us, as long as a 48-chunk K loop): only
+// launches that would leave most of the chip idle split.
+extern "C" int vc_tune_igemm_override(int bm, int kg, int splitk);
+extern int g_force_bm, g_force_kg, g_force_sk;   // vc_conv_igemm.hip (tools/tune_igemm.py); kg = 4 selects the 4-stage ring here
 void conv_bf16_config(ConvBf16Args& a) {
-    a.mtiles = (a.M + 127) / 128; a.ntiles = (a.Ptot + 127) / 128;
+    a.ntiles = (a.Ptot + 127) / 128;
+    const long t128 = (long)((a.M + 127) / 128) * a.ntiles * a.groups;
+    a.bm = a.M <= 64 ? 64 : 128;
+    a.nst = t128 <= 256 ? 4 : 2;                  // one workgroup per CU: deep ring; more: two resident workgroups, two stages each
+    if (g_force_bm) { a.bm = g_force_bm; a.nst = g_force_kg == 4 ? 4 : 2; }
+    a.mtiles = (a.M + a.bm - 1) / a.bm;
     const long tiles = (long)a.mtiles * a.ntiles * a.groups;
     const int nchunks = a.koct / 8;
     int sk = 1;
-    while (tiles * sk < 384 && nchunks / (sk * 2) >= 4 && sk < 16) sk *= 2;
+    while (tiles * sk < 128 && nchunks / (sk * 2) >= 8 && sk < 16) sk *= 2;
+    if (g_force_bm) sk = std::min(g_force_sk, std::max(1, nchunks / 2));
     a.splitk = sk;
 }
 
@@ -285,7 +345,8 @@ int launch_conv_bf16(const ConvBf16Args& a, hipStream_t s, double flops) {
     if (a.splitk > 1 && !a.accumulate) { vc_set_error("launch_conv_bf16: split-K requires accumulate semantics"); return -1; }
     dim3 grid(a.mtiles * a.ntiles, 1, a.groups * a.splitk);
     ProfScope ps(0, flops, s);
-    conv_bf16_kernel<<<grid, 256, 0, s>>>(a);
+    if (a.bm == 64) { if (a.nst == 4) conv_bf16_kernel<64, 4><<<grid, 256, 0, s>>>(a); else conv_bf16_kernel<64, 2><<<grid, 256, 0, s>>>(a); }
+    else { if (a.nst == 4) conv_bf16_kernel<128, 4><<<grid, 256, 0, s>>>(a); else conv_bf16_kernel<128, 2><<<grid, 256, 0, s>>>(a); }
     VC_HIP(hipGetLastError());
     return 0;
 }
@@ -444,7 +505,7 @@ void wgrad_bf16_config(WgradBf16Args& a) {
     a.ktiles = (a.koct + 15) / 16; a.ntiles = (a.N + 127) / 128;
     const long tiles = (long)a.ktiles * a.ntiles * a.groups;
     int sk = 1;
-    while (tiles * sk < 512 && a.nchunks / (sk * 2) >= 4 && sk < 32) sk *= 2;
+    while (tiles * sk < 128 && a.nchunks / (sk * 2) >= 8 && sk < 32) sk *= 2;      // as conv_bf16_config: atomics on dW are dear
     a.splitk = sk;
 }
 int launch_wgrad_bf16(const WgradBf16Args& a, hipStream_t s, double flops) {

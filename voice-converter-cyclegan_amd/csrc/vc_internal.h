@@ -98,12 +98,13 @@ struct WgradArgs {
 
 // The 16-bit data path of the bf16 mode (vc_conv_bf16.hip): Y[g][b][m][P] (+)= sum_k Ap[g][m][k] * Xp-gather[k][P].
 //   X      packed gathered tensor  [g][b][C/8][Hl*Wl][8] bf16 (16-byte units: 8 channels of one pixel)
-//   A      packed filter image     [g][M][8*koct] bf16, k in the order of the octet table, padding octets 0
+//   A      packed filter image     [g][koct][M][8] bf16, k in the order of the octet table, padding octets 0
+//   zeros  at least 16 zero bytes (where lanes of padding taps read)
 //   xsoff  per K octet: byte offset ((c/8)*Hl*Wl + dh*xW + dw)*16 + xbias of the unit (SGPR offset of the load)
 //   otap   per K octet: 1 << tap (0 = padding octet: the load is sent out of range and returns 0)
 // Pixel grid / output fields as IgemmArgs.  Strides of A and X in BYTES, of Y / bias / addend in floats.
 struct ConvBf16Args {
-    const void* A; const void* X; float* Y; const float* bias; const float* addend;
+    const void* A; const void* X; const void* zeros; float* Y; const float* bias; const float* addend;
     const int* xsoff; const unsigned* otap; const Tap* taps; int ntaps; int xbias;
     unsigned x_bytes, a_bytes;
     long a_gs, x_gs, x_bs;                        // bytes
@@ -114,11 +115,12 @@ struct ConvBf16Args {
     int NPB, OWc, Ptot; float inv_npb, inv_ow;
     int yHW, yW, so_h, so_w, o_h0, o_w0, vec4;
     int splitk, accumulate, mtiles, ntiles, groups;
+    int bm, nst;                                  // tile rows (128 / 64), LDS ring depth (2 / 4)
 };
-void conv_bf16_config(ConvBf16Args& a);           // fills mtiles / ntiles / splitk
+void conv_bf16_config(ConvBf16Args& a);           // fills bm / nst / mtiles / ntiles / splitk
 int launch_conv_bf16(const ConvBf16Args& a, hipStream_t s, double flops);
 int launch_pack_act_bf16(const float* x, long x_gs, void* xp, long xp_gs_bytes, int G, int B, int C, int HW, hipStream_t s);
-// Ap[g][m][k] = bf16(W[g][wsrc[k] + m * a_ms]), 0 where wsrc[k] < 0; kp = 8 * koct
+// Ap[g][k/8][m][k%8] = bf16(W[g][wsrc[k] + m * a_ms]), 0 where wsrc[k] < 0; kp = 8 * koct
 int launch_pack_filter_bf16(const float* w, long w_gs, void* ap, long ap_gs_bytes, const int* wsrc, int a_ms, int G, int M, int kp, hipStream_t s);
 
 // Filter gradient on the 16-bit data path: X channel-octet packed (as ConvBf16Args), dY planar bf16 [g][b][N][NPB].
