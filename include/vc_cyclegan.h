@@ -61,6 +61,10 @@ int  vc_get_math_mode(void);
  * following implicit-GEMM launch of the process; (0, 0, 0) restores the automatic choice.  Not thread-safe, not for
  * production use -- it exists so that the measured table (csrc/vc_tuned_igemm.h) can be regenerated. */
 int  vc_tune_igemm_override(int tile_rows, int k_groups, int splitk);
+/* Same for the 16-bit data path of the bf16 mode (csrc/vc_conv_bf16.hip): tile rows (64 / 128), LDS ring stages (2 / 4),
+ * split-K (1..16); (0, 0, 0) restores the automatic choice.  Tests use it to run every built configuration against the
+ * oracle; not thread-safe, not for production use. */
+int  vc_tune_conv_bf16_override(int tile_rows, int stages, int splitk);
 /* Opt-in per-launch timing of the implicit-GEMM kernels (bench.py roofline leg).
  * While enabled every igemm/wgrad launch is bracketed by hipEvents on its stream. */
 int  vc_prof_enable(int on);

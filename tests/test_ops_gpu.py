@@ -95,6 +95,30 @@ def test_conv_bf16_modes(built_lib, case, mode):
     assert lib.vc_set_math_mode(3) != 0 and lib.vc_get_math_mode() == 0      # unknown mode is refused
 
 
+@pytest.mark.parametrize('cfg', [(128, 2, 1), (128, 4, 1), (64, 2, 1), (64, 4, 1), (128, 4, 2), (64, 2, 4)])
+@pytest.mark.parametrize('case', [(128, 1, 128, 512, 1, 5, 1, 2, 4),      # G.d1: stride 2 -> two input-gradient parity classes
+                                  (512, 1, 32, 2048, 1, 3, 1, 1, 8),      # residual h1
+                                  (256, 12, 32, 1024, 3, 3, 2, 2, 2),     # D.d2: 2-D, four parity classes
+                                  (64, 1, 132, 192, 1, 5, 1, 1, 3)])      # ragged: M and the pixel count are not tile multiples
+def test_conv_bf16_data_path_every_configuration(built_lib, case, cfg):
+    """conv_bf16_kernel<tile rows, LDS ring stages> x split-K (vc_conv_bf16.hip): every built configuration against the
+    oracle with bf16 operand rounding (module.py:32-40, 54-62 and their input gradients).  The automatic choice only
+    reaches (128, 2) and (64, *) at batch >= 32 -- the sizes bench.py --math bf16 --batch 64 times -- so they are forced
+    here (vc_tune_conv_bf16_override) on sizes the oracle finishes in seconds."""
+    from voice_converter_cyclegan_amd._lib import lib, check
+    O = _oracle()
+    check(lib.vc_set_math_mode(1))
+    check(lib.vc_tune_conv_bf16_override(*cfg))
+    O.set_operand_rounding('bf16')
+    try:
+        _conv_check(case)
+    finally:
+        O.set_operand_rounding(None)
+        check(lib.vc_tune_conv_bf16_override(0, 0, 0))
+        check(lib.vc_set_math_mode(0))
+    assert lib.vc_tune_conv_bf16_override(96, 2, 1) != 0          # not a built configuration
+
+
 def test_bf16_mode_is_really_bf16(built_lib):
     """The bf16 mode must differ from fp32 by bf16-sized errors (guards against a silent fp32 fallback)."""
     from tests import gpu_util as U

@@ -38,6 +38,7 @@ SIGNATURES = [
     ('vc_set_math_mode', i32, [i32]),
     ('vc_get_math_mode', i32, []),
     ('vc_tune_igemm_override', i32, [i32, i32, i32]),
+    ('vc_tune_conv_bf16_override', i32, [i32, i32, i32]),
     ('vc_prof_enable', i32, [i32]),
     ('vc_prof_collect', i32, [i32, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_double)]),
     ('vc_prof_records', i32, [i32, C.POINTER(C.c_double), C.POINTER(C.c_double), i32]),

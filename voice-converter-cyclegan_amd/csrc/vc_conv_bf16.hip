@@ -324,20 +324,27 @@ template <int BM, int NST> __global__ __launch_bounds__(256, NST <= 2 ? 2 : 1) v
 // workgroups at 3/4 of the LDS traffic per workgroup).  Split-K across workgroups costs fp32 atomics on the whole output
 // plus its zero-fill (~1 TB/s of read-modify-write: 17 MB of output is ~20 us, as long as a 48-chunk K loop): only
 // launches that would leave most of the chip idle split.
-extern "C" int vc_tune_igemm_override(int bm, int kg, int splitk);
-extern int g_force_bm, g_force_kg, g_force_sk;   // vc_conv_igemm.hip (tools/tune_igemm.py); kg = 4 selects the 4-stage ring here
+// tests / tuning: force one configuration of conv_bf16_kernel for every following launch of the process (0 = automatic)
+static int g_bf16_bm = 0, g_bf16_nst = 0, g_bf16_sk = 0;
+extern "C" int vc_tune_conv_bf16_override(int tile_rows, int stages, int splitk) {
+    const bool ok = (tile_rows == 0 && stages == 0 && splitk == 0) ||
+                    ((tile_rows == 64 || tile_rows == 128) && (stages == 2 || stages == 4) && splitk >= 1 && splitk <= 16);
+    if (!ok) { vc_set_error("vc_tune_conv_bf16_override: tile rows %d, stages %d, split-K %d is not a built configuration", tile_rows, stages, splitk); return -1; }
+    g_bf16_bm = tile_rows; g_bf16_nst = stages; g_bf16_sk = splitk;
+    return 0;
+}
 void conv_bf16_config(ConvBf16Args& a) {
     a.ntiles = (a.Ptot + 127) / 128;
     const long t128 = (long)((a.M + 127) / 128) * a.ntiles * a.groups;
     a.bm = a.M <= 64 ? 64 : 128;
     a.nst = t128 <= 256 ? 4 : 2;                  // one workgroup per CU: deep ring; more: two resident workgroups, two stages each
-    if (g_force_bm) { a.bm = g_force_bm; a.nst = g_force_kg == 4 ? 4 : 2; }
+    if (g_bf16_bm) { a.bm = g_bf16_bm; a.nst = g_bf16_nst; }
     a.mtiles = (a.M + a.bm - 1) / a.bm;
     const long tiles = (long)a.mtiles * a.ntiles * a.groups;
     const int nchunks = a.koct / 8;
     int sk = 1;
     while (tiles * sk < 128 && nchunks / (sk * 2) >= 8 && sk < 16) sk *= 2;
-    if (g_force_bm) sk = std::min(g_force_sk, std::max(1, nchunks / 2));
+    if (g_bf16_bm) sk = std::min(g_bf16_sk, std::max(1, nchunks / 2));
     a.splitk = sk;
 }
 

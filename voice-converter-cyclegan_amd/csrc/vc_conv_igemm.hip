@@ -302,7 +302,7 @@ static int resident_per_cu(int bm, int kg) {            // LDS: 55 KB (128 rows)
     return std::max(1, std::min(std::min(by_lds, by_waves), bm == 128 ? 2 : 4));
 }
 // tools/tune_igemm.py: force one configuration for every following launch of the process (0 = automatic)
-int g_force_bm = 0, g_force_kg = 0, g_force_sk = 0;   // also read by conv_bf16_config (vc_conv_bf16.hip)
+static int g_force_bm = 0, g_force_kg = 0, g_force_sk = 0;
 extern "C" int vc_tune_igemm_override(int bm, int kg, int splitk) {
     const bool ok = (bm == 0 && kg == 0 && splitk == 0) ||
                     ((bm == 64 || bm == 128) && (kg == 1 || kg == 2 || (kg == 4 && bm == 64)) && splitk >= 1 && splitk <= 64);
