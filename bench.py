@@ -32,7 +32,7 @@ sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: Peak FP32 (matrix)
 BF16_MFMA_PEAK_TFLOPS = 2500.0     # same guide: Peak BF16 MFMA, dense
-MATH_TEXT = {'fp32': 'fp32', 'bf16': 'bf16 MFMA operands (fp32 accumulate, fp32 storage + instance-norm statistics)',
+MATH_TEXT = {'fp32': 'fp32', 'bf16': 'bf16 conv operands in HBM and LDS (packed 16-bit data path), fp32 accumulate, fp32 conv outputs / instance-norm statistics / Adam',
              'bf16x3': 'fp32 emulated as 3 bf16 MFMAs per product (hi/lo operand split)'}
 HBM_PEAK_GBS = 8000.0
 
@@ -127,7 +127,7 @@ def main():
     ap.add_argument('--features', type=int, default=24)
     ap.add_argument('--math', choices=['fp32', 'bf16', 'bf16x3'], default='fp32',
                     help='arithmetic of the conv kernels; fp32 (default) is the reference precision and the headline, '
-                         'bf16 is BASELINE configs[2] (bf16 MFMA operands, fp32 accumulate/storage/statistics)')
+                         'bf16 is BASELINE configs[2] (bf16 conv operands in HBM, fp32 accumulate/outputs/statistics)')
     ap.add_argument('--graph', action='store_true', help='replay the step as one hipGraph (vc_train_step_graph) instead of launching it')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
@@ -237,7 +237,11 @@ def main():
             eng.train_step(A, Bm, *hp, sync=False)
         torch.cuda.synchronize()
         stats = {}
-        for kind, name in ((0, 'igemm_kernel (conv fwd + dgrad, every Cin > 1 layer)'), (1, 'wgrad_kernel'), (2, 'wsconv1d_kernel')):
+        knames = ((0, 'igemm_kernel (conv fwd + dgrad, every Cin > 1 layer)'), (1, 'wgrad_kernel'), (2, 'wsconv1d_kernel'))
+        if args.math == 'bf16':       # 16-bit data path (csrc/vc_conv_bf16.hip); launches too small for its tiles stay on igemm / wgrad_kernel
+            knames = ((0, 'conv_bf16_kernel (conv fwd + dgrad; + igemm_kernel for the few launches below its tile size)'),
+                      (1, 'wgrad_bf16_kernel (+ wgrad_kernel for o1)'), (2, 'wsconv1d_kernel'))
+        for kind, name in knames:
             ms, n, fl = C.c_double(0), C.c_longlong(0), C.c_double(0)
             lib.vc_prof_collect(kind, C.byref(ms), C.byref(n), C.byref(fl))
             stats[kind] = (name, ms.value, n.value, fl.value)

@@ -23,8 +23,10 @@ for k in sorted(f, key=lambda k: -sum(f[k])):
     tot += fe + wr
     print('%s, %.1f, %.1f, %.1f' % (k, len(f[k]) / steps, fe, wr))
 print('TOTAL MB/step, %.1f' % tot)
-for tag in ('igemm', 'wgrad'):
-    ks = [k for k in f if tag in k]
+for tag, pats in (('igemm', ('igemm_kernel', 'conv_bf16_kernel')), ('wgrad', ('wgrad_kernel', 'wgrad_bf16_kernel'))):
+    ks = [k for k in f if any(k.startswith(p) for p in pats)]
+    if not ks:
+        continue
     n = sum(len(f[k]) for k in ks)
     b = 2 * sum(sum(f[k]) for k in ks) * 1024 + sum(sum(w.get(k, [0])) for k in ks) * 1024
     print('%s: %.1f launches/step, %.2f MB per launch, %.2f GB per step' % (tag, n / steps, b / n / 1e6, b / steps / 1e9))

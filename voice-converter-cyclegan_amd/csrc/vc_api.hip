@@ -813,7 +813,7 @@ struct vc_plan {
     std::vector<StepGraph> graphs;
     hipStream_t gstream = nullptr, ustream = nullptr;     // capture / replay stream, update (exchange + Adam) stream
     hipEvent_t ev_gin = nullptr, ev_gout = nullptr, ev_ujoin = nullptr;
-    float* packed = nullptr;                              // inference plans: packed h1 filters for gated_conv1d_glu_kernel (2 groups)
+    float* packed = nullptr;                              // packed h1 filters for gated_conv1d_glu_kernel (2 groups)
     float* hp_dev = nullptr;                              // {lambda_cycle, lambda_identity, alpha_g, alpha_d} of the step being replayed
     // bf16 data path: filter images of every layer (forward + one per input-gradient parity class), rebuilt from the
     // fp32 weights once at the start of a train step instead of before every launch (a step uses each image 2-3 times)
@@ -880,7 +880,7 @@ static int plan_create(int num_features, int n_frames, bool inference, vc_plan**
     if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_gout, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_ujoin, hipEventDisableTiming);
     if (e == hipSuccess) e = hipMalloc((void**)&p->hp_dev, 4 * sizeof(float));
-    if (e == hipSuccess && inference) e = hipMalloc((void**)&p->packed, (size_t)gated_conv1d_glu_workspace_floats(2, p->G.layers[0].cout) * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&p->packed, (size_t)gated_conv1d_glu_workspace_floats(2, p->G.layers[0].cout) * sizeof(float));
     if (e != hipSuccess) { vc_set_error("hipEventCreate failed: %s", hipGetErrorString(e)); vc_plan_destroy(p); return (int)e; }
     *out = p;
     return 0;
@@ -1006,12 +1006,23 @@ static int net_forward(NetCtx& c, const float* x, long x_gs, float* y_plain, lon
         float* raw = (L.mode == M_PLAIN) ? y_plain : c.save + c.sm.raw[i];
         const long raw_gs = (L.mode == M_PLAIN) ? y_plain_gs : c.save_gs;
         if (L.mode == M_GATED_IN && i + 1 < c.n->layers.size() && c.n->layers[i + 1].mode == M_IN_RES) { blk_in = in; blk_in_gs = in_gs; }
-        if (L.mode == M_GATED && c.fuse_glu && c.packed && c.G <= 2 && wsconv_path(lg.g) && c.math != VC_MATH_BF16X3) {
-            // forward-only (CycleGAN.test): the raw value / gate tensors are never needed again -> the whole block in one kernel
+        if (L.mode == M_GATED && c.packed && c.G <= 2 && wsconv_path(lg.g) && c.math != VC_MATH_BF16X3) {
+            // gated block without instance norm (G.h1, module.py:161-163): convolution pair + GLU in one kernel.  Forward-only
+            // passes (CycleGAN.test) never need the raw value / gate tensors again; a training pass keeps them for backward.
             WsConvArgs f{}; f.x = in; f.w = c.params + L.w; f.bias = c.params + L.b; f.y = c.save + c.sm.act[i];
             f.x_gs = in_gs; f.w_gs = c.par_gs; f.b_gs = c.par_gs; f.y_gs = c.save_gs; f.B = c.B; f.T = lg.g.W; f.Cout = L.cout; f.G = c.G;
+            if (!c.fuse_glu) { f.raw = raw; f.raw_gs = raw_gs; }
             const int r = launch_gated_conv1d_glu(f, lg.g.Cin, lg.g.kw, c.math, c.packed, c.s, 2.0 * c.G * c.B * lg.g.W * (double)L.cout * lg.g.kw * lg.g.Cin);
             if (r != -2) { VC_CHECK(r); in = f.y; in_gs = c.save_gs; continue; }
+        }
+        if (L.mode == M_GATED && c1_path(lg.g)) {
+            // same for the single-input-channel pair (D.h1, module.py:201-203): GLU in the vector-ALU kernel's epilogue
+            VC_CHECK(check_conv_geom(lg.g, c.B));
+            C1Args f = c1_args(lg.g, c.G, c.B, c.math);
+            f.x = in; f.x_gs = in_gs; f.w = c.params + L.w; f.w_gs = c.par_gs; f.bias = c.params + L.b; f.b_gs = c.par_gs;
+            f.y = raw; f.y_gs = raw_gs; f.act = c.save + c.sm.act[i]; f.act_gs = c.save_gs;
+            VC_CHECK(launch_c1_fwd(f, c.s));
+            in = f.act; in_gs = c.save_gs; continue;
         }
         VC_CHECK(conv_fwd(in, in_gs, c.params + L.w, c.par_gs, c.params + L.b, c.par_gs, raw, raw_gs, c.G, c.B, lg.g, c.math, c.s,
                           /*prezeroed=*/L.mode != M_PLAIN, nullptr, c.images ? (*c.images)[i].fwd : nullptr));

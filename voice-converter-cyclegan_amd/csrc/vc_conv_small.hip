@@ -183,17 +183,24 @@ __device__ __forceinline__ void c1_window(const C1Args& a, const float* x, int i
     }
 }
 
-// y[g][b][co][p] = bias[co] + sum_t w[t][co] * window_t(p);  block = 256 pixels x 64 channels, filter slice in LDS
+// y[g][b][co][p] = bias[co] + sum_t w[t][co] * window_t(p);  block = 256 pixels x 64 channels, filter slice in LDS.
+// With a.act set the layer is a gated pair (module.py:201-203: value filters [0, C), gate filters [C, 2C), C = Cout / 2):
+// a block then holds 32 value channels and the matching 32 gate channels, and writes act = value * sigmoid(gate) next to
+// the raw pair (kept for the backward pass) -- the GLU costs no second pass over the raw tensor.
 __global__ __launch_bounds__(256) void c1_fwd_kernel(const C1Args a) {
     __shared__ __attribute__((aligned(16))) float ws[10 * 64];       // [t][c] + bias row
-    const int nch = (a.Cout + 63) / 64;
+    const bool glu = a.act != nullptr;
+    const int C = a.Cout >> 1;
+    const int nch = glu ? (C + 31) / 32 : (a.Cout + 63) / 64;
     const int g = blockIdx.z / nch, cc = blockIdx.z - g * nch, b = blockIdx.y;
     const int P = a.OH * a.OW, p = blockIdx.x * 256 + threadIdx.x, nt = a.kh * a.kw;
     const float* wt = a.w + (long)g * a.w_gs;
     for (int idx = threadIdx.x; idx < 640; idx += 256) {
-        const int t = idx >> 6, c = idx & 63, co = cc * 64 + c;
+        const int t = idx >> 6, c = idx & 63;
+        const int co = glu ? (c < 32 ? 0 : C) + cc * 32 + (c & 31) : cc * 64 + c;
+        const bool cv = glu ? cc * 32 + (c & 31) < C : co < a.Cout;
         float v = 0.f;
-        if (co < a.Cout) { if (t < nt) v = c1_round(wt[t * a.Cout + co], a.math); else if (t == 9 && a.bias) v = a.bias[(long)g * a.b_gs + co]; }
+        if (cv) { if (t < nt) v = c1_round(wt[t * a.Cout + co], a.math); else if (t == 9 && a.bias) v = a.bias[(long)g * a.b_gs + co]; }
         ws[idx] = v;
     }
     __syncthreads();
@@ -203,6 +210,23 @@ __global__ __launch_bounds__(256) void c1_fwd_kernel(const C1Args a) {
     c1_window(a, a.x + (long)g * a.x_gs + (long)b * a.H * a.W, i, j, pv, xv);
     if (!pv) return;
     float* y = a.y + (long)g * a.y_gs + (long)b * a.Cout * P + p;
+    if (glu) {
+        float* o = a.act + (long)g * a.act_gs + (long)b * C * P + p;
+#pragma unroll 2
+        for (int c4 = 0; c4 < 8; ++c4) {
+            f32x4 av = *reinterpret_cast<const f32x4*>(ws + 9 * 64 + c4 * 4), ag = *reinterpret_cast<const f32x4*>(ws + 9 * 64 + 32 + c4 * 4);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                av += xv[t] * *reinterpret_cast<const f32x4*>(ws + t * 64 + c4 * 4);
+                ag += xv[t] * *reinterpret_cast<const f32x4*>(ws + t * 64 + 32 + c4 * 4);
+            }
+            const int c = cc * 32 + c4 * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (c + e < C) { y[(long)(c + e) * P] = av[e]; y[(long)(C + c + e) * P] = ag[e]; o[(long)(c + e) * P] = av[e] * sigmoidf_(ag[e]); }
+        }
+        return;
+    }
 #pragma unroll 4
     for (int c4 = 0; c4 < 16; ++c4) {
         f32x4 acc = *reinterpret_cast<const f32x4*>(ws + 9 * 64 + c4 * 4);
@@ -310,7 +334,8 @@ __global__ __launch_bounds__(256) void c1_wgrad_kernel(const C1Args a) {
 // launchers
 // ------------------------------------------------------------------------------------------------------------------
 int launch_c1_fwd(const C1Args& a, hipStream_t s) {
-    const int P = a.OH * a.OW, nch = (a.Cout + 63) / 64;
+    const int P = a.OH * a.OW, nch = a.act ? (a.Cout / 2 + 31) / 32 : (a.Cout + 63) / 64;
+    if (a.act && (a.Cout & 1)) { vc_set_error("c1_fwd: a gated pair needs an even filter count"); return -1; }
     c1_fwd_kernel<<<dim3((P + 255) / 256, a.B, a.G * nch), 256, 0, s>>>(a);
     VC_HIP(hipGetLastError());
     return 0;
@@ -481,15 +506,24 @@ __global__ __launch_bounds__(BF16 ? 512 : 256, BF16 ? 2 : 1) void gated_conv1d_g
             sw[ml * LDS_S + l31] = (sv[r] + bv[r]) * sigmoidf_(sg[r] + bg[r]);
         }
         // wave-private tile: no workgroup barrier, the LDS queue is in order within a wave
-        {
-            const int b = tile / tps, t = (tile - b * tps) * TP + w4 * 32 + (lane & 7) * 4;
-            float* y = a.y + (long)g * a.y_gs + (long)b * C * a.T + t;
+        const int b = tile / tps, t = (tile - b * tps) * TP + w4 * 32 + (lane & 7) * 4;
+        auto store_plane = [&](float* dst) {          // the staged 32 x 32 tile -> rows (channels) of `dst`, 16 bytes per lane
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int ml = (lane >> 3) + 8 * i, c = slab * 32 + ml;
                 const f32x4 v = *reinterpret_cast<const f32x4*>(sw + ml * LDS_S + (lane & 7) * 4);
-                if (c < C && t < a.T) *reinterpret_cast<f32x4*>(y + (long)c * a.T) = v;
+                if (c < C && t < a.T) *reinterpret_cast<f32x4*>(dst + (long)c * a.T) = v;
             }
+        };
+        store_plane(a.y + (long)g * a.y_gs + (long)b * C * a.T + t);
+        if (a.raw) {                                  // training: the raw value / gate pair is kept for the backward pass
+            float* raw = a.raw + (long)g * a.raw_gs + (long)b * 2 * C * a.T + t;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sw[((r & 3) + 8 * (r >> 2) + 4 * h) * LDS_S + l31] = sv[r] + bv[r];
+            store_plane(raw);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sw[((r & 3) + 8 * (r >> 2) + 4 * h) * LDS_S + l31] = sg[r] + bg[r];
+            store_plane(raw + (long)C * a.T);
         }
     }
 }

@@ -146,6 +146,7 @@ int launch_pack_planar_bf16(const float* x, long x_gs, void* y, long y_gs_bytes,
 struct C1Args {
     const float* x; const float* w; const float* bias; const float* addend; const float* dy;
     float* y; float* dx; float* dw; float* db;
+    float* act; long act_gs;                                      // forward, optional: GLU of the gated pair [G][B][Cout/2][P]
     long x_gs, w_gs, b_gs, y_gs, dx_gs, add_gs, dw_gs, db_gs;     // signed group strides (floats); y_gs also strides dy
     int B, H, W, Cout, kh, kw, sh, sw, OH, OW, pt, pl, G;
     int math;                                               // VC_MATH_*: bf16 mode rounds both operands like the MFMA kernels do
@@ -162,6 +163,7 @@ struct WsConvArgs {
     const float* x; const float* w; const float* bias; float* y;
     long x_gs, w_gs, b_gs, y_gs;          // signed group strides (floats)
     int B, T, Cout, G;
+    float* raw; long raw_gs;              // gated_conv1d_glu only, optional: the raw (value, gate) pair [G][B][Cout][T] for a backward pass
 };
 int launch_wsconv1d(const WsConvArgs& a, int cin, int kw, int math, hipStream_t s, double flops);   // returns -2 when the geometry is not built
 // the whole gated block in one kernel: y [G][B][Cout/2][T] = (conv_v + b_v) * sigmoid(conv_g + b_g); -2 when not built
