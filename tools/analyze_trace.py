@@ -36,3 +36,6 @@ for k, st in enumerate(steps):
     for s, e, n, q in st:
         by[n.split('<')[0]] += (e - s) / 1e3
     print('   by kernel family (us): ' + ', '.join('%s %.0f' % kv for kv in sorted(by.items(), key=lambda kv: -kv[1])[:10]))
+    d = sorted((e - s) / 1e3 for s, e, _, _ in st)
+    print('   kernel durations (us): min %.1f, p10 %.1f, median %.1f, p90 %.1f, max %.1f; kernels under 5 us: %d (%.0f us in total)'
+          % (d[0], d[len(d) // 10], d[len(d) // 2], d[9 * len(d) // 10], d[-1], sum(1 for x in d if x < 5), sum(x for x in d if x < 5)))

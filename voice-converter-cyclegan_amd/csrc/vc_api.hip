@@ -305,6 +305,12 @@ static int zero_page(const void** out) {
 }
 // the path serves launches that fill its 128 x 128 tiles; everything else stays on the table-driven fp32-storage kernels
 static bool bf16_path(const Table& t, int math, int M, long Ptot) { return math == VC_MATH_BF16 && t.koct > 0 && M >= 64 && Ptot >= 64; }
+// the forward of this geometry at batch B runs on the 16-bit data path (the decision conv_fwd takes)
+static bool conv_fwd_packs_input(const Geom& g, int B, int math) {
+    if (math != VC_MATH_BF16 || c1_path(g) || wsconv_path(g)) return false;
+    Table t; if (get_fwd_table(g, &t, nullptr)) return false;
+    return bf16_path(t, math, g.Cout, (long)B * g.OH * g.OW);
+}
 static void bf16_set_vec4(ConvBf16Args& a) {
     a.vec4 = a.so_w == 1 && a.OWc % 4 == 0 && a.o_w0 % 4 == 0 && a.yW % 4 == 0 && a.yHW % 4 == 0 && a.y_bs % 4 == 0 &&
              a.y_gs % 4 == 0 && aligned16(a.Y) && (!a.addend || (aligned16(a.addend) && a.add_gs % 4 == 0));
@@ -313,7 +319,9 @@ static void bf16_set_vec4(ConvBf16Args& a) {
 // query != nullptr: do not launch, only report whether the launch would use split-K atomics (needs a zeroed y)
 static int conv_fwd(const float* x, long x_gs, const float* w, long w_gs, const float* bias, long b_gs,
                     float* y, long y_gs, int G, int B, const Geom& g, int math, hipStream_t s,
-                    bool prezeroed = false, bool* query = nullptr, const char* packed_w = nullptr) {
+                    bool prezeroed = false, bool* query = nullptr, const char* packed_w = nullptr,
+                    char* xp_keep = nullptr, long xp_keep_gs = 0) {
+    // xp_keep: where the packed bf16 copy of x is left for the layer's filter gradient (16-bit data path; group stride in bytes)
     VC_CHECK(check_conv_geom(g, B));
     if (c1_path(g)) {      // Cin = 1 (D.h1): vector-ALU kernel, plain stores, never needs a zeroed destination
         if (query) { *query = false; return 0; }
@@ -343,11 +351,15 @@ static int conv_fwd(const float* x, long x_gs, const float* w, long w_gs, const 
         bf16_set_vec4(a);
         conv_bf16_config(a);
         if (query) { *query = a.splitk > 1; return 0; }
-        char* wsp; VC_CHECK(pack_space(s, xp_g * G + (packed_w ? 0 : ap_g * G), &wsp));
+        char* wsp = nullptr;
+        const size_t need = (xp_keep ? 0 : xp_g * G) + (packed_w ? 0 : ap_g * G);
+        if (need) VC_CHECK(pack_space(s, need, &wsp));
         VC_CHECK(zero_page(&a.zeros));
-        a.X = wsp; a.A = packed_w ? packed_w : wsp + xp_g * G;
-        VC_CHECK(launch_pack_act_bf16(x, x_gs, wsp, (long)xp_g, G, B, g.Cin, g.H * g.W, s));
-        if (!packed_w) VC_CHECK(launch_pack_filter_bf16(w, w_gs, wsp + xp_g * G, (long)ap_g, t.wsrc, 1, G, g.Cout, t.koct * 8, s));
+        char* xp = xp_keep ? xp_keep : wsp;
+        if (xp_keep) a.x_gs = xp_keep_gs;
+        a.X = xp; a.A = packed_w ? packed_w : wsp + (xp_keep ? 0 : xp_g * G);
+        VC_CHECK(launch_pack_act_bf16(x, x_gs, xp, a.x_gs, G, B, g.Cin, g.H * g.W, s));
+        if (!packed_w) VC_CHECK(launch_pack_filter_bf16(w, w_gs, const_cast<void*>(a.A), (long)ap_g, t.wsrc, 1, G, g.Cout, t.koct * 8, s));
         if (a.splitk > 1) {
             if (!prezeroed)
                 for (int gi = 0; gi < G; ++gi) VC_HIP(hipMemsetAsync(y + (long)gi * y_gs, 0, (size_t)B * a.y_bs * sizeof(float), s));
@@ -496,7 +508,8 @@ static int conv_dgrad(const float* dy, long dy_gs, const float* w, long w_gs, fl
 }
 
 // One application of a layer as seen by the filter gradient: its input, the gradient of its raw output, its batch.
-struct WgradApp { const float* x; long x_gs; const float* dy; long dy_gs; int B; };
+struct WgradApp { const float* x; long x_gs; const float* dy; long dy_gs; int B;
+                  const char* xp = nullptr; long xp_gs = 0; };   // xp: x already packed for the 16-bit data path (group stride in bytes)
 // dW (+)= sum over the applications; store: dW holds nothing yet (plain stores when the launch does not split K)
 // query != nullptr: only report whether the launch would accumulate with atomics (needs a zeroed dW)
 static int conv_wgrad(const WgradApp* apps, int napps, float* dw, long dw_gs, int G, const Geom& g, int math, hipStream_t s,
@@ -527,19 +540,20 @@ static int conv_wgrad(const WgradApp* apps, int napps, float* dw, long dw_gs, in
             for (int k = 0; k < napps; ++k) {
                 VC_CHECK(check_conv_geom(g, apps[k].B));
                 WgradBf16Seg& sg = a.seg[k];
-                sg.x_gs = (long)align256((size_t)apps[k].B * a.x_bs); sg.dy_gs = (long)align256((size_t)apps[k].B * a.dy_bs);
+                sg.x_gs = apps[k].xp ? apps[k].xp_gs : (long)align256((size_t)apps[k].B * a.x_bs); sg.dy_gs = (long)align256((size_t)apps[k].B * a.dy_bs);
                 sg.x_bytes = (unsigned)((long)apps[k].B * a.x_bs + t.oxbias); sg.dy_bytes = (unsigned)((long)apps[k].B * a.dy_bs);
                 sg.Ptot = apps[k].B * a.NPB; sg.nchunks = (sg.Ptot + 63) / 64;
                 a.nchunks += sg.nchunks;
-                off[k][0] = tot; tot += (size_t)sg.x_gs * G; off[k][1] = tot; tot += (size_t)sg.dy_gs * G;
+                off[k][0] = tot; if (!apps[k].xp) tot += (size_t)sg.x_gs * G;
+                off[k][1] = tot; tot += (size_t)sg.dy_gs * G;
                 flops += 2.0 * G * apps[k].B * a.NPB * (double)g.Cout * t.valid;
             }
             wgrad_bf16_config(a);
             if (query) { *query = !store || a.splitk > 1; return 0; }
             char* wsp; VC_CHECK(pack_space(s, tot, &wsp));
             for (int k = 0; k < napps; ++k) {
-                a.seg[k].X = wsp + off[k][0]; a.seg[k].dY = wsp + off[k][1];
-                VC_CHECK(launch_pack_act_bf16(apps[k].x, apps[k].x_gs, wsp + off[k][0], a.seg[k].x_gs, G, apps[k].B, g.Cin, g.H * g.W, s));
+                a.seg[k].X = apps[k].xp ? apps[k].xp : wsp + off[k][0]; a.seg[k].dY = wsp + off[k][1];
+                if (!apps[k].xp) VC_CHECK(launch_pack_act_bf16(apps[k].x, apps[k].x_gs, wsp + off[k][0], a.seg[k].x_gs, G, apps[k].B, g.Cin, g.H * g.W, s));
                 VC_CHECK(launch_pack_planar_bf16(apps[k].dy, apps[k].dy_gs, wsp + off[k][1], a.seg[k].dy_gs, G, (long)apps[k].B * g.Cout * a.NPB, s));
             }
             return launch_wgrad_bf16(a, s, flops);
@@ -924,7 +938,10 @@ extern "C" int vc_plan_get_math_mode(const vc_plan* p) { return p ? p->math : VC
 
 static long align64(long x) { return (x + 63) & ~63L; }
 // save map: for every layer raw output, activation, stats -- offsets (floats) inside one group's save area
-struct SaveMap { std::vector<long> raw, act, st; long total; };
+// actp: the activation once more as bf16 in channel-octet packed layout [B][C/8][L][8] (what the 16-bit data path of the
+// bf16 mode reads, vc_conv_bf16.hip): written when the next layer's forward packs it, read again by that layer's filter
+// gradient.  Half the size of act; unused in the other modes.
+struct SaveMap { std::vector<long> raw, act, st, actp; long total; };
 static SaveMap save_map(const NetDesc& n, const std::vector<LayerGeo>& geo, int B) {
     SaveMap m; long o = 0;
     for (size_t i = 0; i < n.layers.size(); ++i) {
@@ -935,6 +952,10 @@ static SaveMap save_map(const NetDesc& n, const std::vector<LayerGeo>& geo, int 
         m.st.push_back(o);
         if (L.mode == M_GATED_IN) o = align64(o + (long)B * 2 * L.C * 2);
         else if (L.mode == M_IN_RES) o = align64(o + (long)B * L.C * 2);
+    }
+    for (size_t i = 0; i < n.layers.size(); ++i) {
+        m.actp.push_back(o);
+        if (n.layers[i].mode != M_PLAIN) o = align64(o + (geo[i].act_ps * B + 1) / 2);
     }
     m.total = o;
     return m;
@@ -973,6 +994,7 @@ struct NetCtx {
     hipStream_t ws = nullptr; const hipEvent_t* ev_layer = nullptr; hipEvent_t ev_wjoin = nullptr;   // wgrad stream (null: same stream)
     float* packed = nullptr;               // packed filter image of the fused gated block (plan-owned, 2 groups)
     const std::vector<vc_plan::LayerImages>* images = nullptr;   // bf16 data path: this step's prebuilt filter images
+    bool keep_packed = false;              // bf16 data path, inside a train step: forward leaves the packed inputs in the save area (SaveMap::actp)
     bool fuse_glu = false;                 // forward only: gated blocks without instance norm go out as one conv + GLU kernel
     int wmode = W_SELF;                    // W_NONE: leave the conv filter gradients to a later application (DeferredApp)
     bool wgrad_store = false;              // this backward's filter gradients are the step's only contribution to dparams' conv kernels
@@ -1025,7 +1047,8 @@ static int net_forward(NetCtx& c, const float* x, long x_gs, float* y_plain, lon
             in = f.act; in_gs = c.save_gs; continue;
         }
         VC_CHECK(conv_fwd(in, in_gs, c.params + L.w, c.par_gs, c.params + L.b, c.par_gs, raw, raw_gs, c.G, c.B, lg.g, c.math, c.s,
-                          /*prezeroed=*/L.mode != M_PLAIN, nullptr, c.images ? (*c.images)[i].fwd : nullptr));
+                          /*prezeroed=*/L.mode != M_PLAIN, nullptr, c.images ? (*c.images)[i].fwd : nullptr,
+                          (c.keep_packed && i > 0) ? (char*)(c.save + c.sm.actp[i - 1]) : nullptr, c.save_gs * 4));
         if (L.mode == M_PLAIN) break;
         NormArgs a{};
         a.y = raw; a.y_gs = raw_gs; a.out = c.save + c.sm.act[i]; a.out_gs = c.save_gs;
@@ -1098,8 +1121,14 @@ static int net_backward(NetCtx& c, const float* x, long x_gs, const float* dtop,
                 const DeferredApp& d = *c.deferred;
                 apps[na++] = WgradApp{i == 0 ? d.x : d.save + d.sm->act[i - 1], i == 0 ? d.x_gs : d.save_gs,
                                       L.mode == M_PLAIN ? d.dtop : d.scratch + dYd[i], L.mode == M_PLAIN ? d.dtop_gs : d.scr_gs, d.B};
+                if (c.keep_packed && i > 0 && conv_fwd_packs_input(lg.g, d.B, c.math)) {   // d.B: the batch of that forward
+                    apps[na - 1].xp = (const char*)(d.save + d.sm->actp[i - 1]); apps[na - 1].xp_gs = d.save_gs * 4;
+                }
             }
             apps[na++] = WgradApp{in, in_gs, dyp, dy_gs, c.B};
+            if (c.keep_packed && i > 0 && conv_fwd_packs_input(lg.g, c.Bl, c.math)) {       // c.Bl: the batch the forward ran (and laid out) with
+                apps[na - 1].xp = (const char*)(c.save + c.sm.actp[i - 1]); apps[na - 1].xp_gs = c.save_gs * 4;
+            }
             VC_CHECK(conv_wgrad(apps, na, c.dparams + L.w, c.dpar_gs, c.G, lg.g, c.math, ws, c.wgrad_store));
         }
         for (int k = 0; k < c.n_ev; ++k) if (c.ev_first[k] == i) VC_HIP(hipEventRecord(c.ev[k], ws));
@@ -1149,7 +1178,7 @@ static const std::vector<vc_plan::LayerImages>* step_images(const vc_plan* p, bo
 static int gen_forward(const vc_plan* p, const float* params, long par_gs, const float* x, long x_gs,
                        float* y, long y_gs, float* save, int G, int B, hipStream_t s) {
     NetCtx c = gen_ctx(p, params, par_gs, nullptr, 0, save, G, B, B, s);
-    c.images = step_images(p, true, G);
+    c.images = step_images(p, true, G); c.keep_packed = c.images != nullptr;
     c.fuse_glu = p->inference; c.packed = p->packed;
     return net_forward(c, x, x_gs, y, y_gs);
 }
@@ -1161,7 +1190,7 @@ static int gen_backward(const vc_plan* p, const float* params, long par_gs, cons
     VC_ARG(!p->inference, "this plan was created for inference only (vc_plan_create_inference)");
     NetCtx c = gen_ctx(p, params, par_gs, dparams, dpar_gs, save, G, B, Bl, s);
     c.wgrad_store = o.wgrad_store; c.wmode = o.wmode; c.deferred = o.deferred;
-    c.images = step_images(p, true, G);
+    c.images = step_images(p, true, G); c.keep_packed = c.images != nullptr;
     if ((p->use_side & 2) && dparams && o.wmode != W_NONE) { c.ws = p->wstream; c.ev_layer = p->ev_layer; c.ev_wjoin = p->ev_wjoin; }
     if (o.record_buckets) { c.ev_first = p->bucket_first; c.ev = p->g_ready; c.ev_free = p->g_free; c.n_ev = vc_plan::kBuckets; }
     return net_backward(c, x, x_gs, dy, dy_gs, dx, dx_gs, dx_acc, scratch, scr_gs);
@@ -1170,7 +1199,7 @@ static int disc_forward(const vc_plan* p, const float* params, long par_gs, cons
                         float* o, long o_gs, float* save, int G, int B, hipStream_t s) {
     VC_ARG(!p->inference, "this plan was created for inference only (vc_plan_create_inference)");
     NetCtx c = disc_ctx(p, params, par_gs, nullptr, 0, save, G, B, B, s);
-    c.images = step_images(p, false, G);
+    c.images = step_images(p, false, G); c.keep_packed = c.images != nullptr;
     VC_CHECK(net_forward(c, x, x_gs, nullptr, 0));
     const int last = (int)p->D.layers.size() - 1;
     return launch_head_fwd(save + c.sm.act[last], c.save_gs, params + p->D.head_w, params + p->D.head_b, par_gs,
@@ -1184,7 +1213,7 @@ static int disc_backward(const vc_plan* p, const float* params, long par_gs, con
     VC_ARG(!p->inference, "this plan was created for inference only (vc_plan_create_inference)");
     NetCtx c = disc_ctx(p, params, par_gs, dparams, dpar_gs, save, G, B, Bl, s);
     c.wgrad_store = wgrad_store;
-    c.images = step_images(p, false, G);
+    c.images = step_images(p, false, G); c.keep_packed = c.images != nullptr;
     if ((p->use_side & 4) && dparams) { c.ws = p->wstream_d; c.ev_layer = p->ev_layer_d; c.ev_wjoin = p->ev_wjoin_d; }
     const int last = (int)p->D.layers.size() - 1;
     // the head's input gradient goes where net_backward's scratch map puts dA[last]

@@ -55,9 +55,18 @@ class GradSync:
             ident = (C.c_ubyte * 128).from_buffer_copy(box[0])
             torch.cuda.set_device(device)
             h = _lib.vp()
-            check(lib.vc_comm_init(self.rank, self.world, ident, C.byref(h)), 'vc_comm_init')
-            self.comm = h
-            assert lib.vc_comm_world(h) == self.world
+            rc = lib.vc_comm_init(self.rank, self.world, ident, C.byref(h))
+            # every rank must take the same path: agree on the outcome (MIN over ranks) before using the communicator
+            ok = torch.tensor([1 if rc == 0 and lib.vc_comm_world(h) == self.world else 0], device=device, dtype=torch.int32)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+            if int(ok.item()) == 1:
+                self.comm = h
+            else:
+                import warnings
+                warnings.warn('native RCCL communicator unavailable on at least one rank (%s); gradient exchange falls back to '
+                              'torch.distributed' % (lib.vc_last_error().decode() if rc else 'rank count mismatch'))
+                if rc == 0:
+                    lib.vc_comm_destroy(h)
 
     def close(self):
         if self.comm is not None:
