@@ -1509,6 +1509,15 @@ extern "C" int vc_train_step_graph(vc_plan* p, float* params, float* grads, floa
         // the side stream) crashes hipStreamEndCapture; the captured schedule keeps those launches on the side stream
         const int overlap = p->use_side;
         p->use_side &= ~4;
+        if (p->math == VC_MATH_BF16) {
+            // the 16-bit data path keeps packed operands in per-stream workspaces and per-plan filter images that are
+            // allocated on first use -- not allowed while capturing: run the schedule once, eagerly, on the capture streams
+            // (it writes only gradients, losses and the generation outputs, all of which the replay overwrites)
+            int r0 = step_grads_impl(p, params, grads, A, Bm, batch, lambda_cycle, lambda_identity, nullptr, losses, gen_A, gen_B,
+                                     ws, ws_floats, p->gstream);
+            const hipError_t e0 = hipStreamSynchronize(p->gstream);
+            if (r0 || e0 != hipSuccess) { p->use_side = overlap; if (r0) return r0; VC_HIP(e0); }
+        }
         VC_HIP(hipStreamBeginCapture(p->gstream, hipStreamCaptureModeThreadLocal));
         int r = step_grads_impl(p, params, grads, A, Bm, batch, lambda_cycle, lambda_identity, p->hp_dev, losses, gen_A, gen_B,
                                 ws, ws_floats, p->gstream);
