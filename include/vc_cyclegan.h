@@ -57,6 +57,10 @@ uint32_t vc_crc32c(const void* data, uint64_t n, uint32_t crc);
  * Returns VC_E_ARG on an unknown mode. */
 int  vc_set_math_mode(int mode);
 int  vc_get_math_mode(void);
+/* bf16 mode keeps packed bf16 copies of the convolution operands in one workspace per stream, grown on first use and
+ * reused afterwards (steady state never allocates).  This frees them all (synchronises the device); they regrow on demand.
+ * Step graphs captured in bf16 mode (vc_train_step_graph) hold their addresses: destroy those plans first. */
+int  vc_release_workspaces(void);
 /* tools/tune_igemm.py ONLY: forces the tile rows (64 / 128), K groups per workgroup (1, 2, 4) and split-K factor of every
  * following implicit-GEMM launch of the process; (0, 0, 0) restores the automatic choice.  Not thread-safe, not for
  * production use -- it exists so that the measured table (csrc/vc_tuned_igemm.h) can be regenerated. */

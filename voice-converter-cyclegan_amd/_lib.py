@@ -37,6 +37,7 @@ SIGNATURES = [
     ('vc_crc32c', C.c_uint32, [vp, C.c_uint64, C.c_uint32]),
     ('vc_set_math_mode', i32, [i32]),
     ('vc_get_math_mode', i32, []),
+    ('vc_release_workspaces', i32, []),
     ('vc_tune_igemm_override', i32, [i32, i32, i32]),
     ('vc_tune_conv_bf16_override', i32, [i32, i32, i32]),
     ('vc_prof_enable', i32, [i32]),

@@ -293,6 +293,14 @@ static int pack_space(hipStream_t s, size_t bytes, char** out) {
     *out = w.p;
     return 0;
 }
+// gives the packed-operand workspaces of every stream back to the driver (they regrow on the next bf16 convolution)
+extern "C" int vc_release_workspaces(void) {
+    VC_HIP(hipDeviceSynchronize());              // nothing in flight may still read them
+    std::lock_guard<std::mutex> l(g_ws_mu);
+    for (auto& kv : g_ws) if (kv.second.p) (void)hipFree(kv.second.p);
+    g_ws.clear();
+    return 0;
+}
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 // 256 zero bytes in device memory (process lifetime): where the LDS-direct copies of padding taps read
 static int zero_page(const void** out) {

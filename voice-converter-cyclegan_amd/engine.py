@@ -161,7 +161,8 @@ class CycleGANEngine:
         self.sync.broadcast(self.params, 0)       # identical replicas
 
     def close(self):
-        """release the native plans (streams, events, geometry tables) and the RCCL communicator"""
+        """release the native plans (streams, events, geometry tables, filter images) and the RCCL communicator.  The packed-
+        operand workspaces of the bf16 mode belong to the process (vc_release_workspaces frees them explicitly)."""
         torch.cuda.synchronize()
         self._plans.clear()
         self._infer_plans.clear()
