@@ -240,7 +240,7 @@ def main():
         knames = ((0, 'igemm_kernel (conv fwd + dgrad, every Cin > 1 layer)'), (1, 'wgrad_kernel'), (2, 'wsconv1d_kernel'))
         if args.math == 'bf16':       # 16-bit data path (csrc/vc_conv_bf16.hip); launches too small for its tiles stay on igemm / wgrad_kernel
             knames = ((0, 'conv_bf16_kernel (conv fwd + dgrad; + igemm_kernel for the few launches below its tile size)'),
-                      (1, 'wgrad_bf16_kernel (+ wgrad_kernel for o1)'), (2, 'wsconv1d_kernel'))
+                      (1, 'filter gradient: conv_bf16_kernel as a GEMM over the pixel axis on im2col / pixel-octet packed operands (+ wgrad_kernel for o1)'), (2, 'wsconv1d_kernel'))
         for kind, name in knames:
             ms, n, fl = C.c_double(0), C.c_longlong(0), C.c_double(0)
             lib.vc_prof_collect(kind, C.byref(ms), C.byref(n), C.byref(fl))

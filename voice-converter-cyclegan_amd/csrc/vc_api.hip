@@ -515,6 +515,28 @@ static int conv_dgrad(const float* dy, long dy_gs, const float* w, long w_gs, fl
     return 0;
 }
 
+// Octet table of a plain GEMM on conv_bf16_kernel (the filter gradient): K octet o is unit row o of an operand laid out
+// [octet][N][8]; padding octets up to a whole chunk.  Cached per (N, octets); a few KB each.
+struct GemmTab { int* xs; unsigned* ot; Tap* taps; int koct; };
+static int get_gemm_table(int N, int noct, GemmTab* out) {
+    static std::mutex mu; static std::map<std::pair<int, int>, GemmTab> cache;
+    std::lock_guard<std::mutex> l(mu);
+    auto it = cache.find({N, noct});
+    if (it == cache.end()) {
+        VC_ARG((long)noct * N * 16 < 0x7fffff00L, "GEMM operand too large for 32-bit byte offsets");
+        std::vector<int> xs; std::vector<unsigned> ot;
+        for (int o = 0; o < noct; ++o) { xs.push_back(o * N * 16); ot.push_back(1u); }
+        while (xs.size() % 8) { xs.push_back(0); ot.push_back(0u); }
+        GemmTab t{}; t.koct = (int)xs.size();
+        for (int i = 0; i < 8; ++i) { xs.push_back(0); ot.push_back(0u); }
+        std::vector<Tap> tp{Tap{0, 0}};
+        VC_CHECK(to_device(xs, &t.xs)); VC_CHECK(to_device(ot, &t.ot)); VC_CHECK(to_device(tp, &t.taps));
+        it = cache.emplace(std::make_pair(N, noct), t).first;
+    }
+    *out = it->second;
+    return 0;
+}
+
 // One application of a layer as seen by the filter gradient: its input, the gradient of its raw output, its batch.
 struct WgradApp { const float* x; long x_gs; const float* dy; long dy_gs; int B;
                   const char* xp = nullptr; long xp_gs = 0; };   // xp: x already packed for the 16-bit data path (group stride in bytes)
@@ -536,35 +558,49 @@ static int conv_wgrad(const WgradApp* apps, int napps, float* dw, long dw_gs, in
     Table t; VC_CHECK(get_fwd_table(g, &t));
     {
         long ptot = 0; for (int k = 0; k < napps; ++k) ptot += (long)apps[k].B * g.OH * g.OW;
-        if (bf16_path(t, math, g.Cout, ptot) && (g.OH * g.OW) % 8 == 0) {
-            // 16-bit data path: X channel-octet packed, dY planar bf16 (one pack launch each per application)
-            WgradBf16Args a{};
-            a.dW = dw; a.dw_gs = dw_gs; a.oxs = t.oxs; a.otap = t.otap; a.wsrc = t.wsrc; a.taps = t.taps; a.xbias = t.oxbias;
-            a.x_bs = (long)g.Cin * g.H * g.W * 2; a.dy_bs = (long)g.Cout * g.OH * g.OW * 2;
-            a.koct = t.koct; a.N = g.Cout; a.Hl = g.H; a.Wl = g.W; a.xW = g.W; a.si = g.sh; a.sj = g.sw;
-            a.NPB = g.OH * g.OW; a.OWc = g.OW; a.inv_npb = 1.0f / (float)a.NPB; a.inv_ow = 1.0f / (float)g.OW;
-            a.groups = G; a.nseg = napps; a.nchunks = 0; a.store = store ? 1 : 0;
-            size_t off[2][2], tot = 0; double flops = 0;
-            for (int k = 0; k < napps; ++k) {
-                VC_CHECK(check_conv_geom(g, apps[k].B));
-                WgradBf16Seg& sg = a.seg[k];
-                sg.x_gs = apps[k].xp ? apps[k].xp_gs : (long)align256((size_t)apps[k].B * a.x_bs); sg.dy_gs = (long)align256((size_t)apps[k].B * a.dy_bs);
-                sg.x_bytes = (unsigned)((long)apps[k].B * a.x_bs + t.oxbias); sg.dy_bytes = (unsigned)((long)apps[k].B * a.dy_bs);
-                sg.Ptot = apps[k].B * a.NPB; sg.nchunks = (sg.Ptot + 63) / 64;
-                a.nchunks += sg.nchunks;
-                off[k][0] = tot; if (!apps[k].xp) tot += (size_t)sg.x_gs * G;
-                off[k][1] = tot; tot += (size_t)sg.dy_gs * G;
-                flops += 2.0 * G * apps[k].B * a.NPB * (double)g.Cout * t.valid;
-            }
-            wgrad_bf16_config(a);
+        if (bf16_path(t, math, g.Cout, ptot) && (g.OH * g.OW) % 8 == 0 && g.OW % 8 == 0) {
+            // 16-bit data path: the filter gradient as a GEMM over the pixel axis on conv_bf16_kernel itself,
+            //   dW[k][co] = sum_P Xcol[k][P] * dY[co][P],
+            // with both operands repacked 8 pixels to a unit (im2col of the packed activations; dY by pixel octets): rows =
+            // K rows in TF's own (tap, cin) order, "pixels" = Cout, K octets = pixel octets of both applications back to back.
+            const int NPB = g.OH * g.OW, K = t.valid;
+            int po0[2], npo = 0;
+            for (int k = 0; k < napps; ++k) { VC_CHECK(check_conv_geom(g, apps[k].B)); po0[k] = npo; npo += apps[k].B * NPB / 8; }
+            GemmTab gt; VC_CHECK(get_gemm_table(g.Cout, npo, &gt));
+            ConvBf16Args a{};
+            a.Y = dw; a.bias = nullptr; a.addend = nullptr;
+            a.xsoff = gt.xs; a.otap = gt.ot; a.taps = gt.taps; a.ntaps = 1; a.xbias = 0;
+            const size_t xcol_g = align256((size_t)npo * K * 16), dyq_g = align256((size_t)npo * g.Cout * 16);
+            VC_ARG(xcol_g < 0xfff00000UL && dyq_g < 0xfff00000UL, "conv filter gradient: repacked operands of one group exceed 4 GiB");
+            a.x_bytes = (unsigned)((size_t)npo * g.Cout * 16); a.a_bytes = (unsigned)((size_t)npo * K * 16);
+            a.a_gs = (long)xcol_g; a.x_gs = (long)dyq_g; a.x_bs = 0;
+            a.y_gs = dw_gs; a.bias_gs = 0; a.add_gs = 0; a.y_bs = 0;
+            a.koct = gt.koct; a.M = K; a.Hl = 1; a.Wl = g.Cout; a.xW = g.Cout; a.si = 1; a.sj = 1;
+            a.NPB = g.Cout; a.OWc = g.Cout; a.Ptot = g.Cout; a.inv_npb = 1.0f / (float)g.Cout; a.inv_ow = a.inv_npb;
+            a.yHW = g.Cout; a.yW = g.Cout; a.so_h = 1; a.so_w = 1; a.o_h0 = 0; a.o_w0 = 0;
+            a.accumulate = store ? 0 : 1; a.groups = G;
+            bf16_set_vec4(a);
+            conv_bf16_config(a);
             if (query) { *query = !store || a.splitk > 1; return 0; }
-            char* wsp; VC_CHECK(pack_space(s, tot, &wsp));
+            if (a.splitk > 1) a.accumulate = 1;
+            size_t xp_g[2] = {0, 0}, xp_tot = 0;
+            for (int k = 0; k < napps; ++k) if (!apps[k].xp) { xp_g[k] = align256((size_t)apps[k].B * g.Cin * g.H * g.W * 2); xp_tot += xp_g[k] * G; }
+            char* wsp; VC_CHECK(pack_space(s, (xcol_g + dyq_g) * G + xp_tot, &wsp));
+            VC_CHECK(zero_page(&a.zeros));
+            char* xcol = wsp; char* dyq = wsp + xcol_g * G; char* xtmp = dyq + dyq_g * G;
+            double flops = 0;
             for (int k = 0; k < napps; ++k) {
-                a.seg[k].X = apps[k].xp ? apps[k].xp : wsp + off[k][0]; a.seg[k].dY = wsp + off[k][1];
-                if (!apps[k].xp) VC_CHECK(launch_pack_act_bf16(apps[k].x, apps[k].x_gs, wsp + off[k][0], a.seg[k].x_gs, G, apps[k].B, g.Cin, g.H * g.W, s));
-                VC_CHECK(launch_pack_planar_bf16(apps[k].dy, apps[k].dy_gs, wsp + off[k][1], a.seg[k].dy_gs, G, (long)apps[k].B * g.Cout * a.NPB, s));
+                const char* xp = apps[k].xp; long xp_gs = apps[k].xp_gs;
+                if (!xp) {
+                    VC_CHECK(launch_pack_act_bf16(apps[k].x, apps[k].x_gs, xtmp, (long)xp_g[k], G, apps[k].B, g.Cin, g.H * g.W, s));
+                    xp = xtmp; xp_gs = (long)xp_g[k]; xtmp += xp_g[k] * G;
+                }
+                VC_CHECK(launch_im2col_bf16(xp, xp_gs, xcol, (long)xcol_g, t.taps, t.ntaps, G, apps[k].B, g.Cin, g.H, g.W, g.OH, g.OW, g.sh, g.sw, po0[k], s));
+                VC_CHECK(launch_pack_pixel_octets_bf16(apps[k].dy, apps[k].dy_gs, dyq, (long)dyq_g, G, apps[k].B, g.Cout, NPB, po0[k], s));
+                flops += 2.0 * G * apps[k].B * NPB * (double)g.Cout * t.valid;
             }
-            return launch_wgrad_bf16(a, s, flops);
+            a.A = xcol; a.X = dyq;
+            return launch_conv_bf16(a, s, flops, /*prof_kind=*/1);
         }
     }
     WgradArgs a{};

@@ -99,19 +99,75 @@ __global__ __launch_bounds__(256) void pack_filter_bf16_kernel(const float* __re
     }
 }
 
-// planar fp32 -> planar bf16 (same index order): the filter gradient reads dY with 8 consecutive PIXELS to a unit
-__global__ __launch_bounds__(256) void pack_planar_bf16_kernel(const float* __restrict__ x, long x_gs, u32x4* __restrict__ y, long y_gs16, long n8) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n8) return;
-    const f32x4* src = reinterpret_cast<const f32x4*>(x + (long)blockIdx.y * x_gs) + 2 * i;
-    const f32x4 a = src[0], b = src[1];
-    u32x4 o = {pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]), pack_bf16x2(b[0], b[1]), pack_bf16x2(b[2], b[3])};
-    y[(long)blockIdx.y * y_gs16 + i] = o;
+// ---- filter gradient (autodiff of model.py:107-108 through module.py:32-40, 54-62) --------------------------------------
+//   dW[k][co] = sum over (application, sample, pixel) of Xg[k][P] * dY[co][P],   k = (tap, cin) in TF's own order
+// is a plain GEMM over the pixel axis, so it runs on conv_bf16_kernel itself: rows = K rows, "pixels" = Cout, K octets =
+// pixel octets (vc_api.hip: conv_wgrad).  What it needs is both operands with 8 consecutive PIXELS to a unit:
+// im2col in bf16: Xcol[g][po][k][8] = the 8 consecutive output pixels 8 po .. 8 po + 7 of K row k = tap * Cin + c, read
+// from the channel-octet packed activations.  A thread owns (channel octet, tap, pixel octet): it loads the 8 gathered
+// units (8 pixels x 8 channels, zeros where the tap leaves the image), transposes them in registers (v_perm_b32) and
+// stores 8 units = 128 contiguous bytes; lanes run along the channel octets, so a wave writes 8 KB in one piece.
+struct Im2colArgs {
+    const void* xp; void* xcol; long xp_gs, xcol_gs;      // bytes
+    const Tap* taps; int ntaps;
+    int C8, Hl, Wl, OW, NPB, si, sj, B, K;                  // K = ntaps * 8 * C8
+    int po0;                                                // first pixel octet of this application inside xcol
+    float inv_npb, inv_ow;
+};
+__global__ __launch_bounds__(256) void im2col_bf16_kernel(const Im2colArgs a) {
+    const int cb = blockIdx.x * 64 + threadIdx.x;
+    const int tap = blockIdx.y % a.ntaps, g = blockIdx.y / a.ntaps;
+    const int po = blockIdx.z * 4 + threadIdx.y;
+    if (cb >= a.C8 || po * 8 >= a.B * a.NPB) return;
+    int r, j0; const int b = fast_divmod(po * 8, a.NPB, a.inv_npb, &r); const int i = fast_divmod(r, a.OW, a.inv_ow, &j0);
+    const int ii = i * a.si + a.taps[tap].dh;
+    const u32x4* src = reinterpret_cast<const u32x4*>((const char*)a.xp + (long)g * a.xp_gs) + ((long)b * a.C8 + cb) * a.Hl * a.Wl + (long)ii * a.Wl;
+    u32x4 u[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int jj = (j0 + e) * a.sj + a.taps[tap].dw;
+        const bool ok = (unsigned)ii < (unsigned)a.Hl && (unsigned)jj < (unsigned)a.Wl;
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        u[e] = ok ? src[jj] : z;
+    }
+    u32x4* dst = reinterpret_cast<u32x4*>((char*)a.xcol + (long)g * a.xcol_gs) + (long)(a.po0 + po) * a.K + (long)tap * a.C8 * 8 + cb * 8;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {                // channel c of the octet: halfword c of every unit -> one unit of 8 pixels
+        u32x4 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            o[q] = __builtin_amdgcn_perm(u[2 * q + 1][c >> 1], u[2 * q][c >> 1], (c & 1) ? 0x07060302u : 0x05040100u);
+        dst[c] = o;
+    }
 }
-int launch_pack_planar_bf16(const float* x, long x_gs, void* y, long y_gs_bytes, int G, long n, hipStream_t s) {
-    if (n % 8 || x_gs % 4 || ((uintptr_t)x & 15)) { vc_set_error("pack_planar_bf16: tensor not a multiple of 8 elements / not 16-byte aligned"); return -1; }
-    dim3 grid((unsigned)((n / 8 + 255) / 256), G);
-    pack_planar_bf16_kernel<<<grid, 256, 0, s>>>(x, x_gs, (u32x4*)y, y_gs_bytes / 16, n / 8);
+// dYq[g][po][co][8] = bf16 of the 8 consecutive pixels 8 po .. + 7 of channel co (fp32 planar [g][b][Cout][NPB] in).
+// Lanes along co: 1 KB stores; the 32-byte reads of neighbouring pixel octets share their cache lines.
+__global__ __launch_bounds__(256) void pack_pixel_octets_bf16_kernel(const float* __restrict__ dy, long dy_gs, u32x4* __restrict__ out, long out_gs16,
+                                                                      int Cout, int NPB, int npo, int po0, float inv_npb) {
+    const int co = blockIdx.x * 64 + threadIdx.x, po = blockIdx.y * 4 + threadIdx.y, g = blockIdx.z;
+    if (co >= Cout || po >= npo) return;
+    int r; const int b = fast_divmod(po * 8, NPB, inv_npb, &r);
+    const f32x4* src = reinterpret_cast<const f32x4*>(dy + (long)g * dy_gs + ((long)b * Cout + co) * NPB + r);
+    const f32x4 v0 = src[0], v1 = src[1];
+    u32x4 o = {pack_bf16x2(v0[0], v0[1]), pack_bf16x2(v0[2], v0[3]), pack_bf16x2(v1[0], v1[1]), pack_bf16x2(v1[2], v1[3])};
+    out[(long)g * out_gs16 + (long)(po0 + po) * Cout + co] = o;
+}
+int launch_im2col_bf16(const void* xp, long xp_gs, void* xcol, long xcol_gs, const Tap* taps, int ntaps, int G, int B, int Cin,
+                       int Hl, int Wl, int OH, int OW, int si, int sj, int po0, hipStream_t s) {
+    Im2colArgs a{};
+    a.xp = xp; a.xcol = xcol; a.xp_gs = xp_gs; a.xcol_gs = xcol_gs; a.taps = taps; a.ntaps = ntaps;
+    a.C8 = Cin / 8; a.Hl = Hl; a.Wl = Wl; a.OW = OW; a.NPB = OH * OW; a.si = si; a.sj = sj; a.B = B; a.K = ntaps * Cin; a.po0 = po0;
+    a.inv_npb = 1.0f / (float)a.NPB; a.inv_ow = 1.0f / (float)OW;
+    const int npo = B * a.NPB / 8;
+    if (ntaps * G > 65535 || (npo + 3) / 4 > 65535) { vc_set_error("im2col_bf16: grid too large"); return -1; }
+    im2col_bf16_kernel<<<dim3((a.C8 + 63) / 64, ntaps * G, (npo + 3) / 4), dim3(64, 4), 0, s>>>(a);
+    VC_HIP(hipGetLastError());
+    return 0;
+}
+int launch_pack_pixel_octets_bf16(const float* dy, long dy_gs, void* out, long out_gs_bytes, int G, int B, int Cout, int NPB, int po0, hipStream_t s) {
+    const int npo = B * NPB / 8;
+    if (NPB % 8 || dy_gs % 4 || ((uintptr_t)dy & 15) || (npo + 3) / 4 > 65535) { vc_set_error("pack_pixel_octets_bf16: NPB %% 8 != 0, misaligned tensor or grid too large"); return -1; }
+    pack_pixel_octets_bf16_kernel<<<dim3((Cout + 63) / 64, (npo + 3) / 4, G), dim3(64, 4), 0, s>>>(dy, dy_gs, (u32x4*)out, out_gs_bytes / 16, Cout, NPB, npo, po0, 1.0f / (float)NPB);
     VC_HIP(hipGetLastError());
     return 0;
 }
@@ -348,177 +404,12 @@ void conv_bf16_config(ConvBf16Args& a) {
     a.splitk = sk;
 }
 
-int launch_conv_bf16(const ConvBf16Args& a, hipStream_t s, double flops) {
+int launch_conv_bf16(const ConvBf16Args& a, hipStream_t s, double flops, int prof_kind) {
     if (a.splitk > 1 && !a.accumulate) { vc_set_error("launch_conv_bf16: split-K requires accumulate semantics"); return -1; }
     dim3 grid(a.mtiles * a.ntiles, 1, a.groups * a.splitk);
-    ProfScope ps(0, flops, s);
+    ProfScope ps(prof_kind, flops, s);
     if (a.bm == 64) { if (a.nst == 4) conv_bf16_kernel<64, 4><<<grid, 256, 0, s>>>(a); else conv_bf16_kernel<64, 2><<<grid, 256, 0, s>>>(a); }
     else { if (a.nst == 4) conv_bf16_kernel<128, 4><<<grid, 256, 0, s>>>(a); else conv_bf16_kernel<128, 2><<<grid, 256, 0, s>>>(a); }
-    VC_HIP(hipGetLastError());
-    return 0;
-}
-
-// ------------------------------------------------------------------------------------------------------------------
-// filter gradient on the 16-bit data path (autodiff of model.py:107-108 through module.py:32-40, 54-62):
-//   dW[k][co] = sum over (segment, sample, pixel) of Xg[k][P] * dY[co][P],   k = (tap, cin) in forward-table order
-// The reduction axis is the PIXEL axis, so an MFMA lane needs 8 consecutive pixels of its row:
-//   dY  planar bf16 [b][co][pixel]: a 16-byte unit already is 8 pixels of one channel -> global -> LDS row -> fragment;
-//   X   channel-octet packed (as the forward reads it, so the tap shift is an address, never a misaligned unit):
-//       a unit is 8 channels of ONE gathered pixel and is scattered into 8 LDS rows with 16-bit writes
-//       (ds_write_b16 / _d16_hi), after which the rows are pixel-contiguous like dY's.
-// Tile 128 K rows x 128 Cout x 64 pixels per chunk, 2 x 2 waves of 64 x 64; segments as in vc_conv_wgrad.hip.
-// ------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgradBf16Args p) {
-    constexpr int BM = 128, BN = 128, PITCH = 144;
-    constexpr int ASZ = BM * PITCH, BSZ = BN * PITCH, STAGE = ASZ + BSZ;
-    constexpr int LDY = BN + 4;
-    static_assert(BM * LDY * 4 <= 2 * STAGE, "the epilogue stages the tile inside the operand buffers");
-    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
-    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l31 = lane & 31, h = lane >> 5;
-    const int wm = wv >> 1, wn = wv & 1;
-    const int nt = blockIdx.x % p.ntiles, kt = blockIdx.x / p.ntiles;
-    const int g = blockIdx.z / p.splitk, sp = blockIdx.z - g * p.splitk;
-    const int cps = (p.nchunks + p.splitk - 1) / p.splitk;
-    const int c0 = sp * cps, cn = min(cps, p.nchunks - c0);
-    if (cn <= 0) return;
-
-    // ---- K rows of this wave's X units: octets wv + 4 i of the tile (wave-uniform), their tap offsets
-    c_int_p oxs = (c_int_p)p.oxs; c_uint_p otap = (c_uint_p)p.otap; c_tap_p taps = (c_tap_p)p.taps;
-    int xso[4], dh[4], dw[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int o = kt * 16 + wv + 4 * i;
-        const unsigned tb = otap[o];
-        xso[i] = oxs[o];
-        const int t = tb ? __builtin_ctz(tb) : 0;
-        dh[i] = tb ? taps[t].dh : 0x4000;                 // padding octet: fails every bounds check
-        dw[i] = taps[t].dw;
-    }
-    const int px = lane;                                  // X: pixel of the chunk
-    const int du = tid & 7;                               // dY: unit (8 pixels) of the chunk, rows (tid >> 3) + 32 i
-    unsigned yrow[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) yrow[i] = (unsigned)min(nt * BN + (tid >> 3) + 32 * i, p.N - 1) * (unsigned)(p.NPB * 2);
-
-    u32x4 xr[4], yr[4];
-    auto gload = [&](int c) {
-        const int sg = (p.nseg > 1 && c >= p.seg[0].nchunks) ? 1 : 0;          // uniform
-        const int lc = c - (sg ? p.seg[0].nchunks : 0);
-        const bool live = c < p.nchunks;
-        const int segP = live ? p.seg[sg].Ptot : 0;
-        const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)((const char*)p.seg[sg].X + (long)g * p.seg[sg].x_gs - p.xbias), 0, (int)p.seg[sg].x_bytes, 0x00020000);
-        const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)((const char*)p.seg[sg].dY + (long)g * p.seg[sg].dy_gs), 0, (int)p.seg[sg].dy_bytes, 0x00020000);
-        {
-            const int P = lc * 64 + px;
-            const bool pv = P < segP;
-            int r, j; const int b = fast_divmod(pv ? P : 0, p.NPB, p.inv_npb, &r); const int i0 = fast_divmod(r, p.OWc, p.inv_ow, &j);
-            const int li0 = i0 * p.si, lj0 = j * p.sj;
-            const unsigned xoffb = (unsigned)((long)b * p.x_bs + ((long)li0 * p.xW + lj0) * 16);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const bool ok = pv & ((unsigned)(li0 + dh[i]) < (unsigned)p.Hl) & ((unsigned)(lj0 + dw[i]) < (unsigned)p.Wl);
-                xr[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, ok ? xoffb : VC_OOB, xso[i], 0));
-            }
-        }
-        {
-            const int P0 = lc * 64 + du * 8;
-            const bool pv = P0 < segP;
-            int r; const int b = fast_divmod(pv ? P0 : 0, p.NPB, p.inv_npb, &r);
-            const unsigned yoff = (unsigned)((long)b * p.dy_bs + (long)r * 2);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                yr[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(yrs, pv ? yoff + yrow[i] : VC_OOB, 0, 0));
-        }
-    };
-    auto lstore = [&](int buf) {
-        char* As = smem + buf * STAGE; char* Bs = As + ASZ;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            char* col = As + ((wv + 4 * i) * 8) * PITCH + px * 2;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                *reinterpret_cast<unsigned short*>(col + (2 * q) * PITCH) = (unsigned short)(xr[i][q] & 0xffffu);
-                *reinterpret_cast<unsigned short*>(col + (2 * q + 1) * PITCH) = (unsigned short)(xr[i][q] >> 16);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(Bs + ((tid >> 3) + 32 * i) * PITCH + du * 16) = yr[i];
-    };
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    gload(c0);
-    lstore(0);
-    gload(c0 + 1);
-    __syncthreads();
-    for (int c = 0; c < cn; ++c) {
-        const int buf = c & 1;
-        const char* As = smem + buf * STAGE + (wm * 64 + l31) * PITCH + h * 16;
-        const char* Bs = smem + buf * STAGE + ASZ + (wn * 64 + l31) * PITCH + h * 16;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(As + s * 32), a1 = *reinterpret_cast<const bf16x8*>(As + 32 * PITCH + s * 32);
-            const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(Bs + s * 32), b1 = *reinterpret_cast<const bf16x8*>(Bs + 32 * PITCH + s * 32);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
-        }
-        lstore(buf ^ 1);
-        gload(c0 + c + 2);
-        __syncthreads();
-    }
-
-    float* Ds = reinterpret_cast<float*>(smem);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                Ds[(wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * LDY + wn * 64 + j * 32 + l31] = acc[i][j][r];
-    __syncthreads();
-    float* Wg = p.dW + (long)g * p.dw_gs;
-    const int* wsrc = p.wsrc + kt * BM;
-    if (p.store && p.splitk == 1) {
-#pragma unroll 4
-        for (int i = 0; i < BM * BN / 4 / 256; ++i) {
-            const int idx = tid + i * 256, ml = idx >> 5, n4 = (idx & 31) * 4;
-            const int aoff = wsrc[ml], co = nt * BN + n4;
-            if (aoff < 0 || co >= p.N) continue;
-            *reinterpret_cast<f32x4*>(Wg + aoff + co) = *reinterpret_cast<const f32x4*>(Ds + ml * LDY + n4);
-        }
-    } else {
-#pragma unroll 4
-        for (int i = 0; i < BM * BN / 256; ++i) {
-            const int idx = tid + i * 256, ml = idx >> 7, n = idx & 127;
-            const int aoff = wsrc[ml], co = nt * BN + n;
-            if (aoff < 0 || co >= p.N) continue;
-            atomicAdd(Wg + aoff + co, Ds[ml * LDY + n]);
-        }
-    }
-}
-
-void wgrad_bf16_config(WgradBf16Args& a) {
-    a.ktiles = (a.koct + 15) / 16; a.ntiles = (a.N + 127) / 128;
-    const long tiles = (long)a.ktiles * a.ntiles * a.groups;
-    int sk = 1;
-    while (tiles * sk < 128 && a.nchunks / (sk * 2) >= 8 && sk < 32) sk *= 2;      // as conv_bf16_config: atomics on dW are dear
-    a.splitk = sk;
-}
-int launch_wgrad_bf16(const WgradBf16Args& a, hipStream_t s, double flops) {
-    dim3 grid(a.ktiles * a.ntiles, 1, a.groups * a.splitk);
-    ProfScope ps(1, flops, s);
-    wgrad_bf16_kernel<<<grid, 256, 0, s>>>(a);
     VC_HIP(hipGetLastError());
     return 0;
 }

@@ -118,28 +118,15 @@ struct ConvBf16Args {
     int bm, nst;                                  // tile rows (128 / 64), LDS ring depth (2 / 4)
 };
 void conv_bf16_config(ConvBf16Args& a);           // fills bm / nst / mtiles / ntiles / splitk
-int launch_conv_bf16(const ConvBf16Args& a, hipStream_t s, double flops);
+int launch_conv_bf16(const ConvBf16Args& a, hipStream_t s, double flops, int prof_kind = 0);
+// filter-gradient operands: Xcol[g][po][k][8] (im2col of the packed activations, 8 output pixels to a unit) and
+// dYq[g][po][co][8]; po0 = first pixel octet of this application inside the (two-application) buffers
+int launch_im2col_bf16(const void* xp, long xp_gs, void* xcol, long xcol_gs, const Tap* taps, int ntaps, int G, int B, int Cin,
+                       int Hl, int Wl, int OH, int OW, int si, int sj, int po0, hipStream_t s);
+int launch_pack_pixel_octets_bf16(const float* dy, long dy_gs, void* out, long out_gs_bytes, int G, int B, int Cout, int NPB, int po0, hipStream_t s);
 int launch_pack_act_bf16(const float* x, long x_gs, void* xp, long xp_gs_bytes, int G, int B, int C, int HW, hipStream_t s);
 // Ap[g][k/8][m][k%8] = bf16(W[g][wsrc[k] + m * a_ms]), 0 where wsrc[k] < 0; kp = 8 * koct
 int launch_pack_filter_bf16(const float* w, long w_gs, void* ap, long ap_gs_bytes, const int* wsrc, int a_ms, int G, int M, int kp, hipStream_t s);
-
-// Filter gradient on the 16-bit data path: X channel-octet packed (as ConvBf16Args), dY planar bf16 [g][b][N][NPB].
-// A segment is one application of the layer (WgradArgs).  oxs / otap / taps: octet view of the forward table; wsrc[k]:
-// float offset of K row k inside dW (-1 = padding row).  Strides in BYTES except dw_gs (floats).
-struct WgradBf16Seg { const void* X; const void* dY; long x_gs, dy_gs; unsigned x_bytes, dy_bytes; int Ptot, nchunks; };
-struct WgradBf16Args {
-    WgradBf16Seg seg[2]; int nseg;
-    float* dW; long dw_gs;
-    const int* oxs; const unsigned* otap; const int* wsrc; const Tap* taps; int xbias;
-    long x_bs, dy_bs;
-    int koct, N;
-    int Hl, Wl, xW, si, sj, NPB, OWc; float inv_npb, inv_ow;
-    int nchunks;                                  // 64-pixel chunks, all segments
-    int splitk, ktiles, ntiles, groups, store;
-};
-void wgrad_bf16_config(WgradBf16Args& a);         // fills ktiles / ntiles / splitk
-int launch_wgrad_bf16(const WgradBf16Args& a, hipStream_t s, double flops);
-int launch_pack_planar_bf16(const float* x, long x_gs, void* y, long y_gs_bytes, int G, long n, hipStream_t s);
 
 // Single-input-channel convolution (the discriminator's first layer, module.py:201-202: Cin = 1, 3x3 -> K = 9): a
 // bandwidth job, done on the vector ALU instead of padding K = 9 up to an MFMA tile.  kh*kw <= 9.
