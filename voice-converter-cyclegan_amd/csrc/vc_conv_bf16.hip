@@ -1,8 +1,8 @@
 // vc_conv_bf16.hip -- the bf16 arithmetic of BASELINE configs[2] (vc_plan_set_math_mode(VC_MATH_BF16)) as a 16-bit data
-// path: convolution forward (reference module.py:32-40, 54-62) and input gradient (autodiff of model.py:107-108) on
-// v_mfma_f32_32x32x16_bf16 with BOTH operands stored as bf16, 8 K values to a 16-byte unit, fp32 accumulate and fp32
-// output.  Same arithmetic as the operand-rounding mode of vc_conv_igemm.hip (every operand rounded to bf16 once, RNE;
-// fp32 products and sums), so the oracle's set_operand_rounding('bf16') describes it exactly.
+// path: convolution forward (reference module.py:32-40, 54-62), input gradient and filter gradient (autodiff of
+// model.py:107-108) on v_mfma_f32_32x32x16_bf16 with BOTH operands stored as bf16, 8 K values to a 16-byte unit, fp32
+// accumulate and fp32 output.  Same arithmetic as the operand-rounding mode of vc_conv_igemm.hip (every operand rounded to
+// bf16 once, RNE; fp32 products and sums), so the oracle's set_operand_rounding('bf16') describes it exactly.
 //
 // Layouts (built by the pack kernels below, consumed by conv_bf16_kernel):
 //   gathered operand  Xp[g][b][c/8][pixel][8]   one 16-byte unit = 8 consecutive channels of one pixel.  GEMM-K runs
@@ -10,13 +10,15 @@
 //                     global memory AND the MFMA B fragments of 64 lanes.
 //   filter image      Ap[g][k/8][m][8]          the same shape with the output channel in the pixel's place, K in the order
 //                     of the launch's table (padding octets 0): forward and input gradient read it the same way.
-// Both operands therefore move global -> LDS with global_load_lds_dwordx4 (lane-linear 1 KB copies: no staging registers,
-// no ds_write pass), the LDS stage [octet][row][16 B] is read back with ds_read_b128 at consecutive 16-byte units per
-// lane (conflict-free without padding), and nothing is transposed anywhere.  Lanes of padding taps are sent out of the
-// buffer's range: the hardware returns, and copies, zeros.
+// Both operands therefore move global -> LDS with buffer_load_dwordx4 ... lds (lane-linear 1 KB copies: no staging
+// registers, no ds_write pass), the LDS stage [octet][row][16 B] is read back with ds_read_b128 at consecutive 16-byte
+// units per lane (conflict-free without padding), and nothing is transposed anywhere.  Lanes of padding taps are sent out
+// of the buffer's range: the hardware returns, and copies, zeros.
 //
-// Workgroup: 256 threads = 2 x 2 waves, tile 128 (m) x 128 (pixels), K chunk 64, two 32 KB LDS stages; a wave owns
-// 64 x 64 = 2 x 2 MFMA tiles (16 MFMAs of 32 cycles per chunk against 16 ds_read_b128 and 8 LDS-direct copies).
+// Workgroup: 256 threads = 2 x 2 waves, tile 128 or 64 (m) x 128 (pixels), K chunk 64, a ring of 2 or 4 LDS stages of
+// 32 KB; a wave owns 64 x 64 = 2 x 2 MFMA tiles (16 MFMAs of 32 cycles per chunk against 16 ds_read_b128 and 8 LDS-direct
+// copies).  The filter gradient is the same kernel on operands repacked 8 PIXELS to a unit (im2col_bf16_kernel,
+// pack_pixel_octets_bf16_kernel; launch set-up in vc_api.hip: conv_wgrad).
 #include "vc_internal.h"
 #include <algorithm>
 #include <type_traits>
