@@ -324,11 +324,14 @@ static void bf16_set_vec4(ConvBf16Args& a) {
              a.y_gs % 4 == 0 && aligned16(a.Y) && (!a.addend || (aligned16(a.addend) && a.add_gs % 4 == 0));
 }
 
+// What a forward convolution needs to finish a gated block with instance norm in its own epilogue (IgemmArgs::fuse)
+struct FuseNorm { const float* gamma; const float* beta; long par_gs; float* stats; long st_gs; float* act; long act_gs; bool done; };
 // query != nullptr: do not launch, only report whether the launch would use split-K atomics (needs a zeroed y)
 static int conv_fwd(const float* x, long x_gs, const float* w, long w_gs, const float* bias, long b_gs,
                     float* y, long y_gs, int G, int B, const Geom& g, int math, hipStream_t s,
                     bool prezeroed = false, bool* query = nullptr, const char* packed_w = nullptr,
-                    char* xp_keep = nullptr, long xp_keep_gs = 0) {
+                    char* xp_keep = nullptr, long xp_keep_gs = 0, FuseNorm* fuse = nullptr) {
+    // fuse: the caller would like instance norm + GLU done in the epilogue; fuse->done tells whether this launch did it
     // xp_keep: where the packed bf16 copy of x is left for the layer's filter gradient (16-bit data path; group stride in bytes)
     VC_CHECK(check_conv_geom(g, B));
     if (c1_path(g)) {      // Cin = 1 (D.h1): vector-ALU kernel, plain stores, never needs a zeroed destination
@@ -391,6 +394,10 @@ static int conv_fwd(const float* x, long x_gs, const float* w, long w_gs, const 
     set_vec4(a);
     igemm_config(a, math);
     if (query) { *query = a.splitk > 1; return 0; }
+    if (fuse && a.bm == 64 && a.splitk == 1 && a.vec4 && g.H == 1 && g.kh == 1 && (a.NPB == 32 || a.NPB == 64) && g.Cout % 64 == 0) {
+        a.fuse = 1; a.gamma = fuse->gamma; a.beta = fuse->beta; a.par_gs = fuse->par_gs; a.stats = fuse->stats; a.st_gs = fuse->st_gs;
+        a.act = fuse->act; a.act_gs = fuse->act_gs; fuse->done = true;
+    }
     if (a.splitk > 1) {          // atomics need a zeroed destination
         if (!prezeroed)
             for (int gi = 0; gi < G; ++gi) VC_HIP(hipMemsetAsync(y + (long)gi * y_gs, 0, (size_t)B * a.y_bs * sizeof(float), s));
@@ -1090,10 +1097,18 @@ static int net_forward(NetCtx& c, const float* x, long x_gs, float* y_plain, lon
             VC_CHECK(launch_c1_fwd(f, c.s));
             in = f.act; in_gs = c.save_gs; continue;
         }
+        // gated block with instance norm and no pixel shuffle: the convolution may finish the block in its epilogue
+        FuseNorm fn{};
+        if (L.mode == M_GATED_IN && !L.ps) {
+            fn.gamma = c.params + L.gamma; fn.beta = c.params + L.beta; fn.par_gs = c.par_gs;
+            fn.stats = c.save + c.sm.st[i]; fn.st_gs = c.save_gs; fn.act = c.save + c.sm.act[i]; fn.act_gs = c.save_gs;
+        }
         VC_CHECK(conv_fwd(in, in_gs, c.params + L.w, c.par_gs, c.params + L.b, c.par_gs, raw, raw_gs, c.G, c.B, lg.g, c.math, c.s,
                           /*prezeroed=*/L.mode != M_PLAIN, nullptr, c.images ? (*c.images)[i].fwd : nullptr,
-                          (c.keep_packed && i > 0) ? (char*)(c.save + c.sm.actp[i - 1]) : nullptr, c.save_gs * 4));
+                          (c.keep_packed && i > 0) ? (char*)(c.save + c.sm.actp[i - 1]) : nullptr, c.save_gs * 4,
+                          fn.act ? &fn : nullptr));
         if (L.mode == M_PLAIN) break;
+        if (fn.done) { in = fn.act; in_gs = c.save_gs; continue; }
         NormArgs a{};
         a.y = raw; a.y_gs = raw_gs; a.out = c.save + c.sm.act[i]; a.out_gs = c.save_gs;
         a.G = c.G; a.B = c.B; a.C = L.C; a.ps = L.ps;

@@ -17,7 +17,11 @@
 //     (hardware range check -> 0) when the tap leaves the image for that pixel or the run is table padding;
 //   * the K row's offset rides in the buffer load's SGPR offset, fetched from scalar-cache tables one chunk ahead;
 //   * loader instructions are issued one slice behind every MFMA (sched_barrier-pinned), global loads two chunks ahead.
+//
+// FUSE = true (forward, 64-row tiles): the instance norm + GLU that follow a gated convolution pair (module.py:85-98) run
+// in the epilogue -- see the FUSE branch below; every other launch runs the FUSE = false instantiation, unchanged.
 #include "vc_internal.h"
+#include "vc_device_util.h"
 #include <algorithm>
 #include <type_traits>
 #include <utility>
@@ -26,8 +30,9 @@ typedef const __attribute__((address_space(4))) int* c_int_p;
 typedef const __attribute__((address_space(4))) unsigned* c_uint_p;
 typedef const __attribute__((address_space(4))) Tap* c_tap_p;
 
-template <int BM, bool AT, int KG, int MATH>
+template <int BM, bool AT, int KG, int MATH, bool FUSE = false>
 __global__ __launch_bounds__(64 * (BM / 32) * 2 * KG, (64 * (BM / 32) * 2 * KG >= 1024) ? 4 : 2) void igemm_kernel(const IgemmMulti mm) {
+    static_assert(!FUSE || (BM == 64 && !AT), "the fused instance-norm epilogue exists for forward launches with 64-row tiles");
     const IgemmArgs& p = mm.c[blockIdx.y];                    // blockIdx.y: which fused launch (parity class)
     if (blockIdx.x >= (unsigned)(p.mtiles * p.ntiles) || blockIdx.z >= (unsigned)(p.groups * p.splitk)) return;
     constexpr int BN = 64, KC = VC_KC, LDK = KC + 4;
@@ -107,7 +112,9 @@ __global__ __launch_bounds__(64 * (BM / 32) * 2 * KG, (64 * (BM / 32) * 2 * KG >
 #pragma unroll
         for (int q = 0; q < NMP; ++q) avoff[q] = (unsigned)(min(mt * BM + am + q * MPP, p.M - 1) * p.a_ms) * 4u + (unsigned)aq * 16u;
     } else {
-        avoff[0] = (unsigned)min(mt * BM + am, p.M - 1) * 4u;
+        // FUSE: tile rows 0-31 are value channels 32 mt .., rows 32-63 the matching gate channels C + 32 mt ..
+        const int ch = FUSE ? (am < 32 ? 0 : (p.M >> 1) - 32) + mt * 32 + am : mt * BM + am;
+        avoff[0] = (unsigned)min(ch, p.M - 1) * 4u;
     }
 
     constexpr int NAL = AT ? NMP : NQ * 4, NAS = AT ? NMP : NQ;
@@ -248,6 +255,65 @@ __global__ __launch_bounds__(64 * (BM / 32) * 2 * KG, (64 * (BM / 32) * 2 * KG >
     float* Yg = p.Y + (long)g * p.y_gs;
     const float* Bg = (p.bias && first) ? p.bias + (long)g * p.bias_gs : nullptr;
     const float* Dg = (p.addend && first) ? p.addend + (long)g * p.add_gs : nullptr;
+    if constexpr (FUSE) {
+        // ---- instance norm + GLU in the epilogue (module.py:85-98 as one kernel with the convolution pair).  1-D, vec4
+        //      layout, no split-K (checked by the launcher).  Phase A: sum the K groups, add the bias, store the raw pair and
+        //      leave the sums in LDS region 0; phase B: 16 lanes own one (value row, gate row) pair of the tile, 4 pixels
+        //      each: moments over the sample's NPB pixels by DPP, then the normalised, gated output.
+        const int C = p.M >> 1;
+        constexpr int NV = BM * BN / 4 / NT;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = tid + i * NT, ml = idx >> 4, n4 = (idx & 15) * 4;
+            const int ch = (ml < 32 ? 0 : C - 32) + mt * 32 + ml, P0 = nt * BN + n4;
+            f32x4 v = *reinterpret_cast<const f32x4*>(smem + ml * LDY + n4);
+#pragma unroll
+            for (int k2 = 1; k2 < KG; ++k2) v += *reinterpret_cast<const f32x4*>(smem + k2 * REG + ml * LDY + n4);
+            if (Bg) v += Bg[ch];
+            *reinterpret_cast<f32x4*>(smem + ml * LDY + n4) = v;      // this cell is read and written by this thread only
+            if (P0 < p.Ptot) {
+                int r0; const int b = fast_divmod(P0, p.NPB, p.inv_npb, &r0);
+                *reinterpret_cast<f32x4*>(Yg + (long)b * p.y_bs + (long)ch * p.yHW + r0) = v;
+            }
+        }
+        __syncthreads();
+        constexpr int PT = NT < 512 ? NT : 512;
+        if (tid < PT) {
+            const float invL = p.inv_npb;
+            const float* gam = p.gamma + (long)g * p.par_gs;
+            const float* bet = p.beta + (long)g * p.par_gs;
+            const bool whole = p.NPB == 64;               // 16 lanes = one sample, or two samples of 32 pixels
+            auto rsum = [&](float x) {
+                x += dpp_read<0xB1>(x); x += dpp_read<0x4E>(x); x += dpp_read<0x141>(x);      // sums of 8 lanes
+                if (whole) x += dpp_read<0x140>(x);
+                return x;
+            };
+#pragma unroll
+            for (int pass = 0; pass < 512 / PT; ++pass) {
+                const int pr = (tid >> 4) + pass * (PT / 16), n4 = (tid & 15) * 4;
+                const int c = mt * 32 + pr, P0 = nt * BN + n4;
+                const bool pv = P0 < p.Ptot;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(smem + pr * LDY + n4);
+                const f32x4 gt = *reinterpret_cast<const f32x4*>(smem + (pr + 32) * LDY + n4);
+                const float mu = rsum(pv ? v[0] + v[1] + v[2] + v[3] : 0.f) * invL;
+                const float mu2 = rsum(pv ? gt[0] + gt[1] + gt[2] + gt[3] : 0.f) * invL;
+                const f32x4 dv = v - mu, dg = gt - mu2;
+                const float rs = rsqrtf(rsum(pv ? dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2] + dv[3] * dv[3] : 0.f) * invL + 1e-6f);
+                const float rs2 = rsqrtf(rsum(pv ? dg[0] * dg[0] + dg[1] * dg[1] + dg[2] * dg[2] + dg[3] * dg[3] : 0.f) * invL + 1e-6f);
+                if (!pv) continue;
+                int r0; const int b = fast_divmod(P0, p.NPB, p.inv_npb, &r0);
+                const float ga = gam[c], be = bet[c], ga2 = gam[C + c], be2 = bet[C + c];
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (dv[e] * rs * ga + be) * sigmoidf_(dg[e] * rs2 * ga2 + be2);
+                *reinterpret_cast<f32x4*>(p.act + (long)g * p.act_gs + ((long)b * C + c) * p.NPB + r0) = o;
+                if (r0 == 0) {                            // one lane per (sample, channel pair)
+                    float* st = p.stats + (long)g * p.st_gs + ((long)b * 2 * C) * 2;
+                    st[2 * c] = mu; st[2 * c + 1] = rs; st[2 * (C + c)] = mu2; st[2 * (C + c) + 1] = rs2;
+                }
+            }
+        }
+    } else
     if (p.vec4 && !atomic) {
         // plain stores, 4 consecutive pixels (16 contiguous bytes) per lane: a wave instruction writes 4 rows x 256 B
         constexpr int NV = BM * BN / 4 / NT;
@@ -377,9 +443,19 @@ int launch_igemm_multi(const IgemmArgs* cls, int n, bool a_trans, int math, hipS
         m.c[i] = a; tiles = std::max(tiles, a.mtiles * a.ntiles); z = std::max(z, a.groups * a.splitk);
     }
     const int bm = cls[0].bm, kg = cls[0].kg;
+    const bool fuse = cls[0].fuse != 0;
+    if (fuse) {
+        const IgemmArgs& a = cls[0];
+        if (n != 1 || a_trans || bm != 64 || a.splitk != 1 || a.accumulate || !a.vec4 || (a.NPB != 32 && a.NPB != 64) || (a.M & 63) ||
+            a.so_w != 1 || a.o_w0 != 0 || a.yHW != a.NPB) {
+            vc_set_error("launch_igemm: this launch cannot carry the fused instance-norm epilogue"); return -1;
+        }
+    }
     dim3 grid(tiles, n, z), block(64 * (bm / 32) * 2 * kg);
     ProfScope ps(0, flops, s);
 #define VC_IG(BM, KG, MATH) { if (a_trans) igemm_kernel<BM, true, KG, MATH><<<grid, block, 0, s>>>(m); \
+                              else if constexpr (BM == 64) { if (fuse) igemm_kernel<BM, false, KG, MATH, true><<<grid, block, 0, s>>>(m); \
+                                                             else igemm_kernel<BM, false, KG, MATH><<<grid, block, 0, s>>>(m); } \
                               else igemm_kernel<BM, false, KG, MATH><<<grid, block, 0, s>>>(m); }
 #define VC_IG_MATH(MATH) \
     switch (bm * 8 + kg) { \

@@ -74,6 +74,12 @@ struct IgemmArgs {
     int vec4;                                     // 4 consecutive launch pixels are 16 contiguous, aligned output bytes
     int splitk, accumulate, mtiles, ntiles, groups;
     int bm, kg;                                   // tile rows (64 / 128) and K groups inside a workgroup (1, 2, 4)
+    // fuse != 0 (forward of a gated block with instance norm, module.py:85-98: 64-row tiles, no split-K, a (sample, channel)
+    // row of NPB = 32 or 64 pixels inside the 64-pixel tile): a tile holds 32 value channels and the matching 32 gate
+    // channels, and the epilogue writes the raw pair (for the backward), the statistics and act = IN(value) * sigmoid(IN(gate))
+    int fuse;
+    const float* gamma; const float* beta; float* stats; float* act;
+    long par_gs, st_gs, act_gs;
 };
 
 // Up to 4 launches of the same tile configuration fused into one grid (blockIdx.y): the stride-parity classes of an
