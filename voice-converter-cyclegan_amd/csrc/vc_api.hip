@@ -302,15 +302,6 @@ extern "C" int vc_release_workspaces(void) {
     return 0;
 }
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
-// 256 zero bytes in device memory (process lifetime): where the LDS-direct copies of padding taps read
-static int zero_page(const void** out) {
-    static void* z = nullptr;
-    static std::mutex mu;
-    std::lock_guard<std::mutex> l(mu);
-    if (!z) { VC_HIP(hipMalloc(&z, 256)); VC_HIP(hipMemset(z, 0, 256)); }
-    *out = z;
-    return 0;
-}
 // the path serves launches that fill its 128 x 128 tiles; everything else stays on the table-driven fp32-storage kernels
 static bool bf16_path(const Table& t, int math, int M, long Ptot) { return math == VC_MATH_BF16 && t.koct > 0 && M >= 64 && Ptot >= 64; }
 // the forward of this geometry at batch B runs on the 16-bit data path (the decision conv_fwd takes)
@@ -365,7 +356,6 @@ static int conv_fwd(const float* x, long x_gs, const float* w, long w_gs, const 
         char* wsp = nullptr;
         const size_t need = (xp_keep ? 0 : xp_g * G) + (packed_w ? 0 : ap_g * G);
         if (need) VC_CHECK(pack_space(s, need, &wsp));
-        VC_CHECK(zero_page(&a.zeros));
         char* xp = xp_keep ? xp_keep : wsp;
         if (xp_keep) a.x_gs = xp_keep_gs;
         a.X = xp; a.A = packed_w ? packed_w : wsp + (xp_keep ? 0 : xp_g * G);
@@ -459,7 +449,6 @@ static int conv_dgrad(const float* dy, long dy_gs, const float* w, long w_gs, fl
             }
             if (query) { *query = split; return 0; }
             char* wsp; VC_CHECK(pack_space(s, xp_g * G + (packed_w ? 0 : ap_tot), &wsp));
-            for (int i = 0; i < nc; ++i) VC_CHECK(zero_page(&cl[i].zeros));
             VC_CHECK(launch_pack_act_bf16(dy, dy_gs, wsp, (long)xp_g, G, B, g.Cout, g.OH * g.OW, s));
             if (split && !accumulate) {
                 if (!prezeroed)
@@ -593,7 +582,6 @@ static int conv_wgrad(const WgradApp* apps, int napps, float* dw, long dw_gs, in
             size_t xp_g[2] = {0, 0}, xp_tot = 0;
             for (int k = 0; k < napps; ++k) if (!apps[k].xp) { xp_g[k] = align256((size_t)apps[k].B * g.Cin * g.H * g.W * 2); xp_tot += xp_g[k] * G; }
             char* wsp; VC_CHECK(pack_space(s, (xcol_g + dyq_g) * G + xp_tot, &wsp));
-            VC_CHECK(zero_page(&a.zeros));
             char* xcol = wsp; char* dyq = wsp + xcol_g * G; char* xtmp = dyq + dyq_g * G;
             double flops = 0;
             for (int k = 0; k < napps; ++k) {

@@ -105,12 +105,11 @@ struct WgradArgs {
 // The 16-bit data path of the bf16 mode (vc_conv_bf16.hip): Y[g][b][m][P] (+)= sum_k Ap[g][m][k] * Xp-gather[k][P].
 //   X      packed gathered tensor  [g][b][C/8][Hl*Wl][8] bf16 (16-byte units: 8 channels of one pixel)
 //   A      packed filter image     [g][koct][M][8] bf16, k in the order of the octet table, padding octets 0
-//   zeros  at least 16 zero bytes (where lanes of padding taps read)
 //   xsoff  per K octet: byte offset ((c/8)*Hl*Wl + dh*xW + dw)*16 + xbias of the unit (SGPR offset of the load)
 //   otap   per K octet: 1 << tap (0 = padding octet: the load is sent out of range and returns 0)
 // Pixel grid / output fields as IgemmArgs.  Strides of A and X in BYTES, of Y / bias / addend in floats.
 struct ConvBf16Args {
-    const void* A; const void* X; const void* zeros; float* Y; const float* bias; const float* addend;
+    const void* A; const void* X; float* Y; const float* bias; const float* addend;
     const int* xsoff; const unsigned* otap; const Tap* taps; int ntaps; int xbias;
     unsigned x_bytes, a_bytes;
     long a_gs, x_gs, x_bs;                        // bytes
