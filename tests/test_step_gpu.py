@@ -112,6 +112,19 @@ def test_generator_forward(built_lib, B, T):
         eng.generate(A, 'sideways')          # model.py:134-135
 
 
+def test_inference_in_bf16_mode(built_lib):
+    """CycleGAN.test (model.py:128-137) with the plans in bf16 mode: inference plans run the fused h1 kernel and the 16-bit
+    data path with per-call packing (no step, hence no filter-image cache); against the oracle with bf16 operand rounding,
+    at an utterance length that is no multiple of the pixel tile."""
+    from tests import gpu_util as U
+    O, P, A, Bm, eng = _setup(2, 132, gap=False)
+    with _math('bf16', O, eng):
+        for direction, scope, x in (('A2B', 'generator_A2B', A), ('B2A', 'generator_B2A', Bm)):
+            ref, _ = O.generator_fwd(P, scope, x)
+            e = U.rel_err(eng.generate(x, direction), ref)
+            assert e < BF16_TOL, '%s bf16 inference rel err %g' % (direction, e)
+
+
 @pytest.mark.parametrize('mode', ['fp32', 'bf16', 'bf16x3'])
 def test_generator_backward(built_lib, mode):
     from tests import gpu_util as U
