@@ -378,8 +378,7 @@ template <int BM, int NST> __global__ __launch_bounds__(256, NST <= 2 ? 2 : 1) v
     }
 }
 
-// Tile rows: 128, or 64 where 128-row tiles would leave the chip underfilled (M = 512 layers at batch 64: twice the
-// workgroups at 3/4 of the LDS traffic per workgroup).  Split-K across workgroups costs fp32 atomics on the whole output
+// Tile rows and LDS ring depth by how many tiles the launch has.  Split-K across workgroups costs fp32 atomics on the whole output
 // plus its zero-fill (~1 TB/s of read-modify-write: 17 MB of output is ~20 us, as long as a 48-chunk K loop): only
 // launches that would leave most of the chip idle split.
 // tests / tuning: force one configuration of conv_bf16_kernel for every following launch of the process (0 = automatic)
@@ -394,8 +393,13 @@ extern "C" int vc_tune_conv_bf16_override(int tile_rows, int stages, int splitk)
 void conv_bf16_config(ConvBf16Args& a) {
     a.ntiles = (a.Ptot + 127) / 128;
     const long t128 = (long)((a.M + 127) / 128) * a.ntiles * a.groups;
-    a.bm = a.M <= 64 ? 64 : 128;
-    a.nst = t128 <= 256 ? 4 : 2;                  // one workgroup per CU: deep ring; more: two resident workgroups, two stages each
+    // measured (tools/bench_conv.py + vc_tune_conv_bf16_override per shape, then whole steps at batch 8 - 64 on one box):
+    //   more than one 128-row tile per CU : 128 rows, two resident workgroups with two stages each (1007 TFLOP/s on D.d3)
+    //   about one per CU                  : 128 rows, one workgroup per CU on the 4-stage ring
+    //   fewer                             : 64-row tiles double the workgroups, 4-stage ring (-11 % step time at batch 8)
+    if (t128 > 256 && a.M > 64) { a.bm = 128; a.nst = 2; }
+    else if (t128 > 128 && a.M > 64) { a.bm = 128; a.nst = 4; }
+    else { a.bm = 64; a.nst = 4; }
     if (g_bf16_bm) { a.bm = g_bf16_bm; a.nst = g_bf16_nst; }
     a.mtiles = (a.M + a.bm - 1) / a.bm;
     const long tiles = (long)a.mtiles * a.ntiles * a.groups;
