@@ -227,7 +227,9 @@ def test_train_step_losses_grads_and_updates(built_lib, B):
             # Adam's first steps move every weight by ~lr * sign(g): a weight whose gradient is within rounding of zero
             # may move the other way on the two sides (2 lr per step); they must be rare
             assert diff.max() <= 2.02 * lr * (step + 1), (step, n, float(diff.max()))
-            assert frac < 1e-3, (step, n, frac)
+            # step 0 runs on a tie-free forward (_setup); the weights of the later steps are not searched for ties, and one
+            # flipped L1 sign moves ~1 % of the weights the other way (see test_graph_step_equals_launch_by_launch)
+            assert frac < (1e-3 if step == 0 else 5e-2), (step, n, frac)
 
 
 @pytest.mark.parametrize('mode', ['bf16', 'bf16x3'])
