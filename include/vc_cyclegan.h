@@ -58,16 +58,30 @@ uint32_t vc_crc32c(const void* data, uint64_t n, uint32_t crc);
 int  vc_set_math_mode(int mode);
 int  vc_get_math_mode(void);
 /* bf16 mode keeps packed bf16 copies of the convolution operands in one workspace per stream, grown on first use and
- * reused afterwards (steady state never allocates).  This frees them all (synchronises the device); they regrow on demand.
- * Step graphs captured in bf16 mode (vc_train_step_graph) hold their addresses: destroy those plans first. */
+ * reused afterwards (steady state never allocates; vc_plan_destroy frees those of the plan's own streams).  This frees
+ * them all (synchronises the device); they regrow on demand.  Step graphs captured in bf16 mode (vc_train_step_graph) hold
+ * their addresses: the graph cache is keyed on a workspace generation, so a graph captured before a release / regrowth is
+ * never replayed again (the step is re-captured). */
 int  vc_release_workspaces(void);
-/* tools/tune_igemm.py ONLY: forces the tile rows (64 / 128), K groups per workgroup (1, 2, 4) and split-K factor of every
- * following implicit-GEMM launch of the process; (0, 0, 0) restores the automatic choice.  Not thread-safe, not for
- * production use -- it exists so that the measured table (csrc/vc_tuned_igemm.h) can be regenerated. */
+/* Deterministic mode.  By default a few reductions meet in scheduling order (split-K partial tiles and bias / gamma /
+ * beta sums are combined with fp32 atomics), so two runs on identical inputs agree to rounding, not bitwise -- and
+ * d|x|/dx = sign(x) (utils.py:6-8) can turn one such rounding into a flipped gradient element.  With the mode on, every
+ * launch reduces in a fixed order: K is split only inside a workgroup, per-channel parameter gradients are summed over
+ * the batch inside one lane group, the Cin = 1 input gradient is a gather.  Two runs are then BITWISE equal (also a
+ * hipGraph replay vs the same step launched kernel by kernel).  Slower on small batches (no split-K to fill the chip).
+ * Like the math mode it is a property of a PLAN (vc_plan_set_deterministic); vc_set_deterministic sets the calling
+ * thread's default: the mode of operator-level calls and the initial mode of plans that thread creates. */
+int  vc_set_deterministic(int on);
+int  vc_get_deterministic(void);
+/* Tuning / test hooks (tools/tune_igemm.py regenerates csrc/vc_tuned_igemm.h with them; tests force every built kernel
+ * instantiation against the oracle).  Each forces ONE configuration for the following launches of the CALLING THREAD
+ * (thread-local state); (0, 0, 0) restores the automatic choice.  Not for production use.
+ *   igemm    : conv forward / input gradient, fp32 storage: tile rows (64 / 128), K groups per workgroup (1, 2, 4), split-K
+ *   wgrad    : filter gradient, fp32 storage: tile columns (64 / 128), K groups (1, 2, 4), split-K
+ *   conv_bf16: the 16-bit data path of the bf16 mode (csrc/vc_conv_bf16.hip): tile rows (64 / 128), LDS ring stages (2 / 4),
+ *              split-K (1..16) */
 int  vc_tune_igemm_override(int tile_rows, int k_groups, int splitk);
-/* Same for the 16-bit data path of the bf16 mode (csrc/vc_conv_bf16.hip): tile rows (64 / 128), LDS ring stages (2 / 4),
- * split-K (1..16); (0, 0, 0) restores the automatic choice.  Tests use it to run every built configuration against the
- * oracle; not thread-safe, not for production use. */
+int  vc_tune_wgrad_override(int tile_cols, int k_groups, int splitk);
 int  vc_tune_conv_bf16_override(int tile_rows, int stages, int splitk);
 /* Opt-in per-launch timing of the implicit-GEMM kernels (bench.py roofline leg).
  * While enabled every igemm/wgrad launch is bracketed by hipEvents on its stream. */
@@ -197,6 +211,8 @@ int  vc_plan_create_inference(int num_features, int n_frames, vc_plan** out);
 void vc_plan_destroy(vc_plan* p);
 int  vc_plan_set_math_mode(vc_plan* p, int mode);     /* see vc_set_math_mode */
 int  vc_plan_get_math_mode(const vc_plan* p);
+int  vc_plan_set_deterministic(vc_plan* p, int on);   /* see vc_set_deterministic */
+int  vc_plan_get_deterministic(const vc_plan* p);
 /* Workspace sizes in floats for batch B per group. */
 int64_t vc_generator_save_floats(const vc_plan* p, int B);       /* activations kept for backward */
 int64_t vc_discriminator_save_floats(const vc_plan* p, int B);
@@ -293,12 +309,14 @@ int vc_comm_unique_id(void* id128);
 int vc_comm_init(int rank, int world, const void* id128, vc_comm** out);
 int vc_comm_destroy(vc_comm* c);
 int vc_comm_world(const vc_comm* c);                   /* ranks RCCL reports for this communicator (1 for NULL) */
+int64_t vc_comm_collectives(const vc_comm* c);         /* ncclAllReduce calls enqueued through this communicator so far (diagnostics / tests) */
 /* in-place SUM all-reduce of n floats on `stream` (ncclAllReduce, fp32) */
 int vc_allreduce_f32(const vc_comm* c, float* buf, int64_t n, void* stream);
 /* After vc_cyclegan_step_grads: gradient exchange + both ApplyAdam updates (model.py:107-108 / 112-119), segment by
  * segment on `update_stream` as soon as a segment's gradients are final and its weights no longer read (the events of
- * vc_step_wait_*): SUM all-reduce over `comm` (NULL or world 1: none), then Adam with grad_scale 1/world.  alpha_g /
- * alpha_d as in vc_adam_tf_update, one per optimizer.  The caller makes its main stream wait for `update_stream`
+ * vc_step_wait_*): SUM all-reduce over `comm` (NULL: single GPU, no collective; a communicator of ANY size, one rank
+ * included, gets the collectives: 1 for the discriminator half + a group of 2 per generator bucket), then Adam with
+ * grad_scale 1/world.  alpha_g / alpha_d as in vc_adam_tf_update, one per optimizer.  The caller makes its main stream wait for `update_stream`
  * before the next step. */
 int vc_step_exchange_and_update(const vc_plan* p, const vc_comm* comm, float* params, float* grads, float* m, float* v,
                                 float alpha_g, float alpha_d, float beta1, float beta2, float eps, void* update_stream);

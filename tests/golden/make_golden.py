@@ -9,6 +9,12 @@ and give the GPU tests an oracle-free comparison target; they are not reference 
                          gradient L2 norms, and losses of train steps 1..3.
  train_log_pins.npz    : five numbers copied from the reference's TensorBoard export
                          (train_log/*.csv row 2, step 167) that pin model.py:72's loss weights.
+ golden_f32_b64.npz    : one train step (model.py:110-125) at the batch bench.py times as BASELINE configs[2]
+ golden_bf16_b64.npz     (B=64, 24x128), fp32 and with bf16 operand rounding (O.set_operand_rounding): the 8 logged
+                         scalars, generation_A/B, per-tensor gradient L2 + projection, and the cumulative
+                         distribution of the L1 terms' |y_hat - y| (how many utils.l1_loss elements sit within a
+                         given distance of a sign flip -- the test derives its gradient tolerance from it).
+                         `python tests/golden/make_golden.py b64` (minutes of CPU; not part of the default run).
 """
 import os
 import sys
@@ -64,6 +70,36 @@ def full():
     np.savez_compressed(os.path.join(HERE, 'golden_full_f32.npz'), **out)
 
 
+LOSS_KEYS = ('cycle_loss', 'identity_loss', 'generator_loss_A2B', 'generator_loss_B2A', 'generator_loss',
+             'discriminator_loss_A', 'discriminator_loss_B', 'discriminator_loss')
+L1_CDF_X = np.logspace(-7, -1, 49)          # distances of an L1 element from a tie at which the CDF is recorded
+
+
+def full_b64(rounding):
+    """One step at B=64 (model.py:110-125) with the weights / batch of full(); rounding None or 'bf16'."""
+    P = O.init_params(seed=42, randomize_affine=True)
+    A, B = O.synthetic_batch(64, 24, 128)
+    O.set_operand_rounding(rounding)
+    try:
+        orc = O.CycleGANOracle({k: v.copy() for k, v in P.items()})
+        orc.train(A, B, 10.0, 5.0, 2e-4, 1e-4)
+    finally:
+        O.set_operand_rounding(None)
+    out = {'losses': np.array([orc.last[k] for k in LOSS_KEYS], np.float32)}
+    out['gen_A'], out['gen_B'] = orc.last_fakes
+    Gg, Gd = orc.last_grads
+    G = {**Gg, **Gd}
+    names = sorted(G)
+    out['grad_names'] = np.array(names)
+    out['grad_l2'] = np.array([np.linalg.norm(G[n].astype(np.float64)) for n in names])
+    out['grad_proj'] = np.array([probe(G[n], i) for i, n in enumerate(names)])
+    d = np.sort(orc.last_l1_dist.astype(np.float64))
+    out['l1_cdf_x'] = L1_CDF_X
+    out['l1_cdf_y'] = np.searchsorted(d, L1_CDF_X, side='right') / float(d.size)
+    out['l1_count'] = np.int64(d.size)
+    np.savez_compressed(os.path.join(HERE, 'golden_%s_b64.npz' % ('bf16' if rounding else 'f32')), **out)
+
+
 def train_log_pins():
     # /root/reference/train_log/run_20180619-011402-tag-generator_summaries_*.csv, line 2 (step 167)
     np.savez(os.path.join(HERE, 'train_log_pins.npz'), step=167, cycle_loss=1.444779872894287,
@@ -73,6 +109,9 @@ def train_log_pins():
 
 
 if __name__ == '__main__':
-    shrunk(); full(); train_log_pins()
+    if sys.argv[1:] == ['b64']:
+        full_b64(None); full_b64('bf16')
+    else:
+        shrunk(); full(); train_log_pins()
     for f in sorted(os.listdir(HERE)):
         print(f, os.path.getsize(os.path.join(HERE, f)))

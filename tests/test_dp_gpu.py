@@ -85,8 +85,10 @@ def _nccl_worker(port, outdir):
 def test_rccl_through_the_c_abi_single_rank(built_lib, tmp_path):
     """vc_comm_unique_id / vc_comm_init (ncclCommInitRank) / vc_allreduce_f32 (ncclAllReduce) / vc_step_exchange_and_update
     with a communicator / vc_comm_destroy on a 1-rank RCCL communicator: the only RCCL configuration a 1-GPU box offers
-    (RCCL refuses two ranks on one device).  A SUM over one rank is the identity, so the update with the communicator must
-    equal the update without it bit for bit."""
+    (RCCL refuses two ranks on one device).  With a communicator the native exchange ISSUES its collectives whatever the
+    rank count -- ncclAllReduce of the discriminator half, then ncclGroupStart / 2 x ncclAllReduce / ncclGroupEnd per generator
+    bucket, each on the update stream behind vc_step_wait_d_grads / vc_step_wait_g_bucket -- and a SUM over one rank is the
+    identity: in deterministic mode the parameters after the update must equal the no-communicator update BIT FOR BIT."""
     import ctypes as C
     from voice_converter_cyclegan_amd import _lib
     from voice_converter_cyclegan_amd._lib import lib, ptr, check
@@ -107,14 +109,20 @@ def test_rccl_through_the_c_abi_single_rank(built_lib, tmp_path):
     rng = np.random.default_rng(5)
     A = rng.standard_normal((2, 24, 128)).astype(np.float32); B = rng.standard_normal((2, 24, 128)).astype(np.float32)
     res = []
+    n0 = lib.vc_comm_collectives(h)
     for comm in (h, None):
         eng = CycleGANEngine(24, device='cuda:0', seed=9, data_parallel=False)
+        eng.set_deterministic(True)
         eng.sync.comm = comm                      # as GradSync sets it up on the 'nccl' backend
-        eng.train_step(A, B, 10.0, 5.0, 2e-4, 1e-4)
+        for _ in range(2):
+            eng.train_step(A, B, 10.0, 5.0, 2e-4, 1e-4)
         torch.cuda.synchronize()
-        res.append((float(eng.params.double().sum()), float(eng.params.double().abs().sum())))
+        res.append((eng.params.clone(), eng.m.clone(), eng.v.clone()))
         eng.sync.comm = None
-    assert abs(res[0][0] - res[1][0]) <= 1e-6 * abs(res[1][1]) and abs(res[0][1] - res[1][1]) <= 1e-6 * res[1][1], res
+    nb = lib.vc_step_num_g_buckets(eng.plan(128))
+    assert lib.vc_comm_collectives(h) - n0 == 2 * (1 + 2 * nb), 'the native exchange did not issue its collectives'
+    assert all(torch.equal(a, b) for a, b in zip(res[0], res[1])), 'update through a 1-rank communicator differs from the plain update'
+    assert torch.isfinite(res[0][0]).all()
     check(lib.vc_comm_destroy(h), 'vc_comm_destroy')
     # GradSync on the nccl backend builds the native communicator (world 1: no collective is needed, none is created)
     ctx = mp.get_context('spawn')

@@ -119,6 +119,58 @@ def test_conv_bf16_data_path_every_configuration(built_lib, case, cfg):
     assert lib.vc_tune_conv_bf16_override(96, 2, 1) != 0          # not a built configuration
 
 
+FP32_CFG_CASES = [(128, 1, 128, 512, 1, 5, 1, 2, 4),      # G.d1: stride 2 -> two input-gradient parity classes (fused into one launch)
+                  (512, 1, 32, 2048, 1, 3, 1, 1, 8),      # residual h1
+                  (256, 12, 32, 1024, 3, 3, 2, 2, 2),     # D.d2: 2-D, four parity classes
+                  (64, 1, 132, 192, 1, 5, 1, 1, 3)]       # ragged: M and the pixel count are not tile multiples
+
+
+@pytest.mark.parametrize('cfg', [(64, 1, 1), (64, 2, 1), (64, 4, 1), (128, 1, 1), (128, 2, 1),
+                                 (64, 1, 4), (64, 2, 2), (64, 4, 2), (128, 1, 2), (128, 2, 4)])
+@pytest.mark.parametrize('case', FP32_CFG_CASES)
+def test_conv_fp32_every_configuration(built_lib, case, cfg):
+    """igemm_kernel<tile rows, transposed?, K groups> x split-K (vc_conv_igemm.hip) and wgrad_kernel<tile columns, K groups> x
+    split-K (vc_conv_wgrad.hip): EVERY built fp32 configuration against the oracle (module.py:32-40, 54-62 and their input
+    / filter gradients) at 1e-4.  The B = 8 step takes its configurations from the measured table (vc_tuned_igemm.h); other
+    batches (bench.py --batch 32 / 64 / 256, 36x256) go by the cost model, which reaches 128-row tiles and other K-group /
+    split-K combinations -- they are forced here (vc_tune_igemm_override / vc_tune_wgrad_override) on sizes the oracle
+    finishes in seconds, so no timed instantiation is an untested one."""
+    from voice_converter_cyclegan_amd._lib import lib, check
+    check(lib.vc_tune_igemm_override(*cfg))
+    check(lib.vc_tune_wgrad_override(*cfg))
+    try:
+        _conv_check(case)
+    finally:
+        check(lib.vc_tune_igemm_override(0, 0, 0))
+        check(lib.vc_tune_wgrad_override(0, 0, 0))
+    assert lib.vc_tune_igemm_override(96, 2, 1) != 0 and lib.vc_tune_wgrad_override(128, 4, 1) != 0      # not built
+
+
+@pytest.mark.parametrize('case', [CONV_CASES[i] for i in (1, 3, 8, 10, 11, 15, 27, 28)])
+def test_conv_deterministic_mode(built_lib, case):
+    """vc_set_deterministic: no split-K across workgroups, gather-form Cin = 1 input gradient, one block per Cin = 1 filter-
+    gradient element -- same oracle tolerance, and two calls on the same inputs are BITWISE equal (model.py:110-125 run twice
+    on one feed gives one answer in the reference's own deterministic CPU kernels)."""
+    from tests import gpu_util as U
+    from voice_converter_cyclegan_amd._lib import lib, check
+    check(lib.vc_set_deterministic(1))
+    try:
+        assert lib.vc_get_deterministic() == 1
+        _conv_check(case)
+        Cin, H, W, Cout, kh, kw, sh, sw, B = case
+        rng = np.random.default_rng(5)
+        x = U.dev(rng.standard_normal((2, B, Cin, H, W)).astype(np.float32))
+        w = U.dev((rng.standard_normal((2, kh, kw, Cin, Cout)) / np.sqrt(kh * kw * Cin)).astype(np.float32))
+        b = U.dev(rng.uniform(-0.5, 0.5, (2, Cout)).astype(np.float32))
+        y1 = U.conv_fwd(x, w, b, kh, kw, sh, sw); y2 = U.conv_fwd(x, w, b, kh, kw, sh, sw)
+        assert torch.equal(y1, y2)
+        dy = torch.randn_like(y1)
+        assert torch.equal(U.conv_dgrad(dy, w, H, W, kh, kw, sh, sw), U.conv_dgrad(dy, w, H, W, kh, kw, sh, sw))
+        assert torch.equal(U.conv_wgrad(x, dy, kh, kw, sh, sw), U.conv_wgrad(x, dy, kh, kw, sh, sw))
+    finally:
+        check(lib.vc_set_deterministic(0))
+
+
 def test_bf16_mode_is_really_bf16(built_lib):
     """The bf16 mode must differ from fp32 by bf16-sized errors (guards against a silent fp32 fallback)."""
     from tests import gpu_util as U
@@ -246,6 +298,18 @@ NORM_CASES = [
     (1, 0, 64, 4608, 2), (0, 0, 32, 2304, 2), (2, 0, 16, 3000, 1), (0, 1, 8, 4100, 2), (1, 0, 8, 2049, 1),   # rows > 2048: streaming kernels
     (0, 0, 512, 2, 3), (0, 0, 256, 4, 3), (2, 0, 512, 2, 3), (0, 1, 512, 4, 3), (0, 1, 256, 8, 3), (1, 0, 128, 8, 3),
 ]
+
+
+@pytest.mark.parametrize('case', [NORM_CASES[i] for i in (0, 2, 4, 8, 10, 13, 16, 18, 22)])
+def test_instnorm_glu_deterministic_mode(built_lib, case):
+    """the backward's gamma / beta / conv-bias sums reduced over the batch in a fixed order (norm_bwd_kernel<.., DET>): same
+    oracle tolerance (module.py:9-20 and its gradient); bitwise repeatability is asserted at step level"""
+    from voice_converter_cyclegan_amd._lib import lib, check
+    check(lib.vc_set_deterministic(1))
+    try:
+        test_instnorm_glu(built_lib, case)
+    finally:
+        check(lib.vc_set_deterministic(0))
 
 
 @pytest.mark.parametrize('case', NORM_CASES)

@@ -38,7 +38,10 @@ SIGNATURES = [
     ('vc_set_math_mode', i32, [i32]),
     ('vc_get_math_mode', i32, []),
     ('vc_release_workspaces', i32, []),
+    ('vc_set_deterministic', i32, [i32]),
+    ('vc_get_deterministic', i32, []),
     ('vc_tune_igemm_override', i32, [i32, i32, i32]),
+    ('vc_tune_wgrad_override', i32, [i32, i32, i32]),
     ('vc_tune_conv_bf16_override', i32, [i32, i32, i32]),
     ('vc_prof_enable', i32, [i32]),
     ('vc_prof_collect', i32, [i32, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_double)]),
@@ -64,6 +67,8 @@ SIGNATURES = [
     ('vc_plan_destroy', None, [vp]),
     ('vc_plan_set_math_mode', i32, [vp, i32]),
     ('vc_plan_get_math_mode', i32, [vp]),
+    ('vc_plan_set_deterministic', i32, [vp, i32]),
+    ('vc_plan_get_deterministic', i32, [vp]),
     ('vc_generator_save_floats', i64, [vp, i32]),
     ('vc_discriminator_save_floats', i64, [vp, i32]),
     ('vc_scratch_floats', i64, [vp, i32]),
@@ -86,6 +91,7 @@ SIGNATURES = [
     ('vc_comm_init', i32, [i32, i32, vp, C.POINTER(vp)]),
     ('vc_comm_destroy', i32, [vp]),
     ('vc_comm_world', i32, [vp]),
+    ('vc_comm_collectives', i64, [vp]),
     ('vc_allreduce_f32', i32, [vp, vp, i64, vp]),
     ('vc_step_exchange_and_update', i32, [vp, vp, vp, vp, vp, vp, f32, f32, f32, f32, f32, vp]),
 ]

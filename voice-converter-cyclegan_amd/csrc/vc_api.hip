@@ -5,6 +5,7 @@
 #include "../../include/vc_cyclegan.h"
 #include <algorithm>
 #include <array>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -233,6 +234,14 @@ extern "C" int vc_set_math_mode(int mode) {
 }
 extern "C" int vc_get_math_mode(void) { return t_math; }
 
+// deterministic mode (vc_internal.h): the calling thread's default, and the setting of the plan whose launches are being issued
+static thread_local int t_det = 0, t_det_scope = -1;
+bool vc_det_active() { return (t_det_scope >= 0 ? t_det_scope : t_det) != 0; }
+DetScope::DetScope(int det) : saved(t_det_scope) { t_det_scope = det ? 1 : 0; }
+DetScope::~DetScope() { t_det_scope = saved; }
+extern "C" int vc_set_deterministic(int on) { t_det = on ? 1 : 0; return 0; }
+extern "C" int vc_get_deterministic(void) { return t_det; }
+
 // ------------------------------------------------------------------------------------
 // conv operators
 // ------------------------------------------------------------------------------------
@@ -247,7 +256,7 @@ static bool wsconv_path(const Geom& g) {
 static C1Args c1_args(const Geom& g, int G, int B, int math) {
     C1Args c{};
     c.B = B; c.H = g.H; c.W = g.W; c.Cout = g.Cout; c.kh = g.kh; c.kw = g.kw; c.sh = g.sh; c.sw = g.sw;
-    c.OH = g.OH; c.OW = g.OW; c.pt = g.pt; c.pl = g.pl; c.G = G; c.math = math;
+    c.OH = g.OH; c.OW = g.OW; c.pt = g.pt; c.pl = g.pl; c.G = G; c.math = math; c.det = vc_det_active() ? 1 : 0;
     return c;
 }
 static int check_conv_geom(const Geom& g, int B) {
@@ -275,6 +284,8 @@ static void set_vec4(IgemmArgs& a) {
 struct PackSpace { char* p = nullptr; size_t cap = 0; };
 static std::mutex g_ws_mu;
 static std::map<hipStream_t, PackSpace> g_ws;
+// bumped whenever a workspace block is freed or moved: captured step graphs hold these addresses and are keyed on it
+static std::atomic<long> g_ws_generation{0};
 static int pack_space(hipStream_t s, size_t bytes, char** out) {
     std::lock_guard<std::mutex> l(g_ws_mu);
     PackSpace& w = g_ws[s];
@@ -284,7 +295,7 @@ static int pack_space(hipStream_t s, size_t bytes, char** out) {
             vc_set_error("bf16 data path: the packed-operand workspace would have to grow during stream capture; run one eager step of this batch first");
             return VC_E_STATE;
         }
-        if (w.p) VC_HIP(hipFree(w.p));
+        if (w.p) { VC_HIP(hipFree(w.p)); ++g_ws_generation; }
         w.p = nullptr; w.cap = 0;
         const size_t cap = bytes + bytes / 4 + (1u << 20);
         VC_HIP(hipMalloc((void**)&w.p, cap));
@@ -299,7 +310,18 @@ extern "C" int vc_release_workspaces(void) {
     std::lock_guard<std::mutex> l(g_ws_mu);
     for (auto& kv : g_ws) if (kv.second.p) (void)hipFree(kv.second.p);
     g_ws.clear();
+    ++g_ws_generation;
     return 0;
+}
+// a plan's streams go away with it: free their workspaces (a recycled stream handle must not inherit a stale block)
+static void drop_pack_spaces(std::initializer_list<hipStream_t> streams) {
+    std::lock_guard<std::mutex> l(g_ws_mu);
+    for (hipStream_t s : streams) {
+        auto it = g_ws.find(s);
+        if (it == g_ws.end()) continue;
+        if (it->second.p) { (void)hipFree(it->second.p); ++g_ws_generation; }      // hipFree waits for the device
+        g_ws.erase(it);
+    }
 }
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 // the path serves launches that fill its 128 x 128 tiles; everything else stays on the table-driven fp32-storage kernels
@@ -427,6 +449,8 @@ static int conv_dgrad(const float* dy, long dy_gs, const float* w, long w_gs, fl
             size_t ap_off[4], ap_tot = 0;
             for (int ph = 0; ph < g.sh; ++ph) for (int pw = 0; pw < g.sw; ++pw) {
                 const int Hc = (g.H - ph + g.sh - 1) / g.sh, Wc = (g.W - pw + g.sw - 1) / g.sw;
+                // prebuilt images (refresh_filter_images) are indexed by (ph, pw) without gaps: an empty class would shift them
+                VC_ARG(!(packed_w && (Hc <= 0 || Wc <= 0)), "conv input gradient: an empty stride-parity class with prebuilt filter images");
                 if (Hc <= 0 || Wc <= 0) continue;
                 VC_ARG(nc < 4, "conv input gradient: more than 4 stride-parity classes");
                 Table t; VC_CHECK(get_dgrad_table(g, ph, pw, &t));
@@ -690,7 +714,7 @@ extern "C" int vc_instnorm_glu_bwd(int mode, int ps, const float* y, int64_t y_g
     a.dgamma = dgamma; a.dbeta = dbeta; a.dbias = dbias;
     a.y_gs = y_gs; a.do_gs = do_gs; a.par_gs = par_gs; a.st_gs = st_gs; a.dy_gs = dy_gs;
     a.dpar_gs = dpar_gs; a.dbias_gs = dbias_gs;
-    a.G = G; a.B = B; a.C = C; a.L = L; a.ps = ps;
+    a.G = G; a.B = B; a.C = C; a.L = L; a.ps = ps; a.det = vc_det_active() ? 1 : 0;
     return launch_norm_bwd(mode, a, (hipStream_t)stream);
 }
 extern "C" int vc_disc_head_fwd(const float* x, int64_t x_gs, const float* w, const float* b, int64_t par_gs,
@@ -843,6 +867,7 @@ struct vc_plan {
     std::vector<LayerGeo> gg, dg;
     int d_hw;                     // discriminator output pixels per sample
     int math = VC_MATH_FP32;      // arithmetic of the MFMA kernels for every launch made through this plan
+    int det = 0;                  // deterministic mode (vc_plan_set_deterministic): fixed summation order in every launch of this plan
     bool inference = false;       // generator-forward tables only
     std::vector<TabKey> tables;   // geometry tables this plan holds a reference on
     hipEvent_t d_ready = nullptr;
@@ -896,7 +921,7 @@ static int plan_create(int num_features, int n_frames, bool inference, vc_plan**
     VC_ARG(num_features > 0 && num_features % 4 == 0, "vc_plan_create: num_features must be a positive multiple of 4");
     VC_ARG(n_frames > 0 && n_frames % 4 == 0, "vc_plan_create: n_frames must be a positive multiple of 4 (preprocess.py:146-156)");
     vc_plan* p = new vc_plan();
-    p->F = num_features; p->T = n_frames; p->inference = inference; p->math = t_math;
+    p->F = num_features; p->T = n_frames; p->inference = inference; p->math = t_math; p->det = t_det;
     p->G = make_generator(num_features); p->D = make_discriminator();
     plan_geos(p->G, num_features, 1, n_frames, p->gg);
     plan_geos(p->D, 1, num_features, n_frames, p->dg);
@@ -942,6 +967,7 @@ extern "C" int vc_plan_create(int num_features, int n_frames, vc_plan** out) { r
 extern "C" int vc_plan_create_inference(int num_features, int n_frames, vc_plan** out) { return plan_create(num_features, n_frames, true, out); }
 extern "C" void vc_plan_destroy(vc_plan* p) {
     if (!p) return;
+    drop_pack_spaces({p->side, p->wstream, p->wstream_d, p->gstream, p->ustream});
     if (p->d_ready) (void)hipEventDestroy(p->d_ready);
     if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
     if (p->ev_join) (void)hipEventDestroy(p->ev_join);
@@ -974,6 +1000,12 @@ extern "C" int vc_plan_set_math_mode(vc_plan* p, int mode) {
     return 0;
 }
 extern "C" int vc_plan_get_math_mode(const vc_plan* p) { return p ? p->math : VC_E_STATE; }
+extern "C" int vc_plan_set_deterministic(vc_plan* p, int on) {
+    VC_ARG(p, "vc_plan_set_deterministic: bad plan");
+    p->det = on ? 1 : 0;
+    return 0;
+}
+extern "C" int vc_plan_get_deterministic(const vc_plan* p) { return p ? p->det : VC_E_STATE; }
 
 static long align64(long x) { return (x + 63) & ~63L; }
 // save map: for every layer raw output, activation, stats -- offsets (floats) inside one group's save area
@@ -1151,7 +1183,7 @@ static int net_backward(NetCtx& c, const float* x, long x_gs, const float* dtop,
             NormArgs a{};
             a.y = c.save + c.sm.raw[i]; a.y_gs = c.save_gs; a.dout = dcur; a.do_gs = dcur_gs;
             a.dy = scratch + dYo[i]; a.dy_gs = scr_gs;
-            a.G = c.G; a.B = c.B; a.C = L.C; a.ps = L.ps; a.L = lg.g.OH * lg.g.OW * (L.ps ? 2 : 1);
+            a.G = c.G; a.B = c.B; a.C = L.C; a.ps = L.ps; a.L = lg.g.OH * lg.g.OW * (L.ps ? 2 : 1); a.det = vc_det_active() ? 1 : 0;
             if (L.mode != M_GATED) {
                 a.gamma = c.params + L.gamma; a.beta = c.params + L.beta; a.par_gs = c.par_gs;
                 a.stats_in = c.save + c.sm.st[i]; a.st_gs = c.save_gs;
@@ -1277,6 +1309,7 @@ extern "C" int vc_generator_forward(const vc_plan* p, const float* params, int64
                                     const float* x, int64_t x_gs, float* y, int64_t y_gs,
                                     float* save, int G, int B, void* stream) {
     VC_ARG(p && params && x && y && save && G > 0 && B > 0, "vc_generator_forward: bad args");
+    DetScope det_scope(p->det);
     return gen_forward(p, params, par_gs, x, x_gs, y, y_gs, save, G, B, (hipStream_t)stream);
 }
 extern "C" int vc_generator_backward(const vc_plan* p, const float* params, int64_t par_gs,
@@ -1285,6 +1318,7 @@ extern "C" int vc_generator_backward(const vc_plan* p, const float* params, int6
                                      float* dx, int64_t dx_gs, int dx_accumulate,
                                      float* scratch, int G, int B, void* stream) {
     VC_ARG(p && params && x && dy && save && scratch && G > 0 && B > 0, "vc_generator_backward: bad args");
+    DetScope det_scope(p->det);
     return gen_backward(p, params, par_gs, x, x_gs, dy, dy_gs, const_cast<float*>(save), B, dparams, dpar_gs,
                         dx, dx_gs, dx_accumulate, scratch, vc_scratch_floats(p, B), G, B, (hipStream_t)stream);
 }
@@ -1292,6 +1326,7 @@ extern "C" int vc_discriminator_forward(const vc_plan* p, const float* params, i
                                         const float* x, int64_t x_gs, float* o, int64_t o_gs,
                                         float* save, int G, int B, void* stream) {
     VC_ARG(p && params && x && o && save && G > 0 && B > 0, "vc_discriminator_forward: bad args");
+    DetScope det_scope(p->det);
     return disc_forward(p, params, par_gs, x, x_gs, o, o_gs, save, G, B, (hipStream_t)stream);
 }
 extern "C" int vc_discriminator_backward(const vc_plan* p, const float* params, int64_t par_gs,
@@ -1300,6 +1335,7 @@ extern "C" int vc_discriminator_backward(const vc_plan* p, const float* params, 
                                          float* dx, int64_t dx_gs, int dx_accumulate,
                                          float* scratch, int G, int B, void* stream) {
     VC_ARG(p && params && x && dout && save && scratch && G > 0 && B > 0, "vc_discriminator_backward: bad args");
+    DetScope det_scope(p->det);
     // the sigmoid outputs are recomputed from the saved last activation (cheap) into the tail of scratch
     hipStream_t s = (hipStream_t)stream;
     SaveMap sm = save_map(p->D, p->dg, B);
@@ -1339,7 +1375,7 @@ static StepMap step_map(const vc_plan* p, int B) {
     m.scrc_gs = scratch_floats_net(p->gg, B); m.SCRC = take(m.scrc_gs);   // cycle-hop backward: its dY buffers stay live until the
                                                                           // first-hop backward has reduced them into the filter gradients
     m.SCR2 = take(m.scr_gs);                      // scratch of the discriminator_loss backward (runs on the side stream)
-    m.ACC = o; o += 64;
+    m.ACC = o; o += align64(VC_LOSS_BLOCKS * 10);     // per-block partial sums of the loss kernel
     m.total = o;
     return m;
 }
@@ -1433,6 +1469,7 @@ static int step_grads_impl(const vc_plan* p, const float* params, float* grads,
     VC_ARG(p && params && grads && A && Bm && losses && ws && batch > 0, "vc_cyclegan_step_grads: bad args");
     VC_ARG(!p->inference, "this plan was created for inference only (vc_plan_create_inference)");
     VC_ARG(aligned16(grads) && aligned16(ws), "vc_cyclegan_step_grads: grads and workspace must be 16-byte aligned");
+    DetScope det_scope(p->det);
     hipStream_t s = (hipStream_t)stream;
     const int B = batch;
     const StepMap m = step_map(p, B);
@@ -1548,7 +1585,7 @@ extern "C" int vc_train_step_graph(vc_plan* p, float* params, float* grads, floa
     hipStream_t user = (hipStream_t)stream;
     const std::array<const void*, 12> key{params, grads, m, v, A, Bm, losses, gen_A, gen_B, ws,
                                           (const void*)(intptr_t)(batch * 16 + (lambda_identity == 0.0f ? 1 : 0) * 8 + (p->use_side & 7)),
-                                          (const void*)(intptr_t)p->math};
+                                          (const void*)(intptr_t)(p->math + 16 * p->det + 64 * g_ws_generation.load())};
     vc_plan::StepGraph* sg = nullptr;
     for (auto& g : p->graphs) if (g.key == key) { sg = &g; break; }
     if (!sg) {

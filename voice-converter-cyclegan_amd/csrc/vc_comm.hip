@@ -50,7 +50,7 @@ const Rccl* rccl() {
 const int kFloat32 = 7, kSum = 0;                                // ncclFloat32, ncclSum (rccl.h)
 }  // namespace
 
-struct vc_comm { rcclComm_t comm; int rank, world; };
+struct vc_comm { rcclComm_t comm; int rank, world; mutable long n_allreduce = 0; };   // n_allreduce: collectives enqueued so far
 
 #define VC_RCCL(expr) do { int _e = (expr); if (_e != 0) { \
     vc_set_error("%s failed: %s", #expr, R->GetErrorString ? R->GetErrorString(_e) : "rccl error"); return 1000 + _e; } } while (0)
@@ -58,7 +58,7 @@ struct vc_comm { rcclComm_t comm; int rank, world; };
 extern "C" int vc_comm_unique_id(void* id128) {
     VC_ARG(id128, "vc_comm_unique_id: id is NULL");
     const Rccl* R = rccl();
-    VC_ARG(R, "RCCL (librccl.so.1) could not be loaded: %s", dlerror() ? dlerror() : "no such library");
+    if (!R) { const char* why = dlerror(); vc_set_error("RCCL (librccl.so.1) could not be loaded: %s", why ? why : "no such library"); return VC_E_ARG; }
     rcclUniqueId id;
     VC_RCCL(R->GetUniqueId(&id));
     memcpy(id128, &id, sizeof id);
@@ -71,7 +71,7 @@ extern "C" int vc_comm_init(int rank, int world, const void* id128, vc_comm** ou
     rcclUniqueId id; memcpy(&id, id128, sizeof id);
     rcclComm_t c = nullptr;
     VC_RCCL(R->CommInitRank(&c, world, id, rank));               // on the calling thread's current HIP device
-    *out = new vc_comm{c, rank, world};
+    *out = new vc_comm{c, rank, world, 0};
     return 0;
 }
 extern "C" int vc_comm_destroy(vc_comm* c) {
@@ -88,11 +88,13 @@ extern "C" int vc_comm_world(const vc_comm* c) {
     if (R && R->CommCount) (void)R->CommCount(c->comm, &n);       // what RCCL itself saw
     return n;
 }
+extern "C" int64_t vc_comm_collectives(const vc_comm* c) { return c ? c->n_allreduce : 0; }
 extern "C" int vc_allreduce_f32(const vc_comm* c, float* buf, int64_t n, void* stream) {
     VC_ARG(c && buf && n > 0, "vc_allreduce_f32: bad args");
     const Rccl* R = rccl();
     VC_ARG(R, "RCCL not loaded");
     VC_RCCL(R->AllReduce(buf, buf, (size_t)n, kFloat32, kSum, c->comm, (hipStream_t)stream));
+    ++c->n_allreduce;
     return 0;
 }
 
@@ -104,8 +106,10 @@ extern "C" int vc_allreduce_f32(const vc_comm* c, float* buf, int64_t n, void* s
 int step_update_impl(const vc_plan* p, const vc_comm* comm, float* params, float* grads, float* m, float* v,
                      float alpha_g, float alpha_d, const float* hp, float beta1, float beta2, float eps, hipStream_t us) {
     VC_ARG(p && params && grads && m && v, "vc_step_exchange_and_update: bad args");
-    const Rccl* R = (comm && comm->world > 1) ? rccl() : nullptr;
-    VC_ARG(!(comm && comm->world > 1) || R, "RCCL not loaded");
+    // a communicator means "exchange": also on a single-rank communicator the collectives are issued (RCCL reduces over one
+    // rank: the identity), so the path a multi-GPU job takes is the one the one-GPU tests execute
+    const Rccl* R = comm ? rccl() : nullptr;
+    VC_ARG(!comm || R, "RCCL not loaded");
     const float gscale = comm ? 1.0f / (float)comm->world : 1.0f;
     const int64_t g0 = vc_flat_offset(p, 0), g1 = vc_flat_offset(p, 1), d0 = vc_flat_offset(p, 2), total = vc_flat_param_floats(p);
     auto seg = [&](int64_t lo, int64_t hi, bool disc) -> int {        // hp: {.., .., alpha_g, alpha_d} on the device (captured steps)
@@ -114,7 +118,7 @@ int step_update_impl(const vc_plan* p, const vc_comm* comm, float* params, float
     };
     // discriminator half: one contiguous range
     { int r = vc_step_wait_d_grads(p, us); if (r) return r; }
-    if (R) VC_RCCL(R->AllReduce(grads + d0, grads + d0, (size_t)(total - d0), kFloat32, kSum, comm->comm, us));
+    if (R) { VC_RCCL(R->AllReduce(grads + d0, grads + d0, (size_t)(total - d0), kFloat32, kSum, comm->comm, us)); ++comm->n_allreduce; }
     { int r = seg(d0, total, true); if (r) return r; }
     // generator buckets: the same layer range of both generators, one collective group
     for (int k = 0; k < vc_step_num_g_buckets(p); ++k) {
@@ -123,9 +127,11 @@ int step_update_impl(const vc_plan* p, const vc_comm* comm, float* params, float
         { int r = vc_step_wait_g_bucket(p, k, us); if (r) return r; }
         if (R) {
             VC_RCCL(R->GroupStart());
-            VC_RCCL(R->AllReduce(grads + g0 + lo, grads + g0 + lo, (size_t)(hi - lo), kFloat32, kSum, comm->comm, us));
-            VC_RCCL(R->AllReduce(grads + g1 + lo, grads + g1 + lo, (size_t)(hi - lo), kFloat32, kSum, comm->comm, us));
-            VC_RCCL(R->GroupEnd());
+            int e = R->AllReduce(grads + g0 + lo, grads + g0 + lo, (size_t)(hi - lo), kFloat32, kSum, comm->comm, us);
+            if (!e) e = R->AllReduce(grads + g1 + lo, grads + g1 + lo, (size_t)(hi - lo), kFloat32, kSum, comm->comm, us);
+            const int e2 = R->GroupEnd();                                // always closed, also after a failed enqueue
+            if (!e && !e2) comm->n_allreduce += 2;
+            if (e || e2) { vc_set_error("ncclAllReduce (generator bucket %d) failed: %s", k, R->GetErrorString ? R->GetErrorString(e ? e : e2) : "rccl error"); return 1000 + (e ? e : e2); }
         }
         { int r = seg(g0 + lo, g0 + hi, false); if (r) return r; }
         { int r = seg(g1 + lo, g1 + hi, false); if (r) return r; }

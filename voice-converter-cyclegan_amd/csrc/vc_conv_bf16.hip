@@ -382,7 +382,7 @@ template <int BM, int NST> __global__ __launch_bounds__(256, NST <= 2 ? 2 : 1) v
 // plus its zero-fill (~1 TB/s of read-modify-write: 17 MB of output is ~20 us, as long as a 48-chunk K loop): only
 // launches that would leave most of the chip idle split.
 // tests / tuning: force one configuration of conv_bf16_kernel for every following launch of the process (0 = automatic)
-static int g_bf16_bm = 0, g_bf16_nst = 0, g_bf16_sk = 0;
+static thread_local int g_bf16_bm = 0, g_bf16_nst = 0, g_bf16_sk = 0;      // per calling thread
 extern "C" int vc_tune_conv_bf16_override(int tile_rows, int stages, int splitk) {
     const bool ok = (tile_rows == 0 && stages == 0 && splitk == 0) ||
                     ((tile_rows == 64 || tile_rows == 128) && (stages == 2 || stages == 4) && splitk >= 1 && splitk <= 16);
@@ -407,6 +407,7 @@ void conv_bf16_config(ConvBf16Args& a) {
     int sk = 1;
     while (tiles * sk < 128 && nchunks / (sk * 2) >= 8 && sk < 16) sk *= 2;
     if (g_bf16_bm) sk = std::min(g_bf16_sk, std::max(1, nchunks / 2));
+    if (vc_det_active()) sk = 1;               // deterministic mode: no split-K atomics
     a.splitk = sk;
 }
 

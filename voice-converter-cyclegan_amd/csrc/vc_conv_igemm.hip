@@ -368,7 +368,7 @@ static int resident_per_cu(int bm, int kg) {            // LDS: 55 KB (128 rows)
     return std::max(1, std::min(std::min(by_lds, by_waves), bm == 128 ? 2 : 4));
 }
 // tools/tune_igemm.py: force one configuration for every following launch of the process (0 = automatic)
-static int g_force_bm = 0, g_force_kg = 0, g_force_sk = 0;
+static thread_local int g_force_bm = 0, g_force_kg = 0, g_force_sk = 0;      // per calling thread
 extern "C" int vc_tune_igemm_override(int bm, int kg, int splitk) {
     const bool ok = (bm == 0 && kg == 0 && splitk == 0) ||
                     ((bm == 64 || bm == 128) && (kg == 1 || kg == 2 || (kg == 4 && bm == 64)) && splitk >= 1 && splitk <= 64);
@@ -382,6 +382,7 @@ struct TunedCfg { int at, M, Ptot, krows, groups, bm, kg, sk; };
 
 void igemm_config(IgemmArgs& a, int math) {
     const int nchunks = a.krows / VC_KC;
+    const bool det = vc_det_active();          // deterministic mode: K is split inside the workgroup only (fixed summation order)
     a.mtiles = 0;
     if (math != VC_MATH_FP32 && !g_force_bm) {
         // bf16 operand modes: the MFMAs are 16x shorter, the launch is bound by the loader -> the tile with the least loader
@@ -390,15 +391,15 @@ void igemm_config(IgemmArgs& a, int math) {
         const long tiles = (long)((a.M + a.bm - 1) / a.bm) * ((a.Ptot + 63) / 64) * a.groups;
         int sk = 1;
         while (tiles * sk < 512 && nchunks / (sk * 2) >= 4 && sk < 16) sk *= 2;
-        a.splitk = sk;
+        a.splitk = det ? 1 : sk;
         a.mtiles = (a.M + a.bm - 1) / a.bm; a.ntiles = (a.Ptot + 63) / 64;
         return;
     }
-    if (g_force_bm) { a.bm = g_force_bm; a.kg = g_force_kg; a.splitk = std::min(g_force_sk, std::max(1, nchunks / (2 * a.kg))); }
+    if (g_force_bm) { a.bm = g_force_bm; a.kg = g_force_kg; a.splitk = det ? 1 : std::min(g_force_sk, std::max(1, nchunks / (2 * a.kg))); }
     else {
         const int at = a.a_ms != 1 ? 1 : 0;
         for (const TunedCfg& t : kTunedIgemm)
-            if (t.at == at && t.M == a.M && t.Ptot == a.Ptot && t.krows == a.krows && t.groups == a.groups) { a.bm = t.bm; a.kg = t.kg; a.splitk = t.sk; a.mtiles = 1; break; }
+            if (t.at == at && t.M == a.M && t.Ptot == a.Ptot && t.krows == a.krows && t.groups == a.groups && !(det && t.sk > 1)) { a.bm = t.bm; a.kg = t.kg; a.splitk = t.sk; a.mtiles = 1; break; }
     }
     if (g_force_bm || a.mtiles) { a.mtiles = (a.M + a.bm - 1) / a.bm; a.ntiles = (a.Ptot + 63) / 64; return; }
     // Cost model in microseconds, fitted to the sweep of tools/tune_igemm.py (profiles/r02_tune_sweep_b8.txt): a workgroup
@@ -414,7 +415,7 @@ void igemm_config(IgemmArgs& a, int math) {
         const long tiles = (long)((a.M + bm - 1) / bm) * ((a.Ptot + 63) / 64) * a.groups;
         for (int kg : {1, 2, 4}) {
             if (bm == 128 && kg == 4) continue;
-            for (int sk = 1; sk <= 16; sk *= 2) {
+            for (int sk = 1; sk <= (det ? 1 : 16); sk *= 2) {
                 const int parts = kg * sk;
                 const int cps = (((nchunks + parts - 1) / parts) + 1) & ~1;
                 if (parts > 1 && cps * (parts - 1) >= nchunks) continue;      // a part with no work

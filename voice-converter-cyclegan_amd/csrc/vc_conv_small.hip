@@ -276,11 +276,37 @@ __global__ __launch_bounds__(256) void c1_dgrad_kernel(const C1Args a) {
     }
 }
 
+// Deterministic mode: the same input gradient as a GATHER -- one thread per dx element walks the taps and filters in a fixed
+// order (dy is re-read kh*kw times from L2; this mode trades speed for bitwise reproducibility).  dx = (accumulate ? dx : 0) + sum.
+__global__ __launch_bounds__(256) void c1_dgrad_gather_kernel(const C1Args a, int accumulate) {
+    const int g = blockIdx.z, b = blockIdx.y;
+    const int HW = a.H * a.W, q = blockIdx.x * 256 + threadIdx.x, P = a.OH * a.OW, nt = a.kh * a.kw;
+    if (q >= HW) return;
+    const int h = q / a.W, w = q - h * a.W;
+    const float* wt = a.w + (long)g * a.w_gs;
+    const float* dy = a.dy + (long)g * a.y_gs + (long)b * a.Cout * P;
+    float acc = 0.f;
+    for (int t = 0; t < nt; ++t) {
+        const int di = t / a.kw, dj = t - di * a.kw;
+        const int ih = h + a.pt - di, iw = w + a.pl - dj;
+        if (ih < 0 || iw < 0 || ih % a.sh || iw % a.sw) continue;
+        const int i = ih / a.sh, j = iw / a.sw;
+        if (i >= a.OH || j >= a.OW) continue;
+        const float* d = dy + i * a.OW + j;
+        float z = 0.f;
+        for (int co = 0; co < a.Cout; ++co) z = fmaf(c1_round(d[(long)co * P], a.math), c1_round(wt[t * a.Cout + co], a.math), z);
+        acc += z;
+    }
+    float* dx = a.dx + (long)g * a.dx_gs + (long)b * HW + q;
+    *dx = (accumulate ? *dx : 0.f) + acc;
+}
+
 // dw[g][t][co] += sum_{b,p} window_t(p) * dy[g][b][co][p].  A block owns 8 channels and C1_BPB samples; its 4 waves take a
 // quarter of the pixels each, gather the window of a pixel once for the 8 channels, reduce with wave shuffles and LDS,
 // and issue ONE atomic per (tap, channel) and block (atomics on one cache line serialise: per-wave atomics cost 80 us).
-#define C1_BPB 1
+// (deterministic mode: one block walks ALL samples in order, so every dw element receives exactly one contribution)
 __global__ __launch_bounds__(256) void c1_wgrad_kernel(const C1Args a) {
+    const int C1_BPB = a.det ? a.B : 1;
     __shared__ float red[4][72];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int g = blockIdx.z, co0 = blockIdx.x * 8;
@@ -342,6 +368,11 @@ int launch_c1_fwd(const C1Args& a, hipStream_t s) {
 }
 int launch_c1_dgrad(const C1Args& a, int accumulate, hipStream_t s) {
     const int P = a.OH * a.OW, nch = (a.Cout + 63) / 64;
+    if (a.det) {
+        c1_dgrad_gather_kernel<<<dim3((a.H * a.W + 255) / 256, a.B, a.G), 256, 0, s>>>(a, accumulate);
+        VC_HIP(hipGetLastError());
+        return 0;
+    }
     if (!accumulate)
         for (int g = 0; g < a.G; ++g) VC_HIP(hipMemsetAsync(a.dx + (long)g * a.dx_gs, 0, (size_t)a.B * a.H * a.W * sizeof(float), s));
     c1_dgrad_kernel<<<dim3((P + 255) / 256, a.B, a.G * nch), 256, 0, s>>>(a);
@@ -349,7 +380,7 @@ int launch_c1_dgrad(const C1Args& a, int accumulate, hipStream_t s) {
     return 0;
 }
 int launch_c1_wgrad(const C1Args& a, hipStream_t s) {
-    c1_wgrad_kernel<<<dim3((a.Cout + 7) / 8, (a.B + C1_BPB - 1) / C1_BPB, a.G), 256, 0, s>>>(a);
+    c1_wgrad_kernel<<<dim3((a.Cout + 7) / 8, a.det ? 1 : a.B, a.G), 256, 0, s>>>(a);
     VC_HIP(hipGetLastError());
     return 0;
 }

@@ -235,7 +235,21 @@ __global__ __launch_bounds__(256 * KG, KG == 4 ? 4 : 2) void wgrad_kernel(const 
 // Tile width (Cout columns), K groups and split-K: the cost model of igemm_config (vc_conv_igemm.hip) with this kernel's
 // chunk (32 pixels x (64 + BN) rows; 32 or 16 MFMAs per wave).  us per chunk of one wave among k on its SIMD.
 struct WgradCfg { int bn, kg, sk; };
+// tests / tuning: force one configuration (tile columns 64 / 128, K groups, split-K) for the calling thread's following launches
+static thread_local int g_wforce_bn = 0, g_wforce_kg = 0, g_wforce_sk = 0;
+extern "C" int vc_tune_wgrad_override(int bn, int kg, int splitk) {
+    const bool ok = (bn == 0 && kg == 0 && splitk == 0) ||
+                    ((bn == 64 || bn == 128) && (kg == 1 || kg == 2 || (kg == 4 && bn == 64)) && splitk >= 1 && splitk <= 64);
+    if (!ok) { vc_set_error("vc_tune_wgrad_override: tile columns %d, K groups %d, split-K %d is not a built configuration", bn, kg, splitk); return -1; }
+    g_wforce_bn = bn; g_wforce_kg = kg; g_wforce_sk = splitk;
+    return 0;
+}
 static WgradCfg wgrad_config(const WgradArgs& a) {
+    const bool det = vc_det_active();          // deterministic mode: the pixel axis is split inside the workgroup only
+    if (g_wforce_bn) {
+        const int bn = (g_wforce_bn == 128 && a.N < 128) ? 64 : g_wforce_bn;
+        return WgradCfg{bn, g_wforce_kg, det ? 1 : std::min(g_wforce_sk, std::max(1, a.nchunks / (2 * g_wforce_kg)))};
+    }
     WgradCfg best{128, 1, 1}; double bestc = 1e30;
     const double out_bytes = 4.0 * 64.0 * a.ktiles * (double)a.N * a.groups;
     for (int bn : {128, 64}) {
@@ -243,7 +257,7 @@ static WgradCfg wgrad_config(const WgradArgs& a) {
         const long tiles = (long)a.ktiles * ((a.N + bn - 1) / bn) * a.groups;
         for (int kg : {1, 2, 4}) {
             if (bn == 128 && kg == 4) continue;                              // LDS: 55 KB per group
-            for (int sk = 1; sk <= 16; sk *= 2) {
+            for (int sk = 1; sk <= (det ? 1 : 16); sk *= 2) {
                 const int parts = kg * sk;
                 const int cps = (((a.nchunks + parts - 1) / parts) + 1) & ~1;
                 if (parts > 1 && cps * (parts - 1) >= a.nchunks) continue;   // a part with no work

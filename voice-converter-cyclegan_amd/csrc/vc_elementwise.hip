@@ -9,6 +9,7 @@
 #include "vc_device_util.h"
 #include <algorithm>
 #include <mutex>
+#include <type_traits>
 #include <vector>
 
 // =====================================================================================
@@ -104,114 +105,129 @@ __global__ __launch_bounds__(256) void norm_fwd_kernel(const NormArgs p) {
     }
 }
 
-template <int MODE, int LPR, int NE>
+// DET (deterministic mode): a lane group owns channel c of EVERY sample and walks the batch in order, so dgamma / dbeta /
+// dbias are reduced in registers in a fixed order and added with one plain read-modify-write per element -- no atomics.
+template <int MODE, int LPR, int NE, bool DET>
 __global__ __launch_bounds__(256) void norm_bwd_kernel(const NormArgs p) {
     constexpr int NB = (MODE == 2) ? 1 : 2;
     const int unit = blockIdx.x * (256 / LPR) + threadIdx.x / LPR;
     const int sub = threadIdx.x % LPR;
-    const int total = p.G * p.B * p.C;
-    if (unit >= total) return;
-    const int g = unit / (p.B * p.C); const int rem = unit - g * (p.B * p.C);
-    const int b = rem / p.C, c = rem - b * p.C;
+    const int rows = DET ? p.C : p.B * p.C;
+    if (unit >= p.G * rows) return;
+    const int g = unit / rows; const int rem = unit - g * rows;
+    const int b0 = DET ? 0 : rem / p.C, c = DET ? rem : rem - b0 * p.C;
+    const int b1 = DET ? p.B : b0 + 1;
     const float* y = p.y + (long)g * p.y_gs;
     float* dy = p.dy + (long)g * p.dy_gs;
-    const float* dout = p.dout + (long)g * p.do_gs + ((long)b * p.C + c) * p.L;
     const float invL = 1.f / (float)p.L;
     const bool odd = sub & 1;   // LPR is even: every element this lane owns has parity sub&1
-
-    float v[NE], gt[NE], dO[NE];
-#pragma unroll
-    for (int e = 0; e < NE; ++e) {
-        const int l = sub + e * LPR;
-        const bool ok = l < p.L;
-        v[e] = ok ? y[yoff<NB>(p, b, 0, c, l)] : 0.f;
-        if (NB == 2) gt[e] = ok ? y[yoff<NB>(p, b, 1, c, l)] : 0.f;
-        dO[e] = ok ? dout[l] : 0.f;
-    }
     float* dbias = p.dbias ? p.dbias + (long)g * p.dbias_gs : nullptr;
     // conv channels whose bias gradient this row contributes to
-    const int cb0 = p.ps ? c : c;                       // branch 0, even l (or all l)
+    const int cb0 = c;                                  // branch 0, even l (or all l)
     const int cstride_par = p.ps ? p.C : 0;             // odd l -> +C when shuffled
     const int brstride = p.ps ? 2 * p.C : p.C;          // branch 1 offset in conv channels
+    float* dgam = (MODE != 1 && p.dgamma) ? p.dgamma + (long)g * p.dpar_gs : nullptr;
+    float* dbet = (MODE != 1 && p.dbeta) ? p.dbeta + (long)g * p.dpar_gs : nullptr;
+    // reduction slots (DET: summed over the batch in registers, flushed below; otherwise one atomic per row)
+    float* slot[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (MODE == 1) { if (dbias) { slot[0] = dbias + c; slot[1] = dbias + p.C + c; } }
+    else if (MODE == 2) { if (dgam) { slot[0] = dgam + c; slot[1] = dbet + c; } if (dbias) slot[2] = dbias + c; }
+    else {
+        if (dbias) {
+            slot[0] = dbias + cb0; slot[1] = dbias + brstride + cb0;
+            if (p.ps) { slot[2] = dbias + cstride_par + cb0; slot[3] = dbias + brstride + cstride_par + cb0; }
+        }
+        if (dgam) { slot[4] = dgam + c; slot[5] = dbet + c; slot[6] = dgam + p.C + c; slot[7] = dbet + p.C + c; }
+    }
+    float racc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto reduce = [&](auto KC, float val) {
+        constexpr int K = decltype(KC)::value;
+        if constexpr (DET) racc[K] += val; else { if (sub == 0 && slot[K]) atomicAdd(slot[K], val); }
+    };
+    using K0 = std::integral_constant<int, 0>; using K1 = std::integral_constant<int, 1>; using K2 = std::integral_constant<int, 2>;
+    using K3 = std::integral_constant<int, 3>; using K4 = std::integral_constant<int, 4>; using K5 = std::integral_constant<int, 5>;
+    using K6 = std::integral_constant<int, 6>; using K7 = std::integral_constant<int, 7>;
 
-    if (MODE == 1) {
-        float sv = 0.f, sg = 0.f;
+    for (int b = b0; b < b1; ++b) {
+        const float* dout = p.dout + (long)g * p.do_gs + ((long)b * p.C + c) * p.L;
+        float v[NE], gt[NE], dO[NE];
 #pragma unroll
         for (int e = 0; e < NE; ++e) {
             const int l = sub + e * LPR;
-            const float s = sigmoidf_(gt[e]);
-            const float dv = dO[e] * s, dg = dO[e] * v[e] * s * (1.f - s);
-            if (l < p.L) { dy[yoff<NB>(p, b, 0, c, l)] = dv; dy[yoff<NB>(p, b, 1, c, l)] = dg; }
-            sv += dv; sg += dg;
+            const bool ok = l < p.L;
+            v[e] = ok ? y[yoff<NB>(p, b, 0, c, l)] : 0.f;
+            if (NB == 2) gt[e] = ok ? y[yoff<NB>(p, b, 1, c, l)] : 0.f;
+            dO[e] = ok ? dout[l] : 0.f;
+        }
+        if (MODE == 1) {
+            float sv = 0.f, sg = 0.f;
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+                const int l = sub + e * LPR;
+                const float s = sigmoidf_(gt[e]);
+                const float dv = dO[e] * s, dg = dO[e] * v[e] * s * (1.f - s);
+                if (l < p.L) { dy[yoff<NB>(p, b, 0, c, l)] = dv; dy[yoff<NB>(p, b, 1, c, l)] = dg; }
+                sv += dv; sg += dg;
+            }
+            if (dbias) { reduce(K0{}, group_sum<LPR>(sv)); reduce(K1{}, group_sum<LPR>(sg)); }
+            continue;
+        }
+        const float* gam = p.gamma + (long)g * p.par_gs;
+        const float* bet = p.beta + (long)g * p.par_gs;
+        const float* st = p.stats_in + (long)g * p.st_gs + ((long)b * NB * p.C) * 2;
+        const float mu = st[2 * c], rs = st[2 * c + 1], ga = gam[c], be = bet[c];
+
+        if (MODE == 2) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int e = 0; e < NE; ++e) { const float xh = (v[e] - mu) * rs; s1 += dO[e]; s2 += dO[e] * xh; }
+            s1 = group_sum<LPR>(s1); s2 = group_sum<LPR>(s2);
+            float sb = 0.f;
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+                const int l = sub + e * LPR;
+                const float xh = (v[e] - mu) * rs;
+                const float d = ga * rs * (dO[e] - s1 * invL - xh * s2 * invL);
+                if (l < p.L) { dy[yoff<NB>(p, b, 0, c, l)] = d; sb += d; }
+            }
+            sb = group_sum<LPR>(sb);
+            reduce(K0{}, s2); reduce(K1{}, s1); reduce(K2{}, sb);
+            continue;
+        }
+        const float mu2 = st[2 * (p.C + c)], rs2 = st[2 * (p.C + c) + 1], ga2 = gam[p.C + c], be2 = bet[p.C + c];
+        float s1v = 0.f, s2v = 0.f, s1g = 0.f, s2g = 0.f;
+        float dnv[NE], dng[NE];
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const float xv = (v[e] - mu) * rs, xg = (gt[e] - mu2) * rs2;
+            const float nv = ga * xv + be, ng = ga2 * xg + be2;
+            const float s = sigmoidf_(ng);
+            dnv[e] = dO[e] * s; dng[e] = dO[e] * nv * s * (1.f - s);
+            s1v += dnv[e]; s2v += dnv[e] * xv; s1g += dng[e]; s2g += dng[e] * xg;
+        }
+        s1v = group_sum<LPR>(s1v); s2v = group_sum<LPR>(s2v);
+        s1g = group_sum<LPR>(s1g); s2g = group_sum<LPR>(s2g);
+        float sbv = 0.f, sbg = 0.f;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const int l = sub + e * LPR;
+            const float xv = (v[e] - mu) * rs, xg = (gt[e] - mu2) * rs2;
+            const float dv = ga * rs * (dnv[e] - s1v * invL - xv * s2v * invL);
+            const float dg = ga2 * rs2 * (dng[e] - s1g * invL - xg * s2g * invL);
+            if (l < p.L) { dy[yoff<NB>(p, b, 0, c, l)] = dv; dy[yoff<NB>(p, b, 1, c, l)] = dg; sbv += dv; sbg += dg; }
         }
         if (dbias) {
-            sv = group_sum<LPR>(sv); sg = group_sum<LPR>(sg);
-            if (sub == 0) { atomicAdd(dbias + c, sv); atomicAdd(dbias + p.C + c, sg); }
+            // conv-channel sums; with pixel shuffle even/odd positions belong to different conv channels
+            reduce(K0{}, group_sum<LPR>((p.ps && odd) ? 0.f : sbv)); reduce(K1{}, group_sum<LPR>((p.ps && odd) ? 0.f : sbg));
+            if (p.ps) { reduce(K2{}, group_sum<LPR>(odd ? sbv : 0.f)); reduce(K3{}, group_sum<LPR>(odd ? sbg : 0.f)); }
         }
-        return;
+        if (dgam) { reduce(K4{}, s2v); reduce(K5{}, s1v); reduce(K6{}, s2g); reduce(K7{}, s1g); }
     }
-    const float* gam = p.gamma + (long)g * p.par_gs;
-    const float* bet = p.beta + (long)g * p.par_gs;
-    const float* st = p.stats_in + (long)g * p.st_gs + ((long)b * NB * p.C) * 2;
-    float* dgam = p.dgamma ? p.dgamma + (long)g * p.dpar_gs : nullptr;
-    float* dbet = p.dbeta ? p.dbeta + (long)g * p.dpar_gs : nullptr;
-    const float mu = st[2 * c], rs = st[2 * c + 1], ga = gam[c], be = bet[c];
-
-    if (MODE == 2) {
-        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int e = 0; e < NE; ++e) { const float xh = (v[e] - mu) * rs; s1 += dO[e]; s2 += dO[e] * xh; }
-        s1 = group_sum<LPR>(s1); s2 = group_sum<LPR>(s2);
-        float sb = 0.f;
-#pragma unroll
-        for (int e = 0; e < NE; ++e) {
-            const int l = sub + e * LPR;
-            const float xh = (v[e] - mu) * rs;
-            const float d = ga * rs * (dO[e] - s1 * invL - xh * s2 * invL);
-            if (l < p.L) { dy[yoff<NB>(p, b, 0, c, l)] = d; sb += d; }
-        }
-        sb = group_sum<LPR>(sb);
+    if constexpr (DET) {
         if (sub == 0) {
-            if (dgam) { atomicAdd(dgam + c, s2); atomicAdd(dbet + c, s1); }
-            if (dbias) atomicAdd(dbias + c, sb);
-        }
-        return;
-    }
-    const float mu2 = st[2 * (p.C + c)], rs2 = st[2 * (p.C + c) + 1], ga2 = gam[p.C + c], be2 = bet[p.C + c];
-    float s1v = 0.f, s2v = 0.f, s1g = 0.f, s2g = 0.f;
-    float dnv[NE], dng[NE];
 #pragma unroll
-    for (int e = 0; e < NE; ++e) {
-        const float xv = (v[e] - mu) * rs, xg = (gt[e] - mu2) * rs2;
-        const float nv = ga * xv + be, ng = ga2 * xg + be2;
-        const float s = sigmoidf_(ng);
-        dnv[e] = dO[e] * s; dng[e] = dO[e] * nv * s * (1.f - s);
-        s1v += dnv[e]; s2v += dnv[e] * xv; s1g += dng[e]; s2g += dng[e] * xg;
-    }
-    s1v = group_sum<LPR>(s1v); s2v = group_sum<LPR>(s2v);
-    s1g = group_sum<LPR>(s1g); s2g = group_sum<LPR>(s2g);
-    float sbv = 0.f, sbg = 0.f;
-#pragma unroll
-    for (int e = 0; e < NE; ++e) {
-        const int l = sub + e * LPR;
-        const float xv = (v[e] - mu) * rs, xg = (gt[e] - mu2) * rs2;
-        const float dv = ga * rs * (dnv[e] - s1v * invL - xv * s2v * invL);
-        const float dg = ga2 * rs2 * (dng[e] - s1g * invL - xg * s2g * invL);
-        if (l < p.L) { dy[yoff<NB>(p, b, 0, c, l)] = dv; dy[yoff<NB>(p, b, 1, c, l)] = dg; sbv += dv; sbg += dg; }
-    }
-    if (dbias) {
-        // conv-channel sums; with pixel shuffle even/odd positions belong to different conv channels
-        float ev = group_sum<LPR>((p.ps && odd) ? 0.f : sbv), eg = group_sum<LPR>((p.ps && odd) ? 0.f : sbg);
-        float ov = 0.f, og = 0.f;
-        if (p.ps) { ov = group_sum<LPR>(odd ? sbv : 0.f); og = group_sum<LPR>(odd ? sbg : 0.f); }
-        if (sub == 0) {
-            atomicAdd(dbias + cb0, ev); atomicAdd(dbias + brstride + cb0, eg);
-            if (p.ps) { atomicAdd(dbias + cstride_par + cb0, ov); atomicAdd(dbias + brstride + cstride_par + cb0, og); }
+            for (int k = 0; k < 8; ++k) if (slot[k]) *slot[k] += racc[k];       // the only writer of this element in this launch
         }
-    }
-    if (sub == 0 && dgam) {
-        atomicAdd(dgam + c, s2v); atomicAdd(dbet + c, s1v);
-        atomicAdd(dgam + p.C + c, s2g); atomicAdd(dbet + p.C + c, s1g);
     }
 }
 
@@ -266,79 +282,99 @@ __global__ __launch_bounds__(256) void norm_fwd_stream_kernel(const NormArgs p) 
     }
 }
 
-template <int MODE>
+template <int MODE, bool DET>
 __global__ __launch_bounds__(256) void norm_bwd_stream_kernel(const NormArgs p) {
     constexpr int NB = (MODE == 2) ? 1 : 2;
     __shared__ float red[4];
     const int unit = blockIdx.x;
-    const int g = unit / (p.B * p.C); const int rem = unit - g * (p.B * p.C);
-    const int b = rem / p.C, c = rem - b * p.C;
+    const int rows = DET ? p.C : p.B * p.C;          // DET: a block owns channel c of every sample, walked in order
+    const int g = unit / rows; const int rem = unit - g * rows;
+    const int b0 = DET ? 0 : rem / p.C, c = DET ? rem : rem - b0 * p.C;
+    const int b1 = DET ? p.B : b0 + 1;
     const float* y = p.y + (long)g * p.y_gs;
     float* dy = p.dy + (long)g * p.dy_gs;
-    const float* dout = p.dout + (long)g * p.do_gs + ((long)b * p.C + c) * p.L;
     const float invL = 1.f / (float)p.L;
     float* dbias = p.dbias ? p.dbias + (long)g * p.dbias_gs : nullptr;
     const int cstride_par = p.ps ? p.C : 0, brstride = p.ps ? 2 * p.C : p.C;
-    // conv-channel bias sums: [branch][parity]; without pixel shuffle only parity 0 is used
-    float sb[NB][2];
+    float* dgam = (MODE != 1 && p.dgamma) ? p.dgamma + (long)g * p.dpar_gs : nullptr;
+    float* dbet = (MODE != 1 && p.dbeta) ? p.dbeta + (long)g * p.dpar_gs : nullptr;
+    float tg[NB], tb[NB], te[NB], to[NB];            // DET: batch totals of dgamma, dbeta, dbias (even / odd positions)
 #pragma unroll
-    for (int br = 0; br < NB; ++br) sb[br][0] = sb[br][1] = 0.f;
-    if (MODE == 1) {
-        for (int l = threadIdx.x; l < p.L; l += 256) {
-            const float v = y[yoff<NB>(p, b, 0, c, l)], s = sigmoidf_(y[yoff<NB>(p, b, 1, c, l)]);
-            const float dv = dout[l] * s, dg = dout[l] * v * s * (1.f - s);
-            dy[yoff<NB>(p, b, 0, c, l)] = dv; dy[yoff<NB>(p, b, 1, c, l)] = dg;
-            sb[0][0] += dv; sb[NB - 1][0] += (NB == 2) ? dg : 0.f;
-        }
-    } else {
-        const float* gam = p.gamma + (long)g * p.par_gs;
-        const float* bet = p.beta + (long)g * p.par_gs;
-        const float* st = p.stats_in + (long)g * p.st_gs + ((long)b * NB * p.C) * 2;
-        float* dgam = p.dgamma ? p.dgamma + (long)g * p.dpar_gs : nullptr;
-        float* dbet = p.dbeta ? p.dbeta + (long)g * p.dpar_gs : nullptr;
-        float mu[NB], rs[NB], ga[NB], be[NB], s1[NB], s2[NB];
+    for (int br = 0; br < NB; ++br) tg[br] = tb[br] = te[br] = to[br] = 0.f;
+    for (int b = b0; b < b1; ++b) {
+        const float* dout = p.dout + (long)g * p.do_gs + ((long)b * p.C + c) * p.L;
+        // conv-channel bias sums: [branch][parity]; without pixel shuffle only parity 0 is used
+        float sb[NB][2];
 #pragma unroll
-        for (int br = 0; br < NB; ++br) {
-            mu[br] = st[2 * (br * p.C + c)]; rs[br] = st[2 * (br * p.C + c) + 1];
-            ga[br] = gam[br * p.C + c]; be[br] = bet[br * p.C + c]; s1[br] = s2[br] = 0.f;
-        }
-        auto dn = [&](int l, float* d) {     // gradient w.r.t. the normalised value(s) at position l
-            const float dO = dout[l];
-            if (MODE == 2) { d[0] = dO; return; }
-            const float nv = ga[0] * (y[yoff<NB>(p, b, 0, c, l)] - mu[0]) * rs[0] + be[0];
-            const float ng = ga[NB - 1] * (y[yoff<NB>(p, b, NB - 1, c, l)] - mu[NB - 1]) * rs[NB - 1] + be[NB - 1];
-            const float s = sigmoidf_(ng);
-            d[0] = dO * s; d[NB - 1] = dO * nv * s * (1.f - s);
-        };
-        for (int l = threadIdx.x; l < p.L; l += 256) {
-            float d[NB]; dn(l, d);
-#pragma unroll
-            for (int br = 0; br < NB; ++br) { s1[br] += d[br]; s2[br] += d[br] * (y[yoff<NB>(p, b, br, c, l)] - mu[br]) * rs[br]; }
-        }
-#pragma unroll
-        for (int br = 0; br < NB; ++br) { s1[br] = block_sum_256s(s1[br], red); s2[br] = block_sum_256s(s2[br], red); }
-        for (int l = threadIdx.x; l < p.L; l += 256) {
-            float d[NB]; dn(l, d);
+        for (int br = 0; br < NB; ++br) sb[br][0] = sb[br][1] = 0.f;
+        if (MODE == 1) {
+            for (int l = threadIdx.x; l < p.L; l += 256) {
+                const float v = y[yoff<NB>(p, b, 0, c, l)], s = sigmoidf_(y[yoff<NB>(p, b, 1, c, l)]);
+                const float dv = dout[l] * s, dg = dout[l] * v * s * (1.f - s);
+                dy[yoff<NB>(p, b, 0, c, l)] = dv; dy[yoff<NB>(p, b, 1, c, l)] = dg;
+                sb[0][0] += dv; sb[NB - 1][0] += (NB == 2) ? dg : 0.f;
+            }
+        } else {
+            const float* gam = p.gamma + (long)g * p.par_gs;
+            const float* bet = p.beta + (long)g * p.par_gs;
+            const float* st = p.stats_in + (long)g * p.st_gs + ((long)b * NB * p.C) * 2;
+            float mu[NB], rs[NB], ga[NB], be[NB], s1[NB], s2[NB];
 #pragma unroll
             for (int br = 0; br < NB; ++br) {
-                const float xh = (y[yoff<NB>(p, b, br, c, l)] - mu[br]) * rs[br];
-                const float v = ga[br] * rs[br] * (d[br] - s1[br] * invL - xh * s2[br] * invL);
-                dy[yoff<NB>(p, b, br, c, l)] = v;
-                sb[br][p.ps ? (l & 1) : 0] += v;
+                mu[br] = st[2 * (br * p.C + c)]; rs[br] = st[2 * (br * p.C + c) + 1];
+                ga[br] = gam[br * p.C + c]; be[br] = bet[br * p.C + c]; s1[br] = s2[br] = 0.f;
+            }
+            auto dn = [&](int l, float* d) {     // gradient w.r.t. the normalised value(s) at position l
+                const float dO = dout[l];
+                if (MODE == 2) { d[0] = dO; return; }
+                const float nv = ga[0] * (y[yoff<NB>(p, b, 0, c, l)] - mu[0]) * rs[0] + be[0];
+                const float ng = ga[NB - 1] * (y[yoff<NB>(p, b, NB - 1, c, l)] - mu[NB - 1]) * rs[NB - 1] + be[NB - 1];
+                const float s = sigmoidf_(ng);
+                d[0] = dO * s; d[NB - 1] = dO * nv * s * (1.f - s);
+            };
+            for (int l = threadIdx.x; l < p.L; l += 256) {
+                float d[NB]; dn(l, d);
+#pragma unroll
+                for (int br = 0; br < NB; ++br) { s1[br] += d[br]; s2[br] += d[br] * (y[yoff<NB>(p, b, br, c, l)] - mu[br]) * rs[br]; }
+            }
+#pragma unroll
+            for (int br = 0; br < NB; ++br) { s1[br] = block_sum_256s(s1[br], red); s2[br] = block_sum_256s(s2[br], red); }
+            for (int l = threadIdx.x; l < p.L; l += 256) {
+                float d[NB]; dn(l, d);
+#pragma unroll
+                for (int br = 0; br < NB; ++br) {
+                    const float xh = (y[yoff<NB>(p, b, br, c, l)] - mu[br]) * rs[br];
+                    const float v = ga[br] * rs[br] * (d[br] - s1[br] * invL - xh * s2[br] * invL);
+                    dy[yoff<NB>(p, b, br, c, l)] = v;
+                    sb[br][p.ps ? (l & 1) : 0] += v;
+                }
+            }
+            if (dgam) {
+#pragma unroll
+                for (int br = 0; br < NB; ++br) {
+                    if constexpr (DET) { tg[br] += s2[br]; tb[br] += s1[br]; }
+                    else if (threadIdx.x == 0) { atomicAdd(dgam + br * p.C + c, s2[br]); atomicAdd(dbet + br * p.C + c, s1[br]); }
+                }
             }
         }
-        if (threadIdx.x == 0 && dgam) {
+        if (dbias) {
 #pragma unroll
-            for (int br = 0; br < NB; ++br) { atomicAdd(dgam + br * p.C + c, s2[br]); atomicAdd(dbet + br * p.C + c, s1[br]); }
+            for (int br = 0; br < NB; ++br) {
+                const float e = block_sum_256s(sb[br][0], red), o = block_sum_256s(sb[br][1], red);
+                if constexpr (DET) { te[br] += e; to[br] += o; }
+                else if (threadIdx.x == 0) {
+                    atomicAdd(dbias + br * brstride + c, e);
+                    if (p.ps) atomicAdd(dbias + br * brstride + cstride_par + c, o);
+                }
+            }
         }
     }
-    if (dbias) {
+    if constexpr (DET) {
+        if (threadIdx.x == 0) {
 #pragma unroll
-        for (int br = 0; br < NB; ++br) {
-            const float e = block_sum_256s(sb[br][0], red), o = block_sum_256s(sb[br][1], red);
-            if (threadIdx.x == 0) {
-                atomicAdd(dbias + br * brstride + c, e);
-                if (p.ps) atomicAdd(dbias + br * brstride + cstride_par + c, o);
+            for (int br = 0; br < NB; ++br) {
+                if (dgam) { dgam[br * p.C + c] += tg[br]; dbet[br * p.C + c] += tb[br]; }
+                if (dbias) { dbias[br * brstride + c] += te[br]; if (p.ps) dbias[br * brstride + cstride_par + c] += to[br]; }
             }
         }
     }
@@ -462,14 +498,19 @@ __global__ __launch_bounds__(256) void loss_kernel(const LossArgs a) {
         a.d_dout_D[i] = dAf * inv2;                 a.d_dout_D[n2 + i] = -(1.f - dAr) * inv2;
         a.d_dout_D[a.d_dout_D_gs + i] = dBf * inv2; a.d_dout_D[a.d_dout_D_gs + n2 + i] = -(1.f - dBr) * inv2;
     }
+    // per-block partial sums, combined in block order by loss_finalize_kernel: the 8 scalars are bitwise reproducible
 #pragma unroll
     for (int k = 0; k < 10; ++k) {
         const float t = block_sum_256(s[k], red);
-        if (threadIdx.x == 0) atomicAdd(a.acc + k, t);
+        if (threadIdx.x == 0) a.acc[blockIdx.x * 10 + k] = t;
     }
 }
-__global__ void loss_finalize_kernel(const float* acc, float* L, float n1, float n2, float lc, float li, const float* hp) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
+__global__ __launch_bounds__(256) void loss_finalize_kernel(const float* part, int nblk, float* L, float n1, float n2, float lc, float li, const float* hp) {
+    __shared__ float red[4];
+    float acc[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) acc[k] = block_sum_256((int)threadIdx.x < nblk ? part[threadIdx.x * 10 + k] : 0.f, red);
+    if (threadIdx.x == 0) {
         if (hp) { lc = hp[0]; li = hp[1]; }
         const float cyc = acc[0] / n1 + acc[1] / n1;
         const float idl = acc[2] / n1 + acc[3] / n1;
@@ -609,11 +650,13 @@ extern "C" int vc_prof_records(int kind, double* ms, double* flops, int max_n) {
 
 template <int MODE, bool FWD>
 static int norm_dispatch(const NormArgs& a, hipStream_t s) {
-    const int units = a.G * a.B * a.C;
+    const bool det = !FWD && a.det;                    // deterministic backward: one lane group per (group, channel), batch walked in order
+    const int units = a.G * (det ? 1 : a.B) * a.C;
     dim3 block(256);
 #define VC_NORM_CASE(LPR, NE) { dim3 grid((units + (256 / LPR) - 1) / (256 / LPR)); \
         if (FWD) norm_fwd_kernel<MODE, LPR, NE><<<grid, block, 0, s>>>(a); \
-        else     norm_bwd_kernel<MODE, LPR, NE><<<grid, block, 0, s>>>(a); }
+        else if (det) norm_bwd_kernel<MODE, LPR, NE, true><<<grid, block, 0, s>>>(a); \
+        else     norm_bwd_kernel<MODE, LPR, NE, false><<<grid, block, 0, s>>>(a); }
     if (a.L <= 32) VC_NORM_CASE(32, 1)
     else if (a.L <= 64) VC_NORM_CASE(64, 1)
     else if (a.L <= 128) VC_NORM_CASE(64, 2)
@@ -623,7 +666,8 @@ static int norm_dispatch(const NormArgs& a, hipStream_t s) {
     else if (a.L <= 2048) VC_NORM_CASE(64, 32)
     else {   // streaming: one block per row
         if (FWD) norm_fwd_stream_kernel<MODE><<<dim3(units), block, 0, s>>>(a);
-        else     norm_bwd_stream_kernel<MODE><<<dim3(units), block, 0, s>>>(a);
+        else if (det) norm_bwd_stream_kernel<MODE, true><<<dim3(units), block, 0, s>>>(a);
+        else     norm_bwd_stream_kernel<MODE, false><<<dim3(units), block, 0, s>>>(a);
     }
 #undef VC_NORM_CASE
     VC_HIP(hipGetLastError());
@@ -682,17 +726,17 @@ int launch_adam(float* p, float* m, float* v, const float* g, long n, float alph
 int launch_mean_loss(const float* y, const float* yh, long n, int squared, float* loss, float* d_yhat, hipStream_t s) {
     VC_HIP(hipMemsetAsync(loss, 0, sizeof(float), s));
     long blocks = (n + 255) / 256; if (blocks > 1024) blocks = 1024; if (blocks < 1) blocks = 1;
+    if (vc_det_active()) blocks = 1;              // one contribution to *loss: reproducible
     mean_loss_kernel<<<dim3((unsigned)blocks), 256, 0, s>>>(y, yh, n, squared, loss, d_yhat);
     VC_HIP(hipGetLastError());
     return 0;
 }
 int launch_loss(const LossArgs& a, hipStream_t s) {
-    VC_HIP(hipMemsetAsync(a.acc, 0, 10 * sizeof(float), s));
     const long n1 = (long)a.B * a.FT;
-    long blocks = (n1 + 255) / 256; if (blocks > 1024) blocks = 1024; if (blocks < 1) blocks = 1;
+    long blocks = (n1 + 255) / 256; if (blocks > VC_LOSS_BLOCKS) blocks = VC_LOSS_BLOCKS; if (blocks < 1) blocks = 1;
     loss_kernel<<<dim3((unsigned)blocks), 256, 0, s>>>(a);
-    loss_finalize_kernel<<<1, 64, 0, s>>>(a.acc, a.losses, (float)n1, (float)((long)a.B * a.HW),
-                                          a.lambda_cycle, a.lambda_identity, a.hp);
+    loss_finalize_kernel<<<1, 256, 0, s>>>(a.acc, (int)blocks, a.losses, (float)n1, (float)((long)a.B * a.HW),
+                                           a.lambda_cycle, a.lambda_identity, a.hp);
     VC_HIP(hipGetLastError());
     return 0;
 }

@@ -142,6 +142,7 @@ struct C1Args {
     long x_gs, w_gs, b_gs, y_gs, dx_gs, add_gs, dw_gs, db_gs;     // signed group strides (floats); y_gs also strides dy
     int B, H, W, Cout, kh, kw, sh, sw, OH, OW, pt, pl, G;
     int math;                                               // VC_MATH_*: bf16 mode rounds both operands like the MFMA kernels do
+    int det;                                                // deterministic mode: gather-form input gradient, one block per filter-gradient element
 };
 int launch_c1_fwd(const C1Args& a, hipStream_t s);
 int launch_c1_dgrad(const C1Args& a, int accumulate, hipStream_t s);   // dx (+)= ...; atomics into dx (zeroed here unless accumulate)
@@ -168,6 +169,7 @@ struct NormArgs {
     float* out; float* stats; float* dy; float* dgamma; float* dbeta; float* dbias;
     long y_gs, res_gs, par_gs, out_gs, st_gs, do_gs, dy_gs, dpar_gs, dbias_gs;
     int G, B, C, L, ps;
+    int det;                              // backward: reduce dgamma / dbeta / dbias over the batch inside one lane group (fixed order, no atomics)
 };
 
 // picks tile rows, K groups and split-K for a launch (fills bm/kg/splitk/mtiles/ntiles)
@@ -199,11 +201,12 @@ struct LossArgs {
     float* d_cyc;  long d_cyc_gs;
     float* d_dout_D; long d_dout_D_gs;    // [2][2B][HW] seeds of discriminator_loss
     float* d_dout_G; long d_dout_G_gs;    // [2][B][HW]  seeds of generator_loss_{B2A,A2B}
-    float* acc;                           // 10 fp32 partial sums (zeroed by the launcher)
+    float* acc;                           // VC_LOSS_BLOCKS x 10 per-block partial sums
     float* losses;                        // 8 scalars
     int B, FT, HW; float lambda_cycle, lambda_identity;
     const float* hp;                      // non-null: {lambda_cycle, lambda_identity} are read from device memory (captured steps)
 };
+#define VC_LOSS_BLOCKS 256
 int launch_loss(const LossArgs& a, hipStream_t s);
 int launch_crop_batch(const float* src, const long* off, const int* len, const int* start, float* out,
                       int N, int F, int n_frames, hipStream_t s);
@@ -216,6 +219,15 @@ struct ProfScope {
     ~ProfScope();
 };
 
+// Deterministic mode (vc_plan_set_deterministic / vc_set_deterministic): every reduction of the launches made while it is
+// active has a fixed order -- no split-K across workgroups (K groups inside the workgroup only), no atomics that meet
+// another contribution in scheduling order (bias / gamma / beta / Cin = 1 kernels reduce over the batch inside one
+// thread).  Thread-local: a plan-level entry point activates its plan's setting for the launches it issues (DetScope),
+// operator-level calls use the calling thread's default.
+bool vc_det_active();
+struct DetScope { int saved; explicit DetScope(int det); ~DetScope(); };
+// test / tuning hooks, thread-local (the calling thread's following launches): forced tile configuration of the fp32
+// filter-gradient kernel (tile columns 64 / 128, K groups 1 / 2 / 4, split-K); 0 = automatic
 void vc_set_error(const char* fmt, ...);
 #define VC_HIP(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { \
     vc_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \

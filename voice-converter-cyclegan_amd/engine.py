@@ -48,11 +48,13 @@ class GradSync:
         self.comm = None                       # native RCCL communicator (vc_comm*)
         if self.world > 1 and device is not None and dist.get_backend(group) == 'nccl':
             ident = (C.c_ubyte * 128)()
-            if self.rank == 0:
-                check(lib.vc_comm_unique_id(ident), 'vc_comm_unique_id')
-            box = [bytes(ident)]
+            rc0 = lib.vc_comm_unique_id(ident) if self.rank == 0 else 0
+            # rank 0's outcome travels WITH the id: a failure there must not leave the other ranks waiting in the broadcast
+            box = [(rc0, bytes(ident), lib.vc_last_error().decode() if rc0 else '')]
             dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-            ident = (C.c_ubyte * 128).from_buffer_copy(box[0])
+            if box[0][0] != 0:
+                raise _lib.VcError('vc_comm_unique_id failed on rank 0 (rc=%d): %s' % (box[0][0], box[0][2]))
+            ident = (C.c_ubyte * 128).from_buffer_copy(box[0][1])
             torch.cuda.set_device(device)
             h = _lib.vp()
             rc = lib.vc_comm_init(self.rank, self.world, ident, C.byref(h))
@@ -144,6 +146,7 @@ class CycleGANEngine:
         self.v = torch.zeros(self.n_flat, device=self.device)
         self.losses = torch.zeros(8, device=self.device)
         self._math = 'fp32'
+        self._det = False
         self._overlap = True
         # single GPU: replay the whole step as one hipGraph (vc_train_step_graph).  Off by default: measured on ROCm 7.2 the
         # replay is SLOWER than launching the step's ~330 kernels on its five streams (B=1 3.49 vs 3.21 ms, B=8 8.06 vs 7.67)
@@ -208,6 +211,7 @@ class CycleGANEngine:
         check(create(self.F, int(T), C.byref(h)), 'vc_plan_create')
         assert lib.vc_flat_param_floats(h) == self.n_flat
         check(lib.vc_plan_set_math_mode(h, MATH_MODES[self._math]), 'vc_plan_set_math_mode')
+        check(lib.vc_plan_set_deterministic(h, int(self._det)), 'vc_plan_set_deterministic')
         if not self._overlap:
             lib.vc_plan_set_overlap(h, 0)
         return h
@@ -233,6 +237,15 @@ class CycleGANEngine:
 
     def get_math(self):
         return self._math
+
+    def set_deterministic(self, on):
+        """vc_plan_set_deterministic: every reduction of this engine's launches in a fixed order (no split-K atomics, ordered
+        bias / gamma / beta sums): two runs on identical inputs -- and a hipGraph replay vs launch by launch -- are bitwise
+        equal.  Off by default (split-K fills the chip at small batches)."""
+        self._det = bool(on)
+        for cache in (self._plans, self._infer_plans):
+            for h in cache.values():
+                check(lib.vc_plan_set_deterministic(h, int(self._det)), 'vc_plan_set_deterministic')
 
     def _workspace(self, n):
         if self._ws is None or self._ws.numel() < n:

@@ -205,24 +205,26 @@ class CycleGAN(object):
         if not self._io_rank:                  # replicas are identical: rank 0 writes, everybody leaves together
             eng.sync.barrier()
             return path
-        os.makedirs(directory, exist_ok=True)
-        out = {}
-        out.update(eng.tf_variables())
-        out.update({k + '/Adam': v for k, v in eng._unpack(eng.m).items()})
-        out.update({k + '/Adam_1': v for k, v in eng._unpack(eng.v).items()})
-        # optimizer creation order in model.py:107-108: discriminator first, then generator
-        out['beta1_power'], out['beta2_power'] = eng.b1p[1], eng.b2p[1]
-        out['beta1_power_1'], out['beta2_power_1'] = eng.b1p[0], eng.b2p[0]
-        tmp = path + '.npz.tmp'
-        with open(tmp, 'wb') as f:
-            np.savez(f, **out)
-        os.replace(tmp, path + '.npz')         # a reader never sees a half-written checkpoint
-        if self.save_tf_checkpoint:
-            # the files tf.train.Saver writes (minus the .meta graph): `<path>.index`, `<path>.data-00000-of-00001`, `checkpoint`
-            tfio.write_tf_checkpoint(path, out)
-        if self.mode == 'train' and self.writer is not None:
-            self.writer.flush()
-        eng.sync.barrier()
+        try:                                   # whatever happens here, the other ranks are waiting in the barrier
+            os.makedirs(directory, exist_ok=True)
+            out = {}
+            out.update(eng.tf_variables())
+            out.update({k + '/Adam': v for k, v in eng._unpack(eng.m).items()})
+            out.update({k + '/Adam_1': v for k, v in eng._unpack(eng.v).items()})
+            # optimizer creation order in model.py:107-108: discriminator first, then generator
+            out['beta1_power'], out['beta2_power'] = eng.b1p[1], eng.b2p[1]
+            out['beta1_power_1'], out['beta2_power_1'] = eng.b1p[0], eng.b2p[0]
+            tmp = path + '.npz.tmp'
+            with open(tmp, 'wb') as f:
+                np.savez(f, **out)
+            os.replace(tmp, path + '.npz')         # a reader never sees a half-written checkpoint
+            if self.save_tf_checkpoint:
+                # the files tf.train.Saver writes (minus the .meta graph): `<path>.index`, `<path>.data-00000-of-00001`, `checkpoint`
+                tfio.write_tf_checkpoint(path, out)
+            if self.mode == 'train' and self.writer is not None:
+                self.writer.flush()
+        finally:
+            eng.sync.barrier()
         return path
 
     def load(self, filepath):

@@ -22,12 +22,27 @@ from ._lib import lib, ptr, check
 from .layout import ParamLayout, GENERATOR, DISCRIMINATOR
 
 
+class _PlanHandle(C.c_void_p):
+    """A native plan that is destroyed with its last user: the store's LRU holds one reference, every autograd node that
+    still needs the plan for its backward holds another (ctx.plan)."""
+
+    def __del__(self):
+        try:
+            if self.value:
+                torch.cuda.synchronize()           # nothing in flight may still use the plan's streams / tables
+                lib.vc_plan_destroy(self)
+        except Exception:
+            pass
+
+
 class VariableStore:
     """The analogue of TF's default graph variable collection: scope name -> flat fp32 block."""
+    PLAN_CAPACITY = 8            # geometries kept alive; CycleGAN.test sees a new utterance length on almost every call
 
     def __init__(self):
+        import collections
         self.scopes = {}          # name -> dict(kind, layout, params (leaf tensor), num_features)
-        self._plans = {}
+        self._plans = collections.OrderedDict()
 
     def create(self, name, kind, num_features, device, rng=None, storage=None):
         if name in self.scopes:
@@ -50,11 +65,16 @@ class VariableStore:
 
     def plan(self, F, T):
         key = (F, T)
-        if key not in self._plans:
-            h = _lib.vp()
-            check(lib.vc_plan_create(F, int(T), C.byref(h)), 'vc_plan_create')
-            self._plans[key] = h
-        return self._plans[key]
+        h = self._plans.get(key)
+        if h is not None:
+            self._plans.move_to_end(key)
+            return h
+        while len(self._plans) >= self.PLAN_CAPACITY:
+            self._plans.popitem(last=False)        # destroyed once no pending backward refers to it (_PlanHandle.__del__)
+        h = _PlanHandle()
+        check(lib.vc_plan_create(F, int(T), C.byref(h)), 'vc_plan_create')
+        self._plans[key] = h
+        return h
 
     def trainable_variables(self, substring):
         """model.py:92-95 partitions variables by 'generator' / 'discriminator' in the name."""
