@@ -46,29 +46,43 @@ def _blas_threads():
 
 
 def cpu_baseline(n_steps=10):
-    """oracle/cyclegan_oracle.py on the host cores: B=1, 24x128 (BASELINE configs[0]: 10 steps), 1 warm-up + n timed."""
+    """The reference arithmetic on the host cores (TF1 itself cannot run here), timed two ways on a bounded sample
+    of the workload: oracle/torch_ref.py (torch-CPU: oneDNN / MKL convolutions + autograd, torch.set_num_threads(all cores);
+    SURVEY 8d's stand-in) at B=1 (BASELINE configs[0]) and at the benched B=8, and the numpy oracle at B=1.  `value` is the
+    fastest of them in frames/s; every leg is listed in `sample`."""
     import numpy as np
+    import torch
     from oracle import cyclegan_oracle as O
-    P = O.init_params(seed=42)
-    A, Bm = O.synthetic_batch(1, 24, 128)
-    orc = O.CycleGANOracle(P)
-    orc.train(A, Bm, 10.0, 5.0, 2e-4, 1e-4)
-    ts = []
-    for _ in range(n_steps):
-        t = time.perf_counter()
-        orc.train(A, Bm, 10.0, 5.0, 2e-4, 1e-4)
-        ts.append(time.perf_counter() - t)
-    med = float(np.median(ts))
-    return dict(value=128.0 / med, unit='frames/s', cores=os.cpu_count(), kind='port',
-                sample='numpy oracle (oracle/cyclegan_oracle.py), B=1 x 24x128, 1 warm-up + %d timed full '
-                       'train steps, median %.2f s/step; the GEMMs run in numpy\'s BLAS (%s), the rest single-threaded; '
-                       'TF1 reference not runnable (no tensorflow)' % (n_steps, med, _blas_threads()))
+    from oracle.torch_ref import TorchTrainer
+    cores = os.cpu_count()
+    torch.set_num_threads(cores)
+    legs = []
+
+    def leg(name, B, step, n):
+        A, Bm = O.synthetic_batch(B, 24, 128)
+        step(A, Bm)                               # warm-up
+        ts = []
+        for _ in range(n):
+            t = time.perf_counter(); step(A, Bm); ts.append(time.perf_counter() - t)
+        med = float(np.median(ts))
+        legs.append((B * 128.0 / med, '%s B=%d: 1 warm-up + %d timed full train steps, median %.3f s/step = %.1f frames/s'
+                     % (name, B, n, med, B * 128.0 / med)))
+
+    tt = TorchTrainer(O.init_params(seed=42))
+    leg('torch-CPU (oracle/torch_ref.py TorchTrainer, %d threads)' % torch.get_num_threads(), 1, lambda A, Bm: tt.train(A, Bm, 10.0, 5.0, 2e-4, 1e-4), n_steps)
+    leg('torch-CPU', 8, lambda A, Bm: tt.train(A, Bm, 10.0, 5.0, 2e-4, 1e-4), 3)
+    orc = O.CycleGANOracle(O.init_params(seed=42))
+    leg('numpy oracle (oracle/cyclegan_oracle.py; GEMMs in numpy\'s BLAS: %s, the rest single-threaded)' % _blas_threads(), 1,
+        lambda A, Bm: orc.train(A, Bm, 10.0, 5.0, 2e-4, 1e-4), 5)
+    best = max(legs)
+    return dict(value=best[0], unit='frames/s', cores=cores, kind='port',
+                sample='24x128 MCEP, fp32; ' + '; '.join(l[1] for l in legs) + '; TF1 reference not runnable (no tensorflow)')
 
 
 def _pmc_traffic(B, F, T, world, math):
     """HBM-side bytes per igemm launch from the committed PMC summary of the same configuration (None if not profiled)"""
     try:
-        with open(os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')) as f:
+        with open(os.path.join(ROOT, 'profiles', 'r03_pmc_traffic.json' if os.path.exists(os.path.join(ROOT, 'profiles', 'r03_pmc_traffic.json')) else 'r02_pmc_traffic.json')) as f:
             d = json.load(f)
         return d.get('%s_b%d_%dx%d' % (math, B, F, T)) if world == 1 else None
     except Exception:
@@ -115,6 +129,99 @@ def named_kernel_h1(lib, dev, B=256, reps=20, peak=FP32_MFMA_PEAK_TFLOPS, math='
                      else 'bf16 MFMA operands (rounded once on their way into LDS), fp32 tensors in HBM, fp32 accumulate')}
 
 
+def time_steps(eng, A, Bm, hp, steps, warmup, barrier):
+    for _ in range(warmup):
+        eng.train_step(A, Bm, *hp, sync=False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        eng.train_step(A, Bm, *hp, sync=False)
+    barrier()
+    return time.perf_counter() - t0
+
+
+def roofline_leg(eng, lib, A, Bm, hp, math, peak, world, serial, n_prof=3):
+    """the same steps again with HIP events around every MFMA launch (vc_prof_*), the step's chains serialised on one stream so
+    a launch never time-shares the chip with a launch of another chain (the headline `value` runs them on five streams)"""
+    import torch
+    from voice_converter_cyclegan_amd.engine import CycleGANEngine
+    B, F, T = A.shape
+    eng.set_overlap(False)
+    for _ in range(2):
+        eng.train_step(A, Bm, *hp, sync=False)
+    torch.cuda.synchronize()
+    CycleGANEngine.profiling(True)
+    for _ in range(n_prof):
+        eng.train_step(A, Bm, *hp, sync=False)
+    torch.cuda.synchronize()
+    stats = {}
+    knames = ((0, 'igemm_kernel (conv fwd + dgrad, every Cin > 1 layer)'), (1, 'wgrad_kernel'), (2, 'wsconv1d_kernel'))
+    if math == 'bf16':       # 16-bit data path (csrc/vc_conv_bf16.hip); launches too small for its tiles stay on igemm / wgrad_kernel
+        knames = ((0, 'conv_bf16_kernel (conv fwd + dgrad; + igemm_kernel for the few launches below its tile size)'),
+                  (1, 'filter gradient: conv_bf16_kernel as a GEMM over the pixel axis on im2col / pixel-octet packed operands (+ wgrad_kernel for o1)'), (2, 'wsconv1d_kernel'))
+    for kind, name in knames:
+        ms, n, fl = C.c_double(0), C.c_longlong(0), C.c_double(0)
+        lib.vc_prof_collect(kind, C.byref(ms), C.byref(n), C.byref(fl))
+        stats[kind] = (name, ms.value, n.value, fl.value)
+    CycleGANEngine.profiling(False)
+    eng.set_overlap(not serial)
+    name, ms, n, fl = stats[0]
+    ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    out = {'roofline': {
+        'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak,
+        # HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
+        # (FETCH_SIZE doubled per MI355X_MICROARCH.md, Infinity-Cache hits included)
+        'traffic': _pmc_traffic(B, F, T, world, math),
+        'traffic_unit': 'bytes/launch (offline rocprofv3 PMC passes of this command, profiles/r03_pmc_traffic.json; '
+                        'FETCH_SIZE doubled per MI355X_MICROARCH.md; upper bound: Infinity-Cache hits counted)',
+        'kernel': name, 'launches_per_step': n // n_prof,
+        'condition': 'step chains serialised on one stream (no co-running launches); see --serial',
+        'avg_launch_us': 1e3 * ms / max(n, 1), 'algorithmic_gflop_per_step': fl / n_prof / 1e9,
+        'kernel_ms_per_step': ms / n_prof}}
+    name, ms, n, fl = stats[1]
+    ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    out['roofline_wgrad'] = {'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak, 'kernel': name,
+                             'launches_per_step': n // n_prof, 'kernel_ms_per_step': ms / n_prof}
+    # FLOPs the step executes: every MFMA launch carries its algorithmic FLOPs; the Cin = 1 layer (D.h1, vector ALU)
+    # is added analytically: forward over 2B samples per D, filter gradient over 2B, input gradient over B
+    c1 = 2.0 * 9 * 256 * (F * (T // 2)) * 2 * (2 * B + 2 * B + B)      # 9 taps x 256 filters x F x T/2 pixels, 2 discriminators
+    out['executed_flop_per_step'] = (stats[0][3] + stats[1][3] + stats[2][3]) / n_prof + c1
+    return out
+
+
+def workload_text(math, B, F, T, global_batch):
+    idx = 4 if (F, T) == (36, 256) else 3 if global_batch else 1 if math == 'fp32' else 2
+    return ('BASELINE configs[%d]: full CycleGAN-VC train step (2G+2D fwd/bwd + losses + TF-Adam), %s, batch %d per GPU, '
+            '%dx%d MCEP, random-init weights' % (idx, MATH_TEXT[math], B, F, T))
+
+
+def extra_config(lib, dev, math, B, F, T, steps, warmup, note):
+    """one more BASELINE configuration on this GPU, measured like the headline: wall time of `steps` steps + its own roofline leg"""
+    import numpy as np
+    import torch
+    from voice_converter_cyclegan_amd.engine import CycleGANEngine
+    eng = CycleGANEngine(num_features=F, device=dev, seed=42, data_parallel=False)
+    eng.set_math(math)
+    rng = np.random.default_rng(99)
+    A = torch.from_numpy(rng.standard_normal((B, F, T)).astype(np.float32)).to(dev)
+    Bm = torch.from_numpy(rng.standard_normal((B, F, T)).astype(np.float32)).to(dev)
+    hp = (10.0, 5.0, 2e-4, 1e-4)
+    dt = time_steps(eng, A, Bm, hp, steps, warmup, torch.cuda.synchronize)
+    assert np.isfinite(eng.losses.cpu().numpy()).all()
+    peak = {'fp32': FP32_MFMA_PEAK_TFLOPS, 'bf16': BF16_MFMA_PEAK_TFLOPS}[math]
+    r = roofline_leg(eng, lib, A, Bm, hp, math, peak, 1, False)
+    executed = r.pop('executed_flop_per_step')
+    out = {'workload': workload_text(math, B, F, T, 0) + ' -- ' + note, 'dtype': {'fp32': 'f32'}.get(math, math),
+           'value': B * T * steps / dt, 'unit': 'frames/s', 'ms_per_step': 1e3 * dt / steps, 'steps': steps, 'warmup': warmup,
+           'executed_gflop_per_step': executed / 1e9,
+           'step_flop_frac_of_fp32_peak': executed / (dt / steps) / (FP32_MFMA_PEAK_TFLOPS * 1e12)}
+    out.update(r)
+    eng.close()
+    del eng
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -129,12 +236,18 @@ def main():
                     help='arithmetic of the conv kernels; fp32 (default) is the reference precision and the headline, '
                          'bf16 is BASELINE configs[2] (bf16 conv operands in HBM, fp32 accumulate/outputs/statistics)')
     ap.add_argument('--graph', action='store_true', help='replay the step as one hipGraph (vc_train_step_graph) instead of launching it')
+    ap.add_argument('--deterministic', action='store_true', help='vc_plan_set_deterministic: fixed summation order (bitwise reproducible steps)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-extra', action='store_true',
+                    help='skip the other BASELINE configurations (bf16 B=64, fp32 B=32 = configs[3]\'s share of an 8-GPU node, 36x256 '
+                         'B=64) that a default single-GPU run measures after the headline and reports under extra.configs')
     ap.add_argument('--serial', action='store_true',
                     help='serialise the step\'s two independent chains on one stream for the WHOLE run (the condition the '
                          'roofline leg always uses; for rocprof summaries that must agree with it)')
     args = ap.parse_args()
+    default_workload = (args.batch, args.global_batch, args.frames, args.features, args.math, args.graph, args.serial, args.deterministic) == \
+                       (8, 0, 128, 24, 'fp32', False, False, False)
 
     import numpy as np
     import torch
@@ -166,6 +279,7 @@ def main():
     if args.graph:
         eng.use_graph = True
     eng.set_math(args.math)
+    eng.set_deterministic(args.deterministic)
     peak = {'fp32': FP32_MFMA_PEAK_TFLOPS, 'bf16': BF16_MFMA_PEAK_TFLOPS, 'bf16x3': BF16_MFMA_PEAK_TFLOPS / 3}[args.math]
     if args.global_batch:
         if args.global_batch % world:
@@ -182,14 +296,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        eng.train_step(A, Bm, *hp, sync=False)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        eng.train_step(A, Bm, *hp, sync=False)
-    barrier()
-    dt = time.perf_counter() - t0
+    dt = time_steps(eng, A, Bm, hp, args.steps, args.warmup, barrier)
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -205,14 +312,12 @@ def main():
             'value': frames / dt, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True,
             'scaling': 'strong' if args.global_batch else 'weak', 'vs_baseline': None, 'dtype': {'fp32': 'f32'}.get(args.math, args.math), 'data': 'synthetic',
-            'config': {'workload': 'BASELINE configs[%d]: full CycleGAN-VC train step (2G+2D fwd/bwd + losses + '
-                                   'TF-Adam), %s, batch %d per GPU, %dx%d MCEP, random-init weights'
-                                   % (4 if (F, T) == (36, 256) else 3 if args.global_batch else 1 if args.math == 'fp32' else 2,
-                                      MATH_TEXT[args.math], B, F, T),
+            'config': {'workload': workload_text(args.math, B, F, T, args.global_batch),
                        'global_batch': world * B, 'frames_per_step_per_domain': world * B * T,
                        'parallelism': 'dp%d' % world,
                        'launch': 'one hipGraph replay per step (vc_train_step_graph)' if (eng.use_graph and world == 1 and not args.serial)
                        else 'launch by launch',
+                       'deterministic': bool(args.deterministic),
                        'gradient_exchange': ('native RCCL communicator (vc_comm_init / vc_step_exchange_and_update), %d ranks'
                                              % lib.vc_comm_world(eng.sync.comm)) if eng.sync.comm is not None
                        else ('none (single GPU)' if world == 1 else 'torch.distributed'),
@@ -225,62 +330,32 @@ def main():
     # ---- roofline leg: the same steps again with HIP events around every implicit-GEMM launch
     if not args.no_roofline:
         barrier()
-        # per-kernel timing: serialise the step's chains so a launch is never time-sharing the chip with a launch of the
-        # other chain (the headline `value` above runs them on two streams)
-        eng.set_overlap(False)
-        for _ in range(2):
-            eng.train_step(A, Bm, *hp, sync=False)
-        torch.cuda.synchronize()
-        CycleGANEngine.profiling(True)
-        n_prof = 3
-        for _ in range(n_prof):
-            eng.train_step(A, Bm, *hp, sync=False)
-        torch.cuda.synchronize()
-        stats = {}
-        knames = ((0, 'igemm_kernel (conv fwd + dgrad, every Cin > 1 layer)'), (1, 'wgrad_kernel'), (2, 'wsconv1d_kernel'))
-        if args.math == 'bf16':       # 16-bit data path (csrc/vc_conv_bf16.hip); launches too small for its tiles stay on igemm / wgrad_kernel
-            knames = ((0, 'conv_bf16_kernel (conv fwd + dgrad; + igemm_kernel for the few launches below its tile size)'),
-                      (1, 'filter gradient: conv_bf16_kernel as a GEMM over the pixel axis on im2col / pixel-octet packed operands (+ wgrad_kernel for o1)'), (2, 'wsconv1d_kernel'))
-        for kind, name in knames:
-            ms, n, fl = C.c_double(0), C.c_longlong(0), C.c_double(0)
-            lib.vc_prof_collect(kind, C.byref(ms), C.byref(n), C.byref(fl))
-            stats[kind] = (name, ms.value, n.value, fl.value)
-        CycleGANEngine.profiling(False)
-        eng.set_overlap(not args.serial)
+        r = roofline_leg(eng, lib, A, Bm, hp, args.math, peak, world, args.serial)
         if rank == 0:
-            name, ms, n, fl = stats[0]
-            ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-            out['roofline'] = {
-                'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s',
-                'frac': ach / peak,
-                # HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
-                # (profiles/r01_pmc_hbm_traffic_b8.txt; FETCH_SIZE doubled per MI355X_MICROARCH.md, L3 hits included)
-                'traffic': _pmc_traffic(B, F, T, world, args.math),
-                'traffic_unit': 'bytes/launch (offline rocprofv3 PMC passes of this command, profiles/r02_pmc_traffic.json; '
-                                'FETCH_SIZE doubled per MI355X_MICROARCH.md; upper bound: Infinity-Cache hits counted)',
-                'kernel': name, 'launches_per_step': n // n_prof,
-                'condition': 'step chains serialised on one stream (no co-running launches); see --serial',
-                'avg_launch_us': 1e3 * ms / max(n, 1), 'algorithmic_gflop_per_step': fl / n_prof / 1e9,
-                'kernel_ms_per_step': ms / n_prof,
-            }
-            name, ms, n, fl = stats[1]
-            ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-            out['roofline_wgrad'] = {'bound': 'mfma', 'achieved': ach, 'peak': peak,
-                                     'unit': 'TFLOP/s', 'frac': ach / peak, 'kernel': name,
-                                     'launches_per_step': n // n_prof, 'kernel_ms_per_step': ms / n_prof}
-            # FLOPs the step executes: every MFMA launch carries its algorithmic FLOPs; the Cin = 1 layer (D.h1, vector ALU)
-            # is added analytically: forward over 2B samples per D, filter gradient over 2B, input gradient over B
-            c1 = 2.0 * 9 * 256 * (F * (T // 2)) * 2 * (2 * B + 2 * B + B)      # 9 taps x 256 filters x F x T/2 pixels, 2 discriminators
-            executed = (stats[0][3] + stats[1][3] + stats[2][3]) / n_prof + c1
+            executed = r.pop('executed_flop_per_step')
+            out.update(r)
             out['config']['executed_gflop_per_step'] = world * executed / 1e9
             out['step_flop_frac_of_fp32_peak'] = executed / (out['ms_per_step'] * 1e-3) / (FP32_MFMA_PEAK_TFLOPS * 1e12)
 
-    # ---- the kernel the north_star names: gated-conv1d forward (G.h1: 24 -> 2x128, k=15) at B=256
+    # ---- the kernel the north_star names: gated-conv1d forward (G.h1: 24 -> 2x128, k=15) at B=256 (and B=4096: the asymptote)
     if rank == 0 and not args.no_roofline:
         out['named_kernel'] = named_kernel_h1(lib, dev, peak=FP32_MFMA_PEAK_TFLOPS, math='fp32')
         # the same kernel with bf16 MFMA operands (BASELINE configs[2] arithmetic): the HBM-roofline view the north star asks for
         r = named_kernel_h1(lib, dev, peak=BF16_MFMA_PEAK_TFLOPS, math='bf16')
-        out['named_kernel']['bf16_mode'] = {'us': r['us'], 'hbm_frac': r['hbm']['frac'], 'achieved_TFLOPs': r['mfma']['achieved_TFLOPs']}
+        r4k = named_kernel_h1(lib, dev, B=4096, reps=10, peak=BF16_MFMA_PEAK_TFLOPS, math='bf16')
+        out['named_kernel']['bf16_mode'] = {'us': r['us'], 'hbm_frac': r['hbm']['frac'], 'achieved_TFLOPs': r['mfma']['achieved_TFLOPs'],
+                                            'B4096': {'us': r4k['us'], 'hbm_frac': r4k['hbm']['frac'], 'algorithmic_bytes': r4k['algorithmic_bytes']}}
+        out['named_kernel']['timed'] = 'everything one vc_gated_conv1d_glu_fwd call launches (filter-image pack + the kernel), HIP events on the call\'s stream'
+
+    # ---- the other BASELINE configurations this GPU can hold, each with its own roofline (default single-GPU run only)
+    if rank == 0 and world == 1 and default_workload and not args.no_extra and not args.no_roofline:
+        eng.close()
+        torch.cuda.empty_cache()
+        out['extra'] = {'configs': [
+            extra_config(lib, dev, 'bf16', 64, 24, 128, 10, 3, 'configs[2]: batch 64, bf16'),
+            extra_config(lib, dev, 'fp32', 32, 24, 128, 10, 3, 'configs[3]: the per-GPU share (32) of global batch 256 on an 8-GPU node, measured on one GPU without the exchange'),
+            extra_config(lib, dev, 'fp32', 64, 36, 256, 5, 2, 'configs[4]: the per-GPU share (64) of global batch 512 at 36x256, measured on one GPU without the exchange'),
+        ]}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline()

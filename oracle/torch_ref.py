@@ -113,3 +113,49 @@ def losses_and_grads(P_np, A, Bm, lambda_cycle, lambda_identity):
     G = {n: g.numpy() for n, g in zip(g_names, g_grads)}
     G.update({n: g.numpy() for n, g in zip(d_names, d_grads)})
     return S, G, gen_A.detach().numpy(), gen_B.detach().numpy()
+
+
+class TorchTrainer:
+    """model.CycleGAN.train (model.py:110-125) on torch-CPU (oneDNN / MKL convolutions, autograd, all host threads) with
+    persistent parameters and TF-form Adam (model.py:107-108; rule S7) -- the fair CPU baseline bench.py times beside the
+    numpy oracle.  Same arithmetic as losses_and_grads + cyclegan_oracle.AdamTF (tests/test_oracle.py compares them)."""
+
+    def __init__(self, P_np):
+        self.P = {k: torch.tensor(v, dtype=torch.float32, requires_grad=True) for k, v in P_np.items()}
+        self.g_names = [n for n in self.P if 'generator' in n]
+        self.d_names = [n for n in self.P if 'discriminator' in n]
+        self.m = {k: torch.zeros_like(v) for k, v in self.P.items()}
+        self.v = {k: torch.zeros_like(v) for k, v in self.P.items()}
+        self.b1p = {'g': np.float32(0.5), 'd': np.float32(0.5)}
+        self.b2p = {'g': np.float32(0.999), 'd': np.float32(0.999)}
+
+    def _adam(self, names, grads, lr, k):
+        one = np.float32(1)
+        alpha = float(np.float32(lr) * np.sqrt(one - self.b2p[k]) / (one - self.b1p[k]))
+        with torch.no_grad():
+            for n, g in zip(names, grads):
+                m, v = self.m[n], self.v[n]
+                m.add_(g - m, alpha=0.5)
+                v.add_(g * g - v, alpha=0.001)
+                self.P[n].sub_(m * alpha / (v.sqrt() + 1e-8))
+        self.b1p[k] = np.float32(self.b1p[k] * np.float32(0.5)); self.b2p[k] = np.float32(self.b2p[k] * np.float32(0.999))
+
+    def train(self, A, Bm, lambda_cycle, lambda_identity, lr_g, lr_d):
+        P = self.P
+        A, Bm = torch.as_tensor(A, dtype=torch.float32), torch.as_tensor(Bm, dtype=torch.float32)
+        gen_B = generator(P, 'generator_A2B', A); cyc_A = generator(P, 'generator_B2A', gen_B)
+        gen_A = generator(P, 'generator_B2A', Bm); cyc_B = generator(P, 'generator_A2B', gen_A)
+        id_A = generator(P, 'generator_B2A', A); id_B = generator(P, 'generator_A2B', Bm)
+        dA_f = discriminator(P, 'discriminator_A', gen_A); dB_f = discriminator(P, 'discriminator_B', gen_B)
+        cyc = (A - cyc_A).abs().mean() + (Bm - cyc_B).abs().mean()
+        idl = (A - id_A).abs().mean() + (Bm - id_B).abs().mean()
+        g_loss = ((1 - dB_f) ** 2).mean() + ((1 - dA_f) ** 2).mean() + lambda_cycle * cyc + lambda_identity * idl
+        g_grads = torch.autograd.grad(g_loss, [P[n] for n in self.g_names])
+        fA, fB = gen_A.detach(), gen_B.detach()
+        self._adam(self.g_names, g_grads, lr_g, 'g')                       # model.py:112-114
+        dlA = (((1 - discriminator(P, 'discriminator_A', A)) ** 2).mean() + (discriminator(P, 'discriminator_A', fA) ** 2).mean()) / 2
+        dlB = (((1 - discriminator(P, 'discriminator_B', Bm)) ** 2).mean() + (discriminator(P, 'discriminator_B', fB) ** 2).mean()) / 2
+        d_loss = dlA + dlB
+        d_grads = torch.autograd.grad(d_loss, [P[n] for n in self.d_names])
+        self._adam(self.d_names, d_grads, lr_d, 'd')                       # model.py:118-119
+        return float(g_loss.detach()), float(d_loss.detach())

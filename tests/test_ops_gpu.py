@@ -57,6 +57,11 @@ CONV_CASES = [
     (256, 1, 256, 36, 1, 15, 1, 1, 2),     # config 5's o1
     (1024, 1, 32, 512, 1, 3, 1, 1, 8),     # residual h2, cycle hop: K groups inside the workgroup + split-K
     (256, 1, 128, 24, 1, 15, 1, 1, 8),     # o1 at B = 8: 24-row taps (padded to 32) in the input-gradient table
+    # rowskip (IgemmArgs::rowskip, WgradArgs::rowskip): D.d3's 6 tap rows on 6 image rows, SAME pads (2, 3) -- launch pixels
+    # enumerated (row, sample, column), only the tap rows / output rows that touch the image are walked
+    (512, 6, 16, 2048, 6, 3, 1, 2, 8),     # the B = 8 step's size: 64 pixels per output row = one tile per row
+    (512, 9, 32, 2048, 6, 3, 1, 2, 3),     # 36 MCEPs (9 rows), odd batch: 48 pixels per row, tiles straddle rows
+    (64, 6, 16, 128, 6, 3, 1, 2, 16),      # 128 pixels per row: two tiles per row
 ]
 
 

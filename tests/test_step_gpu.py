@@ -196,24 +196,26 @@ def test_discriminator_forward_backward(built_lib, mode):
 
 @pytest.mark.parametrize('B', [1, 2, 8])
 def test_train_step_losses_grads_and_updates(built_lib, B):
-    """whole step: 8 logged scalars, generation_A/B, all 119.8 M gradients, parameters after
-    1 and 3 steps (model.py:110-125).  B = 8 is BASELINE configs[1], the configuration bench.py times."""
+    """whole step: 8 logged scalars, generation_A/B, all 119.8 M gradients, parameters after the update (model.py:110-125);
+    at the reference's own batch (B = 1, train.py:16) ten consecutive steps.  B = 8 is BASELINE configs[1], the
+    configuration bench.py times."""
     from tests import gpu_util as U
     O, P, A, Bm, eng = _setup(B, seed=16 if B == 8 else 11)      # seed 16: the first tie-free one at B = 8 (gap 6.9e-5)
     orc = O.CycleGANOracle({k: v.copy() for k, v in P.items()})
     gen_A = torch.empty((B, 24, 128), device=U.DEV); gen_B = torch.empty_like(gen_A)
     steps = 10 if B == 1 else 1          # SURVEY 4-3: parameters after 10 steps of the reference's own batch (train.py:16)
-    clean = True                         # no step so far had an L1 element within L1_GAP_MIN of a tie (oracle's own forward)
     for step in range(steps):
         g0, d0 = orc.train(A, Bm, 10.0, 5.0, 2e-4, 1e-4)
-        clean = clean and orc.last_l1_gap >= L1_GAP_MIN
+        # did the ORACLE's own forward of this step keep every L1 element >= L1_GAP_MIN from a tie?  Then no sign(.) of
+        # utils.l1_loss can legitimately differ between two correct implementations (step 0 is tie-free by _setup).
+        clean = orc.last_l1_gap >= L1_GAP_MIN
         g, d = eng.train_step(A, Bm, 10.0, 5.0, 2e-4, 1e-4, gen_A=gen_A, gen_B=gen_B)
         for k, v in orc.last.items():
             got = eng.last_losses[k]
             assert abs(got - v) <= TOL * max(1.0, abs(v)), (step, k, got, float(v))
         assert abs(g - g0) <= TOL * max(1.0, abs(g0)) and abs(d - d0) <= TOL * max(1.0, abs(d0))
-        assert U.rel_err(gen_A.cpu().numpy(), orc.last_fakes[0]) < TOL
-        assert U.rel_err(gen_B.cpu().numpy(), orc.last_fakes[1]) < TOL
+        assert U.rel_err(gen_A.cpu().numpy(), orc.last_fakes[0]) < TOL, step
+        assert U.rel_err(gen_B.cpu().numpy(), orc.last_fakes[1]) < TOL, step
         if step == 0:
             ref = dict(orc.last_grads[0]); ref.update(orc.last_grads[1])
             bad = _cmp_grads(eng.tf_gradients(), ref)
@@ -227,13 +229,26 @@ def test_train_step_losses_grads_and_updates(built_lib, B):
             diff = np.abs(got[n] - r)
             frac = float((diff > 0.05 * lr).mean())
             # Adam's first steps move every weight by ~lr * sign(g): a weight whose gradient is within rounding of zero
-            # may move the other way on the two sides (2 lr per step); they must be rare
-            assert diff.max() <= 2.02 * lr * (step + 1), (step, n, float(diff.max()))
-            # step 0 runs on a tie-free forward (_setup).  A later step is held to the same 1e-3 as long as the ORACLE's own
-            # forward of every step so far kept all L1 elements >= L1_GAP_MIN from a tie (orc.last_l1_gap): then no sign(.)
-            # of utils.l1_loss can legitimately differ.  After a near-tie step, one flipped sign moves ~1 % of the weights
-            # the other way and the difference persists: 5e-2 from there on.
+            # may move the other way on the two sides (2 lr per step); they must be rare: 1e-3 of a tensor on a tie-free
+            # step.  After a near-tie step one flipped L1 sign may move ~1 % of the weights the other way: 5e-2 for that
+            # step only.  Both sides continue from the SAME state (the oracle's parameters and Adam slots, loaded below after
+            # every step), so each of the 10 steps -- Adam step counts 1..10, non-zero moments -- is compared on its own
+            # merits at the tight bound instead of inheriting earlier +-lr differences (which compound: 2.7e-3 on the
+            # generations after a few steps).
+            assert diff.max() <= 2.02 * lr, (step, n, float(diff.max()))
             assert frac < (1e-3 if clean else 5e-2), (step, n, frac, clean)
+        if step + 1 < steps:
+            _load_oracle_state(eng, orc)
+
+
+def _load_oracle_state(eng, orc):
+    """parameters and Adam slots of the oracle -> engine (the beta powers follow the step count on both sides)"""
+    from voice_converter_cyclegan_amd.engine import SCOPES
+    eng.load_tf_variables(orc.P)
+    for buf, slot in ((eng.m, 'm'), (eng.v, 'v')):
+        d = dict(getattr(orc.opt_g, slot)); d.update(getattr(orc.opt_d, slot))
+        buf.copy_(torch.from_numpy(np.concatenate([eng._layout(i).pack(d, s) for i, s in enumerate(SCOPES)])))
+    torch.cuda.synchronize()
 
 
 @pytest.mark.parametrize('kg', [1, 2, 4])

@@ -83,6 +83,7 @@ static Geom make_geom(int Cin, int H, int W, int Cout, int kh, int kw, int sh, i
 struct HostRow { int c, dh, dw, a_off, tap; };
 struct Table { KEntry* dev = nullptr; int* xsoff = nullptr; unsigned* rtap = nullptr; unsigned* aoff = nullptr; Tap* taps = nullptr;
                int ntaps = 0, rows = 0, valid = 0, xbias = 0, refs = 0;
+               int cpt = 0; signed char tdh[32] = {};          // K chunks per filter tap; row offset of every tap (rowskip, IgemmArgs)
                // the same K rows by octets of 8 channels, for the 16-bit data path (vc_internal.h: ConvBf16Args); koct == 0:
                // the channel count is not a multiple of 8 and the path is not available for this geometry
                int* oxs = nullptr; unsigned* otap = nullptr; int* wsrc = nullptr; int koct = 0, oxbias = 0; };
@@ -129,6 +130,11 @@ static int upload_table(const std::vector<HostRow>& rows, const std::vector<int>
         at += n;
     }
     t->valid = (int)rows.size(); t->ntaps = (int)taps.size(); t->xbias = (int)xbias;
+    t->cpt = rows_per_tap.empty() ? 0 : (rows_per_tap[0] + VC_KC - 1) / VC_KC;
+    for (size_t tp = 0; tp < taps.size(); ++tp) {
+        if (rows_per_tap[tp] != rows_per_tap[0] || taps[tp].dh < -100 || taps[tp].dh > 100) t->cpt = 0;   // no uniform tap size: rowskip unavailable
+        t->tdh[tp] = (signed char)taps[tp].dh;
+    }
     auto pad_chunk = [&]() { for (int k = 0; k < VC_KC; ++k) { ke.push_back(KEntry{0, 0, 0, -1}); xs.push_back((int)xbias); ao.push_back(0u); if (k % 4 == 0) rt.push_back(0u); } };
     while (ke.size() % 64 || ke.empty()) pad_chunk();          // the filter-gradient kernel walks 64-row tiles
     t->rows = (int)ke.size();
@@ -270,6 +276,22 @@ static int check_conv_geom(const Geom& g, int B) {
 static void fill_pixel_grid(IgemmArgs& a, int B, int NPB, int OWc) {
     a.NPB = NPB; a.OWc = OWc; a.Ptot = B * NPB; a.inv_npb = 1.0f / (float)NPB; a.inv_ow = 1.0f / (float)OWc;
 }
+// Does walking only the filter rows that touch the image pay for this launch grid?  OHc output rows at row stride si over a
+// gathered tensor of Hl rows: the share of (output row, tap) pairs whose tap row lies in the SAME padding.  D.d3 (6 tap rows
+// on 6 image rows, pads (2, 3)): 25 %; the 3x3 stride-2 layers: 3 %; 1-D layers: one row, never.  VC_NO_ROWSKIP=1 switches
+// it off (A/B measurements).
+static bool rowskip_pays(const Table& t, int OHc, int si, int Hl) {
+    static const bool off = getenv("VC_NO_ROWSKIP") != nullptr;
+    if (off || OHc < 2 || t.ntaps < 2 || t.cpt <= 0) return false;
+    long valid = 0;
+    for (int i = 0; i < OHc; ++i)
+        for (int tp = 0; tp < t.ntaps; ++tp) valid += (i * si + t.tdh[tp] >= 0 && i * si + t.tdh[tp] < Hl) ? 1 : 0;
+    return valid * 100 < 92L * OHc * t.ntaps;
+}
+static void set_rowskip(IgemmArgs& a, const Table& t, int B, int OHc) {
+    a.rowskip = rowskip_pays(t, OHc, a.si, a.Hl) ? 1 : 0;
+    a.RW = B * a.OWc; a.inv_rw = 1.0f / (float)a.RW; a.cpt = t.cpt;
+}
 static void set_vec4(IgemmArgs& a) {
     a.vec4 = a.so_w == 1 && a.OWc % 4 == 0 && a.o_w0 % 4 == 0 && a.yW % 4 == 0 && a.yHW % 4 == 0 && a.y_bs % 4 == 0 &&
              a.y_gs % 4 == 0 && aligned16(a.Y) && (!a.addend || (aligned16(a.addend) && a.add_gs % 4 == 0));
@@ -404,9 +426,10 @@ static int conv_fwd(const float* x, long x_gs, const float* w, long w_gs, const 
     a.yHW = g.OH * g.OW; a.yW = g.OW; a.so_h = 1; a.so_w = 1; a.o_h0 = 0; a.o_w0 = 0;
     a.accumulate = 0; a.groups = G;
     set_vec4(a);
+    set_rowskip(a, t, B, g.OH);
     igemm_config(a, math);
     if (query) { *query = a.splitk > 1; return 0; }
-    if (fuse && a.bm == 64 && a.splitk == 1 && a.vec4 && g.H == 1 && g.kh == 1 && (a.NPB == 32 || a.NPB == 64) && g.Cout % 64 == 0) {
+    if (fuse && !a.rowskip && a.bm == 64 && a.splitk == 1 && a.vec4 && g.H == 1 && g.kh == 1 && (a.NPB == 32 || a.NPB == 64) && g.Cout % 64 == 0) {
         a.fuse = 1; a.gamma = fuse->gamma; a.beta = fuse->beta; a.par_gs = fuse->par_gs; a.stats = fuse->stats; a.st_gs = fuse->st_gs;
         a.act = fuse->act; a.act_gs = fuse->act_gs; fuse->done = true;
     }
@@ -508,6 +531,7 @@ static int conv_dgrad(const float* dy, long dy_gs, const float* w, long w_gs, fl
         a.yHW = g.H * g.W; a.yW = g.W; a.so_h = g.sh; a.so_w = g.sw; a.o_h0 = ph; a.o_w0 = pw;
         a.accumulate = accumulate; a.groups = G;
         set_vec4(a);
+        set_rowskip(a, t, B, Hc);
         igemm_config(a, math);
         any_split = any_split || a.splitk > 1;
         fl[ncls] = 2.0 * G * B * a.NPB * (double)g.Cin * t.valid; cls[ncls++] = a;
@@ -635,10 +659,12 @@ static int conv_wgrad(const WgradApp* apps, int napps, float* dw, long dw_gs, in
         sg.X = apps[k].x; sg.dY = apps[k].dy; sg.x_gs = apps[k].x_gs; sg.dy_gs = apps[k].dy_gs;
         sg.x_bytes = (unsigned)((long)apps[k].B * a.x_bs * 4 + t.xbias); sg.dy_bytes = (unsigned)((long)apps[k].B * a.dy_bs * 4);
         sg.Ptot = apps[k].B * a.NPB; sg.nchunks = (sg.Ptot + VC_KC - 1) / VC_KC;
+        sg.RW = apps[k].B * a.OWc; sg.inv_rw = 1.0f / (float)sg.RW;
         a.nchunks += sg.nchunks;
         flops += 2.0 * G * apps[k].B * a.NPB * (double)g.Cout * t.valid;
     }
     a.store = store ? 1 : 0;
+    a.rowskip = rowskip_pays(t, g.OH, g.sh, g.H) ? 1 : 0;
     if (query) { *query = !store || wgrad_splitk(a) > 1; return 0; }
     return launch_wgrad(a, math, s, flops);
 }

@@ -30,6 +30,13 @@ typedef const __attribute__((address_space(4))) int* c_int_p;
 typedef const __attribute__((address_space(4))) unsigned* c_uint_p;
 typedef const __attribute__((address_space(4))) Tap* c_tap_p;
 
+// launch pixel -> (sample, row, column) of the launch grid; rowskip launches enumerate (row, sample, column)
+__device__ __forceinline__ void px_decode(const IgemmArgs& p, int P, int& b, int& i, int& j) {
+    int r;
+    if (p.rowskip) { i = fast_divmod(P, p.RW, p.inv_rw, &r); b = fast_divmod(r, p.OWc, p.inv_ow, &j); }
+    else { b = fast_divmod(P, p.NPB, p.inv_npb, &r); i = fast_divmod(r, p.OWc, p.inv_ow, &j); }
+}
+
 template <int BM, bool AT, int KG, int MATH, bool FUSE = false>
 __global__ __launch_bounds__(64 * (BM / 32) * 2 * KG, (64 * (BM / 32) * 2 * KG >= 1024) ? 4 : 2) void igemm_kernel(const IgemmMulti mm) {
     static_assert(!FUSE || (BM == 64 && !AT), "the fused instance-norm epilogue exists for forward launches with 64-row tiles");
@@ -64,10 +71,23 @@ __global__ __launch_bounds__(64 * (BM / 32) * 2 * KG, (64 * (BM / 32) * 2 * KG >
     // that reach past the table multiply its all-zero padding chunk.
     const int g = blockIdx.z / p.splitk, sp = blockIdx.z - g * p.splitk;
     const int nchunks = p.krows / KC;
+    // rowskip: only the filter rows (taps) that touch the image for this tile's output rows; everything else is the whole table
+    int cbeg = 0, nch = nchunks;
+    if (p.rowskip) {
+        const int P0 = nt * BN, P1 = min(P0 + BN, p.Ptot) - 1;
+        int r_; const int ilo = fast_divmod(P0, p.RW, p.inv_rw, &r_), ihi = fast_divmod(P1, p.RW, p.inv_rw, &r_);
+        int tlo = 64, thi = -1;
+        c_tap_p taps = (c_tap_p)p.taps;
+        for (int t = 0; t < p.ntaps; ++t) {
+            const int dh = taps[t].dh;
+            if (ihi * p.si + dh >= 0 && ilo * p.si + dh < p.Hl) { tlo = min(tlo, t); thi = max(thi, t); }
+        }
+        if (thi >= tlo) { cbeg = tlo * p.cpt; nch = (thi - tlo + 1) * p.cpt; }
+    }
     const int parts = p.splitk * KG;
-    const int cps = (((nchunks + parts - 1) / parts) + 1) & ~1;
-    if (sp * KG * cps >= nchunks) return;                     // whole workgroup beyond the K range (uniform)
-    const int c0 = (sp * KG + kg) * cps;
+    const int cps = (((nch + parts - 1) / parts) + 1) & ~1;
+    if (sp * KG * cps >= nch) return;                         // whole workgroup beyond the K range (uniform)
+    const int c0 = cbeg + (sp * KG + kg) * cps;
 
     // ---- gathered-operand loader: a lane owns pixel n = lane of the tile and XL consecutive K rows of every chunk
     constexpr int XL = (KC * BN) / GT;                        // 4 (8-wave group) or 8 (4-wave group)
@@ -78,7 +98,7 @@ __global__ __launch_bounds__(64 * (BM / 32) * 2 * KG, (64 * (BM / 32) * 2 * KG >
         const int P = nt * BN + lane;
         const bool pv = P < p.Ptot;
         int xb = 0, xi = 0, xj = 0;
-        if (pv) { int r; xb = fast_divmod(P, p.NPB, p.inv_npb, &r); xi = fast_divmod(r, p.OWc, p.inv_ow, &xj); }
+        if (pv) px_decode(p, P, xb, xi, xj);
         const int li0 = xi * p.si, lj0 = xj * p.sj;
         xoffb = (unsigned)(((long)xb * p.x_bs + (long)li0 * p.xW + lj0) * 4);
         c_tap_p taps = (c_tap_p)p.taps;
@@ -326,7 +346,7 @@ __global__ __launch_bounds__(64 * (BM / 32) * 2 * KG, (64 * (BM / 32) * 2 * KG >
 #pragma unroll
             for (int k2 = 1; k2 < KG; ++k2) v += *reinterpret_cast<const f32x4*>(smem + k2 * REG + ml * LDY + n4);
             if (Bg) v += Bg[m];
-            int r0, j; const int b = fast_divmod(P0, p.NPB, p.inv_npb, &r0); const int ii = fast_divmod(r0, p.OWc, p.inv_ow, &j);
+            int b, ii, j; px_decode(p, P0, b, ii, j);
             const long o = (long)b * p.y_bs + (long)m * p.yHW + (long)(ii * p.so_h + p.o_h0) * p.yW + j + p.o_w0;
             if (Dg) v += *reinterpret_cast<const f32x4*>(Dg + o);
             *reinterpret_cast<f32x4*>(Yg + o) = v;
@@ -338,7 +358,7 @@ __global__ __launch_bounds__(64 * (BM / 32) * 2 * KG, (64 * (BM / 32) * 2 * KG >
         const int n = tid & 63, Pn = nt * BN + n;
         long obase = 0;
         if (Pn < p.Ptot) {
-            int r0, j; const int b = fast_divmod(Pn, p.NPB, p.inv_npb, &r0); const int ii = fast_divmod(r0, p.OWc, p.inv_ow, &j);
+            int b, ii, j; px_decode(p, Pn, b, ii, j);
             obase = (long)b * p.y_bs + (long)(ii * p.so_h + p.o_h0) * p.yW + (j * p.so_w + p.o_w0);
         }
 #pragma unroll 4
@@ -447,7 +467,7 @@ int launch_igemm_multi(const IgemmArgs* cls, int n, bool a_trans, int math, hipS
     const bool fuse = cls[0].fuse != 0;
     if (fuse) {
         const IgemmArgs& a = cls[0];
-        if (n != 1 || a_trans || bm != 64 || a.splitk != 1 || a.accumulate || !a.vec4 || (a.NPB != 32 && a.NPB != 64) || (a.M & 63) ||
+        if (n != 1 || a_trans || bm != 64 || a.rowskip || a.splitk != 1 || a.accumulate || !a.vec4 || (a.NPB != 32 && a.NPB != 64) || (a.M & 63) ||
             a.so_w != 1 || a.o_w0 != 0 || a.yHW != a.NPB) {
             vc_set_error("launch_igemm: this launch cannot carry the fused instance-norm epilogue"); return -1;
         }

@@ -3,6 +3,7 @@
 //  c1_*_kernel     : discriminator h1 (module.py:201-202: Cin = 1, 3x3 -> K = 9) on the vector ALU (HBM-bound)
 #include "vc_internal.h"
 #include "vc_device_util.h"
+#include <cstdlib>
 #include <type_traits>
 #include <utility>
 
@@ -411,12 +412,18 @@ int launch_wsconv1d(const WsConvArgs& a, int cin, int kw, int math, hipStream_t 
 // The window expansion is addressing: a run of R consecutive k (R = 4 fp32 / 8 bf16) is R channels of one tap, i.e.
 // contiguous bytes of Xs row (pixel + tap).
 // =====================================================================================
-template <int CIN, int KW, bool BF16>
-__global__ __launch_bounds__(BF16 ? 512 : 256, BF16 ? 2 : 1) void gated_conv1d_glu_kernel(const WsConvArgs a, const void* __restrict__ packed) {
+// INKW = true (default): the workgroup builds its filter slab in LDS straight from the fp32 weights w[k][Cout] (lanes along the
+// 64 rows: two coalesced 128-byte runs per k; a lane converts R consecutive k of its row and stores them with one 16-byte
+// LDS write) -- no separate packing launch, nothing between the caller's weights and this kernel.  INKW = false: the slab is
+// a straight copy of the image pack_gated_weights_kernel prepared (kept for A/B measurements: VC_GLU_PACKED=1).
+// NWV_ = waves per workgroup (bf16: 8 = one 512-thread workgroup per CU working on two tiles at a time; 4 = TWO 256-thread
+// workgroups per CU, one tile each, whose load / multiply / store phases drift apart and overlap).
+template <int CIN, int KW, bool BF16, bool INKW, int NWV_>
+__global__ __launch_bounds__(64 * NWV_, (BF16 && NWV_ == 4) ? 2 : (NWV_ == 8 ? 2 : 1)) void gated_conv1d_glu_kernel(const WsConvArgs a, const void* __restrict__ packed) {
     typedef typename std::conditional<BF16, __bf16, float>::type T;
     constexpr int R = BF16 ? 8 : 4;                        // k run per lane half and step
     static_assert(CIN % R == 0 && (KW & 1), "runs of R channels inside one tap; odd kernel width");
-    constexpr int NWV = BF16 ? 8 : 4, TP = 128, NSUB = NWV / 4;   // waves, pixels per tile, tiles in flight
+    constexpr int NWV = NWV_, TP = 128, NSUB = NWV / 4;   // waves, pixels per tile, tiles in flight
     constexpr int K = CIN * KW, KR = ((K + 2 * R - 1) / (2 * R)) * (2 * R), NG = KR / (2 * R);   // steps of 2R k (one run per lane half)
     constexpr int LDW = KR + (BF16 ? 8 : 4);               // slab row stride (elements): conflict-free 16-byte reads across 32 rows
     constexpr int PADL = (KW - 1) / 2;
@@ -467,6 +474,7 @@ __global__ __launch_bounds__(BF16 ? 512 : 256, BF16 ? 2 : 1) void gated_conv1d_g
         }
     };
     typedef typename std::conditional<BF16, bf16x8, f32x4>::type frag_t;
+    static_assert(LDW % R == 0, "a slab row is a whole number of R-element runs");
     const frag_t* av = reinterpret_cast<const frag_t*>(Ws + l31 * LDW + R * h);
     const frag_t* ag = reinterpret_cast<const frag_t*>(Ws + (32 + l31) * LDW + R * h);
     const T* xrow = Xt + (w4 * 32 + l31) * CS;
@@ -475,9 +483,40 @@ __global__ __launch_bounds__(BF16 ? 512 : 256, BF16 ? 2 : 1) void gated_conv1d_g
     // persistent over the tiles: trip it handles tiles (blockIdx.x + it * gridDim.x) * NSUB + sub
     int t0i = blockIdx.x * NSUB;
     if (t0i < ntiles) load_tile(t0i + sub);          // the first tile's frames travel while the filter slab is copied
-    // ---- filter slab, once: rows 0-31 = value filters 32*slab.., rows 32-63 = the matching gate filters, already in the
-    //      LDS image (element type, row stride, zero tail) by pack_gated_weights_kernel: a straight 16-byte copy
-    {
+    // ---- filter slab, once: rows 0-31 = value filters 32*slab.., rows 32-63 = the matching gate filters
+    if constexpr (INKW) {
+        // lane = slab row m (channel ch), wave = run of R consecutive k: R coalesced loads (a wave reads the 32 value and the
+        // 32 gate filters of one k: two 128-byte runs), one conversion, one 16-byte LDS store (conflict-free: 8 consecutive
+        // rows are 8 different bank quads).  Two runs are loaded before the first is stored (latency overlap).
+        constexpr int NRUN = LDW / R;                       // runs per row, zero tail included
+        constexpr int NIT = (NRUN + NWV - 1) / NWV;        // runs per wave
+        const int m = lane, ch = (m < 32 ? 0 : C - 32) + slab * 32 + m;
+        const bool valid = slab * 32 + (m & 31) < C;
+        const float* wg = a.w + (long)g * a.w_gs + (valid ? ch : 0);
+        frag_t* dst = reinterpret_cast<frag_t*>(Ws + m * LDW);
+        // every load is issued before the first store: ONE memory round trip for the whole slab (a loop of load-then-store
+        // pays the L2 / HBM latency once per iteration: ~1 us each, the bulk of the round-2 kernel's fixed cost)
+        float v[NIT][R];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it)
+#pragma unroll
+            for (int e = 0; e < R; ++e) {
+                const int k = (wid + it * NWV) * R + e;
+                const bool ok = valid && k < K;
+                v[it][e] = wg[ok ? (long)k * a.Cout : 0];
+                v[it][e] = ok ? v[it][e] : 0.f;
+            }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            if (wid + it * NWV < NRUN) {
+                frag_t f;
+#pragma unroll
+                for (int e = 0; e < R; ++e) f[e] = (T)v[it][e];
+                dst[wid + it * NWV] = f;
+            }
+        }
+    } else {
+        // already in the LDS image (element type, row stride, zero tail) by pack_gated_weights_kernel: a straight 16-byte copy
         constexpr int NV16 = 64 * LDW * (int)sizeof(T) / 16;
         const f32x4* src = reinterpret_cast<const f32x4*>(reinterpret_cast<const T*>(packed) + ((long)g * gridDim.y + slab) * 64 * LDW);
         f32x4* dst = reinterpret_cast<f32x4*>(Ws);
@@ -586,14 +625,22 @@ int launch_gated_conv1d_glu(const WsConvArgs& a, int cin, int kw, int math, floa
     if (cin != 24 || kw != 15 || (a.Cout & 63) || (a.T & 3)) return -2;
     const int C = a.Cout / 2, slabs = C / 32;
     const bool bf = math == VC_MATH_BF16;
-    const int nsub = bf ? 2 : 1, ntiles = a.B * ((a.T + 127) / 128), trips = (ntiles + nsub - 1) / nsub;
-    int parts = 256 / (slabs * a.G); if (parts < 1) parts = 1; if (parts > trips) parts = trips;       // one workgroup per CU, persistent
+    static const bool packed_image = getenv("VC_GLU_PACKED") != nullptr;      // A/B: the round-2 two-launch form
+    static const bool wide = getenv("VC_GLU_WAVES8") != nullptr || packed_image;   // A/B: one 8-wave workgroup per CU instead of two 4-wave ones
+    const int nsub = (bf && wide) ? 2 : 1, ntiles = a.B * ((a.T + 127) / 128), trips = (ntiles + nsub - 1) / nsub;
+    const int wgs = (bf && !wide) ? 512 : 256;        // resident workgroups on the chip, persistent over the tiles
+    int parts = wgs / (slabs * a.G); if (parts < 1) parts = 1; if (parts > trips) parts = trips;
     dim3 grid(parts, slabs, a.G);
-    if (bf) pack_gated_weights_kernel<24, 15, true><<<dim3(slabs, a.G, 16), 256, 0, s>>>(a.w, a.w_gs, a.Cout, workspace);
-    else pack_gated_weights_kernel<24, 15, false><<<dim3(slabs, a.G, 16), 256, 0, s>>>(a.w, a.w_gs, a.Cout, workspace);
-    ProfScope ps(2, flops, s);
-    if (bf) gated_conv1d_glu_kernel<24, 15, true><<<grid, dim3(512), 0, s>>>(a, workspace);
-    else gated_conv1d_glu_kernel<24, 15, false><<<grid, dim3(256), 0, s>>>(a, workspace);
+    ProfScope ps(2, flops, s);                       // everything a call launches
+    if (packed_image) {
+        if (bf) pack_gated_weights_kernel<24, 15, true><<<dim3(slabs, a.G, 16), 256, 0, s>>>(a.w, a.w_gs, a.Cout, workspace);
+        else pack_gated_weights_kernel<24, 15, false><<<dim3(slabs, a.G, 16), 256, 0, s>>>(a.w, a.w_gs, a.Cout, workspace);
+        if (bf) gated_conv1d_glu_kernel<24, 15, true, false, 8><<<grid, dim3(512), 0, s>>>(a, workspace);
+        else gated_conv1d_glu_kernel<24, 15, false, false, 4><<<grid, dim3(256), 0, s>>>(a, workspace);
+    } else if (bf) {
+        if (wide) gated_conv1d_glu_kernel<24, 15, true, true, 8><<<grid, dim3(512), 0, s>>>(a, nullptr);
+        else gated_conv1d_glu_kernel<24, 15, true, true, 4><<<grid, dim3(256), 0, s>>>(a, nullptr);
+    } else gated_conv1d_glu_kernel<24, 15, false, true, 4><<<grid, dim3(256), 0, s>>>(a, nullptr);
     VC_HIP(hipGetLastError());
     return 0;
 }

@@ -42,15 +42,38 @@ __global__ __launch_bounds__(256 * KG, KG == 4 ? 4 : 2) void wgrad_kernel(const 
     const int g = blockIdx.z / p.splitk, sp = blockIdx.z - g * p.splitk;
     // every split-K part runs `cps` chunks (an even count: the loop body is a pair of chunks with static register sets);
     // chunks past the last segment load zeros
-    const int parts = p.splitk * KG;
-    const int cps = (((p.nchunks + parts - 1) / parts) + 1) & ~1;
-    if (sp * KG * cps >= p.nchunks) return;               // whole workgroup beyond the pixel axis (uniform)
-    const int c0 = (sp * KG + kg) * cps;
-
     // ---- loop invariants of the K rows and columns this wave loads
     const KEntry e0 = p.ktab[kt * BM], e1 = p.ktab[kt * BM + 32];          // the two taps of this k-tile (wave-uniform)
     const int dh0 = e0.a_off >= 0 ? e0.dh : 0x4000, dw0 = e0.dw;           // padding chunk: dh = 16384 always fails the bounds check
     const int dh1 = e1.a_off >= 0 ? e1.dh : 0x4000, dw1 = e1.dw;
+    // The reduction axis: the chunks of segment 0, then those of segment 1.  rowskip (pixels enumerated (row, sample,
+    // column)): only the output rows i whose input row i*si + dh lies inside the image for one of the tile's two taps -- the
+    // others would add zeros (a quarter of D.d3's filter-gradient work): per segment a contiguous chunk range [slo, slo + snv).
+    int slo0 = 0, slo1 = 0, snv0 = p.seg[0].nchunks, snv1 = p.nseg > 1 ? p.seg[1].nchunks : 0;
+    if (p.rowskip) {
+        const int OHc = p.NPB / p.OWc;
+        int ilo = OHc, ihi = -1;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int dh = k ? dh1 : dh0;
+            if (dh == 0x4000) continue;
+            // 0 <= i*si + dh <= Hl-1
+            const int a = dh >= 0 ? 0 : (-dh + p.si - 1) / p.si, b = (p.Hl - 1 - dh) >= 0 ? (p.Hl - 1 - dh) / p.si : -1;
+            ilo = min(ilo, max(a, 0)); ihi = max(ihi, min(b, OHc - 1));
+        }
+        if (ihi < ilo) ilo = ihi = 0;                                      // no row reaches the image (table padding): reduce row 0, i.e. zeros
+        const int plo0 = ilo * p.seg[0].RW, phi0 = min((ihi + 1) * p.seg[0].RW, p.seg[0].Ptot);
+        slo0 = plo0 / KC; snv0 = (phi0 + KC - 1) / KC - slo0;
+        if (p.nseg > 1) {
+            const int plo1 = ilo * p.seg[1].RW, phi1 = min((ihi + 1) * p.seg[1].RW, p.seg[1].Ptot);
+            slo1 = plo1 / KC; snv1 = (phi1 + KC - 1) / KC - slo1;
+        }
+    }
+    const int nchunks = snv0 + snv1;
+    const int parts = p.splitk * KG;
+    const int cps = (((nchunks + parts - 1) / parts) + 1) & ~1;
+    if (sp * KG * cps >= nchunks) return;                 // whole workgroup beyond the pixel axis (uniform)
+    const int c0 = (sp * KG + kg) * cps;
     c_int_p xso = (c_int_p)p.xsoff;
     const int xbias = p.xbias;
     int xs[8];                                                             // SGPR offsets of the 8 row pairs (rows 2*(wid+4q), +1 in the upper lane half)
@@ -64,13 +87,14 @@ __global__ __launch_bounds__(256 * KG, KG == 4 ? 4 : 2) void wgrad_kernel(const 
 
     // ---- segment / pixel cursor of the LOADER (runs two chunks ahead of the multiply)
     int lc = c0;                                         // chunk (of the concatenated axis) the next load() fetches
-    int seg = (p.nseg > 1 && lc >= p.seg[0].nchunks) ? 1 : 0;
-    int segbase = seg ? p.seg[0].nchunks : 0, segend = seg ? p.nchunks : p.seg[0].nchunks, segP = p.seg[seg].Ptot;
+    int seg = (p.nseg > 1 && lc >= snv0) ? 1 : 0;
+    int segbase = seg ? snv0 : 0, segend = seg ? nchunks : snv0, segP = p.seg[seg].Ptot;
+    int segRW = p.seg[seg].RW; float seg_inv_rw = p.seg[seg].inv_rw;
     __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
         (void*)((const char*)(p.seg[seg].X + (long)g * p.seg[seg].x_gs) - xbias), 0, (int)p.seg[seg].x_bytes, 0x00020000);
     __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(p.seg[seg].dY + (long)g * p.seg[seg].dy_gs), 0, (int)p.seg[seg].dy_bytes, 0x00020000);
-    int pP = (lc - segbase) * KC + l31;                  // pixel of this lane inside the segment
+    int pP = ((seg ? slo1 : slo0) + lc - segbase) * KC + l31;      // pixel of this lane inside the segment
     int pr, pb = fast_divmod(pP, p.NPB, p.inv_npb, &pr);
 
     f32x16 acc[NJ];
@@ -86,14 +110,17 @@ __global__ __launch_bounds__(256 * KG, KG == 4 ? 4 : 2) void wgrad_kernel(const 
     unsigned vx0 = VC_OOB, vx1 = VC_OOB, vy = VC_OOB;
     auto decode = [&]() {
         if (lc == segend && seg + 1 < p.nseg) {          // uniform: the loader crosses into the next segment
-            seg = 1; segbase = segend; segend = p.nchunks; segP = p.seg[1].Ptot;
+            seg = 1; segbase = segend; segend = nchunks; segP = p.seg[1].Ptot; segRW = p.seg[1].RW; seg_inv_rw = p.seg[1].inv_rw;
             xrs = __builtin_amdgcn_make_buffer_rsrc(
                 (void*)((const char*)(p.seg[1].X + (long)g * p.seg[1].x_gs) - xbias), 0, (int)p.seg[1].x_bytes, 0x00020000);
             yrs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.seg[1].dY + (long)g * p.seg[1].dy_gs), 0, (int)p.seg[1].dy_bytes, 0x00020000);
-            pP = l31; pb = fast_divmod(pP, p.NPB, p.inv_npb, &pr);
+            pP = slo1 * KC + l31; pb = fast_divmod(pP, p.NPB, p.inv_npb, &pr);
         }
         const bool pv = pP < segP && lc < segend;        // chunks past the last segment (loader run-ahead) load zeros
-        int j; const int i = fast_divmod(pr, p.OWc, p.inv_ow, &j);
+        int i, j;
+        if (p.rowskip) {                                  // (row, sample, column) enumeration; pr = pixel inside the sample
+            int rem; i = fast_divmod(pP, segRW, seg_inv_rw, &rem); pb = fast_divmod(rem, p.OWc, p.inv_ow, &j); pr = i * p.OWc + j;
+        } else i = fast_divmod(pr, p.OWc, p.inv_ow, &j);
         const int li0 = i * p.si, lj0 = j * p.sj;
         const unsigned xoffb = (unsigned)(((long)pb * p.x_bs + (long)li0 * p.xW + lj0) * 4) + xhalf;
         const bool ok0 = pv & ((unsigned)(li0 + dh0) < (unsigned)p.Hl) & ((unsigned)(lj0 + dw0) < (unsigned)p.Wl);
@@ -101,7 +128,8 @@ __global__ __launch_bounds__(256 * KG, KG == 4 ? 4 : 2) void wgrad_kernel(const 
         vx0 = ok0 ? xoffb : VC_OOB; vx1 = ok1 ? xoffb : VC_OOB;
         vy = pv ? (unsigned)(((long)pb * p.dy_bs + pr) * 4) + yhalf : VC_OOB;
         ++lc; pP += KC;
-        if (p.NPB >= KC) { pr += KC; const bool w = pr >= p.NPB; pr = w ? pr - p.NPB : pr; pb += (int)w; }   // at most one wrap
+        if (p.rowskip) {}                                                                                    // decoded from pP above
+        else if (p.NPB >= KC) { pr += KC; const bool w = pr >= p.NPB; pr = w ? pr - p.NPB : pr; pb += (int)w; }   // at most one wrap
         else pb = fast_divmod(pP, p.NPB, p.inv_npb, &pr);                                                  // tiny images (uniform branch)
     };
     auto item = [&](auto IC, auto SLC, auto SSC, int sbuf) {
