@@ -1,11 +1,16 @@
 """Measures every implicit-GEMM launch shape of the train step (conv forward + input gradient of every Cin > 1 layer at
 the batch sizes the step uses) under each built configuration (tile rows x K groups x split-K), and the filter
-gradients, through the C-ABI with HIP events (vc_prof_*).  Run on the GPU box:
+gradients (tile columns x K groups x split-K), through the C-ABI with HIP events (vc_prof_*).  Run on the GPU box:
 
-    python tools/tune_igemm.py [--batch 8] [--sweep] [--emit gpurun_out/vc_tuned_igemm.h]
+    python tools/tune_igemm.py [--batch 8] [--features 24 --frames 128] [--sweep] [--emit gpurun_out/tuned_b8]
 
 Without --sweep: one line per (layer, op) with the automatic configuration (what the step will run).
-With --sweep   : every configuration, the best one per shape, and (--emit) the table csrc/vc_tuned_igemm.h is made of.
+With --sweep   : every configuration, the best ones per shape, and (--emit PREFIX) the entries of csrc/vc_tuned_igemm.h
+                 (PREFIX_igemm.h) and csrc/vc_tuned_wgrad.h (PREFIX_wgrad.h) for this batch / geometry.
+
+Filter gradients are measured as the step launches them: plain stores (vc_tune_wgrad_store), the generator's layers
+over 3B samples (first hop 2B + cycle hop B reduce in ONE launch; a single application of 3B samples has the same chunk
+count), the discriminator's over 2B.  Split-K needs a zeroed dW: its zero-fill is added at 3 TB/s.
 """
 import argparse
 import ctypes as C
@@ -21,13 +26,18 @@ ge.build()
 from tests import gpu_util as U  # noqa: E402
 from voice_converter_cyclegan_amd._lib import lib, check  # noqa: E402
 
-# name: (Cin, H, W, Cout, kh, kw, sh, sw, batch factor: samples per group = factor * B)
-G_LAYERS = {'g_d1': (128, 1, 128, 512, 1, 5, 1, 2), 'g_d2': (256, 1, 64, 1024, 1, 5, 1, 2),
-            'g_r_h1': (512, 1, 32, 2048, 1, 3, 1, 1), 'g_r_h2': (1024, 1, 32, 512, 1, 3, 1, 1),
-            'g_u1': (512, 1, 32, 2048, 1, 5, 1, 1), 'g_u2': (512, 1, 64, 1024, 1, 5, 1, 1),
-            'g_o1': (256, 1, 128, 24, 1, 15, 1, 1), 'g_h1': (24, 1, 128, 256, 1, 15, 1, 1)}
-D_LAYERS = {'d_d1': (128, 24, 64, 512, 3, 3, 2, 2), 'd_d2': (256, 12, 32, 1024, 3, 3, 2, 2), 'd_d3': (512, 6, 16, 2048, 6, 3, 1, 2)}
 CONFIGS = [(bm, kg, sk) for bm in (128, 64) for kg in (1, 2, 4) for sk in (1, 2, 4, 8, 16) if not (bm == 128 and kg == 4)]
+
+
+def layers(F, T):
+    """name: (Cin, H, W, Cout, kh, kw, sh, sw) of module.py:148-213 at F MCEPs x T frames"""
+    g = {'g_d1': (128, 1, T, 512, 1, 5, 1, 2), 'g_d2': (256, 1, T // 2, 1024, 1, 5, 1, 2),
+         'g_r_h1': (512, 1, T // 4, 2048, 1, 3, 1, 1), 'g_r_h2': (1024, 1, T // 4, 512, 1, 3, 1, 1),
+         'g_u1': (512, 1, T // 4, 2048, 1, 5, 1, 1), 'g_u2': (512, 1, T // 2, 1024, 1, 5, 1, 1),
+         'g_o1': (256, 1, T, F, 1, 15, 1, 1), 'g_h1': (F, 1, T, 256, 1, 15, 1, 1)}
+    H1, H2 = -(-F // 2), -(-(-(-F // 2)) // 2)
+    d = {'d_d1': (128, F, T // 2, 512, 3, 3, 2, 2), 'd_d2': (256, H1, T // 4, 1024, 3, 3, 2, 2), 'd_d3': (512, H2, T // 8, 2048, 6, 3, 1, 2)}
+    return g, d
 
 
 def time_call(f, kind, reps):
@@ -69,28 +79,30 @@ def launch_keys(op, Cin, H, W, Cout, kh, kw, sh, sw, Bs):
     return keys
 
 
-def shapes(B):
-    out = []
-    for nm, g in G_LAYERS.items():
-        for f in (1, 2):                                    # cycle hop (B) and first hop (2B)
-            out.append((nm + ('' if f == 1 else '_2B'), g, f * B))
-    for nm, g in D_LAYERS.items():
-        for f in (1, 2):                                    # generator-loss backward (B) and forward / D-loss backward (2B)
-            out.append((nm + ('' if f == 1 else '_2B'), g, f * B))
-    return out
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--batch', type=int, default=8)
+    ap.add_argument('--features', type=int, default=24)
+    ap.add_argument('--frames', type=int, default=128)
     ap.add_argument('--sweep', action='store_true')
     ap.add_argument('--emit', default='')
     ap.add_argument('--reps', type=int, default=10)
     ap.add_argument('--only', default='')
     args = ap.parse_args()
+    B = args.batch
+    GL, DL = layers(args.features, args.frames)
     rng = np.random.default_rng(0)
-    rows, table = [], []
-    for nm, (Cin, H, W, Cout, kh, kw, sh, sw), Bs in shapes(args.batch):
+    rows, table, wtable = [], [], []
+    # (name, geometry, samples per group, ops)
+    shapes = []
+    for nm, g in GL.items():
+        shapes.append((nm, g, B, ('fwd', 'dgrad')))              # cycle hop
+        shapes.append((nm + '_2B', g, 2 * B, ('fwd', 'dgrad')))   # first hop
+        shapes.append((nm + '_3B', g, 3 * B, ('wgrad',)))         # both applications in one filter-gradient launch
+    for nm, g in DL.items():
+        shapes.append((nm, g, B, ('dgrad',)))                     # generator-loss backward through D's inputs
+        shapes.append((nm + '_2B', g, 2 * B, ('fwd', 'dgrad', 'wgrad')))
+    for nm, (Cin, H, W, Cout, kh, kw, sh, sw), Bs, oplist in shapes:
         if args.only and args.only not in nm:
             continue
         G = 2
@@ -101,32 +113,44 @@ def main():
         dy = torch.randn_like(y)
         OH, OW = y.shape[3], y.shape[4]
         flops = 2.0 * G * Bs * OH * OW * Cout * kh * kw * Cin
+        dw = torch.zeros((G, kh, kw, Cin, Cout), device=U.DEV)
+
+        def wgrad_call():
+            check(lib.vc_conv2d_wgrad(U.ptr(x), x[0].numel(), U.ptr(dy), dy[0].numel(), U.ptr(dw), dw[0].numel(),
+                                      G, Bs, Cin, H, W, Cout, kh, kw, sh, sw, U.stream()), 'conv_wgrad')
         ops = {'fwd': (lambda: U.conv_fwd(x, w, b, kh, kw, sh, sw), 0), 'dgrad': (lambda: U.conv_dgrad(dy, w, H, W, kh, kw, sh, sw), 0),
-               'wgrad': (lambda: U.conv_wgrad(x, dy, kh, kw, sh, sw), 1)}
-        for op, (f, kind) in ops.items():
-            if nm.startswith('g_h1') and op == 'fwd':
+               'wgrad': (wgrad_call, 1)}
+        for op in oplist:
+            f, kind = ops[op]
+            if nm.startswith('g_h1') and op == 'fwd' and args.features == 24:
                 continue                                    # weight-stationary kernel, not the implicit GEMM
-            check(lib.vc_tune_igemm_override(0, 0, 0))
+            check(lib.vc_tune_igemm_override(0, 0, 0)); check(lib.vc_tune_wgrad_override(0, 0, 0))
+            check(lib.vc_tune_wgrad_store(1 if op == 'wgrad' else 0))
             us, nl = time_call(f, kind, args.reps)
             line = '%-10s %-5s %6.2f GFLOP ideal %6.1f us | auto %7.1f us %6.1f TF (%d launch)' % (
                 nm, op, flops / 1e9, flops / 157.3e12 * 1e6, us, flops / us / 1e6, nl)
-            if args.sweep and op != 'wgrad':
+            if args.sweep:
                 res = []
+                zero_us = 4.0 * dw.numel() / 3e6              # zero-fill of dW at 3 TB/s, paid by split-K filter gradients
                 for bm, kg, sk in CONFIGS:
-                    if bm == 128 and (Cout if op == 'fwd' else Cin) < 128:
+                    if bm == 128 and (Cout if op != 'dgrad' else Cin) < 128:
                         continue
-                    check(lib.vc_tune_igemm_override(bm, kg, sk))
+                    check((lib.vc_tune_wgrad_override if op == 'wgrad' else lib.vc_tune_igemm_override)(bm, kg, sk))
                     try:
                         u, _ = time_call(f, kind, args.reps)
-                    except Exception as e:               # a configuration the launch refuses
+                    except Exception:                       # a configuration the launch refuses
                         continue
-                    res.append((u, bm, kg, sk))
-                check(lib.vc_tune_igemm_override(0, 0, 0))
+                    res.append((u + (zero_us if op == 'wgrad' and sk > 1 else 0.0), bm, kg, sk))
+                check(lib.vc_tune_igemm_override(0, 0, 0)); check(lib.vc_tune_wgrad_override(0, 0, 0))
                 res.sort()
                 line += ' | best ' + '  '.join('%dx%d/%d %.1f' % (bm, kg, sk, u) for u, bm, kg, sk in res[:4])
-                # key: (a_trans, M, Ptot per class is geometry dependent) -> record the forward shape key; dgrad classes differ
-                if res:
+                if res and op == 'wgrad':
+                    ktiles = _pad_rows(kh * kw, Cin) // 64
+                    nchunks = -(-(Bs * OH * OW) // 32) if not nm.endswith('_3B') else (-(-(2 * B * OH * OW) // 32) + -(-(B * OH * OW) // 32))
+                    wtable.append((nm, res[0], us, (ktiles, Cout, nchunks)))
+                elif res:
                     table.append((nm, op, res[0], us, launch_keys(op, Cin, H, W, Cout, kh, kw, sh, sw, Bs)))
+            check(lib.vc_tune_wgrad_store(0))
             print(line, flush=True)
             rows.append((nm, op, flops, us))
     tot = {}
@@ -135,11 +159,18 @@ def main():
     for op, (fl, us) in tot.items():
         print('sum %-5s %7.1f GFLOP %8.1f us  %6.1f TF' % (op, fl / 1e9, us, fl / us / 1e6))
     if args.emit and table:
-        with open(args.emit, 'w') as f:
+        with open(args.emit + '_igemm.h', 'w') as f:
+            f.write('    // ---- batch %d per GPU, %dx%d MCEP\n' % (B, args.features, args.frames))
             for nm, op, (u, bm, kg, sk), auto, keys in table:
-                f.write('    // %s %s: %.1f us (cost model: %.1f us)\n' % (nm, op, u, auto))
+                f.write('    // %s %s: %.1f us (automatic choice before this sweep: %.1f us)\n' % (nm, op, u, auto))
                 for at, M, P, kr in keys:
                     f.write('    {%d, %d, %d, %d, 2, %d, %d, %d},\n' % (at, M, P, kr, bm, kg, sk))
+    if args.emit and wtable:
+        with open(args.emit + '_wgrad.h', 'w') as f:
+            f.write('    // ---- batch %d per GPU, %dx%d MCEP\n' % (B, args.features, args.frames))
+            for nm, (u, bn, kg, sk), auto, (ktiles, N, nchunks) in wtable:
+                f.write('    // %s: %.1f us (automatic choice before this sweep: %.1f us)\n' % (nm, u, auto))
+                f.write('    {%d, %d, %d, 2, 1, %d, %d, %d},\n' % (ktiles, N, nchunks, bn, kg, sk))
 
 
 if __name__ == '__main__':

@@ -685,12 +685,15 @@ extern "C" int vc_conv2d_dgrad(const float* dy, int64_t dy_gs, const float* w, i
     return conv_dgrad(dy, dy_gs, w, w_gs, dx, dx_gs, addend, add_gs, accumulate, G, B,
                       make_geom(Cin, H, W, Cout, kh, kw, sh, sw), t_math, (hipStream_t)stream);
 }
+// tuning hook (tools/tune_igemm.py): operator-level filter gradients OVERWRITE dW (the step's plain-store form) while on
+static thread_local int t_wgrad_store = 0;
+extern "C" int vc_tune_wgrad_store(int on) { t_wgrad_store = on ? 1 : 0; return 0; }
 extern "C" int vc_conv2d_wgrad(const float* x, int64_t x_gs, const float* dy, int64_t dy_gs,
                                float* dw, int64_t dw_gs, int G, int B, int Cin, int H, int W, int Cout,
                                int kh, int kw, int sh, int sw, void* stream) {
     VC_ARG(x && dy && dw && G > 0 && B > 0, "vc_conv2d_wgrad: bad args");
     const WgradApp app{x, x_gs, dy, dy_gs, B};
-    return conv_wgrad(&app, 1, dw, dw_gs, G, make_geom(Cin, H, W, Cout, kh, kw, sh, sw), t_math, (hipStream_t)stream, /*store=*/false);
+    return conv_wgrad(&app, 1, dw, dw_gs, G, make_geom(Cin, H, W, Cout, kh, kw, sh, sw), t_math, (hipStream_t)stream, /*store=*/t_wgrad_store != 0);
 }
 extern "C" int vc_gated_conv1d_glu_fwd(const float* x, int64_t x_gs, const float* w, int64_t w_gs,
                                        const float* bias, int64_t b_gs, float* out, int64_t out_gs,

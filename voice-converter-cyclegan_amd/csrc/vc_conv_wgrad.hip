@@ -272,12 +272,18 @@ extern "C" int vc_tune_wgrad_override(int bn, int kg, int splitk) {
     g_wforce_bn = bn; g_wforce_kg = kg; g_wforce_sk = splitk;
     return 0;
 }
+// measured choices (tools/tune_igemm.py --sweep on MI355X), keyed by the launch shape; everything else goes by the cost model
+struct TunedWgrad { int ktiles, N, nchunks, groups, store, bn, kg, sk; };
+#include "vc_tuned_wgrad.h"
 static WgradCfg wgrad_config(const WgradArgs& a) {
     const bool det = vc_det_active();          // deterministic mode: the pixel axis is split inside the workgroup only
     if (g_wforce_bn) {
         const int bn = (g_wforce_bn == 128 && a.N < 128) ? 64 : g_wforce_bn;
         return WgradCfg{bn, g_wforce_kg, det ? 1 : std::min(g_wforce_sk, std::max(1, a.nchunks / (2 * g_wforce_kg)))};
     }
+    for (const TunedWgrad& t : kTunedWgrad)
+        if (t.ktiles == a.ktiles && t.N == a.N && t.nchunks == a.nchunks && t.groups == a.groups && t.store == a.store && !(det && t.sk > 1))
+            return WgradCfg{t.bn, t.kg, t.sk};
     WgradCfg best{128, 1, 1}; double bestc = 1e30;
     const double out_bytes = 4.0 * 64.0 * a.ktiles * (double)a.N * a.groups;
     for (int bn : {128, 64}) {
