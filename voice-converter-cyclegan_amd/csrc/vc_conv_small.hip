@@ -66,22 +66,24 @@ __global__ __launch_bounds__(256, 2) void wsconv1d_kernel(const WsConvArgs a) {
     }
     const float* xg = a.x + (long)g * a.x_gs;
     float xr[NXF];
+    unsigned xok = 0;                                // bit i: xr[i] is a frame of the tile (else padding -> 0); applied in store_tile
     auto load_tile = [&](int tile) {                 // input frames t0-PADL .. of all channels -> registers (lanes along time: coalesced)
         const int b = tile / tps, t0 = (tile - b * tps) * BN - PADL;
         const float* xb = xg + (long)b * CIN * a.T;
+        xok = 0;
 #pragma unroll
         for (int i = 0; i < NXF; ++i) {
             const int idx = tid + 256 * i, c = idx / XR, pos = idx - c * XR, t = t0 + pos;
             const bool ok = idx < XR * CIN && (unsigned)t < (unsigned)a.T;
-            xr[i] = xb[ok ? c * a.T + t : 0];
-            xr[i] = ok ? xr[i] : 0.f;
+            xr[i] = xb[ok ? c * a.T + t : 0];        // untouched until store_tile: the loads stay in flight during the MFMAs
+            xok |= (unsigned)ok << i;
         }
     };
     auto store_tile = [&]() {
 #pragma unroll
         for (int i = 0; i < NXF; ++i) {
             const int idx = tid + 256 * i, c = idx / XR, pos = idx - c * XR;
-            if (idx < XR * CIN) Xs[pos * CS + c] = xr[i];
+            if (idx < XR * CIN) Xs[pos * CS + c] = ((xok >> i) & 1u) ? xr[i] : 0.f;
         }
     };
     const f32x4* ap = reinterpret_cast<const f32x4*>(Ws + l31 * LDW + 4 * h);
@@ -454,23 +456,28 @@ __global__ __launch_bounds__(64 * NWV_, (BF16 && NWV_ == 4) ? 2 : (NWV_ == 8 ? 2
     const float* xg = a.x + (long)g * a.x_gs;
     T* Xt = Xs + sub * XR * CS;
     float xr[NXF];
+    unsigned xok = 0;                                // bit i: xr[i] is a frame of the tile (else padding -> 0)
+    // The loads are issued and NOT touched until store_tile, one whole tile of MFMAs later: masking the value right behind
+    // its load (as the round-2 kernel did) puts an s_waitcnt between the prefetch and the multiply loop, i.e. a full HBM
+    // round trip (~2 us) in front of every tile.
     auto load_tile = [&](int tile) {                 // input frames t0-PADL .. of all channels -> registers (lanes along time: coalesced)
         const bool tv = tile < ntiles;
         const int b = tv ? tile / tps : 0, t0 = (tile - b * tps) * TP - PADL;
         const float* xb = xg + (long)b * CIN * a.T;
+        xok = 0;
 #pragma unroll
         for (int i = 0; i < NXF; ++i) {
             const int idx = stid + 256 * i, c = idx / XR, pos = idx - c * XR, t = t0 + pos;
             const bool ok = tv && idx < XR * CIN && (unsigned)t < (unsigned)a.T;
             xr[i] = xb[ok ? c * a.T + t : 0];
-            xr[i] = ok ? xr[i] : 0.f;
+            xok |= (unsigned)ok << i;
         }
     };
     auto store_tile = [&]() {
 #pragma unroll
         for (int i = 0; i < NXF; ++i) {
             const int idx = stid + 256 * i, c = idx / XR, pos = idx - c * XR;
-            if (idx < XR * CIN) Xt[pos * CS + c] = (T)xr[i];
+            if (idx < XR * CIN) Xt[pos * CS + c] = (T)(((xok >> i) & 1u) ? xr[i] : 0.f);
         }
     };
     typedef typename std::conditional<BF16, bf16x8, f32x4>::type frag_t;

@@ -1,5 +1,75 @@
-// Measured filter-gradient configurations: tools/tune_igemm.py --sweep on MI355X.  {K tiles, Cout, pixel chunks (all
-// applications), groups, plain stores?, tile columns, K groups, split-K}.  Shapes not listed go by the cost model in wgrad_config.
+// Measured filter-gradient configurations: tools/tune_igemm.py --sweep on MI355X (round 3; profiles/r03_tune_sweep_*.txt), as the
+// train step launches them (plain stores; the generator's layers reduce first hop + cycle hop in one launch).  {K tiles,
+// Cout, pixel chunks (all applications), groups, plain stores?, tile columns, K groups, split-K}.  Shapes not listed go by the
+// cost model in wgrad_config.
 static const TunedWgrad kTunedWgrad[] = {
-    {0, 0, 0, 0, 0, 64, 1, 1},        // (placeholder: never matches)
+    // ---- batch 8 per GPU, 24x128 MCEP
+    // g_d1_3B: 35.9 us (automatic choice before this sweep: 39.2 us)
+    {10, 512, 48, 2, 1, 64, 4, 1},
+    // g_d2_3B: 53.0 us (automatic choice before this sweep: 57.2 us)
+    {20, 1024, 24, 2, 1, 64, 1, 1},
+    // g_r_h1_3B: 95.2 us (automatic choice before this sweep: 109.7 us)
+    {24, 2048, 24, 2, 1, 64, 1, 1},
+    // g_r_h2_3B: 52.0 us (automatic choice before this sweep: 57.7 us)
+    {48, 512, 24, 2, 1, 64, 1, 1},
+    // g_u1_3B: 153.1 us (automatic choice before this sweep: 184.4 us)
+    {40, 2048, 24, 2, 1, 64, 1, 1},
+    // g_u2_3B: 153.4 us (automatic choice before this sweep: 189.9 us)
+    {40, 1024, 48, 2, 1, 64, 2, 1},
+    // g_o1_3B: 37.8 us (automatic choice before this sweep: 40.7 us)
+    {60, 24, 96, 2, 1, 64, 4, 2},
+    // g_h1_3B: 24.7 us (automatic choice before this sweep: 24.8 us)
+    {8, 256, 96, 2, 1, 64, 4, 4},
+    // d_d1_2B: 149.1 us (automatic choice before this sweep: 178.7 us)
+    {18, 512, 192, 2, 1, 64, 1, 8},
+    // d_d2_2B: 152.9 us (automatic choice before this sweep: 172.4 us)
+    {36, 1024, 48, 2, 1, 64, 2, 1},
+    // d_d3_2B: 419.5 us (automatic choice before this sweep: 423.4 us)
+    {144, 2048, 24, 2, 1, 128, 1, 1},
+    // ---- batch 32 per GPU, 24x128 MCEP
+    // g_d1_3B: 93.4 us (automatic choice before this sweep: 107.7 us)
+    {10, 512, 192, 2, 1, 64, 2, 8},
+    // g_d2_3B: 162.2 us (automatic choice before this sweep: 208.9 us)
+    {20, 1024, 96, 2, 1, 64, 2, 2},
+    // g_r_h1_3B: 335.5 us (automatic choice before this sweep: 390.3 us)
+    {24, 2048, 96, 2, 1, 128, 2, 1},
+    // g_r_h2_3B: 175.3 us (automatic choice before this sweep: 209.6 us)
+    {48, 512, 96, 2, 1, 64, 1, 1},
+    // g_u1_3B: 552.2 us (automatic choice before this sweep: 644.7 us)
+    {40, 2048, 96, 2, 1, 64, 2, 1},
+    // g_u2_3B: 552.1 us (automatic choice before this sweep: 690.4 us)
+    {40, 1024, 192, 2, 1, 64, 2, 1},
+    // g_o1_3B: 121.2 us (automatic choice before this sweep: 133.0 us)
+    {60, 24, 384, 2, 1, 64, 4, 2},
+    // g_h1_3B: 69.3 us (automatic choice before this sweep: 68.9 us)
+    {8, 256, 384, 2, 1, 64, 4, 4},
+    // d_d1_2B: 532.8 us (automatic choice before this sweep: 577.0 us)
+    {18, 512, 768, 2, 1, 64, 2, 8},
+    // d_d2_2B: 526.3 us (automatic choice before this sweep: 597.2 us)
+    {36, 1024, 192, 2, 1, 64, 2, 2},
+    // d_d3_2B: 1635.7 us (automatic choice before this sweep: 1688.1 us)
+    {144, 2048, 96, 2, 1, 128, 1, 1},
+    // ---- batch 64 per GPU, 36x256 MCEP
+    // g_d1_3B: 305.0 us (automatic choice before this sweep: 386.9 us)
+    {10, 512, 768, 2, 1, 64, 2, 8},
+    // g_d2_3B: 573.4 us (automatic choice before this sweep: 681.8 us)
+    {20, 1024, 384, 2, 1, 64, 1, 4},
+    // g_r_h1_3B: 1247.3 us (automatic choice before this sweep: 1360.1 us)
+    {24, 2048, 384, 2, 1, 128, 1, 2},
+    // g_r_h2_3B: 652.6 us (automatic choice before this sweep: 756.4 us)
+    {48, 512, 384, 2, 1, 128, 1, 4},
+    // g_u1_3B: 2064.8 us (automatic choice before this sweep: 2209.4 us)
+    {40, 2048, 384, 2, 1, 128, 1, 2},
+    // g_u2_3B: 2054.8 us (automatic choice before this sweep: 2216.0 us)
+    {40, 1024, 768, 2, 1, 128, 1, 4},
+    // g_o1_3B: 435.5 us (automatic choice before this sweep: 501.9 us)
+    {60, 36, 1536, 2, 1, 64, 2, 8},
+    // g_h1_3B: 421.1 us (automatic choice before this sweep: 493.4 us)
+    {15, 256, 1536, 2, 1, 128, 1, 16},
+    // d_d1_2B: 2929.2 us (automatic choice before this sweep: 2925.8 us)
+    {18, 512, 4608, 2, 1, 128, 2, 16},
+    // d_d2_2B: 2846.8 us (automatic choice before this sweep: 2915.0 us)
+    {36, 1024, 1152, 2, 1, 128, 1, 8},
+    // d_d3_2B: 9540.9 us (automatic choice before this sweep: 9729.3 us)
+    {144, 2048, 576, 2, 1, 128, 2, 1},
 };
