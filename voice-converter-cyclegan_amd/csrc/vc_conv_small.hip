@@ -420,7 +420,13 @@ int launch_wsconv1d(const WsConvArgs& a, int cin, int kw, int math, hipStream_t 
 // a straight copy of the image pack_gated_weights_kernel prepared (kept for A/B measurements: VC_GLU_PACKED=1).
 // NWV_ = waves per workgroup (bf16: 8 = one 512-thread workgroup per CU working on two tiles at a time; 4 = TWO 256-thread
 // workgroups per CU, one tile each, whose load / multiply / store phases drift apart and overlap).
-template <int CIN, int KW, bool BF16, bool INKW, int NWV_>
+// RAW = the raw (value, gate) pair is stored too (training).  A template parameter, and the stores are buffer stores whose
+// out-of-range lanes are dropped by the hardware range check, so that EVERY trip issues the same number of store
+// instructions: the wait for the next tile's frames (issued before this tile's stores) can then be a counted
+// s_waitcnt vmcnt(#stores) -- with stores under branches the compiler has to wait for vmcnt(0), i.e. for the stores' own
+// completion in L2, once per tile (gfx950 has one in-order counter for loads and stores).
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+template <int CIN, int KW, bool BF16, bool INKW, int NWV_, bool RAW>
 __global__ __launch_bounds__(64 * NWV_, (BF16 && NWV_ == 4) ? 2 : (NWV_ == 8 ? 2 : 1)) void gated_conv1d_glu_kernel(const WsConvArgs a, const void* __restrict__ packed) {
     typedef typename std::conditional<BF16, __bf16, float>::type T;
     constexpr int R = BF16 ? 8 : 4;                        // k run per lane half and step
@@ -454,6 +460,10 @@ __global__ __launch_bounds__(64 * NWV_, (BF16 && NWV_ == 4) ? 2 : (NWV_ == 8 ? 2
         bg[r] = ok ? a.bias[(long)g * a.b_gs + C + c] : 0.f;
     }
     const float* xg = a.x + (long)g * a.x_gs;
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.y + (long)g * a.y_gs), 0, (int)((unsigned)a.B * (unsigned)C * (unsigned)a.T * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rawrs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(RAW ? a.raw + (long)g * a.raw_gs : a.y), 0, (int)((unsigned)a.B * (unsigned)a.Cout * (unsigned)a.T * 4u), 0x00020000);
     T* Xt = Xs + sub * XR * CS;
     float xr[NXF];
     unsigned xok = 0;                                // bit i: xr[i] is a frame of the tile (else padding -> 0)
@@ -469,8 +479,28 @@ __global__ __launch_bounds__(64 * NWV_, (BF16 && NWV_ == 4) ? 2 : (NWV_ == 8 ? 2
         for (int i = 0; i < NXF; ++i) {
             const int idx = stid + 256 * i, c = idx / XR, pos = idx - c * XR, t = t0 + pos;
             const bool ok = tv && idx < XR * CIN && (unsigned)t < (unsigned)a.T;
-            xr[i] = xb[ok ? c * a.T + t : 0];
+            if constexpr (INKW) {
+                // Issued behind the compiler's back (it would otherwise wait for them with s_waitcnt vmcnt(0) -- it cannot count
+                // the younger stores across the loop's back edge -- and that also waits for the previous tile's output stores
+                // to COMPLETE, once per tile).  wait_tile() below is the matching, counted wait.
+                const float* ap_ = xb + (ok ? c * a.T + t : 0);
+                asm volatile("global_load_dword %0, %1, off" : "=v"(xr[i]) : "v"(ap_) : "memory");
+            } else xr[i] = xb[ok ? c * a.T + t : 0];
             xok |= (unsigned)ok << i;
+        }
+    };
+    // The frames of the tile about to be staged were requested one trip ago, BEFORE that trip's NST output stores: the vector
+    // memory counter retires in order, so "at most NST operations outstanding" means the frames have arrived while the
+    // stores may still be on their way.  (The compiler sees xr[] pass through the asm, so no use can move above the wait.)
+    // NST = buffer stores per trip (store_plane: 4 per plane, all unconditional): 12 with RAW, else 4
+    auto wait_tile = [&](bool stores_behind) {
+        if constexpr (INKW) {
+            static_assert(NXF == 14, "operand list below");
+#define VC_XR_OPS "+v"(xr[0]), "+v"(xr[1]), "+v"(xr[2]), "+v"(xr[3]), "+v"(xr[4]), "+v"(xr[5]), "+v"(xr[6]), "+v"(xr[7]), \
+                  "+v"(xr[8]), "+v"(xr[9]), "+v"(xr[10]), "+v"(xr[11]), "+v"(xr[12]), "+v"(xr[13])
+            if (stores_behind) { if constexpr (RAW) asm volatile("s_waitcnt vmcnt(12)" : VC_XR_OPS :: "memory"); else asm volatile("s_waitcnt vmcnt(4)" : VC_XR_OPS :: "memory"); }
+            else asm volatile("s_waitcnt vmcnt(0)" : VC_XR_OPS :: "memory");
+#undef VC_XR_OPS
         }
     };
     auto store_tile = [&]() {
@@ -529,12 +559,15 @@ __global__ __launch_bounds__(64 * NWV_, (BF16 && NWV_ == 4) ? 2 : (NWV_ == 8 ? 2
         f32x4* dst = reinterpret_cast<f32x4*>(Ws);
         for (int i = tid; i < NV16; i += 64 * NWV) dst[i] = src[i];
     }
+    static_assert(!INKW || NSUB == 1, "the counted wait assumes every trip of a wave stores its tile");
+    bool first_trip = true;
     for (; t0i < ntiles; t0i += gridDim.x * NSUB) {
         const int tile = t0i + sub;
         __syncthreads();                              // the previous tile's readers are done (first trip: orders the slab writes)
+        wait_tile(!first_trip); first_trip = false;
         store_tile();
         __syncthreads();
-        if (t0i + (int)gridDim.x * NSUB < ntiles) load_tile(t0i + gridDim.x * NSUB + sub);   // next tiles' frames are in flight during the MFMAs
+        load_tile(t0i + gridDim.x * NSUB + sub);      // next tiles' frames are in flight during the MFMAs (past the last tile: masked, harmless)
         if (tile >= ntiles) continue;                 // odd tile count: this half idles (barriers are above)
 
         f32x16 accv[2], accg[2];
@@ -584,23 +617,25 @@ __global__ __launch_bounds__(64 * NWV_, (BF16 && NWV_ == 4) ? 2 : (NWV_ == 8 ? 2
         }
         // wave-private tile: no workgroup barrier, the LDS queue is in order within a wave
         const int b = tile / tps, t = (tile - b * tps) * TP + w4 * 32 + (lane & 7) * 4;
-        auto store_plane = [&](float* dst) {          // the staged 32 x 32 tile -> rows (channels) of `dst`, 16 bytes per lane
+        // the staged 32 x 32 tile -> rows (channels) of a [B][nch][T] tensor, 16 bytes per lane; lanes outside the tensor get an
+        // out-of-range offset (dropped by the buffer range check): the instruction count does not depend on the data
+        auto store_plane = [&](__amdgpu_buffer_rsrc_t rs, int nch, int ch0) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int ml = (lane >> 3) + 8 * i, c = slab * 32 + ml;
                 const f32x4 v = *reinterpret_cast<const f32x4*>(sw + ml * LDS_S + (lane & 7) * 4);
-                if (c < C && t < a.T) *reinterpret_cast<f32x4*>(dst + (long)c * a.T) = v;
+                const unsigned off = (c < C && t < a.T) ? (unsigned)((((long)b * nch + ch0 + c) * a.T + t) * 4) : VC_OOB;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, (int)off, 0, 0);
             }
         };
-        store_plane(a.y + (long)g * a.y_gs + (long)b * C * a.T + t);
-        if (a.raw) {                                  // training: the raw value / gate pair is kept for the backward pass
-            float* raw = a.raw + (long)g * a.raw_gs + (long)b * 2 * C * a.T + t;
+        store_plane(yrs, C, 0);
+        if constexpr (RAW) {                          // training: the raw value / gate pair is kept for the backward pass
 #pragma unroll
             for (int r = 0; r < 16; ++r) sw[((r & 3) + 8 * (r >> 2) + 4 * h) * LDS_S + l31] = sv[r] + bv[r];
-            store_plane(raw);
+            store_plane(rawrs, 2 * C, 0);
 #pragma unroll
             for (int r = 0; r < 16; ++r) sw[((r & 3) + 8 * (r >> 2) + 4 * h) * LDS_S + l31] = sg[r] + bg[r];
-            store_plane(raw + (long)C * a.T);
+            store_plane(rawrs, 2 * C, C);
         }
     }
 }
@@ -630,24 +665,25 @@ int64_t gated_conv1d_glu_workspace_floats(int G, int cout2) {
 // y [G][B][Cout/2][T] = GLU of the gated pair; returns -2 when the geometry is not built
 int launch_gated_conv1d_glu(const WsConvArgs& a, int cin, int kw, int math, float* workspace, hipStream_t s, double flops) {
     if (cin != 24 || kw != 15 || (a.Cout & 63) || (a.T & 3)) return -2;
+    if ((long)a.B * a.Cout * a.T * 4 >= 0xfff00000L) return -2;      // 32-bit buffer offsets of the output stores
     const int C = a.Cout / 2, slabs = C / 32;
     const bool bf = math == VC_MATH_BF16;
     static const bool packed_image = getenv("VC_GLU_PACKED") != nullptr;      // A/B: the round-2 two-launch form
-    static const bool wide = getenv("VC_GLU_WAVES8") != nullptr || packed_image;   // A/B: one 8-wave workgroup per CU instead of two 4-wave ones
+    const bool wide = packed_image;                   // the round-2 form: one 8-wave workgroup per CU working on two tiles at a time
     const int nsub = (bf && wide) ? 2 : 1, ntiles = a.B * ((a.T + 127) / 128), trips = (ntiles + nsub - 1) / nsub;
     const int wgs = (bf && !wide) ? 512 : 256;        // resident workgroups on the chip, persistent over the tiles
     int parts = wgs / (slabs * a.G); if (parts < 1) parts = 1; if (parts > trips) parts = trips;
     dim3 grid(parts, slabs, a.G);
     ProfScope ps(2, flops, s);                       // everything a call launches
+#define VC_GLU(BF, INKW, NWV, P) { if (a.raw) gated_conv1d_glu_kernel<24, 15, BF, INKW, NWV, true><<<grid, dim3(64 * NWV), 0, s>>>(a, P); \
+                                  else gated_conv1d_glu_kernel<24, 15, BF, INKW, NWV, false><<<grid, dim3(64 * NWV), 0, s>>>(a, P); }
     if (packed_image) {
         if (bf) pack_gated_weights_kernel<24, 15, true><<<dim3(slabs, a.G, 16), 256, 0, s>>>(a.w, a.w_gs, a.Cout, workspace);
         else pack_gated_weights_kernel<24, 15, false><<<dim3(slabs, a.G, 16), 256, 0, s>>>(a.w, a.w_gs, a.Cout, workspace);
-        if (bf) gated_conv1d_glu_kernel<24, 15, true, false, 8><<<grid, dim3(512), 0, s>>>(a, workspace);
-        else gated_conv1d_glu_kernel<24, 15, false, false, 4><<<grid, dim3(256), 0, s>>>(a, workspace);
-    } else if (bf) {
-        if (wide) gated_conv1d_glu_kernel<24, 15, true, true, 8><<<grid, dim3(512), 0, s>>>(a, nullptr);
-        else gated_conv1d_glu_kernel<24, 15, true, true, 4><<<grid, dim3(256), 0, s>>>(a, nullptr);
-    } else gated_conv1d_glu_kernel<24, 15, false, true, 4><<<grid, dim3(256), 0, s>>>(a, nullptr);
+        if (bf) VC_GLU(true, false, 8, workspace) else VC_GLU(false, false, 4, workspace)
+    } else if (bf) VC_GLU(true, true, 4, nullptr)
+    else VC_GLU(false, true, 4, nullptr)
+#undef VC_GLU
     VC_HIP(hipGetLastError());
     return 0;
 }
