@@ -45,38 +45,61 @@ def _blas_threads():
         return 'unknown'
 
 
-def cpu_baseline(n_steps=10):
-    """The reference arithmetic on the host cores (TF1 itself cannot run here), timed two ways on a bounded sample
-    of the workload: oracle/torch_ref.py (torch-CPU: oneDNN / MKL convolutions + autograd, torch.set_num_threads(all cores);
-    SURVEY 8d's stand-in) at B=1 (BASELINE configs[0]) and at the benched B=8, and the numpy oracle at B=1.  `value` is the
-    fastest of them in frames/s; every leg is listed in `sample`."""
+def _cpu_leg(kind, B, threads, budget_s):
+    """one leg of cpu_baseline, run in its own process (see there): prints one JSON line"""
     import numpy as np
-    import torch
     from oracle import cyclegan_oracle as O
-    from oracle.torch_ref import TorchTrainer
+    if kind == 'torch':
+        import torch
+        from oracle.torch_ref import TorchTrainer
+        torch.set_num_threads(threads)
+        tt = TorchTrainer(O.init_params(seed=42))
+        step = lambda A, Bm: tt.train(A, Bm, 10.0, 5.0, 2e-4, 1e-4)
+        name = 'torch-CPU (oracle/torch_ref.py TorchTrainer: oneDNN / MKL convolutions + autograd, %d threads)' % torch.get_num_threads()
+    else:
+        orc = O.CycleGANOracle(O.init_params(seed=42))
+        step = lambda A, Bm: orc.train(A, Bm, 10.0, 5.0, 2e-4, 1e-4)
+        name = 'numpy oracle (oracle/cyclegan_oracle.py; GEMMs in numpy\'s BLAS: %s, the rest single-threaded)' % _blas_threads()
+    A, Bm = O.synthetic_batch(B, 24, 128)
+    t = time.perf_counter(); step(A, Bm); warm = time.perf_counter() - t          # warm-up (also sizes the sample)
+    n = int(max(1, min(10, budget_s / max(warm, 1e-3))))
+    ts = []
+    for _ in range(n):
+        t = time.perf_counter(); step(A, Bm); ts.append(time.perf_counter() - t)
+    med = float(np.median(ts))
+    print(json.dumps({'fps': B * 128.0 / med, 'threads': threads,
+                      'text': '%s B=%d: 1 warm-up + %d timed full train steps, median %.3f s/step = %.1f frames/s' % (name, B, n, med, B * 128.0 / med)}))
+
+
+def cpu_baseline(budget_s=6.0, leg_timeout_s=75):
+    """The reference arithmetic on the host cores (TF1 itself cannot run here), timed on a bounded sample of the
+    workload: oracle/torch_ref.py (torch-CPU; SURVEY 8d's stand-in) at B=1 (BASELINE configs[0]) and at the benched B=8,
+    with 32 threads and with all host threads (many-core hosts can lose more time synchronising 256 threads over
+    convolutions this small than they gain), and the numpy oracle at B=1.  Every leg runs in its own process under a
+    timeout (a leg that does not finish is reported as such): one warm-up step, then as many timed steps as fit
+    `budget_s` seconds (1..10).  `value` is the fastest leg in frames/s."""
+    import subprocess
     cores = os.cpu_count()
-    torch.set_num_threads(cores)
-    legs = []
-
-    def leg(name, B, step, n):
-        A, Bm = O.synthetic_batch(B, 24, 128)
-        step(A, Bm)                               # warm-up
-        ts = []
-        for _ in range(n):
-            t = time.perf_counter(); step(A, Bm); ts.append(time.perf_counter() - t)
-        med = float(np.median(ts))
-        legs.append((B * 128.0 / med, '%s B=%d: 1 warm-up + %d timed full train steps, median %.3f s/step = %.1f frames/s'
-                     % (name, B, n, med, B * 128.0 / med)))
-
-    tt = TorchTrainer(O.init_params(seed=42))
-    leg('torch-CPU (oracle/torch_ref.py TorchTrainer, %d threads)' % torch.get_num_threads(), 1, lambda A, Bm: tt.train(A, Bm, 10.0, 5.0, 2e-4, 1e-4), n_steps)
-    leg('torch-CPU', 8, lambda A, Bm: tt.train(A, Bm, 10.0, 5.0, 2e-4, 1e-4), 3)
-    orc = O.CycleGANOracle(O.init_params(seed=42))
-    leg('numpy oracle (oracle/cyclegan_oracle.py; GEMMs in numpy\'s BLAS: %s, the rest single-threaded)' % _blas_threads(), 1,
-        lambda A, Bm: orc.train(A, Bm, 10.0, 5.0, 2e-4, 1e-4), 5)
+    legs, notes = [], []
+    plan = [('torch', 1, min(cores, 32)), ('torch', 8, min(cores, 32))]
+    if cores > 32:
+        plan += [('torch', 8, cores)]
+    plan += [('numpy', 1, cores)]
+    for kind, B, threads in plan:
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-leg', '%s,%d,%d,%g' % (kind, B, threads, budget_s)],
+                               capture_output=True, text=True, timeout=leg_timeout_s)
+            d = json.loads(r.stdout.strip().splitlines()[-1])
+            legs.append((d['fps'], d['threads'], d['text']))
+            print('[bench] cpu baseline: ' + d['text'], file=sys.stderr, flush=True)
+        except Exception as e:
+            notes.append('%s B=%d with %d threads: did not finish within %d s (%s)' % (kind, B, threads, leg_timeout_s, type(e).__name__))
+            print('[bench] cpu baseline: ' + notes[-1], file=sys.stderr, flush=True)
+    if not legs:
+        return dict(value=None, unit='frames/s', cores=cores, kind='port', sample='; '.join(notes))
     best = max(legs)
-    return dict(value=best[0], unit='frames/s', cores=cores, kind='port',
-                sample='24x128 MCEP, fp32; ' + '; '.join(l[1] for l in legs) + '; TF1 reference not runnable (no tensorflow)')
+    return dict(value=best[0], unit='frames/s', cores=best[1], host_cores=cores, kind='port',
+                sample='24x128 MCEP, fp32; ' + '; '.join([l[2] for l in legs] + notes) + '; TF1 reference not runnable (no tensorflow)')
 
 
 def _pmc_traffic(B, F, T, world, math):
@@ -200,6 +223,7 @@ def extra_config(lib, dev, math, B, F, T, steps, warmup, note):
     import numpy as np
     import torch
     from voice_converter_cyclegan_amd.engine import CycleGANEngine
+    print('[bench] extra configuration: %s B=%d %dx%d' % (math, B, F, T), file=sys.stderr, flush=True)
     eng = CycleGANEngine(num_features=F, device=dev, seed=42, data_parallel=False)
     eng.set_math(math)
     rng = np.random.default_rng(99)
@@ -238,6 +262,7 @@ def main():
     ap.add_argument('--graph', action='store_true', help='replay the step as one hipGraph (vc_train_step_graph) instead of launching it')
     ap.add_argument('--deterministic', action='store_true', help='vc_plan_set_deterministic: fixed summation order (bitwise reproducible steps)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-leg', default='', help=argparse.SUPPRESS)      # internal: one leg of cpu_baseline in its own process
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-extra', action='store_true',
                     help='skip the other BASELINE configurations (bf16 B=64, fp32 B=32 = configs[3]\'s share of an 8-GPU node, 36x256 '
@@ -246,6 +271,9 @@ def main():
                     help='serialise the step\'s two independent chains on one stream for the WHOLE run (the condition the '
                          'roofline leg always uses; for rocprof summaries that must agree with it)')
     args = ap.parse_args()
+    if args.cpu_leg:
+        kind, B_, th, bud = args.cpu_leg.split(',')
+        return _cpu_leg(kind, int(B_), int(th), float(bud))
     default_workload = (args.batch, args.global_batch, args.frames, args.features, args.math, args.graph, args.serial, args.deterministic) == \
                        (8, 0, 128, 24, 'fp32', False, False, False)
 
@@ -297,6 +325,8 @@ def main():
         torch.cuda.synchronize()
 
     dt = time_steps(eng, A, Bm, hp, args.steps, args.warmup, barrier)
+    if rank == 0:
+        print('[bench] headline: %.3f ms/step' % (1e3 * dt / args.steps), file=sys.stderr, flush=True)
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
