@@ -466,27 +466,57 @@ __global__ __launch_bounds__(64 * NWV_, (BF16 && NWV_ == 4) ? 2 : (NWV_ == 8 ? 2
         (void*)(RAW ? a.raw + (long)g * a.raw_gs : a.y), 0, (int)((unsigned)a.B * (unsigned)a.Cout * (unsigned)a.T * 4u), 0x00020000);
     T* Xt = Xs + sub * XR * CS;
     float xr[NXF];
-    unsigned xok = 0;                                // bit i: xr[i] is a frame of the tile (else padding -> 0)
+    unsigned xok = 0;                                // bit i: xr[i] is a frame of the tile (else padding -> 0)   [INKW = false only]
+    // ---- frame staging.  Per-thread constants, once: element i of a thread is (channel c_i, position pos_i) of EVERY tile;
+    //      its byte offset inside the group's tensor is tile base + goff[i], its LDS slot lds[i].  A tile then costs one add,
+    //      one range compare and one select per element, and the load itself is a BUFFER load whose offset is sent out of
+    //      range for padding positions (hardware returns 0): no 64-bit address arithmetic, no masks, no selects at store time.
+    //      (The PMC pass of the first version of this kernel showed ~600 vector-ALU instructions per tile and wave -- address
+    //      arithmetic and an IEEE division per GLU output -- against 46 MFMAs: VALU-bound at 0.32 MFMA-pipe busy.)
+    int goff[NXF], gpos[NXF]; unsigned lds[NXF];
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    i32x4 xrs_;                                       // buffer descriptor of this group's frames, in SGPRs (inline asm operand)
+    if constexpr (INKW) {
+#pragma unroll
+        for (int i = 0; i < NXF; ++i) {
+            const int idx = stid + 256 * i, c = idx / XR, pos = idx - c * XR;
+            const bool in = idx < XR * CIN;
+            goff[i] = (c * a.T + pos) * 4;
+            gpos[i] = in ? pos : 0x40000000;          // out of the staging area: always fails the range check below
+            lds[i] = (unsigned)((in ? pos * CS + c : CS - 1) * (int)sizeof(T));   // dummy slot: a pad column no fragment reads
+        }
+        const unsigned long long pa = (unsigned long long)xg;
+        xrs_[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)pa);
+        xrs_[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(pa >> 32) & 0xffff);
+        xrs_[2] = __builtin_amdgcn_readfirstlane((int)((unsigned)a.B * CIN * (unsigned)a.T * 4u));
+        xrs_[3] = 0x00020000;
+    }
     // The loads are issued and NOT touched until store_tile, one whole tile of MFMAs later: masking the value right behind
     // its load (as the round-2 kernel did) puts an s_waitcnt between the prefetch and the multiply loop, i.e. a full HBM
     // round trip (~2 us) in front of every tile.
     auto load_tile = [&](int tile) {                 // input frames t0-PADL .. of all channels -> registers (lanes along time: coalesced)
         const bool tv = tile < ntiles;
         const int b = tv ? tile / tps : 0, t0 = (tile - b * tps) * TP - PADL;
-        const float* xb = xg + (long)b * CIN * a.T;
-        xok = 0;
+        if constexpr (INKW) {
+            // Issued behind the compiler's back (it would otherwise wait for them with s_waitcnt vmcnt(0) -- it cannot count the
+            // younger stores across the loop's back edge -- and that also waits for the previous tile's output stores to
+            // COMPLETE, once per tile).  wait_tile() below is the matching, counted wait.
+            const int base = (b * CIN * a.T + t0) * 4, tlim = tv ? a.T : 0;
 #pragma unroll
-        for (int i = 0; i < NXF; ++i) {
-            const int idx = stid + 256 * i, c = idx / XR, pos = idx - c * XR, t = t0 + pos;
-            const bool ok = tv && idx < XR * CIN && (unsigned)t < (unsigned)a.T;
-            if constexpr (INKW) {
-                // Issued behind the compiler's back (it would otherwise wait for them with s_waitcnt vmcnt(0) -- it cannot count
-                // the younger stores across the loop's back edge -- and that also waits for the previous tile's output stores
-                // to COMPLETE, once per tile).  wait_tile() below is the matching, counted wait.
-                const float* ap_ = xb + (ok ? c * a.T + t : 0);
-                asm volatile("global_load_dword %0, %1, off" : "=v"(xr[i]) : "v"(ap_) : "memory");
-            } else xr[i] = xb[ok ? c * a.T + t : 0];
-            xok |= (unsigned)ok << i;
+            for (int i = 0; i < NXF; ++i) {
+                const unsigned off = ((unsigned)(t0 + gpos[i]) < (unsigned)tlim) ? (unsigned)(base + goff[i]) : VC_OOB;
+                asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(xr[i]) : "v"(off), "s"(xrs_) : "memory");
+            }
+        } else {
+            const float* xb = xg + (long)b * CIN * a.T;
+            xok = 0;
+#pragma unroll
+            for (int i = 0; i < NXF; ++i) {
+                const int idx = stid + 256 * i, c = idx / XR, pos = idx - c * XR, t = t0 + pos;
+                const bool ok = tv && idx < XR * CIN && (unsigned)t < (unsigned)a.T;
+                xr[i] = xb[ok ? c * a.T + t : 0];
+                xok |= (unsigned)ok << i;
+            }
         }
     };
     // The frames of the tile about to be staged were requested one trip ago, BEFORE that trip's NST output stores: the vector
@@ -504,10 +534,16 @@ __global__ __launch_bounds__(64 * NWV_, (BF16 && NWV_ == 4) ? 2 : (NWV_ == 8 ? 2
         }
     };
     auto store_tile = [&]() {
+        if constexpr (INKW) {
+            char* xb_ = reinterpret_cast<char*>(Xt);
 #pragma unroll
-        for (int i = 0; i < NXF; ++i) {
-            const int idx = stid + 256 * i, c = idx / XR, pos = idx - c * XR;
-            if (idx < XR * CIN) Xt[pos * CS + c] = (T)(((xok >> i) & 1u) ? xr[i] : 0.f);
+            for (int i = 0; i < NXF; ++i) *reinterpret_cast<T*>(xb_ + lds[i]) = (T)xr[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < NXF; ++i) {
+                const int idx = stid + 256 * i, c = idx / XR, pos = idx - c * XR;
+                if (idx < XR * CIN) Xt[pos * CS + c] = (T)(((xok >> i) & 1u) ? xr[i] : 0.f);
+            }
         }
     };
     typedef typename std::conditional<BF16, bf16x8, f32x4>::type frag_t;
@@ -613,7 +649,8 @@ __global__ __launch_bounds__(64 * NWV_, (BF16 && NWV_ == 4) ? 2 : (NWV_ == 8 ? 2
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int ml = (r & 3) + 8 * (r >> 2) + 4 * h;
-            sw[ml * LDS_S + l31] = (sv[r] + bv[r]) * sigmoidf_(sg[r] + bg[r]);
+            // sigmoid with the hardware reciprocal (1 ulp) instead of an IEEE division: ~5 instead of ~15 instructions per output
+            sw[ml * LDS_S + l31] = (sv[r] + bv[r]) * __builtin_amdgcn_rcpf(1.f + __expf(-(sg[r] + bg[r])));
         }
         // wave-private tile: no workgroup barrier, the LDS queue is in order within a wave
         const int b = tile / tps, t = (tile - b * tps) * TP + w4 * 32 + (lane & 7) * 4;
