@@ -82,6 +82,8 @@ int  vc_get_deterministic(void);
  *              split-K (1..16) */
 int  vc_tune_igemm_override(int tile_rows, int k_groups, int splitk);
 int  vc_tune_wgrad_override(int tile_cols, int k_groups, int splitk);
+int  vc_tune_rowskip(int igemm_on, int wgrad_on);   /* row-major pixel tiles that skip the filter rows lying in the SAME padding (D.d3): default off for
+                                                     * forward / input gradient, on for filter gradients (csrc/vc_api.hip: rowskip_pays); thread-local */
 int  vc_tune_wgrad_store(int on);       /* tuning only: while on, vc_conv2d_wgrad OVERWRITES dw (the train step's plain-store form) */
 int  vc_tune_conv_bf16_override(int tile_rows, int stages, int splitk);
 /* Opt-in per-launch timing of the implicit-GEMM kernels (bench.py roofline leg).

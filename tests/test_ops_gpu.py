@@ -78,6 +78,20 @@ def test_conv_fwd_dgrad_wgrad(built_lib, case):
     _conv_check(case)
 
 
+@pytest.mark.parametrize('modes', [(1, 1), (1, 0), (0, 0)])
+@pytest.mark.parametrize('case', [c for c in CONV_CASES if c[4] == 6] + [(16, 5, 7, 32, 6, 3, 1, 2, 2)])
+def test_conv_rowskip_modes(built_lib, case, modes):
+    """IgemmArgs::rowskip / WgradArgs::rowskip (launch pixels enumerated (row, sample, column); only the filter rows that touch
+    the image for a tile's rows are walked): on by default for filter gradients only (vc_api.hip: rowskip_pays); every
+    combination is forced here (vc_tune_rowskip) on the 6-row-kernel geometries it applies to (module.py:208, D.d3)."""
+    from voice_converter_cyclegan_amd._lib import lib, check
+    check(lib.vc_tune_rowskip(*modes))
+    try:
+        _conv_check(case)
+    finally:
+        check(lib.vc_tune_rowskip(0, 1))
+
+
 # bf16 MFMA modes (vc_set_math_mode): 'bf16' is checked against the oracle with the SAME operand rounding (so only the
 # fp32 accumulation order differs -> same tolerance as fp32); 'bf16x3' against the unrounded oracle (2^-16 per product).
 MATH_CASES = [CONV_CASES[i] for i in (0, 1, 3, 4, 6, 7, 8, 9, 11, 13, 15, 16, 22, 23, 28)]

@@ -278,18 +278,25 @@ static void fill_pixel_grid(IgemmArgs& a, int B, int NPB, int OWc) {
 }
 // Does walking only the filter rows that touch the image pay for this launch grid?  OHc output rows at row stride si over a
 // gathered tensor of Hl rows: the share of (output row, tap) pairs whose tap row lies in the SAME padding.  D.d3 (6 tap rows
-// on 6 image rows, pads (2, 3)): 25 %; the 3x3 stride-2 layers: 3 %; 1-D layers: one row, never.  VC_NO_ROWSKIP=1 switches
-// it off (A/B measurements).
-static bool rowskip_pays(const Table& t, int OHc, int si, int Hl) {
-    static const bool off = getenv("VC_NO_ROWSKIP") != nullptr;
-    if (off || OHc < 2 || t.ntaps < 2 || t.cpt <= 0) return false;
+// on 6 image rows, pads (2, 3)): 25 %; the 3x3 stride-2 layers: 3 %; 1-D layers: one row, never.
+// Measured (profiles/r03_pmc_d3_rowskip.txt): the FILTER GRADIENT gains what the arithmetic says (D.d3 at the B = 8 step:
+// 545 -> 459 us, 420 with its tuned configuration) -- its reduction axis is the pixel axis, the skipped rows are simply not
+// read.  Forward / input gradient do NOT: their pixel tiles share a 2.4 MB weight slab through the XCD's L2 by streaming
+// it in step; with row-dependent K ranges the tiles of a slab walk different parts of it, the L2 hit rate drops (0.81 ->
+// 0.75 / 0.70 -> 0.60), HBM-side fetch doubles and the launch ends up no faster (MFMA-pipe busy 0.76 -> 0.62).  So the
+// mode is ON for filter gradients and OFF for forward / input gradient (vc_tune_rowskip switches either, for the tests
+// and for measurements).
+static thread_local int t_rowskip_igemm = 0, t_rowskip_wgrad = 1;
+extern "C" int vc_tune_rowskip(int igemm_on, int wgrad_on) { t_rowskip_igemm = igemm_on ? 1 : 0; t_rowskip_wgrad = wgrad_on ? 1 : 0; return 0; }
+static bool rowskip_pays(const Table& t, int OHc, int si, int Hl, bool wgrad) {
+    if (!(wgrad ? t_rowskip_wgrad : t_rowskip_igemm) || OHc < 2 || t.ntaps < 2 || t.cpt <= 0) return false;
     long valid = 0;
     for (int i = 0; i < OHc; ++i)
         for (int tp = 0; tp < t.ntaps; ++tp) valid += (i * si + t.tdh[tp] >= 0 && i * si + t.tdh[tp] < Hl) ? 1 : 0;
     return valid * 100 < 92L * OHc * t.ntaps;
 }
 static void set_rowskip(IgemmArgs& a, const Table& t, int B, int OHc) {
-    a.rowskip = rowskip_pays(t, OHc, a.si, a.Hl) ? 1 : 0;
+    a.rowskip = rowskip_pays(t, OHc, a.si, a.Hl, false) ? 1 : 0;
     a.RW = B * a.OWc; a.inv_rw = 1.0f / (float)a.RW; a.cpt = t.cpt;
 }
 static void set_vec4(IgemmArgs& a) {
@@ -664,7 +671,7 @@ static int conv_wgrad(const WgradApp* apps, int napps, float* dw, long dw_gs, in
         flops += 2.0 * G * apps[k].B * a.NPB * (double)g.Cout * t.valid;
     }
     a.store = store ? 1 : 0;
-    a.rowskip = rowskip_pays(t, g.OH, g.sh, g.H) ? 1 : 0;
+    a.rowskip = rowskip_pays(t, g.OH, g.sh, g.H, true) ? 1 : 0;
     if (query) { *query = !store || wgrad_splitk(a) > 1; return 0; }
     return launch_wgrad(a, math, s, flops);
 }

@@ -606,9 +606,11 @@ __global__ __launch_bounds__(64 * NWV_, (BF16 && NWV_ == 4) ? 2 : (NWV_ == 8 ? 2
         load_tile(t0i + gridDim.x * NSUB + sub);      // next tiles' frames are in flight during the MFMAs (past the last tile: masked, harmless)
         if (tile >= ntiles) continue;                 // odd tile count: this half idles (barriers are above)
 
-        f32x16 accv[2], accg[2];
+        // one accumulator per branch, started at the bias: value and gate MFMAs alternate, so two MFMAs (>= the dependent-
+        // accumulate latency) lie between updates of the same registers; no bank sum, no bias add in the epilogue
+        f32x16 accv, accg;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { accv[0][r] = accv[1][r] = 0.f; accg[0][r] = accg[1][r] = 0.f; }
+        for (int r = 0; r < 16; ++r) { accv[r] = bv[r]; accg[r] = bg[r]; }
         // fragment ring RD steps deep, reads pinned ahead of the MFMAs that use them (LDS latency stays covered)
         constexpr int RD = 3, RS = RD + 1;
         frag_t fa[RS], fg[RS], fb[RS];
@@ -628,13 +630,13 @@ __global__ __launch_bounds__(64 * NWV_, (BF16 && NWV_ == 4) ? 2 : (NWV_ == 8 ? 2
             constexpr int Q = decltype(QC)::value;
             const frag_t a_ = fa[Q % RS], g_ = fg[Q % RS], b_ = fb[Q % RS];
             if constexpr (BF16) {
-                accv[Q & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_, b_, accv[Q & 1], 0, 0, 0);
-                accg[Q & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g_, b_, accg[Q & 1], 0, 0, 0);
+                accv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_, b_, accv, 0, 0, 0);
+                accg = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g_, b_, accg, 0, 0, 0);
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    accv[e & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_[e], b_[e], accv[e & 1], 0, 0, 0);
-                    accg[e & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(g_[e], b_[e], accg[e & 1], 0, 0, 0);
+                    accv = __builtin_amdgcn_mfma_f32_32x32x2f32(a_[e], b_[e], accv, 0, 0, 0);
+                    accg = __builtin_amdgcn_mfma_f32_32x32x2f32(g_[e], b_[e], accg, 0, 0, 0);
                 }
             }
         };
@@ -645,12 +647,12 @@ __global__ __launch_bounds__(64 * NWV_, (BF16 && NWV_ == 4) ? 2 : (NWV_ == 8 ? 2
         }(std::make_integer_sequence<int, NG>{});
 
         // ---- epilogue in registers: + bias, GLU; through a per-wave LDS tile so that a lane stores 16 contiguous bytes
-        const f32x16 sv = accv[0] + accv[1], sg = accg[0] + accg[1];
+        const f32x16 sv = accv, sg = accg;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int ml = (r & 3) + 8 * (r >> 2) + 4 * h;
             // sigmoid with the hardware reciprocal (1 ulp) instead of an IEEE division: ~5 instead of ~15 instructions per output
-            sw[ml * LDS_S + l31] = (sv[r] + bv[r]) * __builtin_amdgcn_rcpf(1.f + __expf(-(sg[r] + bg[r])));
+            sw[ml * LDS_S + l31] = sv[r] * __builtin_amdgcn_rcpf(1.f + __expf(-sg[r]));
         }
         // wave-private tile: no workgroup barrier, the LDS queue is in order within a wave
         const int b = tile / tps, t = (tile - b * tps) * TP + w4 * 32 + (lane & 7) * 4;
@@ -668,10 +670,10 @@ __global__ __launch_bounds__(64 * NWV_, (BF16 && NWV_ == 4) ? 2 : (NWV_ == 8 ? 2
         store_plane(yrs, C, 0);
         if constexpr (RAW) {                          // training: the raw value / gate pair is kept for the backward pass
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sw[((r & 3) + 8 * (r >> 2) + 4 * h) * LDS_S + l31] = sv[r] + bv[r];
+            for (int r = 0; r < 16; ++r) sw[((r & 3) + 8 * (r >> 2) + 4 * h) * LDS_S + l31] = sv[r];
             store_plane(rawrs, 2 * C, 0);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sw[((r & 3) + 8 * (r >> 2) + 4 * h) * LDS_S + l31] = sg[r] + bg[r];
+            for (int r = 0; r < 16; ++r) sw[((r & 3) + 8 * (r >> 2) + 4 * h) * LDS_S + l31] = sg[r];
             store_plane(rawrs, 2 * C, C);
         }
     }

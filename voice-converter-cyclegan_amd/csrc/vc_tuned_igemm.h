@@ -92,14 +92,15 @@ static const TunedCfg kTunedIgemm[] = {
     {1, 256, 1536, 2048, 2, 64, 2, 1},
     {1, 256, 1536, 2048, 2, 64, 2, 1},
     {1, 256, 1536, 1024, 2, 64, 2, 1},
-    // d_d3 dgrad: 246.6 us (automatic choice before this sweep: 257.4 us)
+    // d_d3 (forward / input gradient without rowskip: the round-2 sweep, profiles/r02_tune_sweep_b8.txt)
+    // d_d3 dgrad: 254.4 us
     {1, 512, 384, 24576, 2, 64, 1, 8},
     {1, 512, 384, 12288, 2, 64, 1, 8},
-    // d_d3_2B fwd: 423.7 us (automatic choice before this sweep: 546.8 us)
-    {0, 2048, 768, 9216, 2, 128, 2, 2},
-    // d_d3_2B dgrad: 437.3 us (automatic choice before this sweep: 516.4 us)
-    {1, 512, 768, 24576, 2, 64, 1, 4},
-    {1, 512, 768, 12288, 2, 64, 1, 4},
+    // d_d3_2B fwd: 458.1 us
+    {0, 2048, 768, 9216, 2, 64, 1, 4},
+    // d_d3_2B dgrad: 455.5 us
+    {1, 512, 768, 24576, 2, 128, 1, 8},
+    {1, 512, 768, 12288, 2, 128, 1, 8},
     // ---- batch 32 per GPU, 24x128 MCEP
     // g_d1 fwd: 34.6 us (automatic choice before this sweep: 37.2 us)
     {0, 512, 2048, 640, 2, 128, 2, 1},
