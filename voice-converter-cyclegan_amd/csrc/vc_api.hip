@@ -975,14 +975,20 @@ static int plan_create(int num_features, int n_frames, bool inference, vc_plan**
         }
     }
     if (r) { release_tables(p->tables); delete p; return r; }
+    // Filter gradients and the update (exchange + Adam) are leaves of the step: their streams get the LOWEST priority, so the
+    // dispatcher prefers the kernels of the two dependency chains whenever both have workgroups ready (VC_STREAM_PRIO=0: off)
+    static const bool prio = !(getenv("VC_STREAM_PRIO") && atoi(getenv("VC_STREAM_PRIO")) == 0);
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);      // numerically: lo = least urgent
+    auto leaf_stream = [&](hipStream_t* st) { return prio ? hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio_lo) : hipStreamCreateWithFlags(st, hipStreamNonBlocking); };
     hipError_t e = hipEventCreateWithFlags(&p->d_ready, hipEventDisableTiming);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->wstream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = leaf_stream(&p->wstream);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_wjoin, hipEventDisableTiming);
     for (int k = 0; k < 24 && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&p->ev_layer[k], hipEventDisableTiming);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->wstream_d, hipStreamNonBlocking);
+    if (e == hipSuccess) e = leaf_stream(&p->wstream_d);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_wjoin_d, hipEventDisableTiming);
     for (int k = 0; k < 8 && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&p->ev_layer_d[k], hipEventDisableTiming);
     for (int k = 0; k < vc_plan::kBuckets && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&p->g_ready[k], hipEventDisableTiming);

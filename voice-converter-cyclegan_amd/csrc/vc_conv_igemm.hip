@@ -23,6 +23,7 @@
 #include "vc_internal.h"
 #include "vc_device_util.h"
 #include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 #include <utility>
 
@@ -420,6 +421,12 @@ void igemm_config(IgemmArgs& a, int math) {
         const int at = a.a_ms != 1 ? 1 : 0;
         for (const TunedCfg& t : kTunedIgemm)
             if (t.at == at && t.M == a.M && t.Ptot == a.Ptot && t.krows == a.krows && t.groups == a.groups && !(det && t.sk > 1)) { a.bm = t.bm; a.kg = t.kg; a.splitk = t.sk; a.mtiles = 1; break; }
+    }
+    if (!g_force_bm && a.mtiles) {
+        // experiment knob (VC_IGEMM_MAXKG=1|2): cap the K groups of a tuned entry, moving the rest of its K parallelism to
+        // split-K across workgroups -- smaller workgroups (74 / 37 KB of LDS instead of 148) can share a CU with the other chains
+        static const int maxkg = getenv("VC_IGEMM_MAXKG") ? atoi(getenv("VC_IGEMM_MAXKG")) : 0;
+        while (maxkg > 0 && a.kg > maxkg && !det) { a.kg /= 2; a.splitk *= 2; }
     }
     if (g_force_bm || a.mtiles) { a.mtiles = (a.M + a.bm - 1) / a.bm; a.ntiles = (a.Ptot + 63) / 64; return; }
     // Cost model in microseconds, fitted to the sweep of tools/tune_igemm.py (profiles/r02_tune_sweep_b8.txt): a workgroup

@@ -96,11 +96,11 @@ static const TunedCfg kTunedIgemm[] = {
     // d_d3 dgrad: 254.4 us
     {1, 512, 384, 24576, 2, 64, 1, 8},
     {1, 512, 384, 12288, 2, 64, 1, 8},
-    // d_d3_2B fwd: 458.1 us
-    {0, 2048, 768, 9216, 2, 64, 1, 4},
-    // d_d3_2B dgrad: 455.5 us
-    {1, 512, 768, 24576, 2, 128, 1, 8},
-    {1, 512, 768, 12288, 2, 128, 1, 8},
+    // d_d3_2B fwd (round-3 re-sweep without rowskip: 64x2/2 471, 64x2/1 478, 128x2/2 481 on a box where 64x1/4 took 490+)
+    {0, 2048, 768, 9216, 2, 64, 2, 2},
+    // d_d3_2B dgrad (re-sweep: 64x1/4 482, 64x2/4 487, 128x1/8 497)
+    {1, 512, 768, 24576, 2, 64, 1, 4},
+    {1, 512, 768, 12288, 2, 64, 1, 4},
     // ---- batch 32 per GPU, 24x128 MCEP
     // g_d1 fwd: 34.6 us (automatic choice before this sweep: 37.2 us)
     {0, 512, 2048, 640, 2, 128, 2, 1},
@@ -191,8 +191,8 @@ static const TunedCfg kTunedIgemm[] = {
     {1, 256, 6144, 2048, 2, 128, 1, 1},
     {1, 256, 6144, 1024, 2, 128, 1, 1},
     // d_d3 dgrad: 843.1 us (automatic choice before this sweep: 993.7 us)
-    {1, 512, 1536, 24576, 2, 128, 2, 4},
-    {1, 512, 1536, 12288, 2, 128, 2, 4},
+    {1, 512, 1536, 24576, 2, 128, 1, 8},      // (re-sweep without rowskip: 128x1/8 910, 128x1/4 912, 128x2/4 945)
+    {1, 512, 1536, 12288, 2, 128, 1, 8},
     // d_d3_2B fwd: 1463.5 us (automatic choice before this sweep: 2462.7 us)
     {0, 2048, 3072, 9216, 2, 128, 2, 1},
     // d_d3_2B dgrad: 1535.9 us (automatic choice before this sweep: 1643.4 us)
