@@ -975,14 +975,16 @@ static int plan_create(int num_features, int n_frames, bool inference, vc_plan**
         }
     }
     if (r) { release_tables(p->tables); delete p; return r; }
-    // Filter gradients and the update (exchange + Adam) are leaves of the step: their streams get the LOWEST priority, so the
-    // dispatcher prefers the kernels of the two dependency chains whenever both have workgroups ready (VC_STREAM_PRIO=0: off)
-    static const bool prio = !(getenv("VC_STREAM_PRIO") && atoi(getenv("VC_STREAM_PRIO")) == 0);
+    // Stream priorities (VC_STREAM_PRIO, experiment knob; measured in profiles/r03_ab_streams.txt): 0 none (default),
+    // 1 filter-gradient streams lowest, 2 filter-gradient streams highest, 3 = 2 + side stream highest, 4 side stream highest
+    static const int prio = getenv("VC_STREAM_PRIO") ? atoi(getenv("VC_STREAM_PRIO")) : 0;
     int prio_lo = 0, prio_hi = 0;
-    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);      // numerically: lo = least urgent
-    auto leaf_stream = [&](hipStream_t* st) { return prio ? hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio_lo) : hipStreamCreateWithFlags(st, hipStreamNonBlocking); };
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);      // numerically: lo = least urgent, hi = most urgent
+    auto mk_stream = [&](hipStream_t* st, int pr) { return pr ? hipStreamCreateWithPriority(st, hipStreamNonBlocking, pr > 0 ? prio_hi : prio_lo) : hipStreamCreateWithFlags(st, hipStreamNonBlocking); };
+    const int leaf_pr = prio == 1 ? -1 : (prio == 2 || prio == 3) ? 1 : 0, side_pr = (prio == 3 || prio == 4) ? 1 : 0;
+    auto leaf_stream = [&](hipStream_t* st) { return mk_stream(st, leaf_pr); };
     hipError_t e = hipEventCreateWithFlags(&p->d_ready, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking);
+    if (e == hipSuccess) e = mk_stream(&p->side, side_pr);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming);
     if (e == hipSuccess) e = leaf_stream(&p->wstream);
