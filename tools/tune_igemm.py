@@ -27,6 +27,7 @@ from tests import gpu_util as U  # noqa: E402
 from voice_converter_cyclegan_amd._lib import lib, check  # noqa: E402
 
 CONFIGS = [(bm, kg, sk) for bm in (128, 64) for kg in (1, 2, 4) for sk in (1, 2, 4, 8, 16) if not (bm == 128 and kg == 4)]
+CONFIGS_BF16 = [(bm, nst, sk) for bm in (128, 64) for nst in (2, 4) for sk in (1, 2, 4, 8)]      # conv_bf16_kernel<tile rows, ring stages> x split-K
 
 
 def layers(F, T):
@@ -88,11 +89,14 @@ def main():
     ap.add_argument('--emit', default='')
     ap.add_argument('--reps', type=int, default=10)
     ap.add_argument('--only', default='')
+    ap.add_argument('--math', choices=['fp32', 'bf16'], default='fp32', help='bf16: sweep conv_bf16_kernel (the 16-bit data path) instead')
     args = ap.parse_args()
+    bf16 = args.math == 'bf16'
+    check(lib.vc_set_math_mode(1 if bf16 else 0))
     B = args.batch
     GL, DL = layers(args.features, args.frames)
     rng = np.random.default_rng(0)
-    rows, table, wtable = [], [], []
+    rows, table, wtable, btable = [], [], [], []
     # (name, geometry, samples per group, ops)
     shapes = []
     for nm, g in GL.items():
@@ -126,10 +130,31 @@ def main():
                 continue                                    # weight-stationary kernel, not the implicit GEMM
             check(lib.vc_tune_igemm_override(0, 0, 0)); check(lib.vc_tune_wgrad_override(0, 0, 0))
             check(lib.vc_tune_wgrad_store(1 if op == 'wgrad' else 0))
+            if bf16:
+                check(lib.vc_tune_conv_bf16_override(0, 0, 0))
+                kb = (C.c_int * 256)()
+                lib.vc_tune_conv_bf16_keys(kb, 64); f(); torch.cuda.synchronize()
+                nk = lib.vc_tune_conv_bf16_keys(kb, 64)
+                bkeys = sorted({tuple(kb[4 * i:4 * i + 4]) for i in range(min(nk, 64))})
             us, nl = time_call(f, kind, args.reps)
             line = '%-10s %-5s %6.2f GFLOP ideal %6.1f us | auto %7.1f us %6.1f TF (%d launch)' % (
                 nm, op, flops / 1e9, flops / 157.3e12 * 1e6, us, flops / us / 1e6, nl)
-            if args.sweep:
+            if args.sweep and bf16:
+                res = []
+                zero_us = 4.0 * (dw.numel() if op == 'wgrad' else 0) / 3e6
+                for bm, nst, sk in CONFIGS_BF16:
+                    check(lib.vc_tune_conv_bf16_override(bm, nst, sk))
+                    try:
+                        u, _ = time_call(f, kind, args.reps)
+                    except Exception:
+                        continue
+                    res.append((u + (zero_us if sk > 1 else 0.0), bm, nst, sk))
+                check(lib.vc_tune_conv_bf16_override(0, 0, 0))
+                res.sort()
+                line += ' | best ' + '  '.join('%dx%d/%d %.1f' % (bm, nst, sk, u) for u, bm, nst, sk in res[:4])
+                if res and bkeys:
+                    btable.append((nm, op, res[0], us, bkeys))
+            elif args.sweep:
                 res = []
                 zero_us = 4.0 * dw.numel() / 3e6              # zero-fill of dW at 3 TB/s, paid by split-K filter gradients
                 for bm, kg, sk in CONFIGS:
@@ -165,6 +190,13 @@ def main():
                 f.write('    // %s %s: %.1f us (automatic choice before this sweep: %.1f us)\n' % (nm, op, u, auto))
                 for at, M, P, kr in keys:
                     f.write('    {%d, %d, %d, %d, 2, %d, %d, %d},\n' % (at, M, P, kr, bm, kg, sk))
+    if args.emit and btable:
+        with open(args.emit + '_bf16.h', 'w') as f:
+            f.write('    // ---- batch %d per GPU, %dx%d MCEP\n' % (B, args.features, args.frames))
+            for nm, op, (u, bm, nst, sk), auto, keys in btable:
+                f.write('    // %s %s: %.1f us (rule of conv_bf16_config: %.1f us)\n' % (nm, op, u, auto))
+                for M, P, ko, gr in keys:
+                    f.write('    {%d, %d, %d, %d, %d, %d, %d},\n' % (M, P, ko, gr, bm, nst, sk))
     if args.emit and wtable:
         with open(args.emit + '_wgrad.h', 'w') as f:
             f.write('    // ---- batch %d per GPU, %dx%d MCEP\n' % (B, args.features, args.frames))

@@ -20,6 +20,8 @@
 // copies).  The filter gradient is the same kernel on operands repacked 8 PIXELS to a unit (im2col_bf16_kernel,
 // pack_pixel_octets_bf16_kernel; launch set-up in vc_api.hip: conv_wgrad).
 #include "vc_internal.h"
+#include <array>
+#include <vector>
 #include <algorithm>
 #include <type_traits>
 
@@ -390,8 +392,18 @@ extern "C" int vc_tune_conv_bf16_override(int tile_rows, int stages, int splitk)
     g_bf16_bm = tile_rows; g_bf16_nst = stages; g_bf16_sk = splitk;
     return 0;
 }
+// measured choices (tools/tune_igemm.py --math bf16 --sweep on MI355X), keyed by the launch shape; everything else by the rule below
+struct TunedBf16 { int M, Ptot, koct, groups, bm, nst, sk; };
+#include "vc_tuned_bf16.h"
 void conv_bf16_config(ConvBf16Args& a) {
     a.ntiles = (a.Ptot + 127) / 128;
+    if (!g_bf16_bm)
+        for (const TunedBf16& t : kTunedBf16)
+            if (t.M == a.M && t.Ptot == a.Ptot && t.koct == a.koct && t.groups == a.groups) {
+                a.bm = t.bm; a.nst = t.nst; a.mtiles = (a.M + a.bm - 1) / a.bm;
+                a.splitk = vc_det_active() ? 1 : t.sk;
+                return;
+            }
     const long t128 = (long)((a.M + 127) / 128) * a.ntiles * a.groups;
     // measured (tools/bench_conv.py + vc_tune_conv_bf16_override per shape, then whole steps at batch 8 - 64 on one box):
     //   more than one 128-row tile per CU : 128 rows, two resident workgroups with two stages each (1007 TFLOP/s on D.d3)
@@ -411,7 +423,16 @@ void conv_bf16_config(ConvBf16Args& a) {
     a.splitk = sk;
 }
 
+// tuning aid (tools/tune_igemm.py): the shape keys {M, Ptot, K octets, groups} of the calling thread's launches since the last read
+static thread_local std::vector<std::array<int, 4>> t_bf16_keys;
+extern "C" int vc_tune_conv_bf16_keys(int* out, int max_keys) {
+    const int n = (int)t_bf16_keys.size();
+    for (int i = 0; i < n && i < max_keys; ++i) for (int k = 0; k < 4; ++k) out[4 * i + k] = t_bf16_keys[i][k];
+    t_bf16_keys.clear();
+    return n;
+}
 int launch_conv_bf16(const ConvBf16Args& a, hipStream_t s, double flops, int prof_kind) {
+    if (t_bf16_keys.size() < 64) t_bf16_keys.push_back({a.M, a.Ptot, a.koct, a.groups});
     if (a.splitk > 1 && !a.accumulate) { vc_set_error("launch_conv_bf16: split-K requires accumulate semantics"); return -1; }
     dim3 grid(a.mtiles * a.ntiles, 1, a.groups * a.splitk);
     ProfScope ps(prof_kind, flops, s);
