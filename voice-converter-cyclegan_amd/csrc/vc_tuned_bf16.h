@@ -1,6 +1,43 @@
-// Measured configurations of conv_bf16_kernel (the 16-bit data path of the bf16 mode): tools/tune_igemm.py --math bf16 --sweep
-// on MI355X.  {M, Ptot, K octets, groups, tile rows, LDS ring stages, split-K}.  Shapes not listed go by the tile-count rule
-// in conv_bf16_config.
+// Measured configurations of conv_bf16_kernel (the 16-bit data path of the bf16 mode): tools/tune_igemm.py --math bf16 --batch 64
+// --sweep on MI355X (round 3; profiles/r03_tune_sweep_bf16_b64.txt), BASELINE configs[2]'s launch shapes (forward, input gradient,
+// and the filter gradient as a GEMM over the pixel axis).  Only shapes where the sweep beat the tile-count rule of
+// conv_bf16_config by more than the run-to-run spread (4 %) are listed.  {M, Ptot, K octets, groups, tile rows, LDS ring stages,
+// split-K}.
 static const TunedBf16 kTunedBf16[] = {
-    {0, 0, 0, 0, 128, 2, 1},        // (placeholder: never matches)
+    // ---- batch 64 per GPU, 24x128 MCEP
+    // g_d1_3B wgrad: 46.0 us (rule of conv_bf16_config: 54.9 us)
+    {640, 512, 1536, 2, 128, 4, 4},
+    // g_d2 fwd: 23.6 us (rule of conv_bf16_config: 26.4 us)
+    {1024, 2048, 160, 2, 64, 2, 1},
+    // g_d2_3B wgrad: 60.8 us (rule of conv_bf16_config: 70.4 us)
+    {1280, 1024, 768, 2, 64, 2, 1},
+    // g_r_h1 dgrad: 46.7 us (rule of conv_bf16_config: 53.6 us)
+    {512, 2048, 768, 2, 64, 2, 2},
+    // g_r_h1_2B dgrad: 67.1 us (rule of conv_bf16_config: 72.5 us)
+    {512, 4096, 768, 2, 64, 2, 1},
+    // g_r_h2 dgrad: 24.1 us (rule of conv_bf16_config: 25.6 us)
+    {1024, 2048, 192, 2, 64, 2, 1},
+    // g_r_h2_2B fwd: 39.7 us (rule of conv_bf16_config: 43.9 us)
+    {512, 4096, 384, 2, 64, 2, 1},
+    // g_r_h2_3B wgrad: 60.4 us (rule of conv_bf16_config: 70.6 us)
+    {3072, 512, 768, 2, 64, 2, 1},
+    // g_u1 dgrad: 63.9 us (rule of conv_bf16_config: 81.4 us)
+    {512, 2048, 1280, 2, 64, 2, 2},
+    // g_u1_2B dgrad: 101.4 us (rule of conv_bf16_config: 110.2 us)
+    {512, 4096, 1280, 2, 64, 2, 1},
+    // g_u2 dgrad: 56.1 us (rule of conv_bf16_config: 59.7 us)
+    {512, 4096, 640, 2, 64, 2, 1},
+    // g_u2_3B wgrad: 162.5 us (rule of conv_bf16_config: 175.1 us)
+    {2560, 1024, 1536, 2, 64, 2, 1},
+    // d_d1_2B wgrad: 223.4 us (rule of conv_bf16_config: 362.8 us)
+    {1152, 512, 6144, 2, 64, 2, 8},
+    // d_d2 dgrad: 139.0 us (rule of conv_bf16_config: 153.6 us)
+    {256, 6144, 128, 2, 64, 2, 1},
+    {256, 6144, 256, 2, 64, 2, 1},
+    {256, 6144, 512, 2, 64, 2, 1},
+    // d_d3 dgrad: 298.8 us (rule of conv_bf16_config: 396.3 us)
+    {512, 3072, 1536, 2, 128, 2, 2},
+    {512, 3072, 3072, 2, 128, 2, 2},
+    // d_d3_2B fwd: 425.4 us (rule of conv_bf16_config: 480.3 us)
+    {2048, 6144, 1152, 2, 128, 2, 1},
 };
