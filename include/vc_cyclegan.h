@@ -12,8 +12,11 @@
  *   - Every data pointer is a DEVICE pointer owned by the caller (fp32 unless
  *     noted).  `stream` is a hipStream_t passed as void*.  Calls enqueue work on
  *     that stream and return; they never synchronise.  Steady-state calls never
- *     allocate (small geometry tables are created on first use of a geometry, or
- *     ahead of time by vc_plan_create).
+ *     allocate.  What IS allocated, once, on first use: the small geometry tables of
+ *     a convolution geometry (or ahead of time by vc_plan_create); in bf16 mode the
+ *     packed-operand workspace of the stream a convolution is issued on (operator-
+ *     AND plan-level calls; grown with hipMalloc when a larger operand arrives, see
+ *     vc_release_workspaces) and a plan's filter images (first bf16 train step).
  *   - Return value: 0 = ok, <0 = argument error (VC_E_*), >0 = hipError_t.
  *     vc_last_error() returns a human-readable message for the calling thread.
  *   - Layout is time-contiguous: 1-D activations [G][B][C][T], 2-D activations
@@ -137,8 +140,9 @@ int vc_conv2d_wgrad(const float* x, int64_t x_gs, const float* dy, int64_t dy_gs
  * is written: HBM sees the frames once and the activation once (the north-star kernel; inference plans use it, the train
  * step keeps value and gate for the backward).  Built for Cin = 24, k = 15 (24 MCEPs), Cout2 % 64 == 0, T % 4 == 0.
  * Math mode of the calling thread: fp32 (exact) or bf16 (operands rounded once, when the filters are packed / the frames
- * staged).  workspace (vc_gated_conv1d_glu_workspace_floats floats, 16-byte aligned) receives the filters re-laid-out as
- * the kernel's LDS image; it is rebuilt by a small launch on every call. */
+ * staged).  ONE launch: each workgroup builds its filter slab in LDS straight from w (round 3; the round-2 form packed the
+ * filters into `workspace` with a separate launch first).  workspace (vc_gated_conv1d_glu_workspace_floats floats, 16-byte
+ * aligned) is kept in the signature and only written when the library runs with VC_GLU_PACKED=1 (A/B measurements). */
 int64_t vc_gated_conv1d_glu_workspace_floats(int G, int Cout2);
 int vc_gated_conv1d_glu_fwd(const float* x, int64_t x_gs, const float* w, int64_t w_gs,
                             const float* bias, int64_t b_gs, float* out, int64_t out_gs,
