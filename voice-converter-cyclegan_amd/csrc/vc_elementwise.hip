@@ -8,6 +8,7 @@
 #include "vc_internal.h"
 #include "vc_device_util.h"
 #include <algorithm>
+#include <cstdlib>
 #include <mutex>
 #include <type_traits>
 #include <vector>
@@ -228,6 +229,119 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const NormArgs p) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) if (slot[k]) *slot[k] += racc[k];       // the only writer of this element in this launch
         }
+    }
+}
+
+// ---- 16-byte variants for the short rows of the generator (32 / 64 frames) and of D.d2 / D.d3 (96 / 48 pixels): a lane
+// owns 4 consecutive positions (one f32x4 per tensor), LPR = 8 / 16 / 32 lanes a row, up to 32 rows a block.  Same arithmetic
+// as norm_{fwd,bwd}_kernel; four times the bytes in flight per lane -- the scalar forms leave the HBM pipe half empty at
+// batch >= 32 (2.0-2.9 TB/s in profiles/r02_bf16_b64_hbm_gbs_per_kernel.txt).  No pixel shuffle, MODE 0 / 2, L % 4 == 0.
+template <int LPR> __device__ __forceinline__ float rowv_sum(float v) {
+    v += dpp_read<0xB1>(v); v += dpp_read<0x4E>(v); v += dpp_read<0x141>(v);      // sums of 8 lanes
+    if constexpr (LPR >= 16) v += dpp_read<0x140>(v);                             // row of 16
+    if constexpr (LPR >= 32) v += __shfl_xor(v, 16, 64);
+    return v;
+}
+__device__ __forceinline__ float hsum4(const f32x4 v) { return (v[0] + v[1]) + (v[2] + v[3]); }
+
+template <int MODE, int LPR>
+__global__ __launch_bounds__(256) void norm_fwd_v4_kernel(const NormArgs p) {
+    constexpr int NB = (MODE == 2) ? 1 : 2;
+    const int unit = blockIdx.x * (256 / LPR) + threadIdx.x / LPR, sub = threadIdx.x % LPR;
+    if (unit >= p.G * p.B * p.C) return;
+    const int g = unit / (p.B * p.C); const int rem = unit - g * (p.B * p.C);
+    const int b = rem / p.C, c = rem - b * p.C;
+    const bool ok = sub * 4 < p.L;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    const float* y = p.y + (long)g * p.y_gs + ((long)b * NB * p.C + c) * p.L + sub * 4;
+    float* out = p.out + (long)g * p.out_gs + ((long)b * p.C + c) * p.L + sub * 4;
+    const float invL = 1.f / (float)p.L;
+    const f32x4 v = ok ? *reinterpret_cast<const f32x4*>(y) : zero;
+    f32x4 gt = zero, res = zero;
+    if (NB == 2 && ok) gt = *reinterpret_cast<const f32x4*>(y + (long)p.C * p.L);
+    if (MODE == 2 && ok) res = *reinterpret_cast<const f32x4*>(p.res + (long)g * p.res_gs + ((long)b * p.C + c) * p.L + sub * 4);
+    const float* gam = p.gamma + (long)g * p.par_gs;
+    const float* bet = p.beta + (long)g * p.par_gs;
+    float* st = p.stats + (long)g * p.st_gs + ((long)b * NB * p.C) * 2;
+    const float mu = rowv_sum<LPR>(hsum4(v)) * invL;
+    const f32x4 d = ok ? v - mu : zero;
+    const float rs = rsqrtf(rowv_sum<LPR>(hsum4(d * d)) * invL + IN_EPS);
+    const float ga = gam[c], be = bet[c];
+    if (sub == 0) { st[2 * c] = mu; st[2 * c + 1] = rs; }
+    if (MODE == 2) {
+        if (ok) *reinterpret_cast<f32x4*>(out) = res + (d * rs * ga + be);
+        return;
+    }
+    const float mu2 = rowv_sum<LPR>(hsum4(gt)) * invL;
+    const f32x4 d2 = ok ? gt - mu2 : zero;
+    const float rs2 = rsqrtf(rowv_sum<LPR>(hsum4(d2 * d2)) * invL + IN_EPS);
+    const float ga2 = gam[p.C + c], be2 = bet[p.C + c];
+    if (sub == 0) { st[2 * (p.C + c)] = mu2; st[2 * (p.C + c) + 1] = rs2; }
+    if (ok) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (d[e] * rs * ga + be) * sigmoidf_(d2[e] * rs2 * ga2 + be2);
+        *reinterpret_cast<f32x4*>(out) = o;
+    }
+}
+
+template <int MODE, int LPR>
+__global__ __launch_bounds__(256) void norm_bwd_v4_kernel(const NormArgs p) {
+    constexpr int NB = (MODE == 2) ? 1 : 2;
+    const int unit = blockIdx.x * (256 / LPR) + threadIdx.x / LPR, sub = threadIdx.x % LPR;
+    if (unit >= p.G * p.B * p.C) return;
+    const int g = unit / (p.B * p.C); const int rem = unit - g * (p.B * p.C);
+    const int b = rem / p.C, c = rem - b * p.C;
+    const bool ok = sub * 4 < p.L;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    const long row = ((long)b * NB * p.C + c) * p.L + sub * 4;
+    const float* y = p.y + (long)g * p.y_gs + row;
+    float* dy = p.dy + (long)g * p.dy_gs + row;
+    const float invL = 1.f / (float)p.L;
+    const f32x4 v = ok ? *reinterpret_cast<const f32x4*>(y) : zero;
+    const f32x4 dO = ok ? *reinterpret_cast<const f32x4*>(p.dout + (long)g * p.do_gs + ((long)b * p.C + c) * p.L + sub * 4) : zero;
+    f32x4 gt = zero;
+    if (NB == 2 && ok) gt = *reinterpret_cast<const f32x4*>(y + (long)p.C * p.L);
+    const float* gam = p.gamma + (long)g * p.par_gs;
+    const float* bet = p.beta + (long)g * p.par_gs;
+    const float* st = p.stats_in + (long)g * p.st_gs + ((long)b * NB * p.C) * 2;
+    float* dgam = p.dgamma ? p.dgamma + (long)g * p.dpar_gs : nullptr;
+    float* dbet = p.dbeta ? p.dbeta + (long)g * p.dpar_gs : nullptr;
+    float* dbias = p.dbias ? p.dbias + (long)g * p.dbias_gs : nullptr;
+    const float mu = st[2 * c], rs = st[2 * c + 1], ga = gam[c], be = bet[c];
+    const f32x4 xv = ok ? (v - mu) * rs : zero;
+    if (MODE == 2) {
+        const float s1 = rowv_sum<LPR>(hsum4(dO)), s2 = rowv_sum<LPR>(hsum4(dO * xv));
+        const f32x4 d = ok ? (dO - s1 * invL - xv * (s2 * invL)) * (ga * rs) : zero;
+        if (ok) *reinterpret_cast<f32x4*>(dy) = d;
+        const float sb = rowv_sum<LPR>(hsum4(d));
+        if (sub == 0) {
+            if (dgam) { atomicAdd(dgam + c, s2); atomicAdd(dbet + c, s1); }
+            if (dbias) atomicAdd(dbias + c, sb);
+        }
+        return;
+    }
+    const float mu2 = st[2 * (p.C + c)], rs2 = st[2 * (p.C + c) + 1], ga2 = gam[p.C + c], be2 = bet[p.C + c];
+    const f32x4 xg = ok ? (gt - mu2) * rs2 : zero;
+    f32x4 dnv, dng;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float nv = ga * xv[e] + be, ng = ga2 * xg[e] + be2;
+        const float sg = sigmoidf_(ng);
+        dnv[e] = dO[e] * sg; dng[e] = dO[e] * nv * sg * (1.f - sg);
+    }
+    const float s1v = rowv_sum<LPR>(hsum4(dnv)), s2v = rowv_sum<LPR>(hsum4(dnv * xv));
+    const float s1g = rowv_sum<LPR>(hsum4(dng)), s2g = rowv_sum<LPR>(hsum4(dng * xg));
+    const f32x4 dv = ok ? (dnv - s1v * invL - xv * (s2v * invL)) * (ga * rs) : zero;
+    const f32x4 dg = ok ? (dng - s1g * invL - xg * (s2g * invL)) * (ga2 * rs2) : zero;
+    if (ok) { *reinterpret_cast<f32x4*>(dy) = dv; *reinterpret_cast<f32x4*>(dy + (long)p.C * p.L) = dg; }
+    if (dbias) {
+        const float sbv = rowv_sum<LPR>(hsum4(dv)), sbg = rowv_sum<LPR>(hsum4(dg));
+        if (sub == 0) { atomicAdd(dbias + c, sbv); atomicAdd(dbias + p.C + c, sbg); }
+    }
+    if (sub == 0 && dgam) {
+        atomicAdd(dgam + c, s2v); atomicAdd(dbet + c, s1v);
+        atomicAdd(dgam + p.C + c, s2g); atomicAdd(dbet + p.C + c, s1g);
     }
 }
 
@@ -653,6 +767,22 @@ static int norm_dispatch(const NormArgs& a, hipStream_t s) {
     const bool det = !FWD && a.det;                    // deterministic backward: one lane group per (group, channel), batch walked in order
     const int units = a.G * (det ? 1 : a.B) * a.C;
     dim3 block(256);
+    if constexpr (MODE != 1) {
+        // short rows, no pixel shuffle, 16-byte aligned rows: the f32x4 kernels (VC_NORM_V4=0 keeps the scalar forms: A/B)
+        static const bool v4 = !(getenv("VC_NORM_V4") && atoi(getenv("VC_NORM_V4")) == 0);
+        auto al = [](const void* q, long gs) { return ((uintptr_t)q & 15) == 0 && (gs & 3) == 0; };
+        bool ok = v4 && !det && !a.ps && (a.L & 3) == 0 && a.L <= 128 && al(a.y, a.y_gs);
+        if (FWD) ok = ok && al(a.out, a.out_gs) && (MODE != 2 || al(a.res, a.res_gs));
+        else ok = ok && al(a.dy, a.dy_gs) && al(a.dout, a.do_gs);
+        if (ok) {
+#define VC_NORM_V4(LPR) { dim3 grid((units + (256 / LPR) - 1) / (256 / LPR)); \
+            if (FWD) norm_fwd_v4_kernel<MODE, LPR><<<grid, block, 0, s>>>(a); else norm_bwd_v4_kernel<MODE, LPR><<<grid, block, 0, s>>>(a); }
+            if (a.L <= 32) VC_NORM_V4(8) else if (a.L <= 64) VC_NORM_V4(16) else VC_NORM_V4(32)
+#undef VC_NORM_V4
+            VC_HIP(hipGetLastError());
+            return 0;
+        }
+    }
 #define VC_NORM_CASE(LPR, NE) { dim3 grid((units + (256 / LPR) - 1) / (256 / LPR)); \
         if (FWD) norm_fwd_kernel<MODE, LPR, NE><<<grid, block, 0, s>>>(a); \
         else if (det) norm_bwd_kernel<MODE, LPR, NE, true><<<grid, block, 0, s>>>(a); \
