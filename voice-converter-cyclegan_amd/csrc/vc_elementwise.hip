@@ -232,10 +232,12 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const NormArgs p) {
     }
 }
 
-// ---- 16-byte variants for the short rows of the generator (32 / 64 frames) and of D.d2 / D.d3 (96 / 48 pixels): a lane
-// owns 4 consecutive positions (one f32x4 per tensor), LPR = 8 / 16 / 32 lanes a row, up to 32 rows a block.  Same arithmetic
-// as norm_{fwd,bwd}_kernel; four times the bytes in flight per lane -- the scalar forms leave the HBM pipe half empty at
-// batch >= 32 (2.0-2.9 TB/s in profiles/r02_bf16_b64_hbm_gbs_per_kernel.txt).  No pixel shuffle, MODE 0 / 2, L % 4 == 0.
+// ---- 16-byte variants for rows of up to 512 positions (every norm launch of the step except D.h1's 1536-pixel GLU): a lane
+// owns NV groups of 4 consecutive positions (one f32x4 per tensor and group; with pixel shuffle two f32x2: even positions
+// come from conv channel c, odd ones from channel C + c), LPR = 8 / 16 / 32 lanes a row, up to 32 rows a block.  Same
+// arithmetic as norm_{fwd,bwd}_kernel, four times the bytes in flight per lane: the scalar forms leave the HBM pipe half
+// empty (2.0-2.9 TB/s in profiles/r02_bf16_b64_hbm_gbs_per_kernel.txt) and sit on the critical path between two convolutions
+// (measured, whole step: bf16 batch 64 14.98 -> 13.87 ms, fp32 batch 8 7.73 -> 7.53 ms with the first version: L <= 128, no shuffle).
 template <int LPR> __device__ __forceinline__ float rowv_sum(float v) {
     v += dpp_read<0xB1>(v); v += dpp_read<0x4E>(v); v += dpp_read<0x141>(v);      // sums of 8 lanes
     if constexpr (LPR >= 16) v += dpp_read<0x140>(v);                             // row of 16
@@ -243,102 +245,190 @@ template <int LPR> __device__ __forceinline__ float rowv_sum(float v) {
     return v;
 }
 __device__ __forceinline__ float hsum4(const f32x4 v) { return (v[0] + v[1]) + (v[2] + v[3]); }
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// 4 consecutive logical positions starting at pos4 of (sample b, branch br, channel c) in the raw conv layout
+template <int NB, bool PS> struct RowV4 {
+    long even, odd; int C, L;      // float offsets of the row (PS: of conv channels c and C + c, rows of L / 2)
+    __device__ RowV4(const NormArgs& p, int b, int br, int c) : C(p.C), L(p.L) {
+        if (PS) { const int T = p.L >> 1; even = ((long)b * NB * 2 * p.C + br * 2 * p.C + c) * T; odd = even + (long)p.C * T; }
+        else { even = ((long)b * NB * p.C + br * p.C + c) * p.L; odd = 0; }
+    }
+    __device__ f32x4 load(const float* base, int pos4) const {
+        if (PS) {
+            const f32x2 e = *reinterpret_cast<const f32x2*>(base + even + (pos4 >> 1)), o = *reinterpret_cast<const f32x2*>(base + odd + (pos4 >> 1));
+            return f32x4{e[0], o[0], e[1], o[1]};
+        }
+        return *reinterpret_cast<const f32x4*>(base + even + pos4);
+    }
+    __device__ void store(float* base, int pos4, const f32x4 v) const {
+        if (PS) {
+            *reinterpret_cast<f32x2*>(base + even + (pos4 >> 1)) = f32x2{v[0], v[2]};
+            *reinterpret_cast<f32x2*>(base + odd + (pos4 >> 1)) = f32x2{v[1], v[3]};
+        } else *reinterpret_cast<f32x4*>(base + even + pos4) = v;
+    }
+};
 
-template <int MODE, int LPR>
+template <int MODE, int LPR, int NV, bool PS>
 __global__ __launch_bounds__(256) void norm_fwd_v4_kernel(const NormArgs p) {
     constexpr int NB = (MODE == 2) ? 1 : 2;
     const int unit = blockIdx.x * (256 / LPR) + threadIdx.x / LPR, sub = threadIdx.x % LPR;
     if (unit >= p.G * p.B * p.C) return;
     const int g = unit / (p.B * p.C); const int rem = unit - g * (p.B * p.C);
     const int b = rem / p.C, c = rem - b * p.C;
-    const bool ok = sub * 4 < p.L;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    const float* y = p.y + (long)g * p.y_gs + ((long)b * NB * p.C + c) * p.L + sub * 4;
-    float* out = p.out + (long)g * p.out_gs + ((long)b * p.C + c) * p.L + sub * 4;
+    const float* y = p.y + (long)g * p.y_gs;
+    float* out = p.out + (long)g * p.out_gs + ((long)b * p.C + c) * p.L;
     const float invL = 1.f / (float)p.L;
-    const f32x4 v = ok ? *reinterpret_cast<const f32x4*>(y) : zero;
-    f32x4 gt = zero, res = zero;
-    if (NB == 2 && ok) gt = *reinterpret_cast<const f32x4*>(y + (long)p.C * p.L);
-    if (MODE == 2 && ok) res = *reinterpret_cast<const f32x4*>(p.res + (long)g * p.res_gs + ((long)b * p.C + c) * p.L + sub * 4);
+    const RowV4<NB, PS> r0(p, b, 0, c), r1(p, b, NB - 1, c);
+    f32x4 v[NV], gt[NV]; bool ok[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int pos4 = (sub + j * LPR) * 4;
+        ok[j] = pos4 < p.L;
+        v[j] = ok[j] ? r0.load(y, pos4) : zero;
+        gt[j] = (NB == 2 && ok[j]) ? r1.load(y, pos4) : zero;
+    }
+    if (MODE == 1) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) if (ok[j]) {
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = v[j][e] * sigmoidf_(gt[j][e]);
+            *reinterpret_cast<f32x4*>(out + (sub + j * LPR) * 4) = o;
+        }
+        return;
+    }
     const float* gam = p.gamma + (long)g * p.par_gs;
     const float* bet = p.beta + (long)g * p.par_gs;
     float* st = p.stats + (long)g * p.st_gs + ((long)b * NB * p.C) * 2;
-    const float mu = rowv_sum<LPR>(hsum4(v)) * invL;
-    const f32x4 d = ok ? v - mu : zero;
-    const float rs = rsqrtf(rowv_sum<LPR>(hsum4(d * d)) * invL + IN_EPS);
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) s += hsum4(v[j]);
+    const float mu = rowv_sum<LPR>(s) * invL;
+    float q = 0.f; f32x4 d[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) { d[j] = ok[j] ? v[j] - mu : zero; q += hsum4(d[j] * d[j]); }
+    const float rs = rsqrtf(rowv_sum<LPR>(q) * invL + IN_EPS);
     const float ga = gam[c], be = bet[c];
     if (sub == 0) { st[2 * c] = mu; st[2 * c + 1] = rs; }
     if (MODE == 2) {
-        if (ok) *reinterpret_cast<f32x4*>(out) = res + (d * rs * ga + be);
+        const float* res = p.res + (long)g * p.res_gs + ((long)b * p.C + c) * p.L;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) if (ok[j]) {
+            const int pos4 = (sub + j * LPR) * 4;
+            *reinterpret_cast<f32x4*>(out + pos4) = *reinterpret_cast<const f32x4*>(res + pos4) + (d[j] * rs * ga + be);
+        }
         return;
     }
-    const float mu2 = rowv_sum<LPR>(hsum4(gt)) * invL;
-    const f32x4 d2 = ok ? gt - mu2 : zero;
-    const float rs2 = rsqrtf(rowv_sum<LPR>(hsum4(d2 * d2)) * invL + IN_EPS);
+    float s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) s2 += hsum4(gt[j]);
+    const float mu2 = rowv_sum<LPR>(s2) * invL;
+    float q2 = 0.f; f32x4 d2[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) { d2[j] = ok[j] ? gt[j] - mu2 : zero; q2 += hsum4(d2[j] * d2[j]); }
+    const float rs2 = rsqrtf(rowv_sum<LPR>(q2) * invL + IN_EPS);
     const float ga2 = gam[p.C + c], be2 = bet[p.C + c];
     if (sub == 0) { st[2 * (p.C + c)] = mu2; st[2 * (p.C + c) + 1] = rs2; }
-    if (ok) {
+#pragma unroll
+    for (int j = 0; j < NV; ++j) if (ok[j]) {
         f32x4 o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (d[e] * rs * ga + be) * sigmoidf_(d2[e] * rs2 * ga2 + be2);
-        *reinterpret_cast<f32x4*>(out) = o;
+        for (int e = 0; e < 4; ++e) o[e] = (d[j][e] * rs * ga + be) * sigmoidf_(d2[j][e] * rs2 * ga2 + be2);
+        *reinterpret_cast<f32x4*>(out + (sub + j * LPR) * 4) = o;
     }
 }
 
-template <int MODE, int LPR>
+template <int MODE, int LPR, int NV, bool PS>
 __global__ __launch_bounds__(256) void norm_bwd_v4_kernel(const NormArgs p) {
     constexpr int NB = (MODE == 2) ? 1 : 2;
     const int unit = blockIdx.x * (256 / LPR) + threadIdx.x / LPR, sub = threadIdx.x % LPR;
     if (unit >= p.G * p.B * p.C) return;
     const int g = unit / (p.B * p.C); const int rem = unit - g * (p.B * p.C);
     const int b = rem / p.C, c = rem - b * p.C;
-    const bool ok = sub * 4 < p.L;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    const long row = ((long)b * NB * p.C + c) * p.L + sub * 4;
-    const float* y = p.y + (long)g * p.y_gs + row;
-    float* dy = p.dy + (long)g * p.dy_gs + row;
+    const float* y = p.y + (long)g * p.y_gs;
+    float* dy = p.dy + (long)g * p.dy_gs;
+    const float* dout = p.dout + (long)g * p.do_gs + ((long)b * p.C + c) * p.L;
     const float invL = 1.f / (float)p.L;
-    const f32x4 v = ok ? *reinterpret_cast<const f32x4*>(y) : zero;
-    const f32x4 dO = ok ? *reinterpret_cast<const f32x4*>(p.dout + (long)g * p.do_gs + ((long)b * p.C + c) * p.L + sub * 4) : zero;
-    f32x4 gt = zero;
-    if (NB == 2 && ok) gt = *reinterpret_cast<const f32x4*>(y + (long)p.C * p.L);
+    const RowV4<NB, PS> r0(p, b, 0, c), r1(p, b, NB - 1, c);
+    float* dbias = p.dbias ? p.dbias + (long)g * p.dbias_gs : nullptr;
+    // conv channels whose bias gradient this row feeds: branch br, even positions (or all) -> cb(br), odd (shuffled) -> + C
+    const int brs = PS ? 2 * p.C : p.C;
+    f32x4 v[NV], gt[NV], dO[NV]; bool ok[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int pos4 = (sub + j * LPR) * 4;
+        ok[j] = pos4 < p.L;
+        v[j] = ok[j] ? r0.load(y, pos4) : zero;
+        gt[j] = (NB == 2 && ok[j]) ? r1.load(y, pos4) : zero;
+        dO[j] = ok[j] ? *reinterpret_cast<const f32x4*>(dout + pos4) : zero;
+    }
+    auto bias_sums = [&](const f32x4 (&dv)[NV], int br) {          // conv-bias gradient of one branch (even / odd positions apart when shuffled)
+        float se = 0.f, so = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) { se += PS ? dv[j][0] + dv[j][2] : hsum4(dv[j]); so += PS ? dv[j][1] + dv[j][3] : 0.f; }
+        se = rowv_sum<LPR>(se); if (PS) so = rowv_sum<LPR>(so);
+        if (sub == 0) { atomicAdd(dbias + br * brs + c, se); if (PS) atomicAdd(dbias + br * brs + p.C + c, so); }
+    };
+    if (MODE == 1) {
+        f32x4 dv[NV], dg[NV];
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float sg = sigmoidf_(gt[j][e]); dv[j][e] = dO[j][e] * sg; dg[j][e] = dO[j][e] * v[j][e] * sg * (1.f - sg); }
+            if (ok[j]) { r0.store(dy, (sub + j * LPR) * 4, dv[j]); r1.store(dy, (sub + j * LPR) * 4, dg[j]); }
+        }
+        if (dbias) { bias_sums(dv, 0); bias_sums(dg, 1); }
+        return;
+    }
     const float* gam = p.gamma + (long)g * p.par_gs;
     const float* bet = p.beta + (long)g * p.par_gs;
     const float* st = p.stats_in + (long)g * p.st_gs + ((long)b * NB * p.C) * 2;
     float* dgam = p.dgamma ? p.dgamma + (long)g * p.dpar_gs : nullptr;
     float* dbet = p.dbeta ? p.dbeta + (long)g * p.dpar_gs : nullptr;
-    float* dbias = p.dbias ? p.dbias + (long)g * p.dbias_gs : nullptr;
     const float mu = st[2 * c], rs = st[2 * c + 1], ga = gam[c], be = bet[c];
-    const f32x4 xv = ok ? (v - mu) * rs : zero;
+    f32x4 xv[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) xv[j] = ok[j] ? (v[j] - mu) * rs : zero;
     if (MODE == 2) {
-        const float s1 = rowv_sum<LPR>(hsum4(dO)), s2 = rowv_sum<LPR>(hsum4(dO * xv));
-        const f32x4 d = ok ? (dO - s1 * invL - xv * (s2 * invL)) * (ga * rs) : zero;
-        if (ok) *reinterpret_cast<f32x4*>(dy) = d;
-        const float sb = rowv_sum<LPR>(hsum4(d));
-        if (sub == 0) {
-            if (dgam) { atomicAdd(dgam + c, s2); atomicAdd(dbet + c, s1); }
-            if (dbias) atomicAdd(dbias + c, sb);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) { s1 += hsum4(dO[j]); s2 += hsum4(dO[j] * xv[j]); }
+        s1 = rowv_sum<LPR>(s1); s2 = rowv_sum<LPR>(s2);
+        f32x4 d[NV];
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            d[j] = ok[j] ? (dO[j] - s1 * invL - xv[j] * (s2 * invL)) * (ga * rs) : zero;
+            if (ok[j]) r0.store(dy, (sub + j * LPR) * 4, d[j]);
         }
+        if (dbias) bias_sums(d, 0);
+        if (sub == 0 && dgam) { atomicAdd(dgam + c, s2); atomicAdd(dbet + c, s1); }
         return;
     }
     const float mu2 = st[2 * (p.C + c)], rs2 = st[2 * (p.C + c) + 1], ga2 = gam[p.C + c], be2 = bet[p.C + c];
-    const f32x4 xg = ok ? (gt - mu2) * rs2 : zero;
-    f32x4 dnv, dng;
+    f32x4 xg[NV], dnv[NV], dng[NV];
+    float s1v = 0.f, s2v = 0.f, s1g = 0.f, s2g = 0.f;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const float nv = ga * xv[e] + be, ng = ga2 * xg[e] + be2;
-        const float sg = sigmoidf_(ng);
-        dnv[e] = dO[e] * sg; dng[e] = dO[e] * nv * sg * (1.f - sg);
+    for (int j = 0; j < NV; ++j) {
+        xg[j] = ok[j] ? (gt[j] - mu2) * rs2 : zero;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float nv = ga * xv[j][e] + be, ng = ga2 * xg[j][e] + be2;
+            const float sg = sigmoidf_(ng);
+            dnv[j][e] = dO[j][e] * sg; dng[j][e] = dO[j][e] * nv * sg * (1.f - sg);
+        }
+        s1v += hsum4(dnv[j]); s2v += hsum4(dnv[j] * xv[j]); s1g += hsum4(dng[j]); s2g += hsum4(dng[j] * xg[j]);
     }
-    const float s1v = rowv_sum<LPR>(hsum4(dnv)), s2v = rowv_sum<LPR>(hsum4(dnv * xv));
-    const float s1g = rowv_sum<LPR>(hsum4(dng)), s2g = rowv_sum<LPR>(hsum4(dng * xg));
-    const f32x4 dv = ok ? (dnv - s1v * invL - xv * (s2v * invL)) * (ga * rs) : zero;
-    const f32x4 dg = ok ? (dng - s1g * invL - xg * (s2g * invL)) * (ga2 * rs2) : zero;
-    if (ok) { *reinterpret_cast<f32x4*>(dy) = dv; *reinterpret_cast<f32x4*>(dy + (long)p.C * p.L) = dg; }
-    if (dbias) {
-        const float sbv = rowv_sum<LPR>(hsum4(dv)), sbg = rowv_sum<LPR>(hsum4(dg));
-        if (sub == 0) { atomicAdd(dbias + c, sbv); atomicAdd(dbias + p.C + c, sbg); }
+    s1v = rowv_sum<LPR>(s1v); s2v = rowv_sum<LPR>(s2v); s1g = rowv_sum<LPR>(s1g); s2g = rowv_sum<LPR>(s2g);
+    f32x4 dv[NV], dg[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        dv[j] = ok[j] ? (dnv[j] - s1v * invL - xv[j] * (s2v * invL)) * (ga * rs) : zero;
+        dg[j] = ok[j] ? (dng[j] - s1g * invL - xg[j] * (s2g * invL)) * (ga2 * rs2) : zero;
+        if (ok[j]) { r0.store(dy, (sub + j * LPR) * 4, dv[j]); r1.store(dy, (sub + j * LPR) * 4, dg[j]); }
     }
+    if (dbias) { bias_sums(dv, 0); bias_sums(dg, 1); }
     if (sub == 0 && dgam) {
         atomicAdd(dgam + c, s2v); atomicAdd(dbet + c, s1v);
         atomicAdd(dgam + p.C + c, s2g); atomicAdd(dbet + p.C + c, s1g);
@@ -767,18 +857,21 @@ static int norm_dispatch(const NormArgs& a, hipStream_t s) {
     const bool det = !FWD && a.det;                    // deterministic backward: one lane group per (group, channel), batch walked in order
     const int units = a.G * (det ? 1 : a.B) * a.C;
     dim3 block(256);
-    if constexpr (MODE != 1) {
-        // short rows, no pixel shuffle, 16-byte aligned rows: the f32x4 kernels (VC_NORM_V4=0 keeps the scalar forms: A/B)
+    {
+        // rows of up to 512 positions, 16-byte aligned tensors: the f32x4 kernels (VC_NORM_V4=0 keeps the scalar forms: A/B)
         static const bool v4 = !(getenv("VC_NORM_V4") && atoi(getenv("VC_NORM_V4")) == 0);
         auto al = [](const void* q, long gs) { return ((uintptr_t)q & 15) == 0 && (gs & 3) == 0; };
-        bool ok = v4 && !det && !a.ps && (a.L & 3) == 0 && a.L <= 128 && al(a.y, a.y_gs);
+        bool ok = v4 && !det && (a.L & 3) == 0 && a.L <= 512 && al(a.y, a.y_gs);
         if (FWD) ok = ok && al(a.out, a.out_gs) && (MODE != 2 || al(a.res, a.res_gs));
         else ok = ok && al(a.dy, a.dy_gs) && al(a.dout, a.do_gs);
         if (ok) {
-#define VC_NORM_V4(LPR) { dim3 grid((units + (256 / LPR) - 1) / (256 / LPR)); \
-            if (FWD) norm_fwd_v4_kernel<MODE, LPR><<<grid, block, 0, s>>>(a); else norm_bwd_v4_kernel<MODE, LPR><<<grid, block, 0, s>>>(a); }
-            if (a.L <= 32) VC_NORM_V4(8) else if (a.L <= 64) VC_NORM_V4(16) else VC_NORM_V4(32)
+#define VC_NORM_V4P(LPR, NV, PS) { dim3 grid((units + (256 / LPR) - 1) / (256 / LPR)); \
+            if (FWD) norm_fwd_v4_kernel<MODE, LPR, NV, PS><<<grid, block, 0, s>>>(a); else norm_bwd_v4_kernel<MODE, LPR, NV, PS><<<grid, block, 0, s>>>(a); }
+#define VC_NORM_V4(LPR, NV) { if (a.ps) VC_NORM_V4P(LPR, NV, true) else VC_NORM_V4P(LPR, NV, false) }
+            if (a.L <= 32) VC_NORM_V4(8, 1) else if (a.L <= 64) VC_NORM_V4(16, 1) else if (a.L <= 128) VC_NORM_V4(32, 1)
+            else if (a.L <= 256) VC_NORM_V4(32, 2) else if (a.L <= 384) VC_NORM_V4(32, 3) else VC_NORM_V4(32, 4)
 #undef VC_NORM_V4
+#undef VC_NORM_V4P
             VC_HIP(hipGetLastError());
             return 0;
         }
