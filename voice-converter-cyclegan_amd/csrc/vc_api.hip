@@ -1520,7 +1520,6 @@ static int step_grads_impl(const vc_plan* p, const float* params, float* grads,
     if (ws_floats < m.total) { vc_set_error("workspace too small: %lld < %lld floats", (long long)ws_floats, (long long)m.total); return VC_E_NOMEM; }
     auto gs = [](long n) { return align64(n); };     // group stride of a two-group region
     const long PG = p->G.total, PD = p->D.total;
-    const long FTb = (long)B * p->F * p->T * sizeof(float);
     const long ft1 = m.ft1;
     float *X1 = ws + m.X1, *O1 = ws + m.O1, *CY = ws + m.CY, *DX = ws + m.DX, *DO = ws + m.DO;
     float *dO1 = ws + m.dO1, *dCY = ws + m.dCY, *dDO_D = ws + m.dDO_D, *dDO_G = ws + m.dDO_G;
@@ -1538,10 +1537,7 @@ static int step_grads_impl(const vc_plan* p, const float* params, float* grads,
     if (p->math == VC_MATH_BF16) VC_CHECK(refresh_filter_images(p, params, s));
     StepImages scope(p->math == VC_MATH_BF16 ? p : nullptr);
     // 1. first-hop inputs: g0 = A2B on [A;B], g1 = B2A on [B;A]   (model.py:44,51 / 47,50)
-    VC_HIP(hipMemcpyAsync(X1, A, FTb, hipMemcpyDeviceToDevice, s));
-    VC_HIP(hipMemcpyAsync(X1 + ft1, Bm, FTb, hipMemcpyDeviceToDevice, s));
-    VC_HIP(hipMemcpyAsync(X1 + X1g, Bm, FTb, hipMemcpyDeviceToDevice, s));
-    VC_HIP(hipMemcpyAsync(X1 + X1g + ft1, A, FTb, hipMemcpyDeviceToDevice, s));
+    VC_CHECK(launch_copy_list({{X1, A, ft1}, {X1 + ft1, Bm, ft1}, {X1 + X1g, Bm, ft1}, {X1 + X1g + ft1, A, ft1}}, s));
     // 0. zero the accumulated parts of the flat gradient on the side stream, under the first-hop forward (nothing touches
     //    them before step 7; the fork/join pairs below order it before every consumer).  The fork comes AFTER the first
     //    work on `stream`: under hipGraph capture, an event recorded on a stream that has captured nothing yet does not
@@ -1558,13 +1554,14 @@ static int step_grads_impl(const vc_plan* p, const float* params, float* grads,
     VC_CHECK(fork());
     // 3. cycle hop: g0 = A2B(gen_A) = cycle_B, g1 = B2A(gen_B) = cycle_A   (model.py:45,48)
     VC_CHECK(gen_forward(p, params, PG, O1 + O1g, -O1g, CY, CYg, S2, 2, B, s));
-    if (gen_A) VC_HIP(hipMemcpyAsync(gen_A, O1 + O1g, FTb, hipMemcpyDeviceToDevice, s));
-    if (gen_B) VC_HIP(hipMemcpyAsync(gen_B, O1, FTb, hipMemcpyDeviceToDevice, s));
-    // 4. discriminator inputs: g0 = D_A on [gen_A; A], g1 = D_B on [gen_B; B]   (model.py:53-54,75-78)
-    VC_HIP(hipMemcpyAsync(DX, O1 + O1g, FTb, hipMemcpyDeviceToDevice, s2));
-    VC_HIP(hipMemcpyAsync(DX + ft1, A, FTb, hipMemcpyDeviceToDevice, s2));
-    VC_HIP(hipMemcpyAsync(DX + DXg, O1, FTb, hipMemcpyDeviceToDevice, s2));
-    VC_HIP(hipMemcpyAsync(DX + DXg + ft1, Bm, FTb, hipMemcpyDeviceToDevice, s2));
+    // 4. discriminator inputs: g0 = D_A on [gen_A; A], g1 = D_B on [gen_B; B]   (model.py:53-54,75-78); the caller's copies of
+    //    generation_A / generation_B (model.py:112) ride in the same launch, on the side stream (joined before the step returns)
+    {
+        std::vector<CopyItem> items{{DX, O1 + O1g, ft1}, {DX + ft1, A, ft1}, {DX + DXg, O1, ft1}, {DX + DXg + ft1, Bm, ft1}};
+        if (gen_A) items.push_back({gen_A, O1 + O1g, ft1});
+        if (gen_B) items.push_back({gen_B, O1, ft1});
+        VC_CHECK(launch_copy_list(items, s2));
+    }
     // 5. D forward (the fake half doubles as D(fake) of the D sub-step: D weights are unchanged by the G update)
     VC_CHECK(disc_forward(p, params + 2 * PG, PD, DX, DXg, DO, DOg, SD, 2, 2 * B, s2));
     VC_CHECK(join());

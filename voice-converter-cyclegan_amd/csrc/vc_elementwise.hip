@@ -596,33 +596,53 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const float* dy, long dy
     if (threadIdx.x == 0) atomicAdd(db + (long)g * db_gs + c, s);
 }
 
-__global__ __launch_bounds__(256) void head_fwd_kernel(const float* x, long x_gs, const float* w, const float* bias,
-                                                       long par_gs, float* o, long o_gs, int C, int HW) {
-    __shared__ float red[4][64];
+// 16 waves a block: lanes along 64 pixels, the waves split the channels, 8 loads in flight per lane (the round-2 form -- 4
+// waves, one dependent load per trip -- took 63 us for 6 MB at the B = 8 step, on the critical path between D.d3 and the losses)
+#define VC_HEAD_WAVES 16
+__global__ __launch_bounds__(64 * VC_HEAD_WAVES) void head_fwd_kernel(const float* x, long x_gs, const float* w, const float* bias,
+                                                                    long par_gs, float* o, long o_gs, int C, int HW) {
+    __shared__ float red[VC_HEAD_WAVES][64];
     const int g = blockIdx.z, b = blockIdx.y;
     const int px = blockIdx.x * 64 + (threadIdx.x & 63), cq = threadIdx.x >> 6;
     const float* xb = x + (long)g * x_gs + (long)b * C * HW;
     const float* wg = w + (long)g * par_gs;
     float s = 0.f;
-    if (px < HW) for (int c = cq; c < C; c += 4) s += xb[(long)c * HW + px] * wg[c];
+    if (px < HW) {
+        int c = cq;
+#pragma unroll 1
+        for (; c + 7 * VC_HEAD_WAVES < C; c += 8 * VC_HEAD_WAVES) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = xb[(long)(c + u * VC_HEAD_WAVES) * HW + px];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u] * wg[c + u * VC_HEAD_WAVES];
+        }
+        for (; c < C; c += VC_HEAD_WAVES) s += xb[(long)c * HW + px] * wg[c];
+    }
     red[cq][threadIdx.x & 63] = s;
     __syncthreads();
     if (cq == 0 && px < HW) {
-        const float z = red[0][px & 63] + red[1][px & 63] + red[2][px & 63] + red[3][px & 63] + bias[(long)g * par_gs];
+        float z = bias[(long)g * par_gs];
+#pragma unroll
+        for (int q = 0; q < VC_HEAD_WAVES; ++q) z += red[q][px & 63];
         o[(long)g * o_gs + (long)b * HW + px] = sigmoidf_(z);
     }
 }
 
-// dx[b][c][p] = dz[b][p] * w[c], dz = dout*o*(1-o)
+// dx[b][c][p] = dz[b][p] * w[c], dz = dout*o*(1-o): a wave per (sample, channel) row, lanes along the pixels (32-bit index
+// arithmetic only: the flat 64-bit div / mod of the round-2 form cost more than the 3 MB it wrote)
 __global__ __launch_bounds__(256) void head_bwd_dx_kernel(const float* w, long par_gs, const float* o, long o_gs,
                                                           const float* dout, long do_gs, float* dx, long dx_gs, int B, int C, int HW) {
-    const int g = blockIdx.y;
-    const long n = (long)B * C * HW;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-        const int pxl = (int)(i % HW); const long bc = i / HW; const int c = (int)(bc % C); const int b = (int)(bc / C);
-        const float ov = o[(long)g * o_gs + (long)b * HW + pxl];
-        const float dz = dout[(long)g * do_gs + (long)b * HW + pxl] * ov * (1.f - ov);
-        dx[(long)g * dx_gs + i] = dz * w[(long)g * par_gs + c];
+    const int g = blockIdx.y, lane = threadIdx.x & 63;
+    const int rows = B * C;
+    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += gridDim.x * 4) {
+        const int b = row / C, c = row - b * C;
+        const float wc = w[(long)g * par_gs + c];
+        for (int pxl = lane; pxl < HW; pxl += 64) {
+            const float ov = o[(long)g * o_gs + (long)b * HW + pxl];
+            const float dz = dout[(long)g * do_gs + (long)b * HW + pxl] * ov * (1.f - ov);
+            dx[(long)g * dx_gs + (long)row * HW + pxl] = dz * wc;
+        }
     }
 }
 // one wave per channel: dw[c] += sum_{b,p} dz*x ; the wave of channel 0 also does db
@@ -822,6 +842,32 @@ int launch_set4(float* dst, float a, float b, float c, float d, hipStream_t s) {
     VC_HIP(hipGetLastError());
     return 0;
 }
+// one launch copies a whole list of (dst, src, floats) chunks -- the step's input assembly (was 4 + 4 + 2 hipMemcpyAsync per step)
+struct CopyList { float* d[8]; const float* s[8]; long n[8]; int count; };
+__global__ __launch_bounds__(256) void copy_list_kernel(const CopyList z) {
+    float* d = z.d[blockIdx.y]; const float* s = z.s[blockIdx.y]; const long n = z.n[blockIdx.y];
+    const long n4 = n >> 2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) reinterpret_cast<f32x4*>(d)[i] = reinterpret_cast<const f32x4*>(s)[i];
+    if (blockIdx.x == 0) for (long i = n4 * 4 + threadIdx.x; i < n; i += 256) d[i] = s[i];
+}
+int launch_copy_list(const std::vector<CopyItem>& items, hipStream_t s) {
+    for (size_t i0 = 0; i0 < items.size(); i0 += 8) {
+        CopyList z{}; long mx = 0; bool al = true;
+        z.count = (int)std::min<size_t>(8, items.size() - i0);
+        for (int i = 0; i < z.count; ++i) {
+            z.d[i] = items[i0 + i].dst; z.s[i] = items[i0 + i].src; z.n[i] = items[i0 + i].n; mx = std::max(mx, z.n[i]);
+            al = al && ((uintptr_t)z.d[i] % 16 == 0) && ((uintptr_t)z.s[i] % 16 == 0);
+        }
+        if (!al) {      // unaligned buffers: plain copies
+            for (int i = 0; i < z.count; ++i) VC_HIP(hipMemcpyAsync(z.d[i], z.s[i], (size_t)z.n[i] * sizeof(float), hipMemcpyDeviceToDevice, s));
+            continue;
+        }
+        long bx = (mx / 4 + 255) / 256; if (bx > 128) bx = 128; if (bx < 1) bx = 1;
+        copy_list_kernel<<<dim3((unsigned)bx, z.count), 256, 0, s>>>(z);
+    }
+    VC_HIP(hipGetLastError());
+    return 0;
+}
 int launch_zero_list(const std::vector<std::pair<float*, long>>& bufs, hipStream_t s) {
     for (size_t i0 = 0; i0 < bufs.size(); i0 += 48) {
         ZeroList z{}; long mx = 0;
@@ -922,7 +968,7 @@ int launch_bias_grad(const float* dy, long dy_gs, float* db, long db_gs, int G, 
 }
 int launch_head_fwd(const float* x, long x_gs, const float* w, const float* b, long par_gs,
                     float* o, long o_gs, int G, int B, int C, int HW, hipStream_t s) {
-    head_fwd_kernel<<<dim3((HW + 63) / 64, B, G), 256, 0, s>>>(x, x_gs, w, b, par_gs, o, o_gs, C, HW);
+    head_fwd_kernel<<<dim3((HW + 63) / 64, B, G), 64 * VC_HEAD_WAVES, 0, s>>>(x, x_gs, w, b, par_gs, o, o_gs, C, HW);
     VC_HIP(hipGetLastError());
     return 0;
 }
@@ -930,8 +976,8 @@ int launch_head_bwd(const float* x, long x_gs, const float* w, long par_gs, cons
                     const float* dout, long do_gs, float* dx, long dx_gs, float* dw, float* db,
                     long dpar_gs, int G, int B, int C, int HW, hipStream_t s) {
     if (dx) {
-        const long n = (long)B * C * HW;
-        const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+        const long rows = (long)B * C;
+        const int blocks = (int)((rows + 3) / 4 < 4096 ? (rows + 3) / 4 : 4096);
         head_bwd_dx_kernel<<<dim3(blocks, G), 256, 0, s>>>(w, par_gs, o, o_gs, dout, do_gs, dx, dx_gs, B, C, HW);
     }
     if (dw) head_bwd_dw_kernel<<<dim3((C + 3) / 4, G), 256, 0, s>>>(x, x_gs, o, o_gs, dout, do_gs, dw, db, dpar_gs, B, C, HW);

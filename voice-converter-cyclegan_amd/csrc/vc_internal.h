@@ -186,6 +186,8 @@ int launch_igemm_multi(const IgemmArgs* cls, int n, bool a_trans, int math, hipS
 int wgrad_splitk(const WgradArgs& a);            // the split-K factor launch_wgrad will use (1 = plain stores possible)
 int launch_wgrad(const WgradArgs& a, int math, hipStream_t s, double flops);
 int launch_zero_list(const std::vector<std::pair<float*, long>>& bufs, hipStream_t s);
+struct CopyItem { float* dst; const float* src; long n; };
+int launch_copy_list(const std::vector<CopyItem>& items, hipStream_t s);      // dst[i][0..n) = src[i][0..n), one launch per 8 items
 int launch_add(float* dst, const float* src, long n, hipStream_t s);   // dst += src
 int launch_norm_fwd(int mode, const NormArgs& a, hipStream_t s);
 int launch_norm_bwd(int mode, const NormArgs& a, hipStream_t s);
