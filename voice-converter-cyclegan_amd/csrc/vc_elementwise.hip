@@ -435,6 +435,36 @@ __global__ __launch_bounds__(256) void norm_bwd_v4_kernel(const NormArgs p) {
     }
 }
 
+// GLU backward without norm (module.py:201-203 / 161-163: the two h1 blocks) for rows of ANY length that is a multiple of 4
+// (D.h1: 1536 pixels at 24x128, 4608 at 36x256): no row statistics, so the row is streamed, 32 lanes x 16 bytes a trip
+__global__ __launch_bounds__(256) void glu_bwd_v4_kernel(const NormArgs p) {
+    constexpr int LPR = 32;
+    const int unit = blockIdx.x * (256 / LPR) + threadIdx.x / LPR, sub = threadIdx.x % LPR;
+    if (unit >= p.G * p.B * p.C) return;
+    const int g = unit / (p.B * p.C); const int rem = unit - g * (p.B * p.C);
+    const int b = rem / p.C, c = rem - b * p.C;
+    const long rv = ((long)b * 2 * p.C + c) * p.L, rg = rv + (long)p.C * p.L;
+    const float* y = p.y + (long)g * p.y_gs;
+    float* dy = p.dy + (long)g * p.dy_gs;
+    const float* dout = p.dout + (long)g * p.do_gs + ((long)b * p.C + c) * p.L;
+    float sv = 0.f, sg = 0.f;
+#pragma unroll 2
+    for (int pos4 = sub * 4; pos4 < p.L; pos4 += LPR * 4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(y + rv + pos4), gt = *reinterpret_cast<const f32x4*>(y + rg + pos4);
+        const f32x4 dO = *reinterpret_cast<const f32x4*>(dout + pos4);
+        f32x4 dv, dg;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float s = sigmoidf_(gt[e]); dv[e] = dO[e] * s; dg[e] = dO[e] * v[e] * s * (1.f - s); }
+        *reinterpret_cast<f32x4*>(dy + rv + pos4) = dv; *reinterpret_cast<f32x4*>(dy + rg + pos4) = dg;
+        sv += hsum4(dv); sg += hsum4(dg);
+    }
+    if (p.dbias) {
+        float* dbias = p.dbias + (long)g * p.dbias_gs;
+        sv = rowv_sum<LPR>(sv); sg = rowv_sum<LPR>(sg);
+        if (sub == 0) { atomicAdd(dbias + c, sv); atomicAdd(dbias + p.C + c, sg); }
+    }
+}
+
 // ---- streaming variants for rows longer than 2048 (36x256 discriminator, long utterances): one 256-thread block
 // per (g, b, c) row, the row is re-read from L2 for each pass instead of living in registers.
 __device__ __forceinline__ float block_sum_256s(float v, float* red) {
@@ -907,9 +937,15 @@ static int norm_dispatch(const NormArgs& a, hipStream_t s) {
         // rows of up to 512 positions, 16-byte aligned tensors: the f32x4 kernels (VC_NORM_V4=0 keeps the scalar forms: A/B)
         static const bool v4 = !(getenv("VC_NORM_V4") && atoi(getenv("VC_NORM_V4")) == 0);
         auto al = [](const void* q, long gs) { return ((uintptr_t)q & 15) == 0 && (gs & 3) == 0; };
-        bool ok = v4 && !det && (a.L & 3) == 0 && a.L <= 512 && al(a.y, a.y_gs);
+        bool ok = v4 && !det && (a.L & 3) == 0 && al(a.y, a.y_gs);
         if (FWD) ok = ok && al(a.out, a.out_gs) && (MODE != 2 || al(a.res, a.res_gs));
         else ok = ok && al(a.dy, a.dy_gs) && al(a.dout, a.do_gs);
+        if (ok && MODE == 1 && !FWD && !a.ps && a.L > 512) {          // long GLU rows (D.h1): streamed
+            glu_bwd_v4_kernel<<<dim3((units + 7) / 8), block, 0, s>>>(a);
+            VC_HIP(hipGetLastError());
+            return 0;
+        }
+        ok = ok && a.L <= 512;
         if (ok) {
 #define VC_NORM_V4P(LPR, NV, PS) { dim3 grid((units + (256 / LPR) - 1) / (256 / LPR)); \
             if (FWD) norm_fwd_v4_kernel<MODE, LPR, NV, PS><<<grid, block, 0, s>>>(a); else norm_bwd_v4_kernel<MODE, LPR, NV, PS><<<grid, block, 0, s>>>(a); }
