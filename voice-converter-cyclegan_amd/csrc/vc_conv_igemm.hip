@@ -23,6 +23,7 @@
 #include "vc_internal.h"
 #include "vc_device_util.h"
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <type_traits>
 #include <utility>
@@ -421,6 +422,31 @@ void igemm_config(IgemmArgs& a, int math) {
         const int at = a.a_ms != 1 ? 1 : 0;
         for (const TunedCfg& t : kTunedIgemm)
             if (t.at == at && t.M == a.M && t.Ptot == a.Ptot && t.krows == a.krows && t.groups == a.groups && !(det && t.sk > 1)) { a.bm = t.bm; a.kg = t.kg; a.splitk = t.sk; a.mtiles = 1; break; }
+    }
+    if (!g_force_bm && !a.mtiles) {
+        // No exact entry: the same LAYER (same filter-side shape: transposed?, M, K rows, groups) measured at another pixel
+        // count.  The nearest one in log(pixels) within a factor of 4 lends its tile rows and K groups; split-K halves /
+        // doubles with the pixel count (more pixel tiles -> less need to split K).  Makes the measured tables serve every
+        // batch size instead of the three benched ones (the cost model below remains for layers never measured).
+        const int at = a.a_ms != 1 ? 1 : 0;
+        const TunedCfg* nb = nullptr; double bd = 1e30;
+        for (const TunedCfg& t : kTunedIgemm)
+            if (t.at == at && t.M == a.M && t.krows == a.krows && t.groups == a.groups && !(det && t.sk > 1)) {
+                const double d = std::fabs(std::log((double)t.Ptot / (double)a.Ptot));
+                if (d < bd) { bd = d; nb = &t; }
+            }
+        if (nb && bd <= std::log(4.0) + 1e-9) {
+            a.bm = nb->bm; a.kg = nb->kg;
+            int sk = nb->sk;
+            for (double r = (double)a.Ptot / nb->Ptot; r >= 1.99 && sk > 1; r *= 0.5) sk /= 2;
+            if (!det) for (double r = (double)a.Ptot / nb->Ptot; r <= 0.501 && sk < 16; r *= 2.0) sk *= 2;
+            while (sk > 1) {          // every part must have work
+                const int parts = a.kg * sk, cps = (((nchunks + parts - 1) / parts) + 1) & ~1;
+                if (cps * (parts - 1) < nchunks) break;
+                sk /= 2;
+            }
+            a.splitk = sk; a.mtiles = 1;
+        }
     }
     if (!g_force_bm && a.mtiles) {
         // experiment knob (VC_IGEMM_MAXKG=1|2): cap the K groups of a tuned entry, moving the rest of its K parallelism to

@@ -14,6 +14,7 @@
 // upper lane half) in the VGPR offset, VC_OOB where the tap leaves the image for that pixel (hardware range check -> 0).
 #include "vc_internal.h"
 #include <algorithm>
+#include <cmath>
 #include <type_traits>
 #include <utility>
 
@@ -284,6 +285,25 @@ static WgradCfg wgrad_config(const WgradArgs& a) {
     for (const TunedWgrad& t : kTunedWgrad)
         if (t.ktiles == a.ktiles && t.N == a.N && t.nchunks == a.nchunks && t.groups == a.groups && t.store == a.store && !(det && t.sk > 1))
             return WgradCfg{t.bn, t.kg, t.sk};
+    {
+        // no exact entry: the same layer (K tiles, Cout, groups) measured at another reduction length, nearest in log(chunks)
+        // within a factor of 4, lends its configuration (see igemm_config)
+        const TunedWgrad* nb = nullptr; double bd = 1e30;
+        for (const TunedWgrad& t : kTunedWgrad)
+            if (t.ktiles == a.ktiles && t.N == a.N && t.groups == a.groups && t.store == a.store && t.nchunks > 0 && !(det && t.sk > 1)) {
+                const double d = std::fabs(std::log((double)t.nchunks / (double)a.nchunks));
+                if (d < bd) { bd = d; nb = &t; }
+            }
+        if (nb && bd <= std::log(4.0) + 1e-9) {
+            int sk = nb->sk;
+            while (sk > 1) {
+                const int parts = nb->kg * sk, cps = (((a.nchunks + parts - 1) / parts) + 1) & ~1;
+                if (cps * (parts - 1) < a.nchunks) break;
+                sk /= 2;
+            }
+            return WgradCfg{nb->bn, nb->kg, sk};
+        }
+    }
     WgradCfg best{128, 1, 1}; double bestc = 1e30;
     const double out_bytes = 4.0 * 64.0 * a.ktiles * (double)a.N * a.groups;
     for (int bn : {128, 64}) {
