@@ -218,6 +218,11 @@ def test_oracle_against_tensorflow_reference():
     for i, n in enumerate(z['grad_names']):                          # parameters after three TF-Adam steps
         n = str(n)
         assert abs(np.linalg.norm(orc.P[n].astype(np.float64)) - z['param_l2'][i]) <= 1e-4 * z['param_l2'][i] + 1e-6, n
+        if 'param_proj' in z.files:
+            # random projection of the parameters after three TF-Adam steps: three moves of <= lr = 2e-4 per element; a flipped
+            # near-zero gradient is 2 lr on one element, so the bound is in units of lr * sqrt(size)
+            tol = 3e-3 * z['param_l2'][i] + 0.1 * 2e-4 * np.sqrt(orc.P[n].size)
+            assert abs(_probe(orc.P[n], i) - z['param_proj'][i]) <= tol, n
 
 
 def test_bf16_operand_rounding_is_round_to_nearest_even():
