@@ -695,26 +695,47 @@ __global__ __launch_bounds__(256) void head_bwd_dw_kernel(const float* x, long x
     if (c == 0) { sb = wave_sum(sb); if (lane == 0) atomicAdd(db + (long)g * dpar_gs, sb); }
 }
 
+// NT: the Adam slots m and v are pure streams (read once, written once per step, 2 x 479 MB): non-temporal loads / stores
+// keep them from evicting the weights and gradients the rest of the step re-reads from L2 / Infinity Cache.  Two float4
+// groups per thread and trip: twice the bytes in flight.
+template <bool NT>
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
                                                    const float* __restrict__ g, long n4, long n, float alpha_arg,
                                                    float b1, float b2, float eps, float gs, const float* __restrict__ alpha_dev) {
     const float alpha = alpha_dev ? *alpha_dev : alpha_arg;      // captured steps (hipGraph) read the step size from device memory
     const float omb1 = 1.f - b1, omb2 = 1.f - b2;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
-        float4 P = reinterpret_cast<float4*>(p)[i], M = reinterpret_cast<float4*>(m)[i], V = reinterpret_cast<float4*>(v)[i];
-        float4 G = reinterpret_cast<const float4*>(g)[i];
-#define VC_ADAM1(x) { const float gg = G.x * gs; M.x += (gg - M.x) * omb1; V.x += (gg * gg - V.x) * omb2; \
-                      P.x -= (M.x * alpha) / (sqrtf(V.x) + eps); }
-        VC_ADAM1(x) VC_ADAM1(y) VC_ADAM1(z) VC_ADAM1(w)
-        reinterpret_cast<float4*>(p)[i] = P; reinterpret_cast<float4*>(m)[i] = M; reinterpret_cast<float4*>(v)[i] = V;
+    auto ld = [](const f32x4* q) { return NT ? __builtin_nontemporal_load(q) : *q; };
+    auto st = [](f32x4* q, const f32x4 x) { if (NT) __builtin_nontemporal_store(x, q); else *q = x; };
+    auto upd = [&](f32x4& P, f32x4& M, f32x4& V, const f32x4 G) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float gg = G[e] * gs;
+            M[e] += (gg - M[e]) * omb1; V[e] += (gg * gg - V[e]) * omb2;
+            P[e] -= (M[e] * alpha) / (sqrtf(V[e]) + eps);
+        }
+    };
+    f32x4* p4 = reinterpret_cast<f32x4*>(p); f32x4* m4 = reinterpret_cast<f32x4*>(m); f32x4* v4 = reinterpret_cast<f32x4*>(v);
+    const f32x4* g4 = reinterpret_cast<const f32x4*>(g);
+    const long stride = (long)gridDim.x * 256;
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    for (; i + stride < n4; i += 2 * stride) {
+        f32x4 P0 = p4[i], M0 = ld(m4 + i), V0 = ld(v4 + i), P1 = p4[i + stride], M1 = ld(m4 + i + stride), V1 = ld(v4 + i + stride);
+        const f32x4 G0 = g4[i], G1 = g4[i + stride];
+        upd(P0, M0, V0, G0); upd(P1, M1, V1, G1);
+        p4[i] = P0; st(m4 + i, M0); st(v4 + i, V0); p4[i + stride] = P1; st(m4 + i + stride, M1); st(v4 + i + stride, V1);
+    }
+    if (i < n4) {
+        f32x4 P0 = p4[i], M0 = ld(m4 + i), V0 = ld(v4 + i);
+        upd(P0, M0, V0, g4[i]);
+        p4[i] = P0; st(m4 + i, M0); st(v4 + i, V0);
     }
     if (blockIdx.x == 0) {
-        for (long i = n4 * 4 + threadIdx.x; i < n; i += 256) {
-            const float gg = g[i] * gs;
-            float mm = m[i], vv = v[i];
+        for (long k = n4 * 4 + threadIdx.x; k < n; k += 256) {
+            const float gg = g[k] * gs;
+            float mm = m[k], vv = v[k];
             mm += (gg - mm) * omb1; vv += (gg * gg - vv) * omb2;
-            p[i] -= (mm * alpha) / (sqrtf(vv) + eps);
-            m[i] = mm; v[i] = vv;
+            p[k] -= (mm * alpha) / (sqrtf(vv) + eps);
+            m[k] = mm; v[k] = vv;
         }
     }
 }
@@ -1024,7 +1045,9 @@ int launch_adam(float* p, float* m, float* v, const float* g, long n, float alph
                 float b2, float eps, float gscale, hipStream_t s, const float* alpha_dev) {
     const long n4 = n / 4;
     long blocks = (n4 + 255) / 256; if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
-    adam_kernel<<<dim3((unsigned)blocks), 256, 0, s>>>(p, m, v, g, n4, n, alpha, b1, b2, eps, gscale, alpha_dev);
+    static const bool nt = !(getenv("VC_ADAM_NT") && atoi(getenv("VC_ADAM_NT")) == 0);      // A/B: VC_ADAM_NT=0 = plain loads / stores
+    if (nt) adam_kernel<true><<<dim3((unsigned)blocks), 256, 0, s>>>(p, m, v, g, n4, n, alpha, b1, b2, eps, gscale, alpha_dev);
+    else adam_kernel<false><<<dim3((unsigned)blocks), 256, 0, s>>>(p, m, v, g, n4, n, alpha, b1, b2, eps, gscale, alpha_dev);
     VC_HIP(hipGetLastError());
     return 0;
 }
