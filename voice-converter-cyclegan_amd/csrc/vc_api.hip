@@ -1125,14 +1125,19 @@ static void scratch_map(const std::vector<LayerGeo>& geo, int B, long* dY, long*
 
 static int net_forward(NetCtx& c, const float* x, long x_gs, float* y_plain, long y_plain_gs) {
     // one launch zeroes every raw conv output of this pass whose convolution will reduce over split-K with atomics
+    bool plain_zeroed = true;
     {
         std::vector<std::pair<float*, long>> zl;
         for (size_t i = 0; i < c.n->layers.size(); ++i) {
             const Layer& L = c.n->layers[i];
-            if (L.mode == M_PLAIN) continue;
             bool split = false;
             VC_CHECK(conv_fwd(nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0, c.G, c.B, (*c.geo)[i].g, c.math, c.s, false, &split));
-            if (split) for (int g = 0; g < c.G; ++g) zl.push_back({c.save + c.sm.raw[i] + (long)g * c.save_gs, (*c.geo)[i].raw_ps * c.B});
+            if (!split) continue;
+            // the network's output (the plain last layer writes it directly) rides in the same list when it is 16-byte aligned
+            float* dst = (L.mode == M_PLAIN) ? y_plain : c.save + c.sm.raw[i];
+            const long dst_gs = (L.mode == M_PLAIN) ? y_plain_gs : c.save_gs;
+            if (L.mode == M_PLAIN && (!aligned16(y_plain) || (y_plain_gs & 3))) { plain_zeroed = false; continue; }
+            for (int g = 0; g < c.G; ++g) zl.push_back({dst + (long)g * dst_gs, (*c.geo)[i].raw_ps * c.B});
         }
         if (!zl.empty()) VC_CHECK(launch_zero_list(zl, c.s));
     }
@@ -1168,7 +1173,7 @@ static int net_forward(NetCtx& c, const float* x, long x_gs, float* y_plain, lon
             fn.stats = c.save + c.sm.st[i]; fn.st_gs = c.save_gs; fn.act = c.save + c.sm.act[i]; fn.act_gs = c.save_gs;
         }
         VC_CHECK(conv_fwd(in, in_gs, c.params + L.w, c.par_gs, c.params + L.b, c.par_gs, raw, raw_gs, c.G, c.B, lg.g, c.math, c.s,
-                          /*prezeroed=*/L.mode != M_PLAIN, nullptr, c.images ? (*c.images)[i].fwd : nullptr,
+                          /*prezeroed=*/L.mode != M_PLAIN || plain_zeroed, nullptr, c.images ? (*c.images)[i].fwd : nullptr,
                           (c.keep_packed && i > 0) ? (char*)(c.save + c.sm.actp[i - 1]) : nullptr, c.save_gs * 4,
                           fn.act ? &fn : nullptr));
         if (L.mode == M_PLAIN) break;

@@ -376,8 +376,16 @@ int launch_c1_dgrad(const C1Args& a, int accumulate, hipStream_t s) {
         VC_HIP(hipGetLastError());
         return 0;
     }
-    if (!accumulate)
-        for (int g = 0; g < a.G; ++g) VC_HIP(hipMemsetAsync(a.dx + (long)g * a.dx_gs, 0, (size_t)a.B * a.H * a.W * sizeof(float), s));
+    if (!accumulate) {          // the scatter accumulates with atomics: one launch zeroes dx of every group
+        bool al = true;
+        for (int g = 0; g < a.G; ++g) al = al && ((uintptr_t)(a.dx + (long)g * a.dx_gs) % 16 == 0);
+        if (al) {
+            std::vector<std::pair<float*, long>> zl;
+            for (int g = 0; g < a.G; ++g) zl.push_back({a.dx + (long)g * a.dx_gs, (long)a.B * a.H * a.W});
+            const int r = launch_zero_list(zl, s); if (r) return r;
+        } else
+            for (int g = 0; g < a.G; ++g) VC_HIP(hipMemsetAsync(a.dx + (long)g * a.dx_gs, 0, (size_t)a.B * a.H * a.W * sizeof(float), s));
+    }
     c1_dgrad_kernel<<<dim3((P + 255) / 256, a.B, a.G * nch), 256, 0, s>>>(a);
     VC_HIP(hipGetLastError());
     return 0;
