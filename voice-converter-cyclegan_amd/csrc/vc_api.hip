@@ -84,6 +84,9 @@ struct HostRow { int c, dh, dw, a_off, tap; };
 struct Table { KEntry* dev = nullptr; int* xsoff = nullptr; unsigned* rtap = nullptr; unsigned* aoff = nullptr; Tap* taps = nullptr;
                int ntaps = 0, rows = 0, valid = 0, xbias = 0, refs = 0;
                int cpt = 0; signed char tdh[32] = {};          // K chunks per filter tap; row offset of every tap (rowskip, IgemmArgs)
+               // the same chunks in channel-block-major, tap-minor order for the implicit-GEMM launches (upload_table); null
+               // when the table has one tap or no uniform tap size
+               int* xsoff_p = nullptr; unsigned* rtap_p = nullptr; unsigned* aoff_p = nullptr;
                // the same K rows by octets of 8 channels, for the 16-bit data path (vc_internal.h: ConvBf16Args); koct == 0:
                // the channel count is not a multiple of 8 and the path is not available for this geometry
                int* oxs = nullptr; unsigned* otap = nullptr; int* wsrc = nullptr; int koct = 0, oxbias = 0; };
@@ -98,6 +101,7 @@ template <class T> static int to_device(const std::vector<T>& h, T** d) {
 }
 static void free_table(Table& t) {
     (void)hipFree(t.dev); (void)hipFree(t.xsoff); (void)hipFree(t.rtap); (void)hipFree(t.aoff); (void)hipFree(t.taps);
+    (void)hipFree(t.xsoff_p); (void)hipFree(t.rtap_p); (void)hipFree(t.aoff_p);
     (void)hipFree(t.oxs); (void)hipFree(t.otap); (void)hipFree(t.wsrc);
     t = Table{};
 }
@@ -135,11 +139,35 @@ static int upload_table(const std::vector<HostRow>& rows, const std::vector<int>
         if (rows_per_tap[tp] != rows_per_tap[0] || taps[tp].dh < -100 || taps[tp].dh > 100) t->cpt = 0;   // no uniform tap size: rowskip unavailable
         t->tdh[tp] = (signed char)taps[tp].dh;
     }
-    auto pad_chunk = [&]() { for (int k = 0; k < VC_KC; ++k) { ke.push_back(KEntry{0, 0, 0, -1}); xs.push_back((int)xbias); ao.push_back(0u); if (k % 4 == 0) rt.push_back(0u); } };
+    // Second K order for the implicit-GEMM launches (forward / input gradient), whole chunks permuted: channel block major,
+    // tap minor.  The taps of one channel block gather the same lines of the tensor shifted by a pixel or a row; next to
+    // each other, kh*kw - 1 of every kh*kw fetches hit the L1 / L2 instead of re-streaming the whole gathered tensor once
+    // per tap through every XCD (round-3 PMC: 133 MB of L2-miss traffic per launch against ~25 MB of operands).  Any
+    // order of whole chunks is correct: a chunk stays inside one tap and contiguous in the filter.  The filter gradient and
+    // the rowskip mode keep the tap-major arrays (their chunk ranges are per tap).
+    std::vector<int> xs_p; std::vector<unsigned> rt_p, ao_p;
+    if (t->cpt > 0 && taps.size() > 1) {
+        const int cpt = t->cpt, nt = (int)taps.size();
+        for (int cb = 0; cb < cpt; ++cb)
+            for (int tp = 0; tp < nt; ++tp) {
+                const size_t c = (size_t)tp * cpt + cb;
+                xs_p.insert(xs_p.end(), xs.begin() + c * VC_KC, xs.begin() + (c + 1) * VC_KC);
+                ao_p.insert(ao_p.end(), ao.begin() + c * VC_KC, ao.begin() + (c + 1) * VC_KC);
+                rt_p.insert(rt_p.end(), rt.begin() + c * (VC_KC / 4), rt.begin() + (c + 1) * (VC_KC / 4));
+            }
+    }
+    const bool perm = !xs_p.empty();
+    auto pad_chunk = [&]() {
+        for (int k = 0; k < VC_KC; ++k) {
+            ke.push_back(KEntry{0, 0, 0, -1}); xs.push_back((int)xbias); ao.push_back(0u); if (k % 4 == 0) rt.push_back(0u);
+            if (perm) { xs_p.push_back((int)xbias); ao_p.push_back(0u); if (k % 4 == 0) rt_p.push_back(0u); }
+        }
+    };
     while (ke.size() % 64 || ke.empty()) pad_chunk();          // the filter-gradient kernel walks 64-row tiles
     t->rows = (int)ke.size();
     for (int i = 0; i < 4; ++i) pad_chunk();                   // the loaders run ahead of the K range without branching
     VC_CHECK(to_device(ke, &t->dev)); VC_CHECK(to_device(xs, &t->xsoff)); VC_CHECK(to_device(rt, &t->rtap)); VC_CHECK(to_device(ao, &t->aoff));
+    if (perm) { VC_CHECK(to_device(xs_p, &t->xsoff_p)); VC_CHECK(to_device(rt_p, &t->rtap_p)); VC_CHECK(to_device(ao_p, &t->aoff_p)); }
     std::vector<Tap> tp = taps; if (tp.empty()) tp.push_back(Tap{0, 0});
     VC_CHECK(to_device(tp, &t->taps));
     // octet view: unit offsets inside the packed tensor [C/8][xH*xW][8] (16 bytes per unit), filter source offset per K row
@@ -295,9 +323,12 @@ static bool rowskip_pays(const Table& t, int OHc, int si, int Hl, bool wgrad) {
         for (int tp = 0; tp < t.ntaps; ++tp) valid += (i * si + t.tdh[tp] >= 0 && i * si + t.tdh[tp] < Hl) ? 1 : 0;
     return valid * 100 < 92L * OHc * t.ntaps;
 }
+static bool korder_channel_major() { static const bool on = !(getenv("VC_KORDER") && !strcmp(getenv("VC_KORDER"), "tap")); return on; }
 static void set_rowskip(IgemmArgs& a, const Table& t, int B, int OHc) {
     a.rowskip = rowskip_pays(t, OHc, a.si, a.Hl, false) ? 1 : 0;
     a.RW = B * a.OWc; a.inv_rw = 1.0f / (float)a.RW; a.cpt = t.cpt;
+    // channel-block-major K order (upload_table) unless the launch skips filter rows by tap ranges
+    if (!a.rowskip && t.xsoff_p && korder_channel_major()) { a.xsoff = t.xsoff_p; a.rtap = t.rtap_p; a.aoff = t.aoff_p; }
 }
 static void set_vec4(IgemmArgs& a) {
     a.vec4 = a.so_w == 1 && a.OWc % 4 == 0 && a.o_w0 % 4 == 0 && a.yW % 4 == 0 && a.yHW % 4 == 0 && a.y_bs % 4 == 0 &&
