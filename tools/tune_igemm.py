@@ -115,6 +115,15 @@ def main():
         b = U.dev(rng.standard_normal((G, Cout)).astype(np.float32))
         y = U.conv_fwd(x, w, b, kh, kw, sh, sw)
         dy = torch.randn_like(y)
+        zmode = os.environ.get('VC_TUNE_DATA', '')      # timing experiments: 'zero' = all-zero operands, 'zw' = zero filter only, 'one' = constant 1
+        if zmode == 'zero':
+            x.zero_(); w.zero_(); dy.zero_()
+        elif zmode == 'zw':
+            w.zero_()
+        elif zmode == 'zx':
+            x.zero_(); dy.zero_()
+        elif zmode == 'one':
+            x.fill_(1.0); w.fill_(1.0); dy.fill_(1.0)
         OH, OW = y.shape[3], y.shape[4]
         flops = 2.0 * G * Bs * OH * OW * Cout * kh * kw * Cin
         dw = torch.zeros((G, kh, kw, Cin, Cout), device=U.DEV)
