@@ -218,8 +218,11 @@ def workload_text(math, B, F, T, global_batch):
             '%dx%d MCEP, random-init weights' % (idx, MATH_TEXT[math], B, F, T))
 
 
-def extra_config(lib, dev, math, B, F, T, steps, warmup, note):
-    """one more BASELINE configuration on this GPU, measured like the headline: wall time of `steps` steps + its own roofline leg"""
+def extra_config(lib, dev, math, B, F, T, steps, warmup, note, constant_operands=False):
+    """one more BASELINE configuration on this GPU, measured like the headline: wall time of `steps` steps + its own roofline leg.
+    constant_operands: every parameter and every input 0 (activations and weight gradients stay 0, only biases move) -- the
+    same launches on zero-entropy data (a DIAGNOSTIC of the
+    chip's data-dependent power management, DESIGN 4.1 / profiles/r03_data_dependent_power.txt; never a performance figure)"""
     import numpy as np
     import torch
     from voice_converter_cyclegan_amd.engine import CycleGANEngine
@@ -230,6 +233,8 @@ def extra_config(lib, dev, math, B, F, T, steps, warmup, note):
     A = torch.from_numpy(rng.standard_normal((B, F, T)).astype(np.float32)).to(dev)
     Bm = torch.from_numpy(rng.standard_normal((B, F, T)).astype(np.float32)).to(dev)
     hp = (10.0, 5.0, 2e-4, 1e-4)
+    if constant_operands:
+        eng.params.zero_(); A.zero_(); Bm.zero_()
     dt = time_steps(eng, A, Bm, hp, steps, warmup, torch.cuda.synchronize)
     assert np.isfinite(eng.losses.cpu().numpy()).all()
     peak = {'fp32': FP32_MFMA_PEAK_TFLOPS, 'bf16': BF16_MFMA_PEAK_TFLOPS}[math]
@@ -386,6 +391,11 @@ def main():
             extra_config(lib, dev, 'fp32', 32, 24, 128, 10, 3, 'configs[3]: the per-GPU share (32) of global batch 256 on an 8-GPU node, measured on one GPU without the exchange'),
             extra_config(lib, dev, 'fp32', 64, 36, 256, 5, 2, 'configs[4]: the per-GPU share (64) of global batch 512 at 36x256, measured on one GPU without the exchange'),
         ]}
+        # diagnostic, not a result: the headline configuration's launches on constant operands (data-dependent power management)
+        out['extra']['constant_operands_diagnostic'] = extra_config(
+            lib, dev, 'fp32', 8, 24, 128, 20, 5, 'DIAGNOSTIC: configs[1] with every parameter and every input 0 (same launches, '
+            'zero-entropy operands); compare its roofline.frac with the headline\'s -- the difference is the chip\'s power management, not the kernels',
+            constant_operands=True)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline()

@@ -235,7 +235,13 @@ __global__ __launch_bounds__(64 * (BM / 32) * 2 * KG, (64 * (BM / 32) * 2 * KG >
                 accb[bank] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, accb[bank], 0, 0, 0);
             }
             items(std::integral_constant<int, sidx * IPS>{}, std::integral_constant<int, IPS>{}, SLC, SSC, buf ^ 1);
-            if constexpr (sidx * IPS < NLOAD && (sidx + 1) * IPS >= NLOAD) fetch_tab(cl + 1);
+            if constexpr (sidx * IPS < NLOAD && (sidx + 1) * IPS >= NLOAD) {
+                // Scalar loads return out of order and share lgkmcnt with the LDS: once one is in flight, the next wait for an
+                // LDS fragment read can only be lgkmcnt(0), i.e. a full scalar-memory round trip in front of an MFMA.  The
+                // chunk's 8 fragment reads were issued ~8 MFMAs ago: retire them first (free), then fetch the tables.
+                __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0)
+                fetch_tab(cl + 1);
+            }
             __builtin_amdgcn_sched_barrier(0);
         };
         [&]<int... Sx>(std::integer_sequence<int, Sx...>) { (slot(std::integral_constant<int, Sx>{}), ...); }
