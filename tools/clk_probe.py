@@ -1,3 +1,4 @@
+# needs a -DVC_CLKPROBE build of csrc/vc_conv_igemm.hip (tools/igemm_ablation.patch); prints the effective shader clock inside the igemm launches of the train step
 
 import ctypes as C, sys, os, numpy as np, torch
 sys.path.insert(0, os.getcwd())
