@@ -103,11 +103,17 @@ __global__ __launch_bounds__(64 * (BM / 32) * 2 * KG, (64 * (BM / 32) * 2 * KG >
         if (pv) px_decode(p, P, xb, xi, xj);
         const int li0 = xi * p.si, lj0 = xj * p.sj;
         xoffb = (unsigned)(((long)xb * p.x_bs + (long)li0 * p.xW + lj0) * 4);
-        c_tap_p taps = (c_tap_p)p.taps;
-        for (int t = 0; t < p.ntaps; ++t) {
-            const int dh = taps[t].dh, dw = taps[t].dw;
-            const bool ok = pv && (unsigned)(li0 + dh) < (unsigned)p.Hl && (unsigned)(lj0 + dw) < (unsigned)p.Wl;
-            tapmask |= (unsigned)ok << t;
+        // one vector load brings the whole tap table (lane t holds tap t; at most 32 taps), the loop reads a tap back with
+        // v_readlane: no scalar-memory round trip per tap (the probe of tools/igemm_ablation.patch put 4 us of a launch
+        // between its entry and its first operand load, most of it this loop's dependent s_loads)
+        int vdh = 0, vdw = 0;
+        if (lane < p.ntaps) { const Tap tp = p.taps[lane]; vdh = tp.dh; vdw = tp.dw; }
+        const unsigned Hl = (unsigned)p.Hl, Wl = (unsigned)p.Wl;
+        const int ntaps = p.ntaps;
+        for (int t = 0; t < ntaps; ++t) {                // branch-free body: no kernel-argument reload, no exec juggling per tap
+            const int dh = __builtin_amdgcn_readlane(vdh, t), dw = __builtin_amdgcn_readlane(vdw, t);
+            const unsigned ok = (unsigned)pv & (unsigned)((unsigned)(li0 + dh) < Hl) & (unsigned)((unsigned)(lj0 + dw) < Wl);
+            tapmask |= ok << t;
         }
     }
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
