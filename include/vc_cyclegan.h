@@ -89,6 +89,7 @@ int  vc_tune_rowskip(int igemm_on, int wgrad_on);   /* row-major pixel tiles tha
                                                      * forward / input gradient, on for filter gradients (csrc/vc_api.hip: rowskip_pays); thread-local */
 int  vc_tune_wgrad_store(int on);       /* tuning only: while on, vc_conv2d_wgrad OVERWRITES dw (the train step's plain-store form) */
 int  vc_tune_conv_bf16_override(int tile_rows, int stages, int splitk);
+int  vc_tune_glu_version(int version);   /* A/B only: 1 = the round-3 form of vc_gated_conv1d_glu_fwd (filter slab in LDS), 2 = current */
 int  vc_tune_conv_bf16_keys(int* keys4, int max_keys);   /* tuning only: shape keys {M, Ptot, K octets, groups} of this thread's conv_bf16 launches since the last call */
 /* Opt-in per-launch timing of the implicit-GEMM kernels (bench.py roofline leg).
  * While enabled every igemm/wgrad launch is bracketed by hipEvents on its stream. */

@@ -9,6 +9,8 @@ and give the GPU tests an oracle-free comparison target; they are not reference 
                          gradient L2 norms, and losses of train steps 1..3.
  train_log_pins.npz    : five numbers copied from the reference's TensorBoard export
                          (train_log/*.csv row 2, step 167) that pin model.py:72's loss weights.
+ golden_f32_b32.npz / golden_f32_36x256_b8.npz / golden_bf16_b64_lam0.npz : the same record at the other sizes
+                         bench.py reports (`make_golden.py b32|36x256|b64lam0`); lam0 = lambda_cycle = lambda_identity = 0.
  golden_f32_b64.npz    : one train step (model.py:110-125) at the batch bench.py times as BASELINE configs[2]
  golden_bf16_b64.npz     (B=64, 24x128), fp32 and with bf16 operand rounding (O.set_operand_rounding): the 8 logged
                          scalars, generation_A/B, per-tensor gradient L2 + projection, and the cumulative
@@ -75,18 +77,24 @@ LOSS_KEYS = ('cycle_loss', 'identity_loss', 'generator_loss_A2B', 'generator_los
 L1_CDF_X = np.logspace(-7, -1, 49)          # distances of an L1 element from a tie at which the CDF is recorded
 
 
-def full_b64(rounding):
-    """One step at B=64 (model.py:110-125) with the weights / batch of full(); rounding None or 'bf16'."""
-    P = O.init_params(seed=42, randomize_affine=True)
-    A, B = O.synthetic_batch(64, 24, 128)
+def step_golden(batch, rounding, F=24, T=128, lam=(10.0, 5.0), name=None, keep_samples=0):
+    """One step (model.py:110-125) at `batch` x F x T with the weights / batch generator of full(); rounding None or 'bf16';
+    lam = (lambda_cycle, lambda_identity)."""
+    P = O.init_params(seed=42, num_features=F, randomize_affine=True)
+    A, B = O.synthetic_batch(batch, F, T)
     O.set_operand_rounding(rounding)
     try:
         orc = O.CycleGANOracle({k: v.copy() for k, v in P.items()})
-        orc.train(A, B, 10.0, 5.0, 2e-4, 1e-4)
+        orc.train(A, B, lam[0], lam[1], 2e-4, 1e-4)
     finally:
         O.set_operand_rounding(None)
     out = {'losses': np.array([orc.last[k] for k in LOSS_KEYS], np.float32)}
-    out['gen_A'], out['gen_B'] = orc.last_fakes
+    gA, gB = orc.last_fakes
+    if keep_samples:      # large batches: the first samples verbatim, the whole tensors by L2 norm + random projection
+        out['gen_l2'] = np.array([np.linalg.norm(gA.astype(np.float64)), np.linalg.norm(gB.astype(np.float64))])
+        out['gen_proj'] = np.array([probe(gA, 777), probe(gB, 778)])
+        gA, gB = gA[:keep_samples], gB[:keep_samples]
+    out['gen_A'], out['gen_B'] = gA, gB
     Gg, Gd = orc.last_grads
     G = {**Gg, **Gd}
     names = sorted(G)
@@ -97,7 +105,11 @@ def full_b64(rounding):
     out['l1_cdf_x'] = L1_CDF_X
     out['l1_cdf_y'] = np.searchsorted(d, L1_CDF_X, side='right') / float(d.size)
     out['l1_count'] = np.int64(d.size)
-    np.savez_compressed(os.path.join(HERE, 'golden_%s_b64.npz' % ('bf16' if rounding else 'f32')), **out)
+    np.savez_compressed(os.path.join(HERE, name or 'golden_%s_b64.npz' % ('bf16' if rounding else 'f32')), **out)
+
+
+def full_b64(rounding):
+    step_golden(64, rounding)
 
 
 def train_log_pins():
@@ -111,6 +123,14 @@ def train_log_pins():
 if __name__ == '__main__':
     if sys.argv[1:] == ['b64']:
         full_b64(None); full_b64('bf16')
+    elif sys.argv[1:] == ['b32']:              # BASELINE configs[3]'s per-GPU share (bench.py extra.configs): fp32, B=32, 24x128
+        step_golden(32, None, name='golden_f32_b32.npz')
+    elif sys.argv[1:] == ['36x256']:           # BASELINE configs[4]'s geometry at a batch the oracle finishes in minutes
+        step_golden(8, None, F=36, T=256, name='golden_f32_36x256_b8.npz')
+    elif sys.argv[1:] == ['36x256b64']:        # ... and at configs[4]'s per-GPU share itself (the size bench.py times; ~4 min of CPU)
+        step_golden(64, None, F=36, T=256, name='golden_f32_36x256_b64.npz', keep_samples=4)
+    elif sys.argv[1:] == ['b64lam0']:          # bf16 B=64 with the L1 terms switched off: a smooth objective, tight gradient bound
+        step_golden(64, 'bf16', lam=(0.0, 0.0), name='golden_bf16_b64_lam0.npz')
     else:
         shrunk(); full(); train_log_pins()
     for f in sorted(os.listdir(HERE)):

@@ -435,7 +435,7 @@ int launch_wsconv1d(const WsConvArgs& a, int cin, int kw, int math, hipStream_t 
 // completion in L2, once per tile (gfx950 has one in-order counter for loads and stores).
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 template <int CIN, int KW, bool BF16, bool INKW, int NWV_, bool RAW>
-__global__ __launch_bounds__(64 * NWV_, (BF16 && NWV_ == 4) ? 2 : (NWV_ == 8 ? 2 : 1)) void gated_conv1d_glu_kernel(const WsConvArgs a, const void* __restrict__ packed) {
+__global__ __launch_bounds__(64 * NWV_, (BF16 && NWV_ == 4) ? 2 : (NWV_ == 8 ? 2 : 1)) void gated_conv1d_glu_v1_kernel(const WsConvArgs a, const void* __restrict__ packed) {
     typedef typename std::conditional<BF16, __bf16, float>::type T;
     constexpr int R = BF16 ? 8 : 4;                        // k run per lane half and step
     static_assert(CIN % R == 0 && (KW & 1), "runs of R channels inside one tap; odd kernel width");
@@ -710,7 +710,7 @@ int64_t gated_conv1d_glu_workspace_floats(int G, int cout2) {
 }
 
 // y [G][B][Cout/2][T] = GLU of the gated pair; returns -2 when the geometry is not built
-int launch_gated_conv1d_glu(const WsConvArgs& a, int cin, int kw, int math, float* workspace, hipStream_t s, double flops) {
+int launch_gated_conv1d_glu_v1(const WsConvArgs& a, int cin, int kw, int math, float* workspace, hipStream_t s, double flops) {
     if (cin != 24 || kw != 15 || (a.Cout & 63) || (a.T & 3)) return -2;
     if ((long)a.B * a.Cout * a.T * 4 >= 0xfff00000L) return -2;      // 32-bit buffer offsets of the output stores
     const int C = a.Cout / 2, slabs = C / 32;
@@ -722,8 +722,8 @@ int launch_gated_conv1d_glu(const WsConvArgs& a, int cin, int kw, int math, floa
     int parts = wgs / (slabs * a.G); if (parts < 1) parts = 1; if (parts > trips) parts = trips;
     dim3 grid(parts, slabs, a.G);
     ProfScope ps(2, flops, s);                       // everything a call launches
-#define VC_GLU(BF, INKW, NWV, P) { if (a.raw) gated_conv1d_glu_kernel<24, 15, BF, INKW, NWV, true><<<grid, dim3(64 * NWV), 0, s>>>(a, P); \
-                                  else gated_conv1d_glu_kernel<24, 15, BF, INKW, NWV, false><<<grid, dim3(64 * NWV), 0, s>>>(a, P); }
+#define VC_GLU(BF, INKW, NWV, P) { if (a.raw) gated_conv1d_glu_v1_kernel<24, 15, BF, INKW, NWV, true><<<grid, dim3(64 * NWV), 0, s>>>(a, P); \
+                                  else gated_conv1d_glu_v1_kernel<24, 15, BF, INKW, NWV, false><<<grid, dim3(64 * NWV), 0, s>>>(a, P); }
     if (packed_image) {
         if (bf) pack_gated_weights_kernel<24, 15, true><<<dim3(slabs, a.G, 16), 256, 0, s>>>(a.w, a.w_gs, a.Cout, workspace);
         else pack_gated_weights_kernel<24, 15, false><<<dim3(slabs, a.G, 16), 256, 0, s>>>(a.w, a.w_gs, a.Cout, workspace);
