@@ -62,7 +62,7 @@ def _cpu_leg(kind, B, threads, budget_s):
         name = 'numpy oracle (oracle/cyclegan_oracle.py; GEMMs in numpy\'s BLAS: %s, the rest single-threaded)' % _blas_threads()
     A, Bm = O.synthetic_batch(B, 24, 128)
     t = time.perf_counter(); step(A, Bm); warm = time.perf_counter() - t          # warm-up (also sizes the sample)
-    n = int(max(1, min(10, budget_s / max(warm, 1e-3))))
+    n = int(max(5, min(10, budget_s / max(warm, 1e-3))))                          # median of >= 5 timed steps
     ts = []
     for _ in range(n):
         t = time.perf_counter(); step(A, Bm); ts.append(time.perf_counter() - t)
@@ -71,21 +71,20 @@ def _cpu_leg(kind, B, threads, budget_s):
                       'text': '%s B=%d: 1 warm-up + %d timed full train steps, median %.3f s/step = %.1f frames/s' % (name, B, n, med, B * 128.0 / med)}))
 
 
-def cpu_baseline(budget_s=6.0, leg_timeout_s=75):
+def cpu_baseline(leg_timeout_s=150):
     """The reference arithmetic on the host cores (TF1 itself cannot run here), timed on a bounded sample of the
     workload: oracle/torch_ref.py (torch-CPU; SURVEY 8d's stand-in) at B=1 (BASELINE configs[0]) and at the benched B=8,
     with 32 threads and with all host threads (many-core hosts can lose more time synchronising 256 threads over
     convolutions this small than they gain), and the numpy oracle at B=1.  Every leg runs in its own process under a
-    timeout (a leg that does not finish is reported as such): one warm-up step, then as many timed steps as fit
-    `budget_s` seconds (1..10).  `value` is the fastest leg in frames/s."""
+    timeout (a leg that does not finish is reported as such): one warm-up step, then 5..10 timed steps (as many as fit the
+    leg's budget: 25 s at B=8, 15 s at B=1), the MEDIAN is reported.  `value` is the fastest leg in frames/s.  The
+    all-threads leg of earlier rounds is gone: with 256 threads a B=8 step did not finish in 75 s (oneDNN synchronising 256
+    threads over convolutions this small); 32 threads is what the stated `cores` means."""
     import subprocess
     cores = os.cpu_count()
     legs, notes = [], []
-    plan = [('torch', 1, min(cores, 32)), ('torch', 8, min(cores, 32))]
-    if cores > 32:
-        plan += [('torch', 8, cores)]
-    plan += [('numpy', 1, cores)]
-    for kind, B, threads in plan:
+    plan = [('torch', 1, min(cores, 32), 15.0), ('torch', 8, min(cores, 32), 25.0), ('numpy', 1, cores, 15.0)]
+    for kind, B, threads, budget_s in plan:
         try:
             r = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-leg', '%s,%d,%d,%g' % (kind, B, threads, budget_s)],
                                capture_output=True, text=True, timeout=leg_timeout_s)

@@ -76,29 +76,7 @@ int  vc_release_workspaces(void);
  * thread's default: the mode of operator-level calls and the initial mode of plans that thread creates. */
 int  vc_set_deterministic(int on);
 int  vc_get_deterministic(void);
-/* Tuning / test hooks (tools/tune_igemm.py regenerates csrc/vc_tuned_igemm.h with them; tests force every built kernel
- * instantiation against the oracle).  Each forces ONE configuration for the following launches of the CALLING THREAD
- * (thread-local state); (0, 0, 0) restores the automatic choice.  Not for production use.
- *   igemm    : conv forward / input gradient, fp32 storage: tile rows (64 / 128), K groups per workgroup (1, 2, 4), split-K
- *   wgrad    : filter gradient, fp32 storage: tile columns (64 / 128), K groups (1, 2, 4), split-K
- *   conv_bf16: the 16-bit data path of the bf16 mode (csrc/vc_conv_bf16.hip): tile rows (64 / 128), LDS ring stages (2 / 4),
- *              split-K (1..16) */
-int  vc_tune_igemm_override(int tile_rows, int k_groups, int splitk);
-int  vc_tune_wgrad_override(int tile_cols, int k_groups, int splitk);
-int  vc_tune_rowskip(int igemm_on, int wgrad_on);   /* row-major pixel tiles that skip the filter rows lying in the SAME padding (D.d3): default off for
-                                                     * forward / input gradient, on for filter gradients (csrc/vc_api.hip: rowskip_pays); thread-local */
-int  vc_tune_wgrad_store(int on);       /* tuning only: while on, vc_conv2d_wgrad OVERWRITES dw (the train step's plain-store form) */
-int  vc_tune_conv_bf16_override(int tile_rows, int stages, int splitk);
-int  vc_tune_glu_version(int version);   /* A/B only: 1 = the round-3 form of vc_gated_conv1d_glu_fwd (filter slab in LDS), 2 = current */
-int  vc_tune_conv_bf16_keys(int* keys4, int max_keys);   /* tuning only: shape keys {M, Ptot, K octets, groups} of this thread's conv_bf16 launches since the last call */
-/* Opt-in per-launch timing of the implicit-GEMM kernels (bench.py roofline leg).
- * While enabled every igemm/wgrad launch is bracketed by hipEvents on its stream. */
-int  vc_prof_enable(int on);
-/* Collect: sum of kernel ms, launch count and algorithmic FLOPs since enable/reset,
- * kind 0 = igemm (conv fwd + dgrad), 1 = wgrad, 2 = wsconv1d (generator h1 forward).  Synchronises the recorded events. */
-int  vc_prof_collect(int kind, double* ms, long long* launches, double* flops);
-/* Per-launch records (in launch order) since enable: fills ms[i], flops[i] for i < max_n; returns the record count. */
-int  vc_prof_records(int kind, double* ms, double* flops, int max_n);
+/* Tuning, test and profiling hooks (vc_tune_*, vc_prof_*): include/vc_cyclegan_testing.h -- not part of the product API. */
 
 /* ---- parameter layout (replaces tf.get_variable bookkeeping, module.py:154-159,
  *      194-199; variable names of SURVEY.md section 8a row 13) ------------------ */

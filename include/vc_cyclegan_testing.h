@@ -1,0 +1,51 @@
+/* vc_cyclegan_testing.h -- tuning, test and profiling hooks of libvcgan_hip.so.
+ *
+ * NOT part of the product API (include/vc_cyclegan.h): nothing in model.py / module.py / engine.py's training or
+ * inference path calls these.  Users: tests/ (force every built kernel configuration against the oracle, check that the
+ * benched shapes hit their measured table rows), tools/tune_igemm.py (regenerates csrc/vc_tuned_*.h) and bench.py's
+ * roofline leg (per-launch HIP-event timing).  All state is per calling thread.
+ */
+#ifndef VC_CYCLEGAN_TESTING_H
+#define VC_CYCLEGAN_TESTING_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Tuning / test hooks (tools/tune_igemm.py regenerates csrc/vc_tuned_igemm.h with them; tests force every built kernel
+ * instantiation against the oracle).  Each forces ONE configuration for the following launches of the CALLING THREAD
+ * (thread-local state); (0, 0, 0) restores the automatic choice.  Not for production use.
+ *   igemm    : conv forward / input gradient, fp32 storage: tile rows (64 / 128), K groups per workgroup (1, 2, 4), split-K
+ *   wgrad    : filter gradient, fp32 storage: tile columns (64 / 128), K groups (1, 2, 4), split-K
+ *   conv_bf16: the 16-bit data path of the bf16 mode (csrc/vc_conv_bf16.hip): tile rows (64 / 128), LDS ring stages (2 / 4),
+ *              split-K (1..16) */
+int  vc_tune_igemm_override(int tile_rows, int k_groups, int splitk);
+int  vc_tune_wgrad_override(int tile_cols, int k_groups, int splitk);
+int  vc_tune_rowskip(int igemm_on, int wgrad_on);   /* row-major pixel tiles that skip the filter rows lying in the SAME padding (D.d3): default off for
+                                                     * forward / input gradient, on for filter gradients (csrc/vc_api.hip: rowskip_pays); thread-local */
+int  vc_tune_wgrad_store(int on);       /* tuning only: while on, vc_conv2d_wgrad OVERWRITES dw (the train step's plain-store form) */
+int  vc_tune_conv_bf16_override(int tile_rows, int stages, int splitk);
+int  vc_tune_glu_version(int version);   /* A/B only: 1 = the round-3 form of vc_gated_conv1d_glu_fwd (filter slab in LDS), 2 = current */
+/* Which configuration did the calling thread's last conv forward / input-gradient launch (igemm) or filter-gradient launch
+ * (wgrad) run with, and where did it come from?  out4 = {tile rows | columns, K groups, split-K, source}; source: 0 cost
+ * model, 1 exact row of the measured table (csrc/vc_tuned_igemm.h / vc_tuned_wgrad.h), 2 the same layer's row measured at
+ * the nearest size, 3 forced by vc_tune_*_override, 4 the bf16-operand rule. */
+int  vc_tune_last_igemm_config(int* out4);
+int  vc_tune_last_wgrad_config(int* out4);
+/* The same answer for a launch SHAPE, without launching (host only; works without a GPU): the table keys are
+ * {transposed filter?, M, launch pixels, K rows, groups} and {K tiles of 64 rows, Cout, 32-pixel chunks, groups, plain-store?}. */
+int  vc_tune_query_igemm(int a_trans, int M, int Ptot, int krows, int groups, int* out4);
+int  vc_tune_query_wgrad(int ktiles, int N, int nchunks, int groups, int store, int* out4);
+int  vc_tune_conv_bf16_keys(int* keys4, int max_keys);   /* tuning only: shape keys {M, Ptot, K octets, groups} of this thread's conv_bf16 launches since the last call */
+/* Opt-in per-launch timing of the implicit-GEMM kernels (bench.py roofline leg).
+ * While enabled every igemm/wgrad launch is bracketed by hipEvents on its stream. */
+int  vc_prof_enable(int on);
+/* Collect: sum of kernel ms, launch count and algorithmic FLOPs since enable/reset,
+ * kind 0 = igemm (conv fwd + dgrad), 1 = wgrad, 2 = wsconv1d (generator h1 forward).  Synchronises the recorded events. */
+int  vc_prof_collect(int kind, double* ms, long long* launches, double* flops);
+/* Per-launch records (in launch order) since enable: fills ms[i], flops[i] for i < max_n; returns the record count. */
+int  vc_prof_records(int kind, double* ms, double* flops, int max_n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,32 +1,43 @@
-"""Times the north star's named kernel (vc_gated_conv1d_glu_fwd: G.h1 value + gate conv1d + GLU, module.py:161-163) with HIP
-events around everything a call launches, at several batch sizes, fp32 and bf16.  Run on the GPU box:
-
-    python tools/bench_named.py [--batches 256,1024,4096]
-    VC_GLU_PACKED=1 python tools/bench_named.py        # the round-2 two-launch form (pack kernel + 8-wave kernel)
-    VC_GLU_WAVES8=1 python tools/bench_named.py        # in-kernel filter slab, one 8-wave workgroup per CU
-"""
-import argparse
+"""A/B of the north-star kernel (vc_gated_conv1d_glu_fwd): round-3 form (filter slab in LDS) vs round-4 form (filter
+fragments in registers), fp32 and bf16, B = 256 and B = 4096, HIP events around every call.  Run on the GPU box."""
+import ctypes as C
 import os
 import sys
 
+import torch
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import bench  # noqa: E402
+import __graft_entry__ as ge  # noqa: E402
+ge.build()
+from voice_converter_cyclegan_amd._lib import lib, ptr, check, vp  # noqa: E402
 
-
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--batches', default='256,1024,4096')
-    args = ap.parse_args()
-    import __graft_entry__ as ge
-    ge.build()
-    from voice_converter_cyclegan_amd._lib import lib
-    tag = 'packed' if os.environ.get('VC_GLU_PACKED') else 'waves8' if os.environ.get('VC_GLU_WAVES8') else 'default'
-    for math, peak in (('fp32', bench.FP32_MFMA_PEAK_TFLOPS), ('bf16', bench.BF16_MFMA_PEAK_TFLOPS)):
-        for B in (int(b) for b in args.batches.split(',')):
-            r = bench.named_kernel_h1(lib, 'cuda:0', B=B, reps=20, peak=peak, math=math)
-            print('%-8s %-5s B=%-5d %8.2f us   HBM %6.1f GB/s = %.3f of 8 TB/s   %7.1f TFLOP/s = %.3f of the %s MFMA peak'
-                  % (tag, math, B, r['us'], r['hbm']['achieved_GBs'], r['hbm']['frac'], r['mfma']['achieved_TFLOPs'], r['mfma']['frac'], math), flush=True)
-
-
-if __name__ == '__main__':
-    main()
+dev = 'cuda:0'
+for ver in (1, 2):
+    check(lib.vc_tune_glu_version(ver))
+    for math in ('fp32', 'bf16'):
+        for B, T in ((256, 128), (4096, 128), (8, 2048), (16, 128)):
+            x = torch.randn((1, B, 24, T), device=dev)
+            w = torch.randn((1, 15, 24, 256), device=dev) * 0.05
+            b = torch.randn((1, 256), device=dev) * 0.1
+            y = torch.empty((1, B, 128, T), device=dev)
+            wsp = torch.empty(lib.vc_gated_conv1d_glu_workspace_floats(1, 256), device=dev)
+            s = vp(torch.cuda.current_stream().cuda_stream)
+            check(lib.vc_set_math_mode({'fp32': 0, 'bf16': 1}[math]))
+            call = lambda: check(lib.vc_gated_conv1d_glu_fwd(ptr(x), 0, ptr(w), 0, ptr(b), 0, ptr(y), 0, 1, B, 24, T, 256, 15, ptr(wsp), wsp.numel(), s))
+            for _ in range(3):
+                call()
+            torch.cuda.synchronize()
+            lib.vc_prof_enable(1)
+            reps = 20 if B <= 256 else 10
+            for _ in range(reps):
+                call()
+            torch.cuda.synchronize()
+            ms, n, fl = C.c_double(0), C.c_longlong(0), C.c_double(0)
+            lib.vc_prof_collect(2, C.byref(ms), C.byref(n), C.byref(fl))
+            lib.vc_prof_enable(0)
+            check(lib.vc_set_math_mode(0))
+            t = ms.value * 1e-3 / max(n.value, 1)
+            algo = B * (24 * T + 128 * T) * 4 + (15 * 24 * 256 + 256) * 4
+            flops = 2.0 * B * T * 256 * 15 * 24
+            print('v%d %-4s B=%-4d T=%-4d %8.2f us  HBM %6.3f of 8 TB/s  %7.1f TFLOP/s' % (ver, math, B, T, t * 1e6, algo / t / 8e12, flops / t / 1e12), flush=True)
+check(lib.vc_tune_glu_version(2))

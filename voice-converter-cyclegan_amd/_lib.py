@@ -47,6 +47,10 @@ SIGNATURES = [
     ('vc_tune_conv_bf16_override', i32, [i32, i32, i32]),
     ('vc_tune_conv_bf16_keys', i32, [vp, i32]),
     ('vc_tune_glu_version', i32, [i32]),
+    ('vc_tune_last_igemm_config', i32, [C.POINTER(C.c_int)]),
+    ('vc_tune_last_wgrad_config', i32, [C.POINTER(C.c_int)]),
+    ('vc_tune_query_igemm', i32, [i32, i32, i32, i32, i32, C.POINTER(C.c_int)]),
+    ('vc_tune_query_wgrad', i32, [i32, i32, i32, i32, i32, C.POINTER(C.c_int)]),
     ('vc_prof_enable', i32, [i32]),
     ('vc_prof_collect', i32, [i32, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_double)]),
     ('vc_prof_records', i32, [i32, C.POINTER(C.c_double), C.POINTER(C.c_double), i32]),

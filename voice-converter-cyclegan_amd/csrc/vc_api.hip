@@ -3,6 +3,7 @@
 // Everything exported here is declared (with reference citations) in include/vc_cyclegan.h.
 #include "vc_internal.h"
 #include "../../include/vc_cyclegan.h"
+#include "../../include/vc_cyclegan_testing.h"
 #include <algorithm>
 #include <array>
 #include <atomic>

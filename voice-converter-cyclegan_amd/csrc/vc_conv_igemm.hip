@@ -414,7 +414,26 @@ extern "C" int vc_tune_igemm_override(int bm, int kg, int splitk) {
 struct TunedCfg { int at, M, Ptot, krows, groups, bm, kg, sk; };
 #include "vc_tuned_igemm.h"
 
+// where the calling thread's last igemm_config took its answer from (tests: a benched shape must hit its measured row)
+enum { CFG_MODEL = 0, CFG_EXACT = 1, CFG_NEIGHBOUR = 2, CFG_FORCED = 3, CFG_BF16_RULE = 4 };
+static thread_local int g_last_igemm[4] = {0, 0, 0, 0};
+static void igemm_config_impl(IgemmArgs& a, int math, int& src);
 void igemm_config(IgemmArgs& a, int math) {
+    int src = CFG_MODEL;
+    igemm_config_impl(a, math, src);
+    g_last_igemm[0] = a.bm; g_last_igemm[1] = a.kg; g_last_igemm[2] = a.splitk; g_last_igemm[3] = src;
+}
+extern "C" int vc_tune_last_igemm_config(int* out4) { for (int i = 0; i < 4; ++i) out4[i] = g_last_igemm[i]; return 0; }
+// host-only: the configuration a launch of this shape would get (no launch; runs without a GPU)
+extern "C" int vc_tune_query_igemm(int a_trans, int M, int Ptot, int krows, int groups, int* out4) {
+    if (M <= 0 || Ptot <= 0 || krows <= 0 || krows % VC_KC || groups <= 0 || !out4) { vc_set_error("vc_tune_query_igemm: bad shape"); return -1; }
+    IgemmArgs a{}; a.M = M; a.Ptot = Ptot; a.krows = krows; a.groups = groups; a.a_ms = a_trans ? 2 : 1;
+    int src = CFG_MODEL;
+    igemm_config_impl(a, VC_MATH_FP32, src);
+    out4[0] = a.bm; out4[1] = a.kg; out4[2] = a.splitk; out4[3] = src;
+    return 0;
+}
+static void igemm_config_impl(IgemmArgs& a, int math, int& src) {
     const int nchunks = a.krows / VC_KC;
     const bool det = vc_det_active();          // deterministic mode: K is split inside the workgroup only (fixed summation order)
     a.mtiles = 0;
@@ -427,13 +446,14 @@ void igemm_config(IgemmArgs& a, int math) {
         while (tiles * sk < 512 && nchunks / (sk * 2) >= 4 && sk < 16) sk *= 2;
         a.splitk = det ? 1 : sk;
         a.mtiles = (a.M + a.bm - 1) / a.bm; a.ntiles = (a.Ptot + 63) / 64;
+        src = CFG_BF16_RULE;
         return;
     }
-    if (g_force_bm) { a.bm = g_force_bm; a.kg = g_force_kg; a.splitk = det ? 1 : std::min(g_force_sk, std::max(1, nchunks / (2 * a.kg))); }
+    if (g_force_bm) { src = CFG_FORCED; a.bm = g_force_bm; a.kg = g_force_kg; a.splitk = det ? 1 : std::min(g_force_sk, std::max(1, nchunks / (2 * a.kg))); }
     else {
         const int at = a.a_ms != 1 ? 1 : 0;
         for (const TunedCfg& t : kTunedIgemm)
-            if (t.at == at && t.M == a.M && t.Ptot == a.Ptot && t.krows == a.krows && t.groups == a.groups && !(det && t.sk > 1)) { a.bm = t.bm; a.kg = t.kg; a.splitk = t.sk; a.mtiles = 1; break; }
+            if (t.at == at && t.M == a.M && t.Ptot == a.Ptot && t.krows == a.krows && t.groups == a.groups && !(det && t.sk > 1)) { a.bm = t.bm; a.kg = t.kg; a.splitk = t.sk; a.mtiles = 1; src = CFG_EXACT; break; }
     }
     if (!g_force_bm && !a.mtiles) {
         // No exact entry: the same LAYER (same filter-side shape: transposed?, M, K rows, groups) measured at another pixel
@@ -457,7 +477,7 @@ void igemm_config(IgemmArgs& a, int math) {
                 if (cps * (parts - 1) < nchunks) break;
                 sk /= 2;
             }
-            a.splitk = sk; a.mtiles = 1;
+            a.splitk = sk; a.mtiles = 1; src = CFG_NEIGHBOUR;
         }
     }
     if (!g_force_bm && a.mtiles) {

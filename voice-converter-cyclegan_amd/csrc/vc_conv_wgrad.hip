@@ -263,7 +263,7 @@ __global__ __launch_bounds__(256 * KG, KG == 4 ? 4 : 2) void wgrad_kernel(const 
 
 // Tile width (Cout columns), K groups and split-K: the cost model of igemm_config (vc_conv_igemm.hip) with this kernel's
 // chunk (32 pixels x (64 + BN) rows; 32 or 16 MFMAs per wave).  us per chunk of one wave among k on its SIMD.
-struct WgradCfg { int bn, kg, sk; };
+struct WgradCfg { int bn, kg, sk; int src = 0; };   // src: 0 cost model, 1 exact measured row, 2 neighbour row, 3 forced
 // tests / tuning: force one configuration (tile columns 64 / 128, K groups, split-K) for the calling thread's following launches
 static thread_local int g_wforce_bn = 0, g_wforce_kg = 0, g_wforce_sk = 0;
 extern "C" int vc_tune_wgrad_override(int bn, int kg, int splitk) {
@@ -280,11 +280,11 @@ static WgradCfg wgrad_config(const WgradArgs& a) {
     const bool det = vc_det_active();          // deterministic mode: the pixel axis is split inside the workgroup only
     if (g_wforce_bn) {
         const int bn = (g_wforce_bn == 128 && a.N < 128) ? 64 : g_wforce_bn;
-        return WgradCfg{bn, g_wforce_kg, det ? 1 : std::min(g_wforce_sk, std::max(1, a.nchunks / (2 * g_wforce_kg)))};
+        return WgradCfg{bn, g_wforce_kg, det ? 1 : std::min(g_wforce_sk, std::max(1, a.nchunks / (2 * g_wforce_kg))), 3};
     }
     for (const TunedWgrad& t : kTunedWgrad)
         if (t.ktiles == a.ktiles && t.N == a.N && t.nchunks == a.nchunks && t.groups == a.groups && t.store == a.store && !(det && t.sk > 1))
-            return WgradCfg{t.bn, t.kg, t.sk};
+            return WgradCfg{t.bn, t.kg, t.sk, 1};
     {
         // no exact entry: the same layer (K tiles, Cout, groups) measured at another reduction length, nearest in log(chunks)
         // within a factor of 4, lends its configuration (see igemm_config)
@@ -301,10 +301,10 @@ static WgradCfg wgrad_config(const WgradArgs& a) {
                 if (cps * (parts - 1) < a.nchunks) break;
                 sk /= 2;
             }
-            return WgradCfg{nb->bn, nb->kg, sk};
+            return WgradCfg{nb->bn, nb->kg, sk, 2};
         }
     }
-    WgradCfg best{128, 1, 1}; double bestc = 1e30;
+    WgradCfg best{128, 1, 1, 0}; double bestc = 1e30;
     const double out_bytes = 4.0 * 64.0 * a.ktiles * (double)a.N * a.groups;
     for (int bn : {128, 64}) {
         if (bn == 128 && a.N < 128) continue;
@@ -323,17 +323,28 @@ static WgradCfg wgrad_config(const WgradArgs& a) {
                 const double k = (double)conc * kg;                          // waves per SIMD
                 const double t_chunk = bn == 128 ? 0.3 + 1.25 * k : 0.25 + 0.72 * k;
                 const double c = 5.0 + rounds * (cps * t_chunk + 1.5) + ((sk > 1 || !a.store) ? 6.0 + out_bytes * sk / 0.4e6 : 0.0);
-                if (c < bestc) { bestc = c; best = WgradCfg{bn, kg, sk}; }
+                if (c < bestc) { bestc = c; best = WgradCfg{bn, kg, sk, 0}; }
             }
         }
     }
     return best;
 }
 int wgrad_splitk(const WgradArgs& a) { return wgrad_config(a).sk; }
+static thread_local int g_last_wgrad[4] = {0, 0, 0, 0};
+extern "C" int vc_tune_last_wgrad_config(int* out4) { for (int i = 0; i < 4; ++i) out4[i] = g_last_wgrad[i]; return 0; }
+// host-only: the configuration a filter-gradient launch of this shape would get (no launch; runs without a GPU)
+extern "C" int vc_tune_query_wgrad(int ktiles, int N, int nchunks, int groups, int store, int* out4) {
+    if (ktiles <= 0 || N <= 0 || nchunks <= 0 || groups <= 0 || !out4) { vc_set_error("vc_tune_query_wgrad: bad shape"); return -1; }
+    WgradArgs a{}; a.ktiles = ktiles; a.N = N; a.nchunks = nchunks; a.groups = groups; a.store = store ? 1 : 0;
+    const WgradCfg c = wgrad_config(a);
+    out4[0] = c.bn; out4[1] = c.kg; out4[2] = c.sk; out4[3] = c.src;
+    return 0;
+}
 
 int launch_wgrad(const WgradArgs& a0, int math, hipStream_t s, double flops) {
     WgradArgs a = a0;
     const WgradCfg c = wgrad_config(a);
+    g_last_wgrad[0] = c.bn; g_last_wgrad[1] = c.kg; g_last_wgrad[2] = c.sk; g_last_wgrad[3] = c.src;
     a.ntiles = (a.N + c.bn - 1) / c.bn;
     a.splitk = c.sk;
     if (a.splitk > 1) a.store = 0;
