@@ -114,7 +114,7 @@ def test_conv_bf16_modes(built_lib, case, mode):
     assert lib.vc_set_math_mode(3) != 0 and lib.vc_get_math_mode() == 0      # unknown mode is refused
 
 
-@pytest.mark.parametrize('cfg', [(128, 2, 1), (128, 4, 1), (64, 2, 1), (64, 4, 1), (128, 4, 2), (64, 2, 4)])
+@pytest.mark.parametrize('cfg', [(128, 2, 1), (128, 4, 1), (64, 2, 1), (64, 4, 1), (128, 4, 2), (64, 2, 4), (256, 3, 1), (256, 3, 2)])
 @pytest.mark.parametrize('case', [(128, 1, 128, 512, 1, 5, 1, 2, 4),      # G.d1: stride 2 -> two input-gradient parity classes
                                   (512, 1, 32, 2048, 1, 3, 1, 1, 8),      # residual h1
                                   (256, 12, 32, 1024, 3, 3, 2, 2, 2),     # D.d2: 2-D, four parity classes

@@ -466,8 +466,9 @@ def _check_step_golden(mode, B, F, T, fname, lam=(10.0, 5.0)):
             assert abs(float(t.reshape(-1).astype(np.float64) @ r) - z['gen_proj'][k]) <= 3.0 * tol_g * z['gen_l2'][k], k
     dfw = np.concatenate([(gA[:n] - z['gen_A']).ravel(), (gB[:n] - z['gen_B']).ravel()]).astype(np.float64)
     delta = 3.0 * float(np.sqrt((dfw ** 2).mean()))
-    f = float(np.interp(delta, z['l1_cdf_x'], z['l1_cdf_y']))            # fraction of L1 elements within delta of a tie
-    flip = 2.0 * np.sqrt(f) if (lam[0] != 0.0 or lam[1] != 0.0) else 0.0
+    smooth = lam[0] == 0.0 and lam[1] == 0.0                              # no L1 term in the objective: nothing can flip
+    f = 0.0 if smooth else float(np.interp(delta, z['l1_cdf_x'], z['l1_cdf_y']))   # fraction of L1 elements within delta of a tie
+    flip = 2.0 * np.sqrt(f)
     print('%s B=%d %dx%d: forward diff rms %.3g; L1 elements within 3 rms of a tie: %.3g -> sign-flip allowance %.3g' % (mode, B, F, T, delta / 3, f, flip))
     assert f < 1e-2
     G = eng.tf_gradients()

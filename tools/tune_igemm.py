@@ -27,7 +27,7 @@ from tests import gpu_util as U  # noqa: E402
 from voice_converter_cyclegan_amd._lib import lib, check  # noqa: E402
 
 CONFIGS = [(bm, kg, sk) for bm in (128, 64) for kg in (1, 2, 4) for sk in (1, 2, 4, 8, 16) if not (bm == 128 and kg == 4)]
-CONFIGS_BF16 = [(bm, nst, sk) for bm in (128, 64) for nst in (2, 4) for sk in (1, 2, 4, 8)]      # conv_bf16_kernel<tile rows, ring stages> x split-K
+CONFIGS_BF16 = [(bm, nst, sk) for bm in (128, 64) for nst in (2, 4) for sk in (1, 2, 4, 8)] + [(256, 3, sk) for sk in (1, 2, 4)]      # conv_bf16_kernel<tile rows, ring stages> x split-K
 
 
 def layers(F, T):

@@ -21,6 +21,7 @@
 // pack_pixel_octets_bf16_kernel; launch set-up in vc_api.hip: conv_wgrad).
 #include "vc_internal.h"
 #include <array>
+#include <cstdlib>
 #include <vector>
 #include <algorithm>
 #include <type_traits>
@@ -192,6 +193,9 @@ int launch_pack_filter_bf16(const float* w, long w_gs, void* ap, long ap_gs_byte
 // ------------------------------------------------------------------------------------------------------------------
 // the convolution
 // ------------------------------------------------------------------------------------------------------------------
+// BM = 256 (round 4): a wave owns 4 x 2 MFMA tiles (128 rows x 64 pixels, 128 accumulator registers): 6 fragment reads feed 8
+// MFMAs (4 feed 4 at BM = 128), a chunk is 32 MFMAs per wave instead of 16 -- the per-chunk barrier, table fetch and LDS
+// round trip weigh half as much -- on a 3-stage ring (48 KB per stage), one workgroup per CU.
 template <int BM, int NST> __global__ __launch_bounds__(256, NST <= 2 ? 2 : 1) void conv_bf16_kernel(const ConvBf16Args p) {
     constexpr int BN = 128, MI = BM / 64;                 // a wave owns MI x 2 MFMA tiles: rows [wm * BM/2, +BM/2), pixels [wn * 64, +64)
     constexpr int ASZ = 8 * BM * 16, XSZ = 8 * BN * 16, STAGE = ASZ + XSZ;      // one K chunk: [octet][row][16 B] for both operands
@@ -255,17 +259,27 @@ template <int BM, int NST> __global__ __launch_bounds__(256, NST <= 2 ? 2 : 1) v
 #pragma unroll
         for (int q = 0; q < 2; ++q) { tso[q] = xsoff[c * 8 + 2 * wv + q]; ttb[q] = otap[c * 8 + 2 * wv + q]; }
     };
-    auto issue = [&](int c, int buf) {                  // chunk c of the K range (table entries already in tso / ttb) -> LDS stage buf
+    // chunk c of the K range (table entries already in tso / ttb) -> LDS stage buf, as GL = 2 (2 + MI) copies in a fixed order;
+    // issue_part<PART> sends out the PART-th quarter of them.  In the K loop a quarter rides behind the MFMAs of each of the
+    // four steps: an LDS-direct copy costs ~60 cycles of issue, and with one workgroup per CU (one wave per SIMD) nothing
+    // else covers GL of them in a row at the top of the iteration (round 3 issued them there: 0.5 - 0.7 us per chunk with
+    // the matrix pipe idle, which is why two workgroups per CU measured faster whenever they fitted).
+    constexpr int GL = 4 + 2 * MI;
+    auto copy_one = [&](int c, int buf, int i) {          // i-th copy of the chunk: q = octet of the wave's pair, then X halves, then A quarters
         char* As = smem + buf * STAGE; char* Xs = As + ASZ;
+        const int q = i / (2 + MI), k = i - q * (2 + MI);
+        const int oq = 2 * wv + q, o = c * 8 + oq;
+        if (k < 2) lds_copy16(xrs, (lds_ptr_t)(Xs + (oq * BN + k * 64) * 16), (tapmask[k < 2 ? k : 0] & ttb[q]) ? xoffb[k < 2 ? k : 0] : VC_OOB, (unsigned)tso[q]);
+        else lds_copy16(ars, (lds_ptr_t)(As + (oq * BM + (k - 2) * 64) * 16), avoff[k >= 2 ? k - 2 : 0], (unsigned)o * a_os);
+    };
+    auto issue_part = [&](int c, int buf, auto PC) {
+        constexpr int PART = decltype(PC)::value, I0 = GL * PART / 4, I1 = GL * (PART + 1) / 4;
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int oq = 2 * wv + q, o = c * 8 + oq;
+        for (int i = I0; i < I1; ++i) copy_one(c, buf, i);
+    };
+    auto issue = [&](int c, int buf) {
 #pragma unroll
-            for (int hf = 0; hf < 2; ++hf) {
-                lds_copy16(xrs, (lds_ptr_t)(Xs + (oq * BN + hf * 64) * 16), (tapmask[hf] & ttb[q]) ? xoffb[hf] : VC_OOB, (unsigned)tso[q]);
-                if (hf < MI) lds_copy16(ars, (lds_ptr_t)(As + (oq * BM + hf * 64) * 16), avoff[hf < MI ? hf : 0], (unsigned)o * a_os);
-            }
-        }
+        for (int i = 0; i < GL; ++i) copy_one(c, buf, i);
     };
 
     f32x16 acc[MI][2];
@@ -283,9 +297,9 @@ template <int BM, int NST> __global__ __launch_bounds__(256, NST <= 2 ? 2 : 1) v
     // in flight across the barrier), then the barrier tells every wave that chunk c is complete and that chunk c - 1, the
     // previous tenant of the stage refilled next, has been multiplied.  Past the end of the K range the ring keeps
     // copying the last chunk into stages nobody reads, so the count is the same in every iteration.
-    constexpr int GL = 4 + 2 * MI;                          // LDS-direct copies per wave and chunk
     auto wait_landed = [&]() {
         if constexpr (NST == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if constexpr ((NST - 2) * GL == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
         else if constexpr ((NST - 2) * GL == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         else if constexpr ((NST - 2) * GL == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
         else if constexpr ((NST - 2) * GL == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -300,10 +314,8 @@ template <int BM, int NST> __global__ __launch_bounds__(256, NST <= 2 ? 2 : 1) v
         wait_landed();
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        {
-            const int stn = st == 0 ? NST - 1 : st - 1;     // (c + NST - 1) % NST
-            issue(c0 + min(c + NST - 1, cn - 1), stn);
-        }
+        const int stn = st == 0 ? NST - 1 : st - 1;         // (c + NST - 1) % NST: the stage chunk c - 1 has just left
+        const int cnx = c0 + min(c + NST - 1, cn - 1);
         const char* As = smem + st * STAGE + ((wm * (BM / 2) + l31) + h * BM) * 16;
         const char* Xs = smem + st * STAGE + ASZ + ((wn * 64 + l31) + h * BN) * 16;
         // MFMA step s multiplies octets 2 s (lanes 0-31) and 2 s + 1 (lanes 32-63); the fragments of step s + 1 are
@@ -324,7 +336,11 @@ template <int BM, int NST> __global__ __launch_bounds__(256, NST <= 2 ? 2 : 1) v
                 acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s & 1][i], fb[s & 1][0], acc[i][0], 0, 0, 0);
                 acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s & 1][i], fb[s & 1][1], acc[i][1], 0, 0, 0);
             }
-            if (s == 0) fetch_tab(c0 + min(c + NST, cn - 1));      // behind the first MFMAs; next used after the next barrier
+            // a quarter of the refill of stage stn behind this step's MFMAs (the table entries were fetched an iteration ago)
+            if (s == 0) issue_part(cnx, stn, std::integral_constant<int, 0>{});
+            else if (s == 1) issue_part(cnx, stn, std::integral_constant<int, 1>{});
+            else if (s == 2) issue_part(cnx, stn, std::integral_constant<int, 2>{});
+            else { issue_part(cnx, stn, std::integral_constant<int, 3>{}); fetch_tab(c0 + min(c + NST, cn - 1)); }   // next used a barrier + a step of MFMAs from here
             __builtin_amdgcn_sched_barrier(0);
         }
         st = st + 1 == NST ? 0 : st + 1;
@@ -387,7 +403,7 @@ template <int BM, int NST> __global__ __launch_bounds__(256, NST <= 2 ? 2 : 1) v
 static thread_local int g_bf16_bm = 0, g_bf16_nst = 0, g_bf16_sk = 0;      // per calling thread
 extern "C" int vc_tune_conv_bf16_override(int tile_rows, int stages, int splitk) {
     const bool ok = (tile_rows == 0 && stages == 0 && splitk == 0) ||
-                    ((tile_rows == 64 || tile_rows == 128) && (stages == 2 || stages == 4) && splitk >= 1 && splitk <= 16);
+                    ((((tile_rows == 64 || tile_rows == 128) && (stages == 2 || stages == 4)) || (tile_rows == 256 && stages == 3)) && splitk >= 1 && splitk <= 16);
     if (!ok) { vc_set_error("vc_tune_conv_bf16_override: tile rows %d, stages %d, split-K %d is not a built configuration", tile_rows, stages, splitk); return -1; }
     g_bf16_bm = tile_rows; g_bf16_nst = stages; g_bf16_sk = splitk;
     return 0;
@@ -397,6 +413,13 @@ struct TunedBf16 { int M, Ptot, koct, groups, bm, nst, sk; };
 #include "vc_tuned_bf16.h"
 void conv_bf16_config(ConvBf16Args& a) {
     a.ntiles = (a.Ptot + 127) / 128;
+    // 256-row tiles (one workgroup per CU, 128 x 64 per wave) when they fill the chip in whole rounds: at least 3/4 of the
+    // last round's CUs busy.  VC_BF16_WIDE=0 switches the rule off (A/B measurements).
+    static const bool wide_on = !(getenv("VC_BF16_WIDE") && atoi(getenv("VC_BF16_WIDE")) == 0);
+    if (!g_bf16_bm && wide_on && a.M >= 256 && a.M % 256 == 0 && a.koct >= 64) {
+        const long t256 = (long)(a.M / 256) * a.ntiles * a.groups, rounds = (t256 + 255) / 256;
+        if (t256 * 4 >= rounds * 256 * 3) { a.bm = 256; a.nst = 3; a.mtiles = a.M / 256; a.splitk = 1; return; }
+    }
     if (!g_bf16_bm)
         for (const TunedBf16& t : kTunedBf16)
             if (t.M == a.M && t.Ptot == a.Ptot && t.koct == a.koct && t.groups == a.groups) {
@@ -412,7 +435,7 @@ void conv_bf16_config(ConvBf16Args& a) {
     if (t128 > 256 && a.M > 64) { a.bm = 128; a.nst = 2; }
     else if (t128 > 128 && a.M > 64) { a.bm = 128; a.nst = 4; }
     else { a.bm = 64; a.nst = 4; }
-    if (g_bf16_bm) { a.bm = g_bf16_bm; a.nst = g_bf16_nst; }
+    if (g_bf16_bm) { a.bm = (g_bf16_bm == 256 && a.M <= 128) ? 128 : g_bf16_bm; a.nst = a.bm == g_bf16_bm ? g_bf16_nst : 4; }
     a.mtiles = (a.M + a.bm - 1) / a.bm;
     const long tiles = (long)a.mtiles * a.ntiles * a.groups;
     const int nchunks = a.koct / 8;
@@ -436,7 +459,8 @@ int launch_conv_bf16(const ConvBf16Args& a, hipStream_t s, double flops, int pro
     if (a.splitk > 1 && !a.accumulate) { vc_set_error("launch_conv_bf16: split-K requires accumulate semantics"); return -1; }
     dim3 grid(a.mtiles * a.ntiles, 1, a.groups * a.splitk);
     ProfScope ps(prof_kind, flops, s);
-    if (a.bm == 64) { if (a.nst == 4) conv_bf16_kernel<64, 4><<<grid, 256, 0, s>>>(a); else conv_bf16_kernel<64, 2><<<grid, 256, 0, s>>>(a); }
+    if (a.bm == 256) conv_bf16_kernel<256, 3><<<grid, 256, 0, s>>>(a);
+    else if (a.bm == 64) { if (a.nst == 4) conv_bf16_kernel<64, 4><<<grid, 256, 0, s>>>(a); else conv_bf16_kernel<64, 2><<<grid, 256, 0, s>>>(a); }
     else { if (a.nst == 4) conv_bf16_kernel<128, 4><<<grid, 256, 0, s>>>(a); else conv_bf16_kernel<128, 2><<<grid, 256, 0, s>>>(a); }
     VC_HIP(hipGetLastError());
     return 0;

@@ -177,7 +177,28 @@ __global__ __launch_bounds__(256, 1) void gated_conv1d_glu_kernel(const WsConvAr
         return p;
     };
     // NST stores per tile, always issued: lanes outside the tensor carry an out-of-range offset (dropped by the hardware)
-    auto glu1 = [&](const f32x16& sv, const f32x16& sg, f32x16& o, int r) { o[r] = sv[r] * __builtin_amdgcn_rcpf(1.f + __expf(-sg[r])); };
+    // value * sigmoid(gate) = value * rcp(1 + exp2(-log2(e) gate)): hardware exp2 and reciprocal (1 ulp each).  One wave per
+    // SIMD means nobody covers a DEPENDENT chain (mul -> exp -> add -> rcp -> mul, ~100 cycles, and the in-order wave cannot
+    // issue the next MFMA pair from behind it): the first build of this kernel ran 2.0 us per tile against 0.64 us of MFMA
+    // time for exactly that reason.  So the chain is cut into STAGES applied to four values at a time: four independent
+    // instructions per stage, one stage per K step (bf16), i.e. a stage's inputs are two MFMAs old when it runs.
+    auto glu_stage = [&](const f32x16& sv, const f32x16& sg, f32x4& t, f32x16& o, int q, int st) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (st == 0) t[j] = sg[4 * q + j] * -1.44269504f;
+            else if (st == 1) t[j] = __builtin_amdgcn_exp2f(t[j]);
+            else if (st == 2) t[j] = 1.f + t[j];
+            else if (st == 3) t[j] = __builtin_amdgcn_rcpf(t[j]);
+            else o[4 * q + j] = sv[4 * q + j] * t[j];
+        }
+    };
+    auto glu_all = [&](const f32x16& sv, const f32x16& sg, f32x16& o) {     // outside the MFMA loop: the scheduler interleaves the 16 chains
+        f32x4 t[4];
+#pragma unroll
+        for (int st = 0; st < 5; ++st)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) glu_stage(sv, sg, t[q], o, q, st);
+    };
     auto store_quad = [&](const f32x16& sv, const f32x16& sg, const f32x16& o, int qd, const OutPos& p) {
         const bool ok = p.tv && p.t + 8 * qd < a.T;
         const unsigned yo = ok ? p.yb + 32u * qd : VC_OOB_ST;
@@ -235,8 +256,7 @@ __global__ __launch_bounds__(256, 1) void gated_conv1d_glu_kernel(const WsConvAr
         if constexpr (!OVERLAP) {
             // fp32: the K loop is 360 MFMAs of 64 cycles; the previous tile's epilogue in front of it is < 2 % of a trip
             issue_loads(xp, tile + 2 * tstep);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) glu1(accv[0], accg[0], o, r);
+            glu_all(accv[0], accg[0], o);
 #pragma unroll
             for (int qd = 0; qd < 4; ++qd) store_quad(accv[0], accg[0], o, qd, pp);
         }
@@ -268,21 +288,22 @@ __global__ __launch_bounds__(256, 1) void gated_conv1d_glu_kernel(const WsConvAr
                 }
             }
         };
-        // bf16: what rides behind the MFMAs of step u.  Steps 0-1: the next-but-one tile's loads; steps 0-15: one GLU value of
-        // the previous tile each, a quad's stores after every fourth; steps 17-18: the next tile's frames -> LDS.
+        // bf16: what rides behind the MFMAs of step u.  Step 0: the next-but-one tile's loads; steps 0-19: stage (u % 5) of the
+        // previous tile's GLU quad (u / 5), the quad's stores behind its last stage; steps 20-21: the next tile's frames -> LDS.
+        f32x4 gt;
         auto side = [&](auto UC) {
             constexpr int u = decltype(UC)::value;
             if constexpr (OVERLAP) {
                 if constexpr (u == 0) issue_loads(xp, tile + 2 * tstep);
-                if constexpr (u < 16) {
-                    glu1(accv[AP], accg[AP], o, u);
-                    if constexpr ((u & 3) == 3) store_quad(accv[AP], accg[AP], o, u >> 2, pp);
+                if constexpr (u < 20) {
+                    glu_stage(accv[AP], accg[AP], gt, o, u / 5, u % 5);
+                    if constexpr (u % 5 == 4) store_quad(accv[AP], accg[AP], o, u / 5, pp);
                 }
-                if constexpr (u == 17) {
+                if constexpr (u == 20) {
                     wait_counted(xq);
                     stage_task(xq, std::integral_constant<int, 0>{}, nslot);
                 }
-                if constexpr (u == 18) stage_task(xq, std::integral_constant<int, 1>{}, nslot);
+                if constexpr (u == 21) stage_task(xq, std::integral_constant<int, 1>{}, nslot);
             }
         };
         [&]<int... U>(std::integer_sequence<int, U...>) { (rd(std::integral_constant<int, U>{}), ...); }(std::make_integer_sequence<int, RD>{});
@@ -297,7 +318,7 @@ __global__ __launch_bounds__(256, 1) void gated_conv1d_glu_kernel(const WsConvAr
         }
         __syncthreads();                                    // slot P ^ 1 is complete; slot P may be overwritten by the next trip
     };
-    static_assert(!OVERLAP || (NU >= 19 && NTPT == 2), "the bf16 side schedule places its work on steps 0-18");
+    static_assert(!OVERLAP || (NU >= 22 && NTPT == 2), "the bf16 side schedule places its work on steps 0-21");
 
     int tile = tile0;
     for (;;) {
@@ -313,13 +334,11 @@ __global__ __launch_bounds__(256, 1) void gated_conv1d_glu_kernel(const WsConvAr
         const OutPos pp = out_pos(ptile);
         f32x16 o;
         if (OVERLAP && !(trips & 1)) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) glu1(accv[1], accg[1], o, r);
+            glu_all(accv[1], accg[1], o);
 #pragma unroll
             for (int qd = 0; qd < 4; ++qd) store_quad(accv[1], accg[1], o, qd, pp);
         } else {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) glu1(accv[0], accg[0], o, r);
+            glu_all(accv[0], accg[0], o);
 #pragma unroll
             for (int qd = 0; qd < 4; ++qd) store_quad(accv[0], accg[0], o, qd, pp);
         }

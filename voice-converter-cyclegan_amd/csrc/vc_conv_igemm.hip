@@ -33,10 +33,15 @@ typedef const __attribute__((address_space(4))) unsigned* c_uint_p;
 typedef const __attribute__((address_space(4))) Tap* c_tap_p;
 
 // launch pixel -> (sample, row, column) of the launch grid; rowskip launches enumerate (row, sample, column)
+// (Selects on values, not two code paths writing through the references: the round-3 form made the compiler park b and i in
+// SCRATCH memory behind a computed offset -- 12 bytes of private memory per lane, and a store / load round trip through the
+// memory system in every workgroup's prologue and again in its epilogue.)
 __device__ __forceinline__ void px_decode(const IgemmArgs& p, int P, int& b, int& i, int& j) {
     int r;
-    if (p.rowskip) { i = fast_divmod(P, p.RW, p.inv_rw, &r); b = fast_divmod(r, p.OWc, p.inv_ow, &j); }
-    else { b = fast_divmod(P, p.NPB, p.inv_npb, &r); i = fast_divmod(r, p.OWc, p.inv_ow, &j); }
+    const bool rs = p.rowskip != 0;
+    const int q0 = fast_divmod(P, rs ? p.RW : p.NPB, rs ? p.inv_rw : p.inv_npb, &r);
+    const int q1 = fast_divmod(r, p.OWc, p.inv_ow, &j);
+    b = rs ? q1 : q0; i = rs ? q0 : q1;
 }
 
 template <int BM, bool AT, int KG, int MATH, bool FUSE = false>
@@ -95,27 +100,14 @@ __global__ __launch_bounds__(64 * (BM / 32) * 2 * KG, (64 * (BM / 32) * 2 * KG >
     constexpr int XL = (KC * BN) / GT;                        // 4 (8-wave group) or 8 (4-wave group)
     static_assert(XL % 4 == 0, "whole 16-byte k runs per thread");
     const int xrow0 = gw * XL;
-    unsigned xoffb = 0, tapmask = 0;
-    {
-        const int P = nt * BN + lane;
-        const bool pv = P < p.Ptot;
-        int xb = 0, xi = 0, xj = 0;
-        if (pv) px_decode(p, P, xb, xi, xj);
-        const int li0 = xi * p.si, lj0 = xj * p.sj;
-        xoffb = (unsigned)(((long)xb * p.x_bs + (long)li0 * p.xW + lj0) * 4);
-        // one vector load brings the whole tap table (lane t holds tap t; at most 32 taps), the loop reads a tap back with
-        // v_readlane: no scalar-memory round trip per tap (the probe of tools/igemm_ablation.patch put 4 us of a launch
-        // between its entry and its first operand load, most of it this loop's dependent s_loads)
-        int vdh = 0, vdw = 0;
-        if (lane < p.ntaps) { const Tap tp = p.taps[lane]; vdh = tp.dh; vdw = tp.dw; }
-        const unsigned Hl = (unsigned)p.Hl, Wl = (unsigned)p.Wl;
-        const int ntaps = p.ntaps;
-        for (int t = 0; t < ntaps; ++t) {                // branch-free body: no kernel-argument reload, no exec juggling per tap
-            const int dh = __builtin_amdgcn_readlane(vdh, t), dw = __builtin_amdgcn_readlane(vdw, t);
-            const unsigned ok = (unsigned)pv & (unsigned)((unsigned)(li0 + dh) < Hl) & (unsigned)((unsigned)(lj0 + dw) < Wl);
-            tapmask |= ok << t;
-        }
-    }
+    // The launch's fixed cost is a chain of dependent memory round trips (kernel arguments -> tap table -> K tables ->
+    // first operands: the round-3 timeline probe put 4.0 us between a workgroup's entry and its first operand load).  The
+    // tap table (one vector load: lane t holds tap t; at most 32 taps) and the first chunk's K-table entries depend on the
+    // kernel arguments only, so both are requested here, side by side; the weight loads of chunk c0 -- which need the table
+    // but not the taps -- go out before the tap loop, the gathered operand's loads behind it.
+    int vdh = 0, vdw = 0;
+    if (lane < p.ntaps) { const Tap tp = p.taps[lane]; vdh = tp.dh; vdw = tp.dw; }
+    unsigned xoffb = 0, tapmask = 0;                          // the lane's pixel offset and tap-validity mask: filled in behind the first table fetch
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
         (void*)((const char*)(p.X + (long)g * p.x_gs) - p.xbias), 0, (int)p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t ars =
@@ -261,7 +253,26 @@ __global__ __launch_bounds__(64 * (BM / 32) * 2 * KG, (64 * (BM / 32) * 2 * KG >
 
     // the loader never branches: it runs up to 3 chunks past the part's range (LDS it then fills is never read)
     fetch_tab(c0);
-    items(ZERO{}, LD0{}, S0{}, S0{}, 0);
+    using XLC = std::integral_constant<int, XL>;
+    using ALC = std::integral_constant<int, NAL>;
+    items(XLC{}, ALC{}, S0{}, S0{}, 0);                       // weight loads of chunk c0: tables only
+    {
+        const int P = nt * BN + lane;
+        const bool pv = P < p.Ptot;
+        int xb = 0, xi = 0, xj = 0;
+        if (pv) px_decode(p, P, xb, xi, xj);
+        const int li0 = xi * p.si, lj0 = xj * p.sj;
+        xoffb = (unsigned)(((long)xb * p.x_bs + (long)li0 * p.xW + lj0) * 4);
+        // the loop reads a tap back with v_readlane: no scalar-memory round trip per tap
+        const unsigned Hl = (unsigned)p.Hl, Wl = (unsigned)p.Wl;
+        const int ntaps = p.ntaps;
+        for (int t = 0; t < ntaps; ++t) {                // branch-free body: no kernel-argument reload, no exec juggling per tap
+            const int dh = __builtin_amdgcn_readlane(vdh, t), dw = __builtin_amdgcn_readlane(vdw, t);
+            const unsigned ok = (unsigned)pv & (unsigned)((unsigned)(li0 + dh) < Hl) & (unsigned)((unsigned)(lj0 + dw) < Wl);
+            tapmask |= ok << t;
+        }
+    }
+    items(ZERO{}, XLC{}, S0{}, S0{}, 0);                      // gathered-operand loads of chunk c0
     fetch_tab(c0 + 1);
     items(ZERO{}, LD0{}, S1{}, S1{}, 0);
     fetch_tab(c0 + 2);
