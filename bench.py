@@ -211,6 +211,64 @@ def roofline_leg(eng, lib, A, Bm, hp, math, peak, world, serial, n_prof=3):
     return out
 
 
+def dp_selftest(eng, lib, A, Bm, hp, steps, warmup):
+    """What one GPU can say about the data-parallel step: the step time with the gradient exchange of
+    vc_step_exchange_and_update actually on the update stream, against the plain single-GPU step.
+      rccl_1rank : a real RCCL communicator of ONE rank (RCCL refuses two ranks on one device): the collectives are issued
+                   (vc_comm_collectives counts them) -- what RCCL launches for a 1-rank in-place SUM is RCCL's business;
+      standin    : the exchange replaced by stand-in traffic on the same stream behind the same events: every gradient
+                   segment is copied out and back (2 reads + 2 writes of the segment = the HBM traffic of a ring
+                   all-reduce's reduce-scatter + all-gather on one rank), so the 479 MB exchange competes with the generator
+                   backward for HBM and CUs the way the real one does.  NOT a measurement of xGMI -- the link time
+                   (2 (N-1)/N x 479 MB / per-link bandwidth) comes on top where it is not hidden.
+    Reported: ms/step of each leg, the exposed (not overlapped) exchange + update time from events, the segment sizes."""
+    import ctypes as C
+    import torch
+    from voice_converter_cyclegan_amd import _lib
+    from voice_converter_cyclegan_amd._lib import check
+    out = {}
+    p = eng.plan(A.shape[2])
+    segs = eng.grad_segments(p)
+    out['segments_MB'] = [round(sum(hi - lo for lo, hi in r) * 4 / 1e6, 1) for _, _, r in segs]
+    eng.measure_exposed = True
+
+    def leg():
+        dt = time_steps(eng, A, Bm, hp, steps, warmup, torch.cuda.synchronize)
+        return 1e3 * dt / steps, eng.exposed_update_ms()
+    ms, ex = leg()
+    out['plain'] = {'ms_per_step': ms, 'exposed_update_ms': ex}
+    ident = (C.c_ubyte * 128)()
+    h = _lib.vp()
+    try:
+        check(lib.vc_comm_unique_id(ident), 'vc_comm_unique_id')
+        check(lib.vc_comm_init(0, 1, ident, C.byref(h)), 'vc_comm_init')
+        n0 = lib.vc_comm_collectives(h)
+        eng.sync.comm = h
+        ms, ex = leg()
+        out['rccl_1rank'] = {'ms_per_step': ms, 'exposed_update_ms': ex,
+                             'collectives_per_step': (lib.vc_comm_collectives(h) - n0) / float(steps + warmup)}
+    except Exception as e:      # no RCCL on this box: say so, keep the stand-in leg
+        out['rccl_1rank'] = {'error': str(e)}
+    finally:
+        eng.sync.comm = None
+        if h:
+            lib.vc_comm_destroy(h)
+    scratch = torch.empty(max(hi - lo for _, _, r in segs for lo, hi in r), device=A.device)
+
+    def standin(g):
+        scratch[:g.numel()].copy_(g)
+        g.copy_(scratch[:g.numel()])
+    eng.exchange_standin = standin
+    ms, ex = leg()
+    eng.exchange_standin = None
+    eng.measure_exposed = False
+    out['standin'] = {'ms_per_step': ms, 'exposed_update_ms': ex}
+    out['slowdown_standin_vs_plain'] = out['standin']['ms_per_step'] / out['plain']['ms_per_step']
+    out['note'] = ('one GPU: rccl_1rank issues the real collectives on a 1-rank communicator; standin moves each gradient segment '
+                   'out and back on the update stream (ring all-reduce HBM traffic without the links)')
+    return out
+
+
 def workload_text(math, B, F, T, global_batch):
     idx = 4 if (F, T) == (36, 256) else 3 if global_batch else 1 if math == 'fp32' else 2
     return ('BASELINE configs[%d]: full CycleGAN-VC train step (2G+2D fwd/bwd + losses + TF-Adam), %s, batch %d per GPU, '
@@ -271,6 +329,9 @@ def main():
     ap.add_argument('--no-extra', action='store_true',
                     help='skip the other BASELINE configurations (bf16 B=64, fp32 B=32 = configs[3]\'s share of an 8-GPU node, 36x256 '
                          'B=64) that a default single-GPU run measures after the headline and reports under extra.configs')
+    ap.add_argument('--dp-selftest', action='store_true',
+                    help='single GPU: time the step with the gradient exchange really on the update stream (1-rank RCCL communicator; '
+                         'stand-in traffic) and report it under extra.dp_overlap; part of the default single-GPU run')
     ap.add_argument('--serial', action='store_true',
                     help='serialise the step\'s two independent chains on one stream for the WHOLE run (the condition the '
                          'roofline leg always uses; for rocprof summaries that must agree with it)')
@@ -328,7 +389,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    eng.measure_exposed = world > 1              # N > 1: how much of exchange + update is NOT hidden under the backward
     dt = time_steps(eng, A, Bm, hp, args.steps, args.warmup, barrier)
+    exposed_ms = eng.exposed_update_ms() if world > 1 else None
+    eng.measure_exposed = False
+    if world > 1:                                # every rank says what it runs with, so a SCALE line explains itself
+        p_ = eng.plan(T)
+        print('[bench] rank %d/%d: %.3f ms/step, exposed exchange+update %.3f ms, communicator %s, gradient segments (MB) %s'
+              % (rank, world, 1e3 * dt / args.steps, exposed_ms or -1.0,
+                 ('native RCCL, %d ranks' % lib.vc_comm_world(eng.sync.comm)) if eng.sync.comm is not None else 'torch.distributed',
+                 [round(sum(hi - lo for lo, hi in r) * 4 / 1e6, 1) for _, _, r in eng.grad_segments(p_)]), file=sys.stderr, flush=True)
     if rank == 0:
         print('[bench] headline: %.3f ms/step' % (1e3 * dt / args.steps), file=sys.stderr, flush=True)
     if world > 1:
@@ -360,6 +430,9 @@ def main():
                        # input gradients nobody consumes: what it EXECUTES is filled in below from the per-launch records
                        'reference_graph_gflop_per_step': 91.41 * world * B if (F, T) == (24, 128) else None},
         }
+        if world > 1:
+            out['config']['exposed_exchange_update_ms_rank0'] = exposed_ms
+            out['config']['gradient_bytes_per_step'] = 4 * int(eng.n_flat)
 
     # ---- roofline leg: the same steps again with HIP events around every implicit-GEMM launch
     if not args.no_roofline:
@@ -381,6 +454,12 @@ def main():
                                             'B4096': {'us': r4k['us'], 'hbm_frac': r4k['hbm']['frac'], 'algorithmic_bytes': r4k['algorithmic_bytes']}}
         out['named_kernel']['timed'] = 'everything one vc_gated_conv1d_glu_fwd call launches (filter-image pack + the kernel), HIP events on the call\'s stream'
 
+    dp = None
+    if rank == 0 and world == 1 and (args.dp_selftest or (default_workload and not args.no_extra and not args.no_roofline)):
+        print('[bench] data-parallel self-test on one GPU', file=sys.stderr, flush=True)
+        dp = dp_selftest(eng, lib, A, Bm, hp, args.steps, args.warmup)
+        if args.dp_selftest:
+            out.setdefault('extra', {})['dp_overlap'] = dp
     # ---- the other BASELINE configurations this GPU can hold, each with its own roofline (default single-GPU run only)
     if rank == 0 and world == 1 and default_workload and not args.no_extra and not args.no_roofline:
         eng.close()
@@ -391,6 +470,7 @@ def main():
             extra_config(lib, dev, 'fp32', 64, 36, 256, 5, 2, 'configs[4]: the per-GPU share (64) of global batch 512 at 36x256, measured on one GPU without the exchange'),
         ]}
         # diagnostic, not a result: the headline configuration's launches on constant operands (data-dependent power management)
+        out['extra']['dp_overlap'] = dp
         out['extra']['constant_operands_diagnostic'] = extra_config(
             lib, dev, 'fp32', 8, 24, 128, 20, 5, 'DIAGNOSTIC: configs[1] with every parameter and every input 0 (same launches, '
             'zero-entropy operands); compare its roofline.frac with the headline\'s -- the difference is the chip\'s power management, not the kernels',

@@ -20,8 +20,8 @@ extern "C" {
  *              split-K (1..16) */
 int  vc_tune_igemm_override(int tile_rows, int k_groups, int splitk);
 int  vc_tune_wgrad_override(int tile_cols, int k_groups, int splitk);
-int  vc_tune_rowskip(int igemm_on, int wgrad_on);   /* row-major pixel tiles that skip the filter rows lying in the SAME padding (D.d3): default off for
-                                                     * forward / input gradient, on for filter gradients (csrc/vc_api.hip: rowskip_pays); thread-local */
+int  vc_tune_rowskip(int wgrad_on);     /* filter gradients of 2-D layers whose taps reach far into the SAME padding (D.d3) enumerate pixels row-major and
+                                         * skip the output rows a K tile's taps never reach (csrc/vc_api.hip: rowskip_pays); default on; thread-local */
 int  vc_tune_wgrad_store(int on);       /* tuning only: while on, vc_conv2d_wgrad OVERWRITES dw (the train step's plain-store form) */
 int  vc_tune_conv_bf16_override(int tile_rows, int stages, int splitk);
 int  vc_tune_glu_version(int version);   /* A/B only: 1 = the round-3 form of vc_gated_conv1d_glu_fwd (filter slab in LDS), 2 = current */

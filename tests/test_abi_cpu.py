@@ -107,7 +107,7 @@ def test_product_path_never_imports_oracle():
 
 
 def test_experiment_patch_still_applies():
-    """tools/igemm_ablation.patch (timing-only switches + probes for csrc/vc_conv_igemm.hip) must track the kernel"""
+    """tools/igemm_timeline.patch (in-kernel phase stamps for csrc/vc_conv_igemm.hip) must track the kernel"""
     import os
     import shutil
     import subprocess
@@ -115,5 +115,5 @@ def test_experiment_patch_still_applies():
     if shutil.which('git') is None:
         pytest.skip('git not available')
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run(['git', 'apply', '--check', os.path.join('tools', 'igemm_ablation.patch')], cwd=root, capture_output=True, text=True)
+    r = subprocess.run(['git', 'apply', '--check', os.path.join('tools', 'igemm_timeline.patch')], cwd=root, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr

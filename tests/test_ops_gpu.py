@@ -57,8 +57,8 @@ CONV_CASES = [
     (256, 1, 256, 36, 1, 15, 1, 1, 2),     # config 5's o1
     (1024, 1, 32, 512, 1, 3, 1, 1, 8),     # residual h2, cycle hop: K groups inside the workgroup + split-K
     (256, 1, 128, 24, 1, 15, 1, 1, 8),     # o1 at B = 8: 24-row taps (padded to 32) in the input-gradient table
-    # rowskip (IgemmArgs::rowskip, WgradArgs::rowskip): D.d3's 6 tap rows on 6 image rows, SAME pads (2, 3) -- launch pixels
-    # enumerated (row, sample, column), only the tap rows / output rows that touch the image are walked
+    # rowskip (WgradArgs::rowskip): D.d3's 6 tap rows on 6 image rows, SAME pads (2, 3) -- the filter gradient enumerates its
+    # pixels (row, sample, column) and walks only the output rows a K tile's taps reach
     (512, 6, 16, 2048, 6, 3, 1, 2, 8),     # the B = 8 step's size: 64 pixels per output row = one tile per row
     (512, 9, 32, 2048, 6, 3, 1, 2, 3),     # 36 MCEPs (9 rows), odd batch: 48 pixels per row, tiles straddle rows
     (64, 6, 16, 128, 6, 3, 1, 2, 16),      # 128 pixels per row: two tiles per row
@@ -78,18 +78,18 @@ def test_conv_fwd_dgrad_wgrad(built_lib, case):
     _conv_check(case)
 
 
-@pytest.mark.parametrize('modes', [(1, 1), (1, 0), (0, 0)])
+@pytest.mark.parametrize('on', [1, 0])
 @pytest.mark.parametrize('case', [c for c in CONV_CASES if c[4] == 6] + [(16, 5, 7, 32, 6, 3, 1, 2, 2)])
-def test_conv_rowskip_modes(built_lib, case, modes):
-    """IgemmArgs::rowskip / WgradArgs::rowskip (launch pixels enumerated (row, sample, column); only the filter rows that touch
-    the image for a tile's rows are walked): on by default for filter gradients only (vc_api.hip: rowskip_pays); every
-    combination is forced here (vc_tune_rowskip) on the 6-row-kernel geometries it applies to (module.py:208, D.d3)."""
+def test_conv_rowskip_modes(built_lib, case, on):
+    """WgradArgs::rowskip (filter gradient: launch pixels enumerated (row, sample, column); a K tile reduces only over the
+    output rows its taps reach): on by default (vc_api.hip: rowskip_pays); both settings are forced here (vc_tune_rowskip) on the
+    6-row-kernel geometries it applies to (module.py:208, D.d3)."""
     from voice_converter_cyclegan_amd._lib import lib, check
-    check(lib.vc_tune_rowskip(*modes))
+    check(lib.vc_tune_rowskip(on))
     try:
         _conv_check(case)
     finally:
-        check(lib.vc_tune_rowskip(0, 1))
+        check(lib.vc_tune_rowskip(1))
 
 
 # bf16 MFMA modes (vc_set_math_mode): 'bf16' is checked against the oracle with the SAME operand rounding (so only the

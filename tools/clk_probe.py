@@ -1,7 +1,6 @@
-# Reads the experiment counters of a -DVC_CLKPROBE / -DVC_TIMELINE build of csrc/vc_conv_igemm.hip (tools/igemm_ablation.patch):
-#   python tools/clk_probe.py [clk|timeline] [batch]
-# clk:      effective shader clock inside the igemm launches of the train step (s_memtime cycles / 100 MHz wall ticks)
-# timeline: mean phase durations of workgroup (0,0,0) over all igemm launches of the step, in cycles and microseconds
+# Reads the phase stamps of a -DVC_TIMELINE build of csrc/vc_conv_igemm.hip (tools/igemm_timeline.patch):
+#   python tools/clk_probe.py timeline [batch]
+# mean phase durations of workgroup (0,0,0) over all igemm launches of the step, in cycles and microseconds
 import ctypes as C
 import os
 import sys
@@ -15,9 +14,9 @@ import vcgan_pkg  # noqa: E402,F401
 from voice_converter_cyclegan_amd.engine import CycleGANEngine  # noqa: E402
 from voice_converter_cyclegan_amd._lib import lib  # noqa: E402
 
-mode = sys.argv[1] if len(sys.argv) > 1 else 'clk'
+mode = 'timeline'
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 8
-fn = lib.vc_debug_clk if mode == 'clk' else lib.vc_debug_timeline
+fn = lib.vc_debug_timeline
 fn.argtypes = [C.c_void_p, C.c_int]
 eng = CycleGANEngine(24, device='cuda:0', seed=1)
 rng = np.random.default_rng(0)

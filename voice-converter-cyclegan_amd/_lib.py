@@ -43,7 +43,7 @@ SIGNATURES = [
     ('vc_tune_igemm_override', i32, [i32, i32, i32]),
     ('vc_tune_wgrad_override', i32, [i32, i32, i32]),
     ('vc_tune_wgrad_store', i32, [i32]),
-    ('vc_tune_rowskip', i32, [i32, i32]),
+    ('vc_tune_rowskip', i32, [i32]),
     ('vc_tune_conv_bf16_override', i32, [i32, i32, i32]),
     ('vc_tune_conv_bf16_keys', i32, [vp, i32]),
     ('vc_tune_glu_version', i32, [i32]),

@@ -84,7 +84,7 @@ static Geom make_geom(int Cin, int H, int W, int Cout, int kh, int kw, int sh, i
 struct HostRow { int c, dh, dw, a_off, tap; };
 struct Table { KEntry* dev = nullptr; int* xsoff = nullptr; unsigned* rtap = nullptr; unsigned* aoff = nullptr; Tap* taps = nullptr;
                int ntaps = 0, rows = 0, valid = 0, xbias = 0, refs = 0;
-               int cpt = 0; signed char tdh[32] = {};          // K chunks per filter tap; row offset of every tap (rowskip, IgemmArgs)
+               int cpt = 0; signed char tdh[32] = {};          // K chunks per filter tap; row offset of every tap (filter-gradient rowskip)
                // the same chunks in channel-block-major, tap-minor order for the implicit-GEMM launches (upload_table); null
                // when the table has one tap or no uniform tap size
                int* xsoff_p = nullptr; unsigned* rtap_p = nullptr; unsigned* aoff_p = nullptr;
@@ -144,8 +144,8 @@ static int upload_table(const std::vector<HostRow>& rows, const std::vector<int>
     // tap minor.  The taps of one channel block gather the same lines of the tensor shifted by a pixel or a row; next to
     // each other, kh*kw - 1 of every kh*kw fetches hit the L1 / L2 instead of re-streaming the whole gathered tensor once
     // per tap through every XCD (round-3 PMC: 133 MB of L2-miss traffic per launch against ~25 MB of operands).  Any
-    // order of whole chunks is correct: a chunk stays inside one tap and contiguous in the filter.  The filter gradient and
-    // the rowskip mode keep the tap-major arrays (their chunk ranges are per tap).
+    // order of whole chunks is correct: a chunk stays inside one tap and contiguous in the filter.  The filter gradient
+    // keeps the tap-major arrays (its rowskip chunk ranges are per tap).
     std::vector<int> xs_p; std::vector<unsigned> rt_p, ao_p;
     if (t->cpt > 0 && taps.size() > 1) {
         const int cpt = t->cpt, nt = (int)taps.size();
@@ -305,31 +305,25 @@ static int check_conv_geom(const Geom& g, int B) {
 static void fill_pixel_grid(IgemmArgs& a, int B, int NPB, int OWc) {
     a.NPB = NPB; a.OWc = OWc; a.Ptot = B * NPB; a.inv_npb = 1.0f / (float)NPB; a.inv_ow = 1.0f / (float)OWc;
 }
-// Does walking only the filter rows that touch the image pay for this launch grid?  OHc output rows at row stride si over a
-// gathered tensor of Hl rows: the share of (output row, tap) pairs whose tap row lies in the SAME padding.  D.d3 (6 tap rows
-// on 6 image rows, pads (2, 3)): 25 %; the 3x3 stride-2 layers: 3 %; 1-D layers: one row, never.
-// Measured (profiles/r03_pmc_d3_rowskip.txt): the FILTER GRADIENT gains what the arithmetic says (D.d3 at the B = 8 step:
-// 545 -> 459 us, 420 with its tuned configuration) -- its reduction axis is the pixel axis, the skipped rows are simply not
-// read.  Forward / input gradient do NOT: their pixel tiles share a 2.4 MB weight slab through the XCD's L2 by streaming
-// it in step; with row-dependent K ranges the tiles of a slab walk different parts of it, the L2 hit rate drops (0.81 ->
-// 0.75 / 0.70 -> 0.60), HBM-side fetch doubles and the launch ends up no faster (MFMA-pipe busy 0.76 -> 0.62).  So the
-// mode is ON for filter gradients and OFF for forward / input gradient (vc_tune_rowskip switches either, for the tests
-// and for measurements).
-static thread_local int t_rowskip_igemm = 0, t_rowskip_wgrad = 1;
-extern "C" int vc_tune_rowskip(int igemm_on, int wgrad_on) { t_rowskip_igemm = igemm_on ? 1 : 0; t_rowskip_wgrad = wgrad_on ? 1 : 0; return 0; }
-static bool rowskip_pays(const Table& t, int OHc, int si, int Hl, bool wgrad) {
-    if (!(wgrad ? t_rowskip_wgrad : t_rowskip_igemm) || OHc < 2 || t.ntaps < 2 || t.cpt <= 0) return false;
+// Filter gradient of a 2-D layer whose kernel height reaches far into the SAME padding: does walking only the output rows a K
+// tile's taps reach pay?  OHc output rows at row stride si over a gathered tensor of Hl rows: the share of (output row, tap)
+// pairs whose tap row lies in the padding.  D.d3 (6 tap rows on 6 image rows, pads (2, 3)): 25 %; the 3x3 stride-2 layers:
+// 3 %; 1-D layers: one row, never.  Measured (profiles/r03_pmc_d3_rowskip.txt): D.d3's filter gradient at the B = 8 step
+// 545 -> 459 us (its reduction axis is the pixel axis, the skipped rows are simply not read).  The same enumeration for the
+// forward / input gradient was built and measured in round 3 (-3 % .. +7 %: pixel tiles of one weight slab then walk different
+// parts of it and lose its sharing through the XCD's L2) and removed in round 4.  vc_tune_rowskip switches it for the tests.
+static thread_local int t_rowskip_wgrad = 1;
+extern "C" int vc_tune_rowskip(int wgrad_on) { t_rowskip_wgrad = wgrad_on ? 1 : 0; return 0; }
+static bool rowskip_pays(const Table& t, int OHc, int si, int Hl) {
+    if (!t_rowskip_wgrad || OHc < 2 || t.ntaps < 2 || t.cpt <= 0) return false;
     long valid = 0;
     for (int i = 0; i < OHc; ++i)
         for (int tp = 0; tp < t.ntaps; ++tp) valid += (i * si + t.tdh[tp] >= 0 && i * si + t.tdh[tp] < Hl) ? 1 : 0;
     return valid * 100 < 92L * OHc * t.ntaps;
 }
-static bool korder_channel_major() { static const bool on = !(getenv("VC_KORDER") && !strcmp(getenv("VC_KORDER"), "tap")); return on; }
-static void set_rowskip(IgemmArgs& a, const Table& t, int B, int OHc) {
-    a.rowskip = rowskip_pays(t, OHc, a.si, a.Hl, false) ? 1 : 0;
-    a.RW = B * a.OWc; a.inv_rw = 1.0f / (float)a.RW; a.cpt = t.cpt;
-    // channel-block-major K order (upload_table) unless the launch skips filter rows by tap ranges
-    if (!a.rowskip && t.xsoff_p && korder_channel_major()) { a.xsoff = t.xsoff_p; a.rtap = t.rtap_p; a.aoff = t.aoff_p; }
+// implicit-GEMM launches (forward / input gradient) walk the table in channel-block-major K order (upload_table)
+static void set_korder(IgemmArgs& a, const Table& t) {
+    if (t.xsoff_p) { a.xsoff = t.xsoff_p; a.rtap = t.rtap_p; a.aoff = t.aoff_p; }
 }
 static void set_vec4(IgemmArgs& a) {
     a.vec4 = a.so_w == 1 && a.OWc % 4 == 0 && a.o_w0 % 4 == 0 && a.yW % 4 == 0 && a.yHW % 4 == 0 && a.y_bs % 4 == 0 &&
@@ -465,10 +459,10 @@ static int conv_fwd(const float* x, long x_gs, const float* w, long w_gs, const 
     a.yHW = g.OH * g.OW; a.yW = g.OW; a.so_h = 1; a.so_w = 1; a.o_h0 = 0; a.o_w0 = 0;
     a.accumulate = 0; a.groups = G;
     set_vec4(a);
-    set_rowskip(a, t, B, g.OH);
+    set_korder(a, t);
     igemm_config(a, math);
     if (query) { *query = a.splitk > 1; return 0; }
-    if (fuse && !a.rowskip && a.bm == 64 && a.splitk == 1 && a.vec4 && g.H == 1 && g.kh == 1 && (a.NPB == 32 || a.NPB == 64) && g.Cout % 64 == 0) {
+    if (fuse && a.bm == 64 && a.splitk == 1 && a.vec4 && g.H == 1 && g.kh == 1 && (a.NPB == 32 || a.NPB == 64) && g.Cout % 64 == 0) {
         a.fuse = 1; a.gamma = fuse->gamma; a.beta = fuse->beta; a.par_gs = fuse->par_gs; a.stats = fuse->stats; a.st_gs = fuse->st_gs;
         a.act = fuse->act; a.act_gs = fuse->act_gs; fuse->done = true;
     }
@@ -570,7 +564,7 @@ static int conv_dgrad(const float* dy, long dy_gs, const float* w, long w_gs, fl
         a.yHW = g.H * g.W; a.yW = g.W; a.so_h = g.sh; a.so_w = g.sw; a.o_h0 = ph; a.o_w0 = pw;
         a.accumulate = accumulate; a.groups = G;
         set_vec4(a);
-        set_rowskip(a, t, B, Hc);
+        set_korder(a, t);
         igemm_config(a, math);
         any_split = any_split || a.splitk > 1;
         fl[ncls] = 2.0 * G * B * a.NPB * (double)g.Cin * t.valid; cls[ncls++] = a;
@@ -703,7 +697,7 @@ static int conv_wgrad(const WgradApp* apps, int napps, float* dw, long dw_gs, in
         flops += 2.0 * G * apps[k].B * a.NPB * (double)g.Cout * t.valid;
     }
     a.store = store ? 1 : 0;
-    a.rowskip = rowskip_pays(t, g.OH, g.sh, g.H, true) ? 1 : 0;
+    a.rowskip = rowskip_pays(t, g.OH, g.sh, g.H) ? 1 : 0;
     if (query) { *query = !store || wgrad_splitk(a) > 1; return 0; }
     return launch_wgrad(a, math, s, flops);
 }
@@ -1007,22 +1001,15 @@ static int plan_create(int num_features, int n_frames, bool inference, vc_plan**
         }
     }
     if (r) { release_tables(p->tables); delete p; return r; }
-    // Stream priorities (VC_STREAM_PRIO, experiment knob; measured in profiles/r03_ab_streams.txt): 0 none (default),
-    // 1 filter-gradient streams lowest, 2 filter-gradient streams highest, 3 = 2 + side stream highest, 4 side stream highest
-    static const int prio = getenv("VC_STREAM_PRIO") ? atoi(getenv("VC_STREAM_PRIO")) : 0;
-    int prio_lo = 0, prio_hi = 0;
-    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);      // numerically: lo = least urgent, hi = most urgent
-    auto mk_stream = [&](hipStream_t* st, int pr) { return pr ? hipStreamCreateWithPriority(st, hipStreamNonBlocking, pr > 0 ? prio_hi : prio_lo) : hipStreamCreateWithFlags(st, hipStreamNonBlocking); };
-    const int leaf_pr = prio == 1 ? -1 : (prio == 2 || prio == 3) ? 1 : 0, side_pr = (prio == 3 || prio == 4) ? 1 : 0;
-    auto leaf_stream = [&](hipStream_t* st) { return mk_stream(st, leaf_pr); };
+    auto mk_stream = [&](hipStream_t* st) { return hipStreamCreateWithFlags(st, hipStreamNonBlocking); };
     hipError_t e = hipEventCreateWithFlags(&p->d_ready, hipEventDisableTiming);
-    if (e == hipSuccess) e = mk_stream(&p->side, side_pr);
+    if (e == hipSuccess) e = mk_stream(&p->side);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming);
-    if (e == hipSuccess) e = leaf_stream(&p->wstream);
+    if (e == hipSuccess) e = mk_stream(&p->wstream);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_wjoin, hipEventDisableTiming);
     for (int k = 0; k < 24 && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&p->ev_layer[k], hipEventDisableTiming);
-    if (e == hipSuccess) e = leaf_stream(&p->wstream_d);
+    if (e == hipSuccess) e = mk_stream(&p->wstream_d);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_wjoin_d, hipEventDisableTiming);
     for (int k = 0; k < 8 && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&p->ev_layer_d[k], hipEventDisableTiming);
     for (int k = 0; k < vc_plan::kBuckets && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&p->g_ready[k], hipEventDisableTiming);

@@ -30,18 +30,14 @@
 
 typedef const __attribute__((address_space(4))) int* c_int_p;
 typedef const __attribute__((address_space(4))) unsigned* c_uint_p;
-typedef const __attribute__((address_space(4))) Tap* c_tap_p;
 
-// launch pixel -> (sample, row, column) of the launch grid; rowskip launches enumerate (row, sample, column)
-// (Selects on values, not two code paths writing through the references: the round-3 form made the compiler park b and i in
-// SCRATCH memory behind a computed offset -- 12 bytes of private memory per lane, and a store / load round trip through the
-// memory system in every workgroup's prologue and again in its epilogue.)
+// launch pixel -> (sample, row, column) of the launch grid.  (Written on values: a form with two code paths assigning through
+// the references made the compiler park b and i in SCRATCH memory behind a computed offset -- 12 bytes of private memory per
+// lane and a store / load round trip through the memory system in every workgroup's prologue and again in its epilogue.)
 __device__ __forceinline__ void px_decode(const IgemmArgs& p, int P, int& b, int& i, int& j) {
     int r;
-    const bool rs = p.rowskip != 0;
-    const int q0 = fast_divmod(P, rs ? p.RW : p.NPB, rs ? p.inv_rw : p.inv_npb, &r);
-    const int q1 = fast_divmod(r, p.OWc, p.inv_ow, &j);
-    b = rs ? q1 : q0; i = rs ? q0 : q1;
+    b = fast_divmod(P, p.NPB, p.inv_npb, &r);
+    i = fast_divmod(r, p.OWc, p.inv_ow, &j);
 }
 
 template <int BM, bool AT, int KG, int MATH, bool FUSE = false>
@@ -78,23 +74,10 @@ __global__ __launch_bounds__(64 * (BM / 32) * 2 * KG, (64 * (BM / 32) * 2 * KG >
     // that reach past the table multiply its all-zero padding chunk.
     const int g = blockIdx.z / p.splitk, sp = blockIdx.z - g * p.splitk;
     const int nchunks = p.krows / KC;
-    // rowskip: only the filter rows (taps) that touch the image for this tile's output rows; everything else is the whole table
-    int cbeg = 0, nch = nchunks;
-    if (p.rowskip) {
-        const int P0 = nt * BN, P1 = min(P0 + BN, p.Ptot) - 1;
-        int r_; const int ilo = fast_divmod(P0, p.RW, p.inv_rw, &r_), ihi = fast_divmod(P1, p.RW, p.inv_rw, &r_);
-        int tlo = 64, thi = -1;
-        c_tap_p taps = (c_tap_p)p.taps;
-        for (int t = 0; t < p.ntaps; ++t) {
-            const int dh = taps[t].dh;
-            if (ihi * p.si + dh >= 0 && ilo * p.si + dh < p.Hl) { tlo = min(tlo, t); thi = max(thi, t); }
-        }
-        if (thi >= tlo) { cbeg = tlo * p.cpt; nch = (thi - tlo + 1) * p.cpt; }
-    }
     const int parts = p.splitk * KG;
-    const int cps = (((nch + parts - 1) / parts) + 1) & ~1;
-    if (sp * KG * cps >= nch) return;                         // whole workgroup beyond the K range (uniform)
-    const int c0 = cbeg + (sp * KG + kg) * cps;
+    const int cps = (((nchunks + parts - 1) / parts) + 1) & ~1;
+    if (sp * KG * cps >= nchunks) return;                     // whole workgroup beyond the K range (uniform)
+    const int c0 = (sp * KG + kg) * cps;
 
     // ---- gathered-operand loader: a lane owns pixel n = lane of the tile and XL consecutive K rows of every chunk
     constexpr int XL = (KC * BN) / GT;                        // 4 (8-wave group) or 8 (4-wave group)
@@ -491,12 +474,6 @@ static void igemm_config_impl(IgemmArgs& a, int math, int& src) {
             a.splitk = sk; a.mtiles = 1; src = CFG_NEIGHBOUR;
         }
     }
-    if (!g_force_bm && a.mtiles) {
-        // experiment knob (VC_IGEMM_MAXKG=1|2): cap the K groups of a tuned entry, moving the rest of its K parallelism to
-        // split-K across workgroups -- smaller workgroups (74 / 37 KB of LDS instead of 148) can share a CU with the other chains
-        static const int maxkg = getenv("VC_IGEMM_MAXKG") ? atoi(getenv("VC_IGEMM_MAXKG")) : 0;
-        while (maxkg > 0 && a.kg > maxkg && !det) { a.kg /= 2; a.splitk *= 2; }
-    }
     if (g_force_bm || a.mtiles) { a.mtiles = (a.M + a.bm - 1) / a.bm; a.ntiles = (a.Ptot + 63) / 64; return; }
     // Cost model in microseconds, fitted to the sweep of tools/tune_igemm.py (profiles/r02_tune_sweep_b8.txt): a workgroup
     // runs `cps` chunks at a pace set by the k waves that share its SIMDs (0.2 + 0.62 k us per chunk: a lone wave
@@ -543,7 +520,7 @@ int launch_igemm_multi(const IgemmArgs* cls, int n, bool a_trans, int math, hipS
     const bool fuse = cls[0].fuse != 0;
     if (fuse) {
         const IgemmArgs& a = cls[0];
-        if (n != 1 || a_trans || bm != 64 || a.rowskip || a.splitk != 1 || a.accumulate || !a.vec4 || (a.NPB != 32 && a.NPB != 64) || (a.M & 63) ||
+        if (n != 1 || a_trans || bm != 64 || a.splitk != 1 || a.accumulate || !a.vec4 || (a.NPB != 32 && a.NPB != 64) || (a.M & 63) ||
             a.so_w != 1 || a.o_w0 != 0 || a.yHW != a.NPB) {
             vc_set_error("launch_igemm: this launch cannot carry the fused instance-norm epilogue"); return -1;
         }

@@ -695,17 +695,16 @@ __global__ __launch_bounds__(256) void head_bwd_dw_kernel(const float* x, long x
     if (c == 0) { sb = wave_sum(sb); if (lane == 0) atomicAdd(db + (long)g * dpar_gs, sb); }
 }
 
-// NT: the Adam slots m and v are pure streams (read once, written once per step, 2 x 479 MB): non-temporal loads / stores
+// The Adam slots m and v are pure streams (read once, written once per step, 2 x 479 MB): non-temporal loads / stores
 // keep them from evicting the weights and gradients the rest of the step re-reads from L2 / Infinity Cache.  Two float4
 // groups per thread and trip: twice the bytes in flight.
-template <bool NT>
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
                                                    const float* __restrict__ g, long n4, long n, float alpha_arg,
                                                    float b1, float b2, float eps, float gs, const float* __restrict__ alpha_dev) {
     const float alpha = alpha_dev ? *alpha_dev : alpha_arg;      // captured steps (hipGraph) read the step size from device memory
     const float omb1 = 1.f - b1, omb2 = 1.f - b2;
-    auto ld = [](const f32x4* q) { return NT ? __builtin_nontemporal_load(q) : *q; };
-    auto st = [](f32x4* q, const f32x4 x) { if (NT) __builtin_nontemporal_store(x, q); else *q = x; };
+    auto ld = [](const f32x4* q) { return __builtin_nontemporal_load(q); };
+    auto st = [](f32x4* q, const f32x4 x) { __builtin_nontemporal_store(x, q); };
     auto upd = [&](f32x4& P, f32x4& M, f32x4& V, const f32x4 G) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -955,10 +954,9 @@ static int norm_dispatch(const NormArgs& a, hipStream_t s) {
     const int units = a.G * (det ? 1 : a.B) * a.C;
     dim3 block(256);
     {
-        // rows of up to 512 positions, 16-byte aligned tensors: the f32x4 kernels (VC_NORM_V4=0 keeps the scalar forms: A/B)
-        static const bool v4 = !(getenv("VC_NORM_V4") && atoi(getenv("VC_NORM_V4")) == 0);
+        // rows of up to 512 positions, 16-byte aligned tensors: the f32x4 kernels
         auto al = [](const void* q, long gs) { return ((uintptr_t)q & 15) == 0 && (gs & 3) == 0; };
-        bool ok = v4 && !det && (a.L & 3) == 0 && al(a.y, a.y_gs);
+        bool ok = !det && (a.L & 3) == 0 && al(a.y, a.y_gs);
         if (FWD) ok = ok && al(a.out, a.out_gs) && (MODE != 2 || al(a.res, a.res_gs));
         else ok = ok && al(a.dy, a.dy_gs) && al(a.dout, a.do_gs);
         if (ok && MODE == 1 && !FWD && !a.ps && a.L > 512) {          // long GLU rows (D.h1): streamed
@@ -1045,9 +1043,7 @@ int launch_adam(float* p, float* m, float* v, const float* g, long n, float alph
                 float b2, float eps, float gscale, hipStream_t s, const float* alpha_dev) {
     const long n4 = n / 4;
     long blocks = (n4 + 255) / 256; if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
-    static const bool nt = !(getenv("VC_ADAM_NT") && atoi(getenv("VC_ADAM_NT")) == 0);      // A/B: VC_ADAM_NT=0 = plain loads / stores
-    if (nt) adam_kernel<true><<<dim3((unsigned)blocks), 256, 0, s>>>(p, m, v, g, n4, n, alpha, b1, b2, eps, gscale, alpha_dev);
-    else adam_kernel<false><<<dim3((unsigned)blocks), 256, 0, s>>>(p, m, v, g, n4, n, alpha, b1, b2, eps, gscale, alpha_dev);
+    adam_kernel<<<dim3((unsigned)blocks), 256, 0, s>>>(p, m, v, g, n4, n, alpha, b1, b2, eps, gscale, alpha_dev);
     VC_HIP(hipGetLastError());
     return 0;
 }

@@ -69,11 +69,6 @@ struct IgemmArgs {
     int si, sj;                                   // pixel stride launch grid -> gathered tensor
     int NPB, OWc, Ptot;                           // launch pixel grid: per sample, width, total
     float inv_npb, inv_ow;                        // 1/NPB, 1/OWc (fast_divmod)
-    // rowskip != 0 (2-D layers whose kernel height reaches far into the SAME padding, D.d3: 6 taps on 6 rows): launch
-    // pixels are enumerated (row, sample, column) instead of (sample, row, column), so a 64-pixel tile lies in one or two
-    // output rows, and the workgroup walks only the K chunks of the filter rows that touch the image for those rows (the
-    // others multiply zeros: a quarter of D.d3's MFMA work).  RW = B * OWc pixels per row, cpt = K chunks per filter tap.
-    int rowskip, RW, cpt; float inv_rw;
     int yHW, yW;                                  // channel / row stride of the output tensor
     int so_h, so_w, o_h0, o_w0;                   // launch pixel -> output pixel
     int vec4;                                     // 4 consecutive launch pixels are 16 contiguous, aligned output bytes
@@ -106,7 +101,8 @@ struct WgradArgs {
     int nchunks;                                  // all segments
     int splitk, ktiles, ntiles, groups;
     int store;                                    // dW holds no earlier contribution and split-K is 1: plain stores
-    int rowskip;                                  // pixels enumerated (row, sample, column); a K tile reduces only over the output rows its two taps reach (IgemmArgs::rowskip)
+    int rowskip;                                  // 2-D layers whose kernel height reaches far into the SAME padding (D.d3: 6 taps on 6 rows): pixels enumerated
+                                                  // (row, sample, column); a K tile reduces only over the output rows its two taps reach
 };
 
 // The 16-bit data path of the bf16 mode (vc_conv_bf16.hip): Y[g][b][m][P] (+)= sum_k Ap[g][m][k] * Xp-gather[k][P].

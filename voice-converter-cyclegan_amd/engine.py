@@ -157,6 +157,9 @@ class CycleGANEngine:
         self._ws = None
         self.sync = GradSync(group, enabled=data_parallel, device=self.device)
         self._comm_stream = torch.cuda.Stream(device=self.device)      # gradient exchange + Adam, beside the backward
+        self.exchange_standin = None      # bench.py --dp-selftest: callable(grad_slice) issued on the update stream in place of the collective
+        self.measure_exposed = False      # bench.py: record events around the exposed part of exchange + update
+        self._exposed = []
         # tf.train.AdamOptimizer keeps beta1_power/beta2_power as fp32 variables (one pair per optimizer)
         self.b1p = [np.float32(ADAM_BETA1), np.float32(ADAM_BETA1)]
         self.b2p = [np.float32(ADAM_BETA2), np.float32(ADAM_BETA2)]
@@ -338,7 +341,9 @@ class CycleGANEngine:
         side = self._comm_stream
         alphas = (self._alpha(generator_learning_rate, 0), self._alpha(discriminator_learning_rate, 1))
         cs = _lib.vp(side.cuda_stream)
-        if self.sync.world == 1 or self.sync.comm is not None:
+        if self.measure_exposed:
+            self._ev_bwd = torch.cuda.Event(enable_timing=True); self._ev_bwd.record(main)     # the step's own work on the main stream ends here
+        if self.exchange_standin is None and (self.sync.world == 1 or self.sync.comm is not None):
             check(lib.vc_step_exchange_and_update(plan, self.sync.comm, ptr(self.params), ptr(self.grads), ptr(self.m),
                                                   ptr(self.v), alphas[0], alphas[1], ADAM_BETA1, ADAM_BETA2, ADAM_EPS, cs),
                   'vc_step_exchange_and_update')
@@ -350,14 +355,32 @@ class CycleGANEngine:
                         check(lib.vc_step_wait_d_grads(plan, cs), 'vc_step_wait_d_grads')
                     else:
                         check(lib.vc_step_wait_g_bucket(plan, k, cs), 'vc_step_wait_g_bucket')
-                    for w in [self.sync.all_reduce(self.grads[lo:hi], async_op=True) for lo, hi in ranges]:
+                    if self.exchange_standin is not None:      # bench.py --dp-selftest: stand-in traffic where the collective would run
+                        for lo, hi in ranges:
+                            self.exchange_standin(self.grads[lo:hi])
+                        ws = []
+                    else:
+                        ws = [self.sync.all_reduce(self.grads[lo:hi], async_op=True) for lo, hi in ranges]
+                    for w in ws:
                         w.wait()                     # makes the side stream wait for the collective
                     for lo, hi in ranges:
                         check(lib.vc_adam_tf_update(ptr(self.params[lo:hi]), ptr(self.m[lo:hi]), ptr(self.v[lo:hi]),
                                                     ptr(self.grads[lo:hi]), hi - lo, alphas[1 if kind == 'd' else 0],
                                                     ADAM_BETA1, ADAM_BETA2, ADAM_EPS, gs, cs), 'vc_adam_tf_update')
         main.wait_stream(side)
+        if self.measure_exposed:
+            ev = torch.cuda.Event(enable_timing=True); ev.record(main)
+            self._exposed.append((self._ev_bwd, ev))
         self._advance_beta_powers()
+
+    def exposed_update_ms(self):
+        """bench.py: mean time per step between the end of the step's own backward work on the main stream and the end of the
+        exchange + Adam on the update stream, i.e. the part of the gradient exchange / update NOT hidden under the backward
+        (measure_exposed = True records one event pair per step; synchronises)."""
+        torch.cuda.synchronize()
+        ts = [a.elapsed_time(b) for a, b in self._exposed]
+        self._exposed = []
+        return float(np.mean(ts)) if ts else None
 
     def _graph_step(self, A, Bm, lambda_cycle, lambda_identity, lr_g, lr_d, gen_A, gen_B):
         """the whole step as ONE hipGraph replay (vc_train_step_graph): inputs are staged into persistent buffers (a
