@@ -1,0 +1,107 @@
+"""CPU: the generated ISA of gated_conv1d_glu_kernel (csrc/vc_conv_glu.hip; reference module.py:161-163) keeps the promises its
+hand-counted waits rely on.  The kernel issues the frames of the next-but-one tile with inline-asm buffer loads into registers
+the compiler knows nothing about until a counted `s_waitcnt vmcnt(16 + 2 NST)` one trip later; that is only correct if
+  * every trip issues exactly 16 such loads and exactly NST output stores (4 inference, 12 training) -- no merged, split or
+    branch-skipped store --, with no other vector-memory operation in between,
+  * nothing reads or overwrites the destination registers between the loads and the wait that retires them,
+  * no register is spilled (scratch would add vector-memory operations of its own) and the loop holds no vmcnt(0).
+A compiler or flag change that breaks one of these would stage garbage frames silently; this test reads the
+assembly hipcc produces for gfx950 and fails instead."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, 'voice-converter-cyclegan_amd', 'csrc', 'vc_conv_glu.hip')
+HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+
+
+@pytest.fixture(scope='module')
+def asm(tmp_path_factory):
+    if shutil.which(HIPCC) is None and not os.path.exists(HIPCC):
+        pytest.skip('hipcc not available')
+    out = str(tmp_path_factory.mktemp('glu') / 'glu.s')
+    from importlib.util import spec_from_file_location, module_from_spec
+    spec = spec_from_file_location('_vcb', os.path.join(ROOT, 'voice-converter-cyclegan_amd', 'build.py'))
+    b = module_from_spec(spec); spec.loader.exec_module(b)
+    subprocess.check_call([HIPCC] + b.FLAGS + ['-S', '--cuda-device-only', SRC, '-o', out], cwd=os.path.dirname(SRC),
+                          stderr=subprocess.DEVNULL)
+    return open(out).read()
+
+
+def _kernels(text):
+    lines = text.split('\n')
+    starts = [i for i, l in enumerate(lines) if re.match(r'^_Z23gated_conv1d_glu_kernel\w+:', l)]
+    for k, a in enumerate(starts):
+        name = lines[a].split(':')[0]
+        body = []
+        for l in lines[a + 1:]:
+            if l.startswith('.Lfunc_end'):
+                break
+            body.append(l)
+        yield name, body
+
+
+def _instrs(body):
+    return [l.strip() for l in body if l.startswith('\t') and not l.strip().startswith(('.', ';'))]
+
+
+def test_no_scratch_and_register_budget(asm):
+    metas = re.findall(r'\.name:\s+(_Z23gated_conv1d_glu_kernel\w+).*?\.private_segment_fixed_size:\s+(\d+)', asm, flags=re.S)
+    seen = {}
+    for blk in re.split(r'\n  - \.agpr_count', asm)[1:]:
+        n = re.search(r'\.name:\s+(\S+)', blk); s = re.search(r'\.private_segment_fixed_size:\s+(\d+)', blk)
+        if n and s and 'gated_conv1d_glu_kernel' in n.group(1):
+            seen[n.group(1)] = int(s.group(1))
+    assert len(seen) == 4 or len(metas) >= 4, (seen, metas)
+    assert all(v == 0 for v in seen.values()), 'scratch in use: %s' % seen
+    assert 'scratch_' not in asm
+
+
+@pytest.mark.parametrize('bf16,raw', [(True, False), (True, True), (False, False), (False, True)])
+def test_trip_issues_the_counted_operations(asm, bf16, raw):
+    tag = 'ILi24ELi15ELb%dELb%dEE' % (int(bf16), int(raw))
+    body = [b for n, b in _kernels(asm) if tag in n]
+    assert len(body) == 1
+    body = body[0]
+    nst = 12 if raw else 4
+    hdr = [i for i, l in enumerate(body) if 'Loop Header' in l]
+    assert hdr, 'tile loop not found'
+    bars = [i for i, l in enumerate(body) if 's_barrier' in l and i > hdr[0]]
+    assert len(bars) >= 2
+    trips = [(hdr[0], bars[0]), (bars[0], bars[1])]          # the loop body is two trips (register sets alternate)
+    dests = []
+    for lo, hi in trips:
+        ins = _instrs(body[lo:hi])
+        loads = [x for x in ins if x.startswith('buffer_load_dword ')]
+        stores = [x for x in ins if x.startswith('buffer_store_dwordx4')]
+        other_vm = [x for x in ins if re.match(r'(buffer_|global_|flat_|scratch_)', x) and x not in loads and x not in stores]
+        waits = [x for x in ins if 'vmcnt' in x]
+        assert len(loads) == 16, (len(loads), tag)
+        assert len(stores) == nst, (len(stores), tag)
+        assert not other_vm, other_vm[:3]
+        assert waits == ['s_waitcnt vmcnt(%d)' % (16 + 2 * nst)], waits
+        assert len([x for x in ins if x.startswith('v_mfma')]) == (46 if bf16 else 360)
+        # program order inside the trip: loads of the next-but-one tile, then the previous tile's stores, then the wait
+        order = [x.split()[0] if 'vmcnt' not in x else 'wait' for x in ins if x in loads or x in stores or 'vmcnt' in x]
+        assert order.index('wait') == len(order) - 1, 'a vector-memory operation behind the counted wait of its trip'
+        dests.append({re.match(r'buffer_load_dword (v\d+),', x).group(1) for x in loads})
+    assert not (dests[0] & dests[1]), 'the two register sets overlap'
+    # a trip's load destinations are retired by the OTHER trip's wait: until then no instruction may touch them
+    for k, (lo, hi) in enumerate(trips):
+        mine, others = dests[k], dests[1 - k]
+        ins = _instrs(body[lo:hi])
+        w = [i for i, x in enumerate(ins) if 'vmcnt' in x][0]
+        last_load = max(i for i, x in enumerate(ins) if x.startswith('buffer_load_dword '))
+        for i, x in enumerate(ins):
+            regs = set(re.findall(r'\bv(\d+)\b', x))
+            for a, b in re.findall(r'v\[(\d+):(\d+)\]', x):
+                regs |= {str(r) for r in range(int(a), int(b) + 1)}
+            regs = {'v' + r for r in regs}
+            if i < w and not x.startswith('buffer_load_dword '):
+                assert not (regs & others), 'trip %d touches frames in flight before its wait: %s' % (k, x)
+            if i > last_load:
+                assert not (regs & mine), 'trip %d touches its own loads before the next trip\'s wait: %s' % (k, x)

@@ -20,6 +20,7 @@
 // copies).  The filter gradient is the same kernel on operands repacked 8 PIXELS to a unit (im2col_bf16_kernel,
 // pack_pixel_octets_bf16_kernel; launch set-up in vc_api.hip: conv_wgrad).
 #include "vc_internal.h"
+#include "vc_device_util.h"
 #include <array>
 #include <cstdlib>
 #include <vector>
@@ -120,6 +121,7 @@ struct Im2colArgs {
     float inv_npb, inv_ow;
 };
 __global__ __launch_bounds__(256) void im2col_bf16_kernel(const Im2colArgs a) {
+    touch_kernarg(a);
     const int cb = blockIdx.x * 64 + threadIdx.x;
     const int tap = blockIdx.y % a.ntaps, g = blockIdx.y / a.ntaps;
     const int po = blockIdx.z * 4 + threadIdx.y;
@@ -197,6 +199,7 @@ int launch_pack_filter_bf16(const float* w, long w_gs, void* ap, long ap_gs_byte
 // MFMAs (4 feed 4 at BM = 128), a chunk is 32 MFMAs per wave instead of 16 -- the per-chunk barrier, table fetch and LDS
 // round trip weigh half as much -- on a 3-stage ring (48 KB per stage), one workgroup per CU.
 template <int BM, int NST> __global__ __launch_bounds__(256, NST <= 2 ? 2 : 1) void conv_bf16_kernel(const ConvBf16Args p) {
+    touch_kernarg(p);
     constexpr int BN = 128, MI = BM / 64;                 // a wave owns MI x 2 MFMA tiles: rows [wm * BM/2, +BM/2), pixels [wn * 64, +64)
     constexpr int ASZ = 8 * BM * 16, XSZ = 8 * BN * 16, STAGE = ASZ + XSZ;      // one K chunk: [octet][row][16 B] for both operands
     constexpr int LDY = BN + 4;

@@ -33,6 +33,7 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 template <int CIN, int KW, bool BF16, bool RAW>
 __global__ __launch_bounds__(256, 1) void gated_conv1d_glu_kernel(const WsConvArgs a) {
+    touch_kernarg(a);
     typedef typename std::conditional<BF16, __bf16, float>::type T;
     typedef typename std::conditional<BF16, bf16x8, f32x4>::type frag_t;
     constexpr int R = BF16 ? 8 : 4;                         // k values per lane and K step (one 16-byte fragment)
@@ -53,6 +54,12 @@ __global__ __launch_bounds__(256, 1) void gated_conv1d_glu_kernel(const WsConvAr
     constexpr bool OVERLAP = BF16;                          // GLU + stores of tile i-1 inside the MFMA loop of tile i
     __shared__ __attribute__((aligned(16))) T Xs[2 * SLOT];
     __shared__ __attribute__((aligned(16))) frag_t Wf[2 * NU * 64];
+    // per-wave 32 x 32 fp32 transposition tiles for the output planes (row = channel, stride 36 floats): the accumulators
+    // hold 4 consecutive pixels of ONE channel per lane; stored straight from there an instruction touched 32 channel rows
+    // with 32 bytes each -- 512 partial-line transactions per tile and CU, measured 2.0 us per tile against 0.64 us of MFMA
+    // time.  Through the tile an instruction writes 8 rows x 128 contiguous bytes.
+    constexpr int LDS_S = 36, NSTT = (BF16 && RAW) ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) float Ss[4 * NSTT * 32 * LDS_S];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w4 = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -158,30 +165,53 @@ __global__ __launch_bounds__(256, 1) void gated_conv1d_glu_kernel(const WsConvAr
         (std::make_integer_sequence<int, NTPT>{});
     issue_loads(xr1, tile0 + tstep);
 
-    // output addressing: lane = channel c, 4 consecutive pixels per 16-byte store; quad qd covers pixels 8 qd + 4 h .. + 3 of
-    // the wave's 32
+    // output addressing: an accumulator quad (4 consecutive pixels of the lane's channel) goes into the wave's transposition
+    // tile; flushing a plane, lane l stores pixels 4 (l & 7) .. + 3 of rows (l >> 3) + 8 i, i < 4: 16 bytes per lane
     const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(a.y + (long)g * a.y_gs), 0, (int)((unsigned)a.B * (unsigned)C * (unsigned)a.T * 4u), 0x00020000);
     const __amdgpu_buffer_rsrc_t rawrs = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(RAW ? a.raw + (long)g * a.raw_gs : a.y), 0, (int)((unsigned)a.B * (unsigned)a.Cout * (unsigned)a.T * 4u), 0x00020000);
     const int CT4 = C * T4;
-    // where the wave's 32 x 32 output tile of `tile` goes: per-lane byte offsets of quad 0 (tile < 0 or past the end: invalid)
-    struct OutPos { bool tv; int t; unsigned yb, rb; };
+    // where the wave's 32 x 32 output tile of `tile` goes: the lane's byte offsets for flush row 0 (tile < 0 or past the end, or
+    // pixels past the end of the sample: invalid -> an out-of-range offset, dropped by the hardware)
+    struct OutPos { bool ok; unsigned yb, rb; };
     auto out_pos = [&](int tile) {
         OutPos p;
-        p.tv = tile >= 0 && tile < ntiles;
-        const int b = p.tv ? tile / tps : 0;
-        p.t = (tile - b * tps) * TP + w4 * 32 + 4 * h;
-        p.yb = (unsigned)(((b * C + c) * a.T + p.t) * 4);
-        p.rb = (unsigned)(((b * 2 * C + c) * a.T + p.t) * 4);
+        const bool tv = tile >= 0 && tile < ntiles;
+        const int b = tv ? tile / tps : 0;
+        const int t = (tile - b * tps) * TP + w4 * 32 + 4 * (lane & 7), row = slab * 32 + (lane >> 3);
+        p.ok = tv && t < a.T;
+        p.yb = (unsigned)(((b * C + row) * a.T + t) * 4);
+        p.rb = (unsigned)(((b * 2 * C + row) * a.T + t) * 4);
         return p;
     };
-    // NST stores per tile, always issued: lanes outside the tensor carry an out-of-range offset (dropped by the hardware)
+    float* const sw_y = Ss + (w4 * NSTT) * 32 * LDS_S;                      // GLU output plane
+    float* const sw_r = Ss + (w4 * NSTT + (NSTT - 1)) * 32 * LDS_S;         // raw value / gate planes, one after the other
+    auto put_quad = [&](float* sw, const f32x16& v, int q) {                // quad q: pixels 8 q + 4 h .. + 3 of channel row l31
+        const f32x4 x = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+        *reinterpret_cast<f32x4*>(sw + l31 * LDS_S + 8 * q + 4 * h) = x;
+    };
+    // A plane leaves in two halves: 4 reads of the tile (lane l: pixels 4 (l & 7) .. + 3 of rows (l >> 3) + 8 i), then -- a K
+    // step later in the bf16 schedule, so that the LDS round trip hides behind MFMAs -- 4 stores, always issued.  Wave-private
+    // tile and the LDS queue is in order within a wave: no barrier between the quads' writes and these reads, nor between
+    // these reads and the next plane's writes.
+    auto read_plane = [&](const float* sw, f32x4 (&r)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r[i] = *reinterpret_cast<const f32x4*>(sw + ((lane >> 3) + 8 * i) * LDS_S + 4 * (lane & 7));
+    };
+    auto store_plane = [&](const f32x4 (&r)[4], __amdgpu_buffer_rsrc_t rs, unsigned base, bool ok, int plane_off) {
+        const unsigned off = ok ? base : VC_OOB_ST;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, r[i]), rs, (int)off, plane_off + i * 8 * T4, 0);
+    };
+    auto flush_plane = [&](const float* sw, __amdgpu_buffer_rsrc_t rs, unsigned base, bool ok, int plane_off) {
+        f32x4 r[4];
+        read_plane(sw, r); store_plane(r, rs, base, ok, plane_off);
+    };
     // value * sigmoid(gate) = value * rcp(1 + exp2(-log2(e) gate)): hardware exp2 and reciprocal (1 ulp each).  One wave per
-    // SIMD means nobody covers a DEPENDENT chain (mul -> exp -> add -> rcp -> mul, ~100 cycles, and the in-order wave cannot
-    // issue the next MFMA pair from behind it): the first build of this kernel ran 2.0 us per tile against 0.64 us of MFMA
-    // time for exactly that reason.  So the chain is cut into STAGES applied to four values at a time: four independent
-    // instructions per stage, one stage per K step (bf16), i.e. a stage's inputs are two MFMAs old when it runs.
+    // SIMD means nobody covers a DEPENDENT chain (mul -> exp -> add -> rcp -> mul: the in-order wave cannot issue the next MFMA
+    // pair from behind it), so the chain is cut into STAGES applied to four values at a time: four independent instructions
+    // per stage, one stage per K step (bf16), i.e. a stage's inputs are two MFMAs old when it runs.
     auto glu_stage = [&](const f32x16& sv, const f32x16& sg, f32x4& t, f32x16& o, int q, int st) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -199,37 +229,39 @@ __global__ __launch_bounds__(256, 1) void gated_conv1d_glu_kernel(const WsConvAr
 #pragma unroll
             for (int q = 0; q < 4; ++q) glu_stage(sv, sg, t[q], o, q, st);
     };
-    auto store_quad = [&](const f32x16& sv, const f32x16& sg, const f32x16& o, int qd, const OutPos& p) {
-        const bool ok = p.tv && p.t + 8 * qd < a.T;
-        const unsigned yo = ok ? p.yb + 32u * qd : VC_OOB_ST;
-        const f32x4 ov = {o[4 * qd], o[4 * qd + 1], o[4 * qd + 2], o[4 * qd + 3]};
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ov), yrs, (int)yo, 0, 0);
+    // a whole tile's planes, one after the other (fp32 trips, the last tile, the dummy tile): NST stores
+    auto store_tile = [&](const f32x16& sv, const f32x16& sg, const f32x16& o, const OutPos& p) {
         if constexpr (RAW) {                                // training: the raw value / gate pair is kept for the backward pass
-            const unsigned ro = ok ? p.rb + 32u * qd : VC_OOB_ST;
-            const f32x4 vv = {sv[4 * qd], sv[4 * qd + 1], sv[4 * qd + 2], sv[4 * qd + 3]};
-            const f32x4 gv = {sg[4 * qd], sg[4 * qd + 1], sg[4 * qd + 2], sg[4 * qd + 3]};
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, vv), rawrs, (int)ro, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, gv), rawrs, (int)ro, CT4, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) put_quad(sw_r, sv, q);
+            flush_plane(sw_r, rawrs, p.rb, p.ok, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) put_quad(sw_r, sg, q);
+            flush_plane(sw_r, rawrs, p.rb, p.ok, CT4);
         }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) put_quad(sw_y, o, q);
+        flush_plane(sw_y, yrs, p.yb, p.ok, 0);
     };
     // dummy "tile -2" stores: with them the first trip sees the same operation count behind its frames as every other
     {
         f32x16 z;
 #pragma unroll
         for (int r = 0; r < 16; ++r) z[r] = 0.f;
-#pragma unroll
-        for (int qd = 0; qd < 4; ++qd) store_quad(z, z, z, qd, out_pos(-1));
+        store_tile(z, z, z, out_pos(-1));
     }
     __syncthreads();                                        // filter fragments and tile 0 are in LDS
-    // bf16: value and gate fragments in registers (184).  fp32: the value fragments (180); the gate fragments would make it
-    // 360 + accumulators + frames in flight > 512, so they are re-read from LDS behind the MFMAs -- one 16-byte read per
-    // eight 64-cycle MFMAs, nowhere near the LDS pipe's capacity.
-    constexpr bool GATE_REGS = BF16;
-    frag_t wv[NU], wgt[GATE_REGS ? NU : 1];
+    // bf16: value and gate fragments in registers (184 of the 512).  fp32: 360 fragment registers + accumulators + frames in
+    // flight do not fit, and a register allocator under pressure parks the in-flight frame registers in AGPRs -- which copies
+    // them BEFORE their loads have landed (tests/test_glu_isa_cpu.py caught exactly that on the first fp32 build).  fp32 is
+    // bound by its 64-cycle MFMAs (8 per K step), so it re-reads both fragments from LDS behind them: two 16-byte reads per
+    // 512 cycles of matrix work, nowhere near the LDS pipe's capacity, and ~130 registers in all.
+    constexpr bool W_REGS = BF16;
+    frag_t wv[W_REGS ? NU : 1], wgt[W_REGS ? NU : 1];
+    if constexpr (W_REGS) {
 #pragma unroll
-    for (int u = 0; u < NU; ++u) {
-        wv[u] = Wf[(2 * u) * 64 + lane];
-        if constexpr (GATE_REGS) {
+        for (int u = 0; u < NU; ++u) {
+            wv[u] = Wf[(2 * u) * 64 + lane];
             wgt[u] = Wf[(2 * u + 1) * 64 + lane];
             // Pin the gate fragments in ACCUMULATOR registers (gfx950: one 512-entry file; an MFMA reads its B operand from
             // either half).  Left alone the allocator keeps all 184 fragment registers in the VGPR half, runs out, "spills"
@@ -257,20 +289,19 @@ __global__ __launch_bounds__(256, 1) void gated_conv1d_glu_kernel(const WsConvAr
             // fp32: the K loop is 360 MFMAs of 64 cycles; the previous tile's epilogue in front of it is < 2 % of a trip
             issue_loads(xp, tile + 2 * tstep);
             glu_all(accv[0], accg[0], o);
-#pragma unroll
-            for (int qd = 0; qd < 4; ++qd) store_quad(accv[0], accg[0], o, qd, pp);
+            store_tile(accv[0], accg[0], o, pp);
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) { accv[AC][r] = bvl; accg[AC][r] = bgl; }
         // fragment ring RD steps deep, reads pinned ahead of the MFMAs that use them
         constexpr int RD = 3, RS = RD + 1;
-        frag_t fx[RS], fw[GATE_REGS ? 1 : RS];
+        frag_t fx[RS], fwv[W_REGS ? 1 : RS], fwg[W_REGS ? 1 : RS];
         auto rd = [&](auto UC) {
             constexpr int u = decltype(UC)::value;
             if constexpr (u < NU) {
                 constexpr int off = BF16 ? 2 * R * u : (u / (RPT / 2)) * CS + (u % (RPT / 2)) * 2 * R;
                 fx[u % RS] = *reinterpret_cast<const frag_t*>(xrow + off);
-                if constexpr (!GATE_REGS) fw[u % RS] = Wf[(2 * u + 1) * 64 + lane];
+                if constexpr (!W_REGS) { fwv[u % RS] = Wf[(2 * u) * 64 + lane]; fwg[u % RS] = Wf[(2 * u + 1) * 64 + lane]; }
             }
         };
         auto mm = [&](auto UC) {
@@ -280,30 +311,42 @@ __global__ __launch_bounds__(256, 1) void gated_conv1d_glu_kernel(const WsConvAr
                 accv[AC] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x_, wv[u], accv[AC], 0, 0, 0);
                 accg[AC] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x_, wgt[u], accg[AC], 0, 0, 0);
             } else {
-                const frag_t g_ = fw[u % RS];
+                const frag_t v_ = fwv[u % RS], g_ = fwg[u % RS];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    accv[AC] = __builtin_amdgcn_mfma_f32_32x32x2f32(x_[e], wv[u][e], accv[AC], 0, 0, 0);
+                    accv[AC] = __builtin_amdgcn_mfma_f32_32x32x2f32(x_[e], v_[e], accv[AC], 0, 0, 0);
                     accg[AC] = __builtin_amdgcn_mfma_f32_32x32x2f32(x_[e], g_[e], accg[AC], 0, 0, 0);
                 }
             }
         };
-        // bf16: what rides behind the MFMAs of step u.  Step 0: the next-but-one tile's loads; steps 0-19: stage (u % 5) of the
-        // previous tile's GLU quad (u / 5), the quad's stores behind its last stage; steps 20-21: the next tile's frames -> LDS.
-        f32x4 gt;
+        // bf16: what rides behind the MFMAs of step u.  Step 0: the next-but-one tile's loads; steps 0-3 (training): the previous
+        // tile's raw value / gate planes through the transposition tile; steps 0-19: stage (u % 5) of its GLU quad (u / 5), the
+        // finished quad into the tile; step 20: the GLU plane back out of the tile, step 21: its stores; steps 21-22: the next
+        // tile's frames -> LDS.
+        f32x4 gt, pl[4];
         auto side = [&](auto UC) {
             constexpr int u = decltype(UC)::value;
             if constexpr (OVERLAP) {
                 if constexpr (u == 0) issue_loads(xp, tile + 2 * tstep);
+                if constexpr (RAW) {
+                    if constexpr (u == 0) { put_quad(sw_r, accv[AP], 0); put_quad(sw_r, accv[AP], 1); put_quad(sw_r, accv[AP], 2); put_quad(sw_r, accv[AP], 3); }
+                    if constexpr (u == 1) read_plane(sw_r, pl);
+                    if constexpr (u == 2) { store_plane(pl, rawrs, pp.rb, pp.ok, 0);
+                                            put_quad(sw_r, accg[AP], 0); put_quad(sw_r, accg[AP], 1); put_quad(sw_r, accg[AP], 2); put_quad(sw_r, accg[AP], 3); }
+                    if constexpr (u == 3) read_plane(sw_r, pl);
+                    if constexpr (u == 5) store_plane(pl, rawrs, pp.rb, pp.ok, CT4);
+                }
                 if constexpr (u < 20) {
                     glu_stage(accv[AP], accg[AP], gt, o, u / 5, u % 5);
-                    if constexpr (u % 5 == 4) store_quad(accv[AP], accg[AP], o, u / 5, pp);
+                    if constexpr (u % 5 == 4) put_quad(sw_y, o, u / 5);
                 }
-                if constexpr (u == 20) {
+                if constexpr (u == 20) read_plane(sw_y, pl);
+                if constexpr (u == 21) {
+                    store_plane(pl, yrs, pp.yb, pp.ok, 0);
                     wait_counted(xq);
                     stage_task(xq, std::integral_constant<int, 0>{}, nslot);
                 }
-                if constexpr (u == 21) stage_task(xq, std::integral_constant<int, 1>{}, nslot);
+                if constexpr (u == 22) stage_task(xq, std::integral_constant<int, 1>{}, nslot);
             }
         };
         [&]<int... U>(std::integer_sequence<int, U...>) { (rd(std::integral_constant<int, U>{}), ...); }(std::make_integer_sequence<int, RD>{});
@@ -318,7 +361,7 @@ __global__ __launch_bounds__(256, 1) void gated_conv1d_glu_kernel(const WsConvAr
         }
         __syncthreads();                                    // slot P ^ 1 is complete; slot P may be overwritten by the next trip
     };
-    static_assert(!OVERLAP || (NU >= 22 && NTPT == 2), "the bf16 side schedule places its work on steps 0-21");
+    static_assert(!OVERLAP || (NU >= 23 && NTPT == 2), "the bf16 side schedule places its work on steps 0-22");
 
     int tile = tile0;
     for (;;) {
@@ -335,12 +378,10 @@ __global__ __launch_bounds__(256, 1) void gated_conv1d_glu_kernel(const WsConvAr
         f32x16 o;
         if (OVERLAP && !(trips & 1)) {
             glu_all(accv[1], accg[1], o);
-#pragma unroll
-            for (int qd = 0; qd < 4; ++qd) store_quad(accv[1], accg[1], o, qd, pp);
+            store_tile(accv[1], accg[1], o, pp);
         } else {
             glu_all(accv[0], accg[0], o);
-#pragma unroll
-            for (int qd = 0; qd < 4; ++qd) store_quad(accv[0], accg[0], o, qd, pp);
+            store_tile(accv[0], accg[0], o, pp);
         }
     }
 }

@@ -191,6 +191,7 @@ __device__ __forceinline__ void c1_window(const C1Args& a, const float* x, int i
 // a block then holds 32 value channels and the matching 32 gate channels, and writes act = value * sigmoid(gate) next to
 // the raw pair (kept for the backward pass) -- the GLU costs no second pass over the raw tensor.
 __global__ __launch_bounds__(256) void c1_fwd_kernel(const C1Args a) {
+    touch_kernarg(a);
     __shared__ __attribute__((aligned(16))) float ws[10 * 64];       // [t][c] + bias row
     const bool glu = a.act != nullptr;
     const int C = a.Cout >> 1;
@@ -244,6 +245,7 @@ __global__ __launch_bounds__(256) void c1_fwd_kernel(const C1Args a) {
 // input gradient as a scatter from dy: z[t] = sum_co w[t][co] * dy[co][p] for the thread's pixel p (dy read once,
 // coalesced), then dx[window_t(p)] += z[t] (atomics; dx zeroed by the launcher unless it accumulates)
 __global__ __launch_bounds__(256) void c1_dgrad_kernel(const C1Args a) {
+    touch_kernarg(a);
     __shared__ __attribute__((aligned(16))) float ws[64 * 12];       // [c][t], t padded to 12
     const int nch = (a.Cout + 63) / 64;
     const int g = blockIdx.z / nch, cc = blockIdx.z - g * nch, b = blockIdx.y;
@@ -309,6 +311,7 @@ __global__ __launch_bounds__(256) void c1_dgrad_gather_kernel(const C1Args a, in
 // and issue ONE atomic per (tap, channel) and block (atomics on one cache line serialise: per-wave atomics cost 80 us).
 // (deterministic mode: one block walks ALL samples in order, so every dw element receives exactly one contribution)
 __global__ __launch_bounds__(256) void c1_wgrad_kernel(const C1Args a) {
+    touch_kernarg(a);
     const int C1_BPB = a.det ? a.B : 1;
     __shared__ float red[4][72];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;

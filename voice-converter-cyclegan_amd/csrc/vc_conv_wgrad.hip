@@ -13,6 +13,7 @@
 // the pair base rides in the buffer load's SGPR offset (loop-invariant), the lane's pixel offset (+ one channel for the
 // upper lane half) in the VGPR offset, VC_OOB where the tap leaves the image for that pixel (hardware range check -> 0).
 #include "vc_internal.h"
+#include "vc_device_util.h"
 #include <algorithm>
 #include <cmath>
 #include <type_traits>
@@ -22,6 +23,7 @@ typedef const __attribute__((address_space(4))) int* c_int_p;
 
 template <int BN, int KG, int MATH>
 __global__ __launch_bounds__(256 * KG, KG == 4 ? 4 : 2) void wgrad_kernel(const WgradArgs p) {
+    touch_kernarg(p);
     // LDS tiles are [row][pixel] with a 36-float row stride: the loader writes whole pixel runs (conflict-free), and a
     // lane reads its 16 k values (pixels 16h..16h+15 of its row; MFMA step u pairs pixels u and 16+u) as 4 ds_read_b128
     constexpr int BM = 64, KC = VC_KC, LDT = KC + 4;

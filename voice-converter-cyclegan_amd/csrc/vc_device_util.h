@@ -2,6 +2,21 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+// A kernel's by-value argument struct lives in the kernarg segment (device memory the host has just written: its first read
+// misses every cache).  Compiled code fetches the fields as it needs them, a 64-byte line at a time, each behind an
+// s_waitcnt -- a 320-byte struct costs five DEPENDENT memory round trips before the first table fetch can even be issued
+// (round-4 ISA reading of igemm_kernel's prologue: ~12 scalar-load waits in a row; the round-3 probe put 3.8 us between a
+// workgroup's entry and its first operand load).  touch_kernarg reads one dword of every line side by side and makes the
+// kernel wait for them once: one round trip, after which every field is a scalar-cache hit.
+template <class T> __device__ __forceinline__ void touch_kernarg(const T& a) {
+    typedef const __attribute__((address_space(4))) int* cint_p;
+    cint_p q = (cint_p)(const void*)&a;
+    int x = 0;
+#pragma unroll
+    for (unsigned o = 0; o < sizeof(T) / 4; o += 16) x |= q[o];
+    asm volatile("" :: "s"(x));
+}
+
 // cross-lane add inside a row of 16 lanes on the DPP path (no LDS round trip): CTRL = quad_perm / row_mirror encodings
 template <int CTRL> __device__ __forceinline__ float dpp_read(float x) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, false));

@@ -41,6 +41,7 @@ template <int NB> __device__ __forceinline__ long yoff(const NormArgs& p, int b,
 
 template <int MODE, int LPR, int NE>
 __global__ __launch_bounds__(256) void norm_fwd_kernel(const NormArgs p) {
+    touch_kernarg(p);
     constexpr int NB = (MODE == 2) ? 1 : 2;
     const int unit = blockIdx.x * (256 / LPR) + threadIdx.x / LPR;
     const int sub = threadIdx.x % LPR;
@@ -110,6 +111,7 @@ __global__ __launch_bounds__(256) void norm_fwd_kernel(const NormArgs p) {
 // dbias are reduced in registers in a fixed order and added with one plain read-modify-write per element -- no atomics.
 template <int MODE, int LPR, int NE, bool DET>
 __global__ __launch_bounds__(256) void norm_bwd_kernel(const NormArgs p) {
+    touch_kernarg(p);
     constexpr int NB = (MODE == 2) ? 1 : 2;
     const int unit = blockIdx.x * (256 / LPR) + threadIdx.x / LPR;
     const int sub = threadIdx.x % LPR;
@@ -270,6 +272,7 @@ template <int NB, bool PS> struct RowV4 {
 
 template <int MODE, int LPR, int NV, bool PS>
 __global__ __launch_bounds__(256) void norm_fwd_v4_kernel(const NormArgs p) {
+    touch_kernarg(p);
     constexpr int NB = (MODE == 2) ? 1 : 2;
     const int unit = blockIdx.x * (256 / LPR) + threadIdx.x / LPR, sub = threadIdx.x % LPR;
     if (unit >= p.G * p.B * p.C) return;
@@ -341,6 +344,7 @@ __global__ __launch_bounds__(256) void norm_fwd_v4_kernel(const NormArgs p) {
 
 template <int MODE, int LPR, int NV, bool PS>
 __global__ __launch_bounds__(256) void norm_bwd_v4_kernel(const NormArgs p) {
+    touch_kernarg(p);
     constexpr int NB = (MODE == 2) ? 1 : 2;
     const int unit = blockIdx.x * (256 / LPR) + threadIdx.x / LPR, sub = threadIdx.x % LPR;
     if (unit >= p.G * p.B * p.C) return;
@@ -438,6 +442,7 @@ __global__ __launch_bounds__(256) void norm_bwd_v4_kernel(const NormArgs p) {
 // GLU backward without norm (module.py:201-203 / 161-163: the two h1 blocks) for rows of ANY length that is a multiple of 4
 // (D.h1: 1536 pixels at 24x128, 4608 at 36x256): no row statistics, so the row is streamed, 32 lanes x 16 bytes a trip
 __global__ __launch_bounds__(256) void glu_bwd_v4_kernel(const NormArgs p) {
+    touch_kernarg(p);
     constexpr int LPR = 32;
     const int unit = blockIdx.x * (256 / LPR) + threadIdx.x / LPR, sub = threadIdx.x % LPR;
     if (unit >= p.G * p.B * p.C) return;
@@ -478,6 +483,7 @@ __device__ __forceinline__ float block_sum_256s(float v, float* red) {
 
 template <int MODE>
 __global__ __launch_bounds__(256) void norm_fwd_stream_kernel(const NormArgs p) {
+    touch_kernarg(p);
     constexpr int NB = (MODE == 2) ? 1 : 2;
     __shared__ float red[4];
     const int unit = blockIdx.x;
@@ -518,6 +524,7 @@ __global__ __launch_bounds__(256) void norm_fwd_stream_kernel(const NormArgs p) 
 
 template <int MODE, bool DET>
 __global__ __launch_bounds__(256) void norm_bwd_stream_kernel(const NormArgs p) {
+    touch_kernarg(p);
     constexpr int NB = (MODE == 2) ? 1 : 2;
     __shared__ float red[4];
     const int unit = blockIdx.x;
@@ -743,6 +750,7 @@ __device__ __forceinline__ float signf_(float x) { return (float)((x > 0.f) - (x
 
 // utils.py:6-12 + model.py:57-90, plus the gradients of every mean w.r.t. its input.
 __global__ __launch_bounds__(256) void loss_kernel(const LossArgs a) {
+    touch_kernarg(a);
     __shared__ float red[4];
     float s[10];
 #pragma unroll
