@@ -271,6 +271,44 @@ __global__ __launch_bounds__(64 * (BM / 32) * 2 * KG, (64 * (BM / 32) * 2 * KG >
 
     // ---- epilogue: every K group parks its tile in its own LDS region; all threads then sum the groups, add
     //      bias (+ addend) and store 4 consecutive pixels per lane (16 bytes when they are contiguous in the output).
+    // Its kernel arguments first, ALL of them side by side and pinned in SGPRs: left to itself the compiler re-reads each field
+    // from the kernarg segment where it is first used, behind its own s_waitcnt and usually a branch -- the round-4 ISA reading
+    // found a dozen such scalar round trips in a row between the last MFMA and the first store (the round-3 probe: 4.7 us).
+    // Fetched here they travel while the accumulators are parked, and so do the bias / addend values of the vec4 path.
+#define VC_PIN_S(x) asm volatile("" : "+s"(x))
+    float* e_Y = p.Y; const float* e_bias = p.bias; const float* e_add = p.addend;
+    long e_ygs = p.y_gs, e_bgs = p.bias_gs, e_ags = p.add_gs, e_ybs = p.y_bs;
+    int e_M = p.M, e_Ptot = p.Ptot, e_yHW = p.yHW, e_yW = p.yW, e_soh = p.so_h, e_sow = p.so_w, e_oh0 = p.o_h0, e_ow0 = p.o_w0;
+    int e_vec4 = p.vec4, e_sk = p.splitk, e_acc = p.accumulate, e_NPB = p.NPB, e_OWc = p.OWc;
+    float e_inpb = p.inv_npb, e_iow = p.inv_ow;
+    VC_PIN_S(e_Y); VC_PIN_S(e_bias); VC_PIN_S(e_add); VC_PIN_S(e_ygs); VC_PIN_S(e_bgs); VC_PIN_S(e_ags); VC_PIN_S(e_ybs);
+    VC_PIN_S(e_M); VC_PIN_S(e_Ptot); VC_PIN_S(e_yHW); VC_PIN_S(e_yW); VC_PIN_S(e_soh); VC_PIN_S(e_sow); VC_PIN_S(e_oh0); VC_PIN_S(e_ow0);
+    VC_PIN_S(e_vec4); VC_PIN_S(e_sk); VC_PIN_S(e_acc); VC_PIN_S(e_NPB); VC_PIN_S(e_OWc); VC_PIN_S(e_inpb); VC_PIN_S(e_iow);
+    auto decode = [&](int P, int& b, int& i, int& j) { int r; b = fast_divmod(P, e_NPB, e_inpb, &r); i = fast_divmod(r, e_OWc, e_iow, &j); };
+    const bool atomic = e_sk > 1 || e_acc;
+    const bool first = sp == 0;
+    float* Yg = e_Y + (long)g * e_ygs;
+    const float* Bg = (e_bias && first) ? e_bias + (long)g * e_bgs : nullptr;
+    const float* Dg = (e_add && first) ? e_add + (long)g * e_ags : nullptr;
+    const bool path_vec4 = !FUSE && e_vec4 && !atomic;
+    // vec4 path: output offsets, bias and addend of this thread's NV quads, requested BEFORE the tile is parked
+    constexpr int NV4 = BM * BN / 4 / NT;
+    long vo[NV4]; float vb[NV4]; f32x4 vd[NV4]; bool vok[NV4];
+    if (path_vec4) {
+#pragma unroll
+        for (int i = 0; i < NV4; ++i) {
+            const int idx = tid + i * NT, ml = idx >> 4, n4 = (idx & 15) * 4;
+            const int m = mt * BM + ml, P0 = nt * BN + n4;
+            vok[i] = m < e_M && P0 < e_Ptot;
+            vo[i] = 0; vb[i] = 0.f; vd[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (vok[i]) {
+                int b, ii, j; decode(P0, b, ii, j);
+                vo[i] = (long)b * e_ybs + (long)m * e_yHW + (long)(ii * e_soh + e_oh0) * e_yW + j + e_ow0;
+                if (Bg) vb[i] = Bg[m];
+                if (Dg) vd[i] = *reinterpret_cast<const f32x4*>(Dg + vo[i]);
+            }
+        }
+    }
     {
         const f32x16 acc = accb[0] + accb[1];
         float* Ys = smem + kg * REG;          // the tile loop ended on a barrier: the region is free
@@ -279,17 +317,17 @@ __global__ __launch_bounds__(64 * (BM / 32) * 2 * KG, (64 * (BM / 32) * 2 * KG >
             Ys[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * LDY + wn * 32 + l31] = acc[r];
     }
     __syncthreads();
-    const bool atomic = p.splitk > 1 || p.accumulate;
-    const bool first = sp == 0;
-    float* Yg = p.Y + (long)g * p.y_gs;
-    const float* Bg = (p.bias && first) ? p.bias + (long)g * p.bias_gs : nullptr;
-    const float* Dg = (p.addend && first) ? p.addend + (long)g * p.add_gs : nullptr;
     if constexpr (FUSE) {
         // ---- instance norm + GLU in the epilogue (module.py:85-98 as one kernel with the convolution pair).  1-D, vec4
         //      layout, no split-K (checked by the launcher).  Phase A: sum the K groups, add the bias, store the raw pair and
         //      leave the sums in LDS region 0; phase B: 16 lanes own one (value row, gate row) pair of the tile, 4 pixels
         //      each: moments over the sample's NPB pixels by DPP, then the normalised, gated output.
-        const int C = p.M >> 1;
+        const int C = e_M >> 1;
+        const float* gam = p.gamma + (long)g * p.par_gs;
+        const float* bet = p.beta + (long)g * p.par_gs;
+        float* actg = p.act + (long)g * p.act_gs;
+        float* stg = p.stats + (long)g * p.st_gs;
+        VC_PIN_S(gam); VC_PIN_S(bet); VC_PIN_S(actg); VC_PIN_S(stg);
         constexpr int NV = BM * BN / 4 / NT;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
@@ -300,18 +338,16 @@ __global__ __launch_bounds__(64 * (BM / 32) * 2 * KG, (64 * (BM / 32) * 2 * KG >
             for (int k2 = 1; k2 < KG; ++k2) v += *reinterpret_cast<const f32x4*>(smem + k2 * REG + ml * LDY + n4);
             if (Bg) v += Bg[ch];
             *reinterpret_cast<f32x4*>(smem + ml * LDY + n4) = v;      // this cell is read and written by this thread only
-            if (P0 < p.Ptot) {
-                int r0; const int b = fast_divmod(P0, p.NPB, p.inv_npb, &r0);
-                *reinterpret_cast<f32x4*>(Yg + (long)b * p.y_bs + (long)ch * p.yHW + r0) = v;
+            if (P0 < e_Ptot) {
+                int r0; const int b = fast_divmod(P0, e_NPB, e_inpb, &r0);
+                *reinterpret_cast<f32x4*>(Yg + (long)b * e_ybs + (long)ch * e_yHW + r0) = v;
             }
         }
         __syncthreads();
         constexpr int PT = NT < 512 ? NT : 512;
         if (tid < PT) {
-            const float invL = p.inv_npb;
-            const float* gam = p.gamma + (long)g * p.par_gs;
-            const float* bet = p.beta + (long)g * p.par_gs;
-            const bool whole = p.NPB == 64;               // 16 lanes = one sample, or two samples of 32 pixels
+            const float invL = e_inpb;
+            const bool whole = e_NPB == 64;               // 16 lanes = one sample, or two samples of 32 pixels
             auto rsum = [&](float x) {
                 x += dpp_read<0xB1>(x); x += dpp_read<0x4E>(x); x += dpp_read<0x141>(x);      // sums of 8 lanes
                 if (whole) x += dpp_read<0x140>(x);
@@ -321,7 +357,9 @@ __global__ __launch_bounds__(64 * (BM / 32) * 2 * KG, (64 * (BM / 32) * 2 * KG >
             for (int pass = 0; pass < 512 / PT; ++pass) {
                 const int pr = (tid >> 4) + pass * (PT / 16), n4 = (tid & 15) * 4;
                 const int c = mt * 32 + pr, P0 = nt * BN + n4;
-                const bool pv = P0 < p.Ptot;
+                const bool pv = P0 < e_Ptot;
+                // the affine parameters are requested before the reductions that do not need them
+                const float ga = gam[c], be = bet[c], ga2 = gam[C + c], be2 = bet[C + c];
                 const f32x4 v = *reinterpret_cast<const f32x4*>(smem + pr * LDY + n4);
                 const f32x4 gt = *reinterpret_cast<const f32x4*>(smem + (pr + 32) * LDY + n4);
                 const float mu = rsum(pv ? v[0] + v[1] + v[2] + v[3] : 0.f) * invL;
@@ -330,35 +368,29 @@ __global__ __launch_bounds__(64 * (BM / 32) * 2 * KG, (64 * (BM / 32) * 2 * KG >
                 const float rs = rsqrtf(rsum(pv ? dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2] + dv[3] * dv[3] : 0.f) * invL + 1e-6f);
                 const float rs2 = rsqrtf(rsum(pv ? dg[0] * dg[0] + dg[1] * dg[1] + dg[2] * dg[2] + dg[3] * dg[3] : 0.f) * invL + 1e-6f);
                 if (!pv) continue;
-                int r0; const int b = fast_divmod(P0, p.NPB, p.inv_npb, &r0);
-                const float ga = gam[c], be = bet[c], ga2 = gam[C + c], be2 = bet[C + c];
+                int r0; const int b = fast_divmod(P0, e_NPB, e_inpb, &r0);
                 f32x4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = (dv[e] * rs * ga + be) * sigmoidf_(dg[e] * rs2 * ga2 + be2);
-                *reinterpret_cast<f32x4*>(p.act + (long)g * p.act_gs + ((long)b * C + c) * p.NPB + r0) = o;
+                *reinterpret_cast<f32x4*>(actg + ((long)b * C + c) * e_NPB + r0) = o;
                 if (r0 == 0) {                            // one lane per (sample, channel pair)
-                    float* st = p.stats + (long)g * p.st_gs + ((long)b * 2 * C) * 2;
+                    float* st = stg + ((long)b * 2 * C) * 2;
                     st[2 * c] = mu; st[2 * c + 1] = rs; st[2 * (C + c)] = mu2; st[2 * (C + c) + 1] = rs2;
                 }
             }
         }
     } else
-    if (p.vec4 && !atomic) {
+    if (path_vec4) {
         // plain stores, 4 consecutive pixels (16 contiguous bytes) per lane: a wave instruction writes 4 rows x 256 B
-        constexpr int NV = BM * BN / 4 / NT;
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
+        for (int i = 0; i < NV4; ++i) {
             const int idx = tid + i * NT, ml = idx >> 4, n4 = (idx & 15) * 4;
-            const int m = mt * BM + ml, P0 = nt * BN + n4;
-            if (m >= p.M || P0 >= p.Ptot) continue;
+            if (!vok[i]) continue;
             f32x4 v = *reinterpret_cast<const f32x4*>(smem + ml * LDY + n4);
 #pragma unroll
             for (int k2 = 1; k2 < KG; ++k2) v += *reinterpret_cast<const f32x4*>(smem + k2 * REG + ml * LDY + n4);
-            if (Bg) v += Bg[m];
-            int b, ii, j; px_decode(p, P0, b, ii, j);
-            const long o = (long)b * p.y_bs + (long)m * p.yHW + (long)(ii * p.so_h + p.o_h0) * p.yW + j + p.o_w0;
-            if (Dg) v += *reinterpret_cast<const f32x4*>(Dg + o);
-            *reinterpret_cast<f32x4*>(Yg + o) = v;
+            v += vb[i]; v += vd[i];
+            *reinterpret_cast<f32x4*>(Yg + vo[i]) = v;
         }
     } else {
         // one pixel per lane, lanes along the pixels of one output row: atomics (split-K across workgroups, accumulate)
@@ -366,23 +398,24 @@ __global__ __launch_bounds__(64 * (BM / 32) * 2 * KG, (64 * (BM / 32) * 2 * KG >
         constexpr int NE = BM * BN / NT;
         const int n = tid & 63, Pn = nt * BN + n;
         long obase = 0;
-        if (Pn < p.Ptot) {
-            int b, ii, j; px_decode(p, Pn, b, ii, j);
-            obase = (long)b * p.y_bs + (long)(ii * p.so_h + p.o_h0) * p.yW + (j * p.so_w + p.o_w0);
+        if (Pn < e_Ptot) {
+            int b, ii, j; decode(Pn, b, ii, j);
+            obase = (long)b * e_ybs + (long)(ii * e_soh + e_oh0) * e_yW + (j * e_sow + e_ow0);
         }
 #pragma unroll 4
         for (int i = 0; i < NE; ++i) {
             const int ml = (tid >> 6) + i * (NT / 64), m = mt * BM + ml;
-            if (m >= p.M || Pn >= p.Ptot) continue;
+            if (m >= e_M || Pn >= e_Ptot) continue;
             float v = smem[ml * LDY + n];
 #pragma unroll
             for (int k2 = 1; k2 < KG; ++k2) v += smem[k2 * REG + ml * LDY + n];
             if (Bg) v += Bg[m];
-            const long o = obase + (long)m * p.yHW;
+            const long o = obase + (long)m * e_yHW;
             if (Dg) v += Dg[o];
             if (atomic) atomicAdd(Yg + o, v); else Yg[o] = v;
         }
     }
+#undef VC_PIN_S
 }
 
 // ------------------------------------------------------------------------------------------------------------------
