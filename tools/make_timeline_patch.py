@@ -51,10 +51,11 @@ extern "C" int vc_debug_timeline(unsigned long long* out, int reset) {
     s = sub(s, a, '    fetch_tab(c0 + 2);\n    VC_TL(1);\n    items(LD0{}, ST0{}, S0{}, S0{}, 0);\n    __syncthreads();\n    VC_TL(2);\n')
     a = '    // ---- epilogue: every K group parks its tile in its own LDS region; all threads then sum the groups, add'
     s = sub(s, a, '    VC_TL(3);\n' + a)
-    a = '            if (atomic) atomicAdd(Yg + o, v); else Yg[o] = v;\n        }\n    }\n}\n'
+    a = '            if (atomic) atomicAdd(Yg + o, v); else Yg[o] = v;\n        }\n    }\n#undef VC_PIN_S\n}\n'
     s = sub(s, a, '''            if (atomic) atomicAdd(Yg + o, v); else Yg[o] = v;
         }
     }
+#undef VC_PIN_S
 #ifdef VC_TIMELINE
     if (tl_on) {
         tl[4] = __builtin_readcyclecounter();
