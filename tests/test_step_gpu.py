@@ -243,6 +243,40 @@ def test_train_step_losses_grads_and_updates(built_lib, B):
             _load_oracle_state(eng, orc)
 
 
+def test_ten_free_running_steps_track_the_oracle(built_lib):
+    """Ten consecutive steps (model.py:110-125 called ten times, train.py:107) with NO resynchronisation: the engine carries its
+    own parameters, Adam moments and beta powers from step to step, the oracle its own.  The per-step test above reloads the
+    oracle's state after every step (so that each step is judged on its own merits at the tight bound); what it cannot see is
+    a bug in the carry-over itself -- stale m / v, beta powers that do not advance, a missed join of the update stream before
+    the next forward.  Those produce O(1) errors within a few steps; honest +-lr differences of near-zero gradients compound
+    to ~3e-3 on the generations.  Bounds: losses and generations within 2e-2 after every step, the accumulated parameter
+    update (theta_10 - theta_0), m and v within 1e-1 / 5e-2 / 5e-2 rel-L2 of the oracle's over the whole flat state."""
+    from tests import gpu_util as U
+    from voice_converter_cyclegan_amd.engine import SCOPES
+    B = 2
+    O, P, A, Bm, eng = _setup(B, seed=11)
+    eng.set_deterministic(True)
+    orc = O.CycleGANOracle({k: v.copy() for k, v in P.items()})
+    gen_A = torch.empty((B, 24, 128), device=U.DEV); gen_B = torch.empty_like(gen_A)
+    theta0 = eng.params.clone()
+    for step in range(10):
+        g0, d0 = orc.train(A, Bm, 10.0, 5.0, 2e-4, 1e-4)
+        g, d = eng.train_step(A, Bm, 10.0, 5.0, 2e-4, 1e-4, gen_A=gen_A, gen_B=gen_B)
+        for k, v in orc.last.items():
+            assert abs(eng.last_losses[k] - v) <= 2e-2 * max(1.0, abs(v)), (step, k, eng.last_losses[k], float(v))
+        assert U.rel_err(gen_A.cpu().numpy(), orc.last_fakes[0]) < 2e-2, step
+        assert U.rel_err(gen_B.cpu().numpy(), orc.last_fakes[1]) < 2e-2, step
+    pack = lambda d: torch.from_numpy(np.concatenate([eng._layout(i).pack(d, s) for i, s in enumerate(SCOPES)])).double()
+    rel = lambda a, b: float((a - b).norm() / (b.norm() + 1e-30))
+    want_p = pack(orc.P)
+    e_p = rel(eng.params.cpu().double() - theta0.cpu().double(), want_p - theta0.cpu().double())
+    ms = dict(orc.opt_g.m); ms.update(orc.opt_d.m); vs = dict(orc.opt_g.v); vs.update(orc.opt_d.v)
+    e_m, e_v = rel(eng.m.cpu().double(), pack(ms)), rel(eng.v.cpu().double(), pack(vs))
+    print('free-running 10 steps: accumulated update rel-L2 %.3g, m %.3g, v %.3g' % (e_p, e_m, e_v))
+    assert e_p < 1e-1 and e_m < 5e-2 and e_v < 5e-2, (e_p, e_m, e_v)
+    assert float((eng.params.cpu().double() - want_p).abs().max()) <= 10 * 2.02 * 2e-4
+
+
 def _load_oracle_state(eng, orc):
     """parameters and Adam slots of the oracle -> engine (the beta powers follow the step count on both sides)"""
     from voice_converter_cyclegan_amd.engine import SCOPES

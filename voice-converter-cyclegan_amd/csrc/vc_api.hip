@@ -339,8 +339,17 @@ static void set_vec4(IgemmArgs& a) {
 struct PackSpace { char* p = nullptr; size_t cap = 0; };
 static std::mutex g_ws_mu;
 static std::map<hipStream_t, PackSpace> g_ws;
-// bumped whenever a workspace block is freed or moved: captured step graphs hold these addresses and are keyed on it
-static std::atomic<long> g_ws_generation{0};
+// Captured step graphs hold workspace addresses: every stream carries a generation, bumped whenever ITS block is freed or
+// moved, and a graph's cache key embeds the generations of the streams its plan launches on -- so destroying an unrelated plan
+// (CycleGAN.test evicts inference plans all the time) does not force the training plan to re-capture.
+static std::map<hipStream_t, long> g_ws_gen;
+static long g_ws_gen_all = 0;                     // vc_release_workspaces: every block went away
+static long ws_generation(std::initializer_list<hipStream_t> streams) {
+    std::lock_guard<std::mutex> l(g_ws_mu);
+    long sum = g_ws_gen_all;
+    for (hipStream_t s : streams) { auto it = g_ws_gen.find(s); if (it != g_ws_gen.end()) sum += it->second; }
+    return sum;
+}
 static int pack_space(hipStream_t s, size_t bytes, char** out) {
     std::lock_guard<std::mutex> l(g_ws_mu);
     PackSpace& w = g_ws[s];
@@ -350,7 +359,7 @@ static int pack_space(hipStream_t s, size_t bytes, char** out) {
             vc_set_error("bf16 data path: the packed-operand workspace would have to grow during stream capture; run one eager step of this batch first");
             return VC_E_STATE;
         }
-        if (w.p) { VC_HIP(hipFree(w.p)); ++g_ws_generation; }
+        if (w.p) { VC_HIP(hipFree(w.p)); ++g_ws_gen[s]; }
         w.p = nullptr; w.cap = 0;
         const size_t cap = bytes + bytes / 4 + (1u << 20);
         VC_HIP(hipMalloc((void**)&w.p, cap));
@@ -365,7 +374,7 @@ extern "C" int vc_release_workspaces(void) {
     std::lock_guard<std::mutex> l(g_ws_mu);
     for (auto& kv : g_ws) if (kv.second.p) (void)hipFree(kv.second.p);
     g_ws.clear();
-    ++g_ws_generation;
+    ++g_ws_gen_all;
     return 0;
 }
 // a plan's streams go away with it: free their workspaces (a recycled stream handle must not inherit a stale block)
@@ -374,8 +383,9 @@ static void drop_pack_spaces(std::initializer_list<hipStream_t> streams) {
     for (hipStream_t s : streams) {
         auto it = g_ws.find(s);
         if (it == g_ws.end()) continue;
-        if (it->second.p) { (void)hipFree(it->second.p); ++g_ws_generation; }      // hipFree waits for the device
+        if (it->second.p) (void)hipFree(it->second.p);      // hipFree waits for the device
         g_ws.erase(it);
+        g_ws_gen.erase(s);                        // the stream is going away with its plan: nobody else's key mentions it
     }
 }
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -1149,12 +1159,14 @@ static int net_forward(NetCtx& c, const float* x, long x_gs, float* y_plain, lon
         std::vector<std::pair<float*, long>> zl;
         for (size_t i = 0; i < c.n->layers.size(); ++i) {
             const Layer& L = c.n->layers[i];
-            bool split = false;
-            VC_CHECK(conv_fwd(nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0, c.G, c.B, (*c.geo)[i].g, c.math, c.s, false, &split));
-            if (!split) continue;
             // the network's output (the plain last layer writes it directly) rides in the same list when it is 16-byte aligned
             float* dst = (L.mode == M_PLAIN) ? y_plain : c.save + c.sm.raw[i];
             const long dst_gs = (L.mode == M_PLAIN) ? y_plain_gs : c.save_gs;
+            // the query sees the REAL destination: whatever the configuration derives from it (alignment, vec4) is what the
+            // launch below will derive too, so "prezeroed" can never describe a different split-K decision than the launch takes
+            bool split = false;
+            VC_CHECK(conv_fwd(nullptr, 0, nullptr, 0, nullptr, 0, dst, dst_gs, c.G, c.B, (*c.geo)[i].g, c.math, c.s, false, &split));
+            if (!split) continue;
             if (L.mode == M_PLAIN && (!aligned16(y_plain) || (y_plain_gs & 3))) { plain_zeroed = false; continue; }
             for (int g = 0; g < c.G; ++g) zl.push_back({dst + (long)g * dst_gs, (*c.geo)[i].raw_ps * c.B});
         }
@@ -1524,9 +1536,10 @@ static int refresh_filter_images(const vc_plan* p, const float* params, hipStrea
             }
         p->img_g = ig; p->img_d = id;
     }
+    std::vector<PackFilterJob> pj;
     for (const Job& j : jobs)
-        VC_CHECK(launch_pack_filter_bf16(j.w, j.w_gs, p->img_block + j.off, (long)j.gs, j.wsrc, j.a_ms, 2, j.M, j.kp, s));
-    return 0;
+        pj.push_back(PackFilterJob{j.w, (unsigned short*)(p->img_block + j.off), j.wsrc, j.w_gs, (long)j.gs / 2, j.a_ms, j.M, j.kp, 0, 0});
+    return launch_pack_filter_multi(pj, 2, s);
 }
 
 static int step_grads_impl(const vc_plan* p, const float* params, float* grads,
@@ -1648,9 +1661,13 @@ extern "C" int vc_train_step_graph(vc_plan* p, float* params, float* grads, floa
     VC_ARG(p && params && grads && m && v && A && Bm && losses && ws && batch > 0, "vc_train_step_graph: bad args");
     VC_ARG(!p->inference, "this plan was created for inference only (vc_plan_create_inference)");
     hipStream_t user = (hipStream_t)stream;
-    const std::array<const void*, 12> key{params, grads, m, v, A, Bm, losses, gen_A, gen_B, ws,
-                                          (const void*)(intptr_t)(batch * 16 + (lambda_identity == 0.0f ? 1 : 0) * 8 + (p->use_side & 7)),
-                                          (const void*)(intptr_t)(p->math + 16 * p->det + 64 * g_ws_generation.load())};
+    auto make_key = [&]() {
+        return std::array<const void*, 12>{params, grads, m, v, A, Bm, losses, gen_A, gen_B, ws,
+                                           (const void*)(intptr_t)(batch * 16 + (lambda_identity == 0.0f ? 1 : 0) * 8 + (p->use_side & 7)),
+                                           (const void*)(intptr_t)(p->math + 16 * p->det +
+                                                                   64 * ws_generation({p->gstream, p->side, p->wstream, p->wstream_d, p->ustream}))};
+    };
+    std::array<const void*, 12> key = make_key();
     vc_plan::StepGraph* sg = nullptr;
     for (auto& g : p->graphs) if (g.key == key) { sg = &g; break; }
     if (!sg) {
@@ -1667,6 +1684,7 @@ extern "C" int vc_train_step_graph(vc_plan* p, float* params, float* grads, floa
             const hipError_t e0 = hipStreamSynchronize(p->gstream);
             if (r0 || e0 != hipSuccess) { p->use_side = overlap; if (r0) return r0; VC_HIP(e0); }
         }
+        key = make_key();                       // the eager run may have grown a workspace: the graph captured below holds the NEW addresses
         VC_HIP(hipStreamBeginCapture(p->gstream, hipStreamCaptureModeThreadLocal));
         int r = step_grads_impl(p, params, grads, A, Bm, batch, lambda_cycle, lambda_identity, p->hp_dev, losses, gen_A, gen_B,
                                 ws, ws_floats, p->gstream);

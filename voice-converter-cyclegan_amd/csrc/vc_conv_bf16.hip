@@ -105,6 +105,67 @@ __global__ __launch_bounds__(256) void pack_filter_bf16_kernel(const float* __re
     }
 }
 
+// The same for MANY filter images in one launch (refresh_filter_images: every layer's forward image and its input-gradient
+// images, once per train step -- 49 launches of a few microseconds each in round 3, 0.8 ms on the step's critical path, most
+// of it launch latency).  blockIdx.x walks the concatenated (k block, m block) grids of the jobs.
+__global__ __launch_bounds__(256) void pack_filter_multi_kernel(const PackFilterJobs jobs) {
+    touch_kernarg(jobs);
+    __shared__ unsigned short tile[64][64 + 2];
+    int ji = 0;
+    for (int q = 1; q < jobs.n; ++q) if ((int)blockIdx.x >= jobs.j[q].blk0) ji = q;      // uniform scan of <= 48 entries
+    const PackFilterJob& J = jobs.j[ji];
+    const int lb = blockIdx.x - J.blk0, kb = lb % J.nkb, mb = lb / J.nkb;
+    const int k0 = kb * 64, m0 = mb * 64, g = blockIdx.z, tid = threadIdx.x, M = J.M, a_ms = J.a_ms;
+    const float* W = J.w + (long)g * J.w_gs;
+    const int* wsrc = J.wsrc;
+    if (a_ms == 1) {
+        const int m = tid & 63;
+#pragma unroll 4
+        for (int i = 0; i < 16; ++i) {
+            const int kk = (tid >> 6) + 4 * i, src = wsrc[k0 + kk];
+            const float v = (src >= 0 && m0 + m < M) ? W[(long)src + m0 + m] : 0.f;
+            tile[kk][m] = __builtin_bit_cast(unsigned short, (__bf16)v);
+        }
+    } else {
+        const int kk = tid & 63, src = wsrc[k0 + kk];
+#pragma unroll 4
+        for (int i = 0; i < 16; ++i) {
+            const int m = (tid >> 6) + 4 * i;
+            const float v = (src >= 0 && m0 + m < M) ? W[(long)src + (long)(m0 + m) * a_ms] : 0.f;
+            tile[kk][m] = __builtin_bit_cast(unsigned short, (__bf16)v);
+        }
+    }
+    __syncthreads();
+    const int m = tid & 63;
+    if (m0 + m < M) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int oct = (tid >> 6) + 4 * i;
+            unsigned q[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) q[e] = (unsigned)tile[oct * 8 + 2 * e][m] | ((unsigned)tile[oct * 8 + 2 * e + 1][m] << 16);
+            u32x4 o = {q[0], q[1], q[2], q[3]};
+            *reinterpret_cast<u32x4*>(J.ap + (long)g * J.ap_gs + ((long)(k0 / 8 + oct) * M + m0 + m) * 8) = o;
+        }
+    }
+}
+int launch_pack_filter_multi(const std::vector<PackFilterJob>& jobs, int G, hipStream_t s) {
+    for (size_t at = 0; at < jobs.size(); at += VC_PACK_JOBS) {
+        PackFilterJobs pj{};
+        int blk = 0;
+        pj.n = (int)std::min<size_t>(VC_PACK_JOBS, jobs.size() - at);
+        for (int i = 0; i < pj.n; ++i) {
+            pj.j[i] = jobs[at + i];
+            pj.j[i].nkb = pj.j[i].kp / 64; pj.j[i].blk0 = blk;
+            blk += pj.j[i].nkb * ((pj.j[i].M + 63) / 64);
+        }
+        if (blk == 0) continue;
+        pack_filter_multi_kernel<<<dim3(blk, 1, G), 256, 0, s>>>(pj);
+        VC_HIP(hipGetLastError());
+    }
+    return 0;
+}
+
 // ---- filter gradient (autodiff of model.py:107-108 through module.py:32-40, 54-62) --------------------------------------
 //   dW[k][co] = sum over (application, sample, pixel) of Xg[k][P] * dY[co][P],   k = (tap, cin) in TF's own order
 // is a plain GEMM over the pixel axis, so it runs on conv_bf16_kernel itself: rows = K rows, "pixels" = Cout, K octets =

@@ -135,6 +135,11 @@ int launch_pack_pixel_octets_bf16(const float* dy, long dy_gs, void* out, long o
 int launch_pack_act_bf16(const float* x, long x_gs, void* xp, long xp_gs_bytes, int G, int B, int C, int HW, hipStream_t s);
 // Ap[g][k/8][m][k%8] = bf16(W[g][wsrc[k] + m * a_ms]), 0 where wsrc[k] < 0; kp = 8 * koct
 int launch_pack_filter_bf16(const float* w, long w_gs, void* ap, long ap_gs_bytes, const int* wsrc, int a_ms, int G, int M, int kp, hipStream_t s);
+// many filter images in one launch: job = one image (both groups); ap_gs in bf16 elements; blk0 / nkb are filled by the launcher
+struct PackFilterJob { const float* w; unsigned short* ap; const int* wsrc; long w_gs, ap_gs; int a_ms, M, kp, blk0, nkb; };
+#define VC_PACK_JOBS 48
+struct PackFilterJobs { PackFilterJob j[VC_PACK_JOBS]; int n; };
+int launch_pack_filter_multi(const std::vector<PackFilterJob>& jobs, int G, hipStream_t s);
 
 // Single-input-channel convolution (the discriminator's first layer, module.py:201-202: Cin = 1, 3x3 -> K = 9): a
 // bandwidth job, done on the vector ALU instead of padding K = 9 up to an MFMA tile.  kh*kw <= 9.

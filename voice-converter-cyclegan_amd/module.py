@@ -22,15 +22,33 @@ from ._lib import lib, ptr, check
 from .layout import ParamLayout, GENERATOR, DISCRIMINATOR
 
 
+_pending_destroy = []          # native plans whose last Python reference is gone; destroyed at the next safe point
+
+
+def _drain_pending_plans():
+    """Destroy the plans queued by _PlanHandle.__del__.  Called where no stream capture can be in progress on this thread (the
+    top of VariableStore.plan, interpreter exit): vc_plan_destroy synchronises the device and frees memory, both illegal
+    inside a capture (vc_train_step_graph runs one in thread-local capture mode)."""
+    if not _pending_destroy:
+        return
+    torch.cuda.synchronize()                       # nothing in flight may still use the plans' streams / tables
+    while _pending_destroy:
+        lib.vc_plan_destroy(C.c_void_p(_pending_destroy.pop()))
+
+
+import atexit  # noqa: E402
+atexit.register(lambda: _drain_pending_plans() if torch.cuda.is_available() else None)
+
+
 class _PlanHandle(C.c_void_p):
-    """A native plan that is destroyed with its last user: the store's LRU holds one reference, every autograd node that
-    still needs the plan for its backward holds another (ctx.plan)."""
+    """A native plan that outlives its last user only until the next safe point: the store's LRU holds one reference, every
+    autograd node that still needs the plan for its backward holds another (ctx.plan).  __del__ can run wherever the garbage
+    collector pleases -- also while another call is capturing a step graph -- so it only QUEUES the handle."""
 
     def __del__(self):
         try:
             if self.value:
-                torch.cuda.synchronize()           # nothing in flight may still use the plan's streams / tables
-                lib.vc_plan_destroy(self)
+                _pending_destroy.append(self.value)
         except Exception:
             pass
 
@@ -64,13 +82,14 @@ class VariableStore:
         return self.scopes[name]
 
     def plan(self, F, T):
+        _drain_pending_plans()
         key = (F, T)
         h = self._plans.get(key)
         if h is not None:
             self._plans.move_to_end(key)
             return h
         while len(self._plans) >= self.PLAN_CAPACITY:
-            self._plans.popitem(last=False)        # destroyed once no pending backward refers to it (_PlanHandle.__del__)
+            self._plans.popitem(last=False)        # queued for destruction once no pending backward refers to it (_PlanHandle.__del__)
         h = _PlanHandle()
         check(lib.vc_plan_create(F, int(T), C.byref(h)), 'vc_plan_create')
         self._plans[key] = h
