@@ -339,6 +339,11 @@ def main():
     if args.cpu_leg:
         kind, B_, th, bud = args.cpu_leg.split(',')
         return _cpu_leg(kind, int(B_), int(th), float(bud))
+    # The contract is ONE JSON line on stdout.  Libraries underneath print there too (RCCL's version banner at communicator
+    # creation, on every rank): from here on file descriptor 1 IS stderr, and the JSON line goes to the saved descriptor.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     default_workload = (args.batch, args.global_batch, args.frames, args.features, args.math, args.graph, args.serial, args.deterministic) == \
                        (8, 0, 128, 24, 'fp32', False, False, False)
 
@@ -479,7 +484,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline()
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + '\n').encode())
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
