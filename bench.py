@@ -125,8 +125,7 @@ def named_kernel_h1(lib, dev, B=256, reps=20, peak=FP32_MFMA_PEAK_TFLOPS, math='
     y = torch.empty((1, B, 128, 128), device=dev)
     s = vp(torch.cuda.current_stream().cuda_stream)
     check(lib.vc_set_math_mode({'fp32': 0, 'bf16': 1}[math]))
-    wsp = torch.empty(lib.vc_gated_conv1d_glu_workspace_floats(1, 256), device=dev)
-    call = lambda: check(lib.vc_gated_conv1d_glu_fwd(ptr(x), 0, ptr(w), 0, ptr(b), 0, ptr(y), 0, 1, B, 24, 128, 256, 15, ptr(wsp), wsp.numel(), s))
+    call = lambda: check(lib.vc_gated_conv1d_glu_fwd(ptr(x), 0, ptr(w), 0, ptr(b), 0, ptr(y), 0, 1, B, 24, 128, 256, 15, s))
     try:
         for _ in range(3):
             call()

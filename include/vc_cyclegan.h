@@ -118,15 +118,12 @@ int vc_conv2d_wgrad(const float* x, int64_t x_gs, const float* dy, int64_t dy_gs
  * with the value filters in [0, Cout2/2) and the gate filters in [Cout2/2, Cout2), bias likewise.  Neither raw convolution
  * is written: HBM sees the frames once and the activation once (the north-star kernel; inference plans use it, the train
  * step keeps value and gate for the backward).  Built for Cin = 24, k = 15 (24 MCEPs), Cout2 % 64 == 0, T % 4 == 0.
- * Math mode of the calling thread: fp32 (exact) or bf16 (operands rounded once, when the filters are packed / the frames
- * staged).  ONE launch: each workgroup builds its filter slab in LDS straight from w (round 3; the round-2 form packed the
- * filters into `workspace` with a separate launch first).  workspace (vc_gated_conv1d_glu_workspace_floats floats, 16-byte
- * aligned) is kept in the signature and only written when the library runs with VC_GLU_PACKED=1 (A/B measurements). */
-int64_t vc_gated_conv1d_glu_workspace_floats(int G, int Cout2);
+ * Math mode of the calling thread: fp32 (exact) or bf16 (operands rounded once: the filters when a workgroup builds its
+ * register-resident fragments straight from w, the frames when they are staged).  ONE launch, no workspace.  Tensors of
+ * one group must stay below 2 GiB (32-bit buffer offsets). */
 int vc_gated_conv1d_glu_fwd(const float* x, int64_t x_gs, const float* w, int64_t w_gs,
                             const float* bias, int64_t b_gs, float* out, int64_t out_gs,
-                            int G, int B, int Cin, int T, int Cout2, int k,
-                            float* workspace, int64_t workspace_floats, void* stream);
+                            int G, int B, int Cin, int T, int Cout2, int k, void* stream);
 /* BiasAddGrad: db[c] += sum_{b,l} dy[g][b][c][l]  (dy [G][B][C][L]). */
 int vc_bias_grad(const float* dy, int64_t dy_gs, float* db, int64_t db_gs,
                  int G, int B, int C, int L, void* stream);

@@ -24,7 +24,6 @@ int  vc_tune_rowskip(int wgrad_on);     /* filter gradients of 2-D layers whose 
                                          * skip the output rows a K tile's taps never reach (csrc/vc_api.hip: rowskip_pays); default on; thread-local */
 int  vc_tune_wgrad_store(int on);       /* tuning only: while on, vc_conv2d_wgrad OVERWRITES dw (the train step's plain-store form) */
 int  vc_tune_conv_bf16_override(int tile_rows, int stages, int splitk);
-int  vc_tune_glu_version(int version);   /* A/B only: 1 = the round-3 form of vc_gated_conv1d_glu_fwd (filter slab in LDS), 2 = current */
 /* Which configuration did the calling thread's last conv forward / input-gradient launch (igemm) or filter-gradient launch
  * (wgrad) run with, and where did it come from?  out4 = {tile rows | columns, K groups, split-K, source}; source: 0 cost
  * model, 1 exact row of the measured table (csrc/vc_tuned_igemm.h / vc_tuned_wgrad.h), 2 the same layer's row measured at

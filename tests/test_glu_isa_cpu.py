@@ -68,11 +68,12 @@ def test_trip_issues_the_counted_operations(asm, bf16, raw):
     assert len(body) == 1
     body = body[0]
     nst = 12 if raw else 4
-    hdr = [i for i, l in enumerate(body) if 'Loop Header' in l]
-    assert hdr, 'tile loop not found'
-    bars = [i for i, l in enumerate(body) if 's_barrier' in l and i > hdr[0]]
-    assert len(bars) >= 2
-    trips = [(hdr[0], bars[0]), (bars[0], bars[1])]          # the loop body is two trips (register sets alternate)
+    # the tile loop's body is two trips (register sets alternate), each ending in the workgroup barrier: the two stretches of
+    # code between consecutive barriers (or the loop header and a barrier) that hold a counted wait
+    cuts = sorted([i for i, l in enumerate(body) if 's_barrier' in l or 'Loop Header' in l])
+    want = 's_waitcnt vmcnt(%d)' % (16 + 2 * nst)
+    trips = [(lo, hi) for lo, hi in zip(cuts[:-1], cuts[1:]) if 's_barrier' in body[hi] and any(want in l for l in body[lo:hi])]
+    assert len(trips) == 2, (tag, len(trips))
     dests = []
     for lo, hi in trips:
         ins = _instrs(body[lo:hi])

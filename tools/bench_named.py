@@ -1,5 +1,4 @@
-"""A/B of the north-star kernel (vc_gated_conv1d_glu_fwd): round-3 form (filter slab in LDS) vs round-4 form (filter
-fragments in registers), fp32 and bf16, B = 256 and B = 4096, HIP events around every call.  Run on the GPU box."""
+"""The north-star kernel (vc_gated_conv1d_glu_fwd) at several sizes, fp32 and bf16, HIP events around every call.  Run on the GPU box."""
 import ctypes as C
 import os
 import sys
@@ -12,18 +11,16 @@ ge.build()
 from voice_converter_cyclegan_amd._lib import lib, ptr, check, vp  # noqa: E402
 
 dev = 'cuda:0'
-for ver in (1, 2):
-    check(lib.vc_tune_glu_version(ver))
+for ver in (2,):
     for math in ('fp32', 'bf16'):
         for B, T in ((256, 128), (4096, 128), (8, 2048), (16, 128)):
             x = torch.randn((1, B, 24, T), device=dev)
             w = torch.randn((1, 15, 24, 256), device=dev) * 0.05
             b = torch.randn((1, 256), device=dev) * 0.1
             y = torch.empty((1, B, 128, T), device=dev)
-            wsp = torch.empty(lib.vc_gated_conv1d_glu_workspace_floats(1, 256), device=dev)
             s = vp(torch.cuda.current_stream().cuda_stream)
             check(lib.vc_set_math_mode({'fp32': 0, 'bf16': 1}[math]))
-            call = lambda: check(lib.vc_gated_conv1d_glu_fwd(ptr(x), 0, ptr(w), 0, ptr(b), 0, ptr(y), 0, 1, B, 24, T, 256, 15, ptr(wsp), wsp.numel(), s))
+            call = lambda: check(lib.vc_gated_conv1d_glu_fwd(ptr(x), 0, ptr(w), 0, ptr(b), 0, ptr(y), 0, 1, B, 24, T, 256, 15, s))
             for _ in range(3):
                 call()
             torch.cuda.synchronize()
@@ -40,4 +37,3 @@ for ver in (1, 2):
             algo = B * (24 * T + 128 * T) * 4 + (15 * 24 * 256 + 256) * 4
             flops = 2.0 * B * T * 256 * 15 * 24
             print('v%d %-4s B=%-4d T=%-4d %8.2f us  HBM %6.3f of 8 TB/s  %7.1f TFLOP/s' % (ver, math, B, T, t * 1e6, algo / t / 8e12, flops / t / 1e12), flush=True)
-check(lib.vc_tune_glu_version(2))

@@ -18,10 +18,9 @@ for math in ('bf16', 'fp32'):
     for B in (256, 4096):
         x = torch.randn((1, B, 24, 128), device=dev); w = torch.randn((1, 15, 24, 256), device=dev) * 0.05
         b = torch.randn((1, 256), device=dev) * 0.1; y = torch.empty((1, B, 128, 128), device=dev)
-        wsp = torch.empty(lib.vc_gated_conv1d_glu_workspace_floats(1, 256), device=dev)
         s = vp(torch.cuda.current_stream().cuda_stream)
         check(lib.vc_set_math_mode({'fp32': 0, 'bf16': 1}[math]))
-        call = lambda: check(lib.vc_gated_conv1d_glu_fwd(ptr(x), 0, ptr(w), 0, ptr(b), 0, ptr(y), 0, 1, B, 24, 128, 256, 15, ptr(wsp), wsp.numel(), s))
+        call = lambda: check(lib.vc_gated_conv1d_glu_fwd(ptr(x), 0, ptr(w), 0, ptr(b), 0, ptr(y), 0, 1, B, 24, 128, 256, 15, s))
         for _ in range(3):
             call()
         torch.cuda.synchronize(); fn(None, 1)

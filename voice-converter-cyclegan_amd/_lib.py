@@ -46,7 +46,6 @@ SIGNATURES = [
     ('vc_tune_rowskip', i32, [i32]),
     ('vc_tune_conv_bf16_override', i32, [i32, i32, i32]),
     ('vc_tune_conv_bf16_keys', i32, [vp, i32]),
-    ('vc_tune_glu_version', i32, [i32]),
     ('vc_tune_last_igemm_config', i32, [C.POINTER(C.c_int)]),
     ('vc_tune_last_wgrad_config', i32, [C.POINTER(C.c_int)]),
     ('vc_tune_query_igemm', i32, [i32, i32, i32, i32, i32, C.POINTER(C.c_int)]),
@@ -58,8 +57,7 @@ SIGNATURES = [
     ('vc_conv2d_fwd', i32, [vp, i64, vp, i64, vp, i64, vp, i64] + [i32] * 10 + [vp]),
     ('vc_conv2d_dgrad', i32, [vp, i64, vp, i64, vp, i64, vp, i64, i32] + [i32] * 10 + [vp]),
     ('vc_conv2d_wgrad', i32, [vp, i64, vp, i64, vp, i64] + [i32] * 10 + [vp]),
-    ('vc_gated_conv1d_glu_workspace_floats', i64, [i32, i32]),
-    ('vc_gated_conv1d_glu_fwd', i32, [vp, i64, vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, i32, i32, vp, i64, vp]),
+    ('vc_gated_conv1d_glu_fwd', i32, [vp, i64, vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, i32, i32, vp]),
     ('vc_bias_grad', i32, [vp, i64, vp, i64, i32, i32, i32, i32, vp]),
     ('vc_instnorm_glu_fwd', i32, [i32, i32, vp, i64, vp, i64, vp, vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, vp]),
     ('vc_instnorm_glu_bwd', i32, [i32, i32, vp, i64, vp, i64, vp, vp, i64, vp, i64, vp, i64, vp, vp, i64, vp, i64,

@@ -740,18 +740,15 @@ extern "C" int vc_conv2d_wgrad(const float* x, int64_t x_gs, const float* dy, in
 }
 extern "C" int vc_gated_conv1d_glu_fwd(const float* x, int64_t x_gs, const float* w, int64_t w_gs,
                                        const float* bias, int64_t b_gs, float* out, int64_t out_gs,
-                                       int G, int B, int Cin, int T, int Cout2, int k,
-                                       float* workspace, int64_t workspace_floats, void* stream) {
-    VC_ARG(x && w && out && workspace && G > 0 && B > 0 && Cin > 0 && T > 0 && Cout2 > 0 && k > 0, "vc_gated_conv1d_glu_fwd: bad args");
-    VC_ARG(aligned16(out) && out_gs % 4 == 0 && aligned16(workspace), "vc_gated_conv1d_glu_fwd: out and workspace must be 16-byte aligned");
-    if (workspace_floats < gated_conv1d_glu_workspace_floats(G, Cout2)) { vc_set_error("workspace too small"); return VC_E_NOMEM; }
+                                       int G, int B, int Cin, int T, int Cout2, int k, void* stream) {
+    VC_ARG(x && w && out && G > 0 && B > 0 && Cin > 0 && T > 0 && Cout2 > 0 && k > 0, "vc_gated_conv1d_glu_fwd: bad args");
+    VC_ARG(aligned16(out) && out_gs % 4 == 0, "vc_gated_conv1d_glu_fwd: out must be 16-byte aligned");
     WsConvArgs c{}; c.x = x; c.w = w; c.bias = bias; c.y = out; c.x_gs = x_gs; c.w_gs = w_gs; c.b_gs = b_gs; c.y_gs = out_gs;
     c.B = B; c.T = T; c.Cout = Cout2; c.G = G;
-    const int r = launch_gated_conv1d_glu(c, Cin, k, t_math, workspace, (hipStream_t)stream, 2.0 * G * B * T * (double)Cout2 * k * Cin);
-    VC_ARG(r != -2, "vc_gated_conv1d_glu_fwd: built for Cin = 24, k = 15, Cout2 %% 64 == 0, T %% 4 == 0 (the generator's h1 block)");
+    const int r = launch_gated_conv1d_glu(c, Cin, k, t_math, (hipStream_t)stream, 2.0 * G * B * T * (double)Cout2 * k * Cin);
+    VC_ARG(r != -2, "vc_gated_conv1d_glu_fwd: built for Cin = 24, k = 15, Cout2 %% 64 == 0, T %% 4 == 0, tensors < 2 GiB (the generator's h1 block)");
     return r;
 }
-extern "C" int64_t vc_gated_conv1d_glu_workspace_floats(int G, int Cout2) { return gated_conv1d_glu_workspace_floats(G, Cout2); }
 extern "C" int vc_bias_grad(const float* dy, int64_t dy_gs, float* db, int64_t db_gs,
                             int G, int B, int C, int L, void* stream) {
     VC_ARG(dy && db, "vc_bias_grad: bad args");
@@ -963,7 +960,6 @@ struct vc_plan {
     std::vector<StepGraph> graphs;
     hipStream_t gstream = nullptr, ustream = nullptr;     // capture / replay stream, update (exchange + Adam) stream
     hipEvent_t ev_gin = nullptr, ev_gout = nullptr, ev_ujoin = nullptr;
-    float* packed = nullptr;                              // packed h1 filters for gated_conv1d_glu_kernel (2 groups)
     float* hp_dev = nullptr;                              // {lambda_cycle, lambda_identity, alpha_g, alpha_d} of the step being replayed
     // bf16 data path: filter images of every layer (forward + one per input-gradient parity class), rebuilt from the
     // fp32 weights once at the start of a train step instead of before every launch (a step uses each image 2-3 times)
@@ -1031,7 +1027,6 @@ static int plan_create(int num_features, int n_frames, bool inference, vc_plan**
     if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_gout, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_ujoin, hipEventDisableTiming);
     if (e == hipSuccess) e = hipMalloc((void**)&p->hp_dev, 4 * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc((void**)&p->packed, (size_t)gated_conv1d_glu_workspace_floats(2, p->G.layers[0].cout) * sizeof(float));
     if (e != hipSuccess) { vc_set_error("hipEventCreate failed: %s", hipGetErrorString(e)); vc_plan_destroy(p); return (int)e; }
     *out = p;
     return 0;
@@ -1061,7 +1056,6 @@ extern "C" void vc_plan_destroy(vc_plan* p) {
     if (p->ev_gout) (void)hipEventDestroy(p->ev_gout);
     if (p->ev_ujoin) (void)hipEventDestroy(p->ev_ujoin);
     if (p->hp_dev) (void)hipFree(p->hp_dev);
-    if (p->packed) (void)hipFree(p->packed);
     if (p->img_block) (void)hipFree(p->img_block);
     release_tables(p->tables);
     delete p;
@@ -1136,7 +1130,6 @@ struct NetCtx {
     int G, B, Bl, math;
     hipStream_t s;
     hipStream_t ws = nullptr; const hipEvent_t* ev_layer = nullptr; hipEvent_t ev_wjoin = nullptr;   // wgrad stream (null: same stream)
-    float* packed = nullptr;               // packed filter image of the fused gated block (plan-owned, 2 groups)
     const std::vector<vc_plan::LayerImages>* images = nullptr;   // bf16 data path: this step's prebuilt filter images
     bool keep_packed = false;              // bf16 data path, inside a train step: forward leaves the packed inputs in the save area (SaveMap::actp)
     bool fuse_glu = false;                 // forward only: gated blocks without instance norm go out as one conv + GLU kernel
@@ -1179,13 +1172,13 @@ static int net_forward(NetCtx& c, const float* x, long x_gs, float* y_plain, lon
         float* raw = (L.mode == M_PLAIN) ? y_plain : c.save + c.sm.raw[i];
         const long raw_gs = (L.mode == M_PLAIN) ? y_plain_gs : c.save_gs;
         if (L.mode == M_GATED_IN && i + 1 < c.n->layers.size() && c.n->layers[i + 1].mode == M_IN_RES) { blk_in = in; blk_in_gs = in_gs; }
-        if (L.mode == M_GATED && c.packed && c.G <= 2 && wsconv_path(lg.g) && c.math != VC_MATH_BF16X3) {
+        if (L.mode == M_GATED && wsconv_path(lg.g) && c.math != VC_MATH_BF16X3) {
             // gated block without instance norm (G.h1, module.py:161-163): convolution pair + GLU in one kernel.  Forward-only
             // passes (CycleGAN.test) never need the raw value / gate tensors again; a training pass keeps them for backward.
             WsConvArgs f{}; f.x = in; f.w = c.params + L.w; f.bias = c.params + L.b; f.y = c.save + c.sm.act[i];
             f.x_gs = in_gs; f.w_gs = c.par_gs; f.b_gs = c.par_gs; f.y_gs = c.save_gs; f.B = c.B; f.T = lg.g.W; f.Cout = L.cout; f.G = c.G;
             if (!c.fuse_glu) { f.raw = raw; f.raw_gs = raw_gs; }
-            const int r = launch_gated_conv1d_glu(f, lg.g.Cin, lg.g.kw, c.math, c.packed, c.s, 2.0 * c.G * c.B * lg.g.W * (double)L.cout * lg.g.kw * lg.g.Cin);
+            const int r = launch_gated_conv1d_glu(f, lg.g.Cin, lg.g.kw, c.math, c.s, 2.0 * c.G * c.B * lg.g.W * (double)L.cout * lg.g.kw * lg.g.Cin);
             if (r != -2) { VC_CHECK(r); in = f.y; in_gs = c.save_gs; continue; }
         }
         if (L.mode == M_GATED && c1_path(lg.g)) {
@@ -1338,7 +1331,7 @@ static int gen_forward(const vc_plan* p, const float* params, long par_gs, const
                        float* y, long y_gs, float* save, int G, int B, hipStream_t s) {
     NetCtx c = gen_ctx(p, params, par_gs, nullptr, 0, save, G, B, B, s);
     c.images = step_images(p, true, G); c.keep_packed = c.images != nullptr;
-    c.fuse_glu = p->inference; c.packed = p->packed;
+    c.fuse_glu = p->inference;
     return net_forward(c, x, x_gs, y, y_gs);
 }
 struct BwdOpts { bool record_buckets = false, wgrad_store = false; int wmode = W_SELF; const DeferredApp* deferred = nullptr; };

@@ -94,9 +94,24 @@ __global__ __launch_bounds__(256, 1) void gated_conv1d_glu_kernel(const WsConvAr
     // frames of `tile` -> a register set: R channels x NTPT rows per thread, lanes along time (coalesced); the channel's offset
     // rides in the load's SGPR offset.  Positions outside the sample (SAME padding) and tiles past the end get an out-of-
     // range VGPR offset: the hardware returns 0.  Always NXL load instructions.
-    auto issue_loads = [&](float (&x)[NXL], int tile) {
-        const bool tv = tile < ntiles;
-        const int b = tv ? tile / tps : 0, t0 = (tile - b * tps) * TP - PADL;
+    // tile -> (sample, tile inside the sample) without a division per trip: a cursor that advances by the workgroup's tile
+    // step (tstep = qs * tps + rs, decomposed once)
+    struct Cursor { int tile, b, tt; };
+    const int tstep_ = gridDim.x, qs = tstep_ / tps, rs = tstep_ - qs * tps;
+    auto cursor_at = [&](int tile) { Cursor c; c.tile = tile; c.b = tile / tps; c.tt = tile - c.b * tps; return c; };
+    auto advance = [&](Cursor& c) {                       // branch-free: one select per trip
+        c.tile += tstep_; c.b += qs; c.tt += rs;
+        const bool w = c.tt >= tps;
+        c.tt = w ? c.tt - tps : c.tt; c.b += (int)w;
+    };
+    auto retreat = [&](Cursor c) {                        // the cursor one step BEFORE c (prologue only): advance(retreat(c)) == c
+        c.tile -= tstep_; c.b -= qs; c.tt -= rs;
+        if (c.tt < 0) { c.tt += tps; --c.b; }
+        return c;
+    };
+    auto issue_loads = [&](float (&x)[NXL], const Cursor& cu) {
+        const bool tv = cu.tile < ntiles;
+        const int b = tv ? cu.b : 0, t0 = (tv ? cu.tt : 0) * TP - PADL;
         const int base = (b * CIN * a.T + t0) * 4, tlim = tv ? a.T : 0;
 #pragma unroll
         for (int j = 0; j < NTPT; ++j) {
@@ -129,7 +144,8 @@ __global__ __launch_bounds__(256, 1) void gated_conv1d_glu_kernel(const WsConvAr
 
     // ---- prologue: first tile's frames travel while the filter fragments are built
     const int tile0 = blockIdx.x, tstep = gridDim.x;
-    issue_loads(xr0, tile0);
+    Cursor lcur = cursor_at(tile0);                      // next tile whose frames are requested
+    issue_loads(xr0, lcur); advance(lcur);
     {
         // Fragment unit U = 2u + vg (K step u; value / gate): lane (channel l31, half h) holds W[k = R (2u + h) + e][channel],
         // e < R.  Wave w builds units w, w + 4, ..: R coalesced loads each (32 channels = 128 bytes per k row), all issued
@@ -163,7 +179,7 @@ __global__ __launch_bounds__(256, 1) void gated_conv1d_glu_kernel(const WsConvAr
     wait_all(xr0);
     [&]<int... J>(std::integer_sequence<int, J...>) { (stage_task(xr0, std::integral_constant<int, J>{}, Xs), ...); }
         (std::make_integer_sequence<int, NTPT>{});
-    issue_loads(xr1, tile0 + tstep);
+    issue_loads(xr1, lcur); advance(lcur);
 
     // output addressing: an accumulator quad (4 consecutive pixels of the lane's channel) goes into the wave's transposition
     // tile; flushing a plane, lane l stores pixels 4 (l & 7) .. + 3 of rows (l >> 3) + 8 i, i < 4: 16 bytes per lane
@@ -175,11 +191,11 @@ __global__ __launch_bounds__(256, 1) void gated_conv1d_glu_kernel(const WsConvAr
     // where the wave's 32 x 32 output tile of `tile` goes: the lane's byte offsets for flush row 0 (tile < 0 or past the end, or
     // pixels past the end of the sample: invalid -> an out-of-range offset, dropped by the hardware)
     struct OutPos { bool ok; unsigned yb, rb; };
-    auto out_pos = [&](int tile) {
+    auto out_pos = [&](const Cursor& cu) {
         OutPos p;
-        const bool tv = tile >= 0 && tile < ntiles;
-        const int b = tv ? tile / tps : 0;
-        const int t = (tile - b * tps) * TP + w4 * 32 + 4 * (lane & 7), row = slab * 32 + (lane >> 3);
+        const bool tv = cu.tile >= 0 && cu.tile < ntiles;
+        const int b = tv ? cu.b : 0;
+        const int t = (tv ? cu.tt : 0) * TP + w4 * 32 + 4 * (lane & 7), row = slab * 32 + (lane >> 3);
         p.ok = tv && t < a.T;
         p.yb = (unsigned)(((b * C + row) * a.T + t) * 4);
         p.rb = (unsigned)(((b * 2 * C + row) * a.T + t) * 4);
@@ -248,7 +264,7 @@ __global__ __launch_bounds__(256, 1) void gated_conv1d_glu_kernel(const WsConvAr
         f32x16 z;
 #pragma unroll
         for (int r = 0; r < 16; ++r) z[r] = 0.f;
-        store_tile(z, z, z, out_pos(-1));
+        store_tile(z, z, z, out_pos(retreat(cursor_at(tile0))));      // tile0 - tstep < 0: every lane out of range
     }
     __syncthreads();                                        // filter fragments and tile 0 are in LDS
     // bf16: value and gate fragments in registers (184 of the 512).  fp32: 360 fragment registers + accumulators + frames in
@@ -271,6 +287,12 @@ __global__ __launch_bounds__(256, 1) void gated_conv1d_glu_kernel(const WsConvAr
         }
     }
 
+    // the bias as two constant accumulator tuples (a lane's 16 outputs are 16 pixels of ONE channel), kept in the AGPR half
+    f32x16 bvv, bgv;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { bvv[r] = bvl; bgv[r] = bgl; }
+    asm volatile("" : "+a"(bvv)); asm volatile("" : "+a"(bgv));
+    Cursor scur = retreat(cursor_at(tile0));             // tile whose planes the next trip stores (the first trip: a dummy in front of tile0)
     f32x16 accv[2], accg[2];
 #pragma unroll
     for (int r = 0; r < 16; ++r) { accv[0][r] = accv[1][r] = 0.f; accg[0][r] = accg[1][r] = 0.f; }
@@ -283,16 +305,14 @@ __global__ __launch_bounds__(256, 1) void gated_conv1d_glu_kernel(const WsConvAr
         float (&xq)[NXL] = P ? xr0 : xr1;                   // set that holds tile + 1 step
         const T* xrow = Xs + P * SLOT + (w4 * 32 + l31) * CS + h * R;
         T* nslot = Xs + (P ^ 1) * SLOT;
-        const OutPos pp = out_pos(tile - tstep);
+        const OutPos pp = out_pos(scur); advance(scur);   // the previous tile's output position
         f32x16 o;
         if constexpr (!OVERLAP) {
             // fp32: the K loop is 360 MFMAs of 64 cycles; the previous tile's epilogue in front of it is < 2 % of a trip
-            issue_loads(xp, tile + 2 * tstep);
+            issue_loads(xp, lcur); advance(lcur);
             glu_all(accv[0], accg[0], o);
             store_tile(accv[0], accg[0], o, pp);
         }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { accv[AC][r] = bvl; accg[AC][r] = bgl; }
         // fragment ring RD steps deep, reads pinned ahead of the MFMAs that use them
         constexpr int RD = 3, RS = RD + 1;
         frag_t fx[RS], fwv[W_REGS ? 1 : RS], fwg[W_REGS ? 1 : RS];
@@ -308,14 +328,15 @@ __global__ __launch_bounds__(256, 1) void gated_conv1d_glu_kernel(const WsConvAr
             constexpr int u = decltype(UC)::value;
             const frag_t x_ = fx[u % RS];
             if constexpr (BF16) {
-                accv[AC] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x_, wv[u], accv[AC], 0, 0, 0);
-                accg[AC] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x_, wgt[u], accg[AC], 0, 0, 0);
+                // step 0 starts the accumulators at the bias: the constant tuples are its C operand (no 32 moves per tile)
+                accv[AC] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x_, wv[u], u == 0 ? bvv : accv[AC], 0, 0, 0);
+                accg[AC] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x_, wgt[u], u == 0 ? bgv : accg[AC], 0, 0, 0);
             } else {
                 const frag_t v_ = fwv[u % RS], g_ = fwg[u % RS];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    accv[AC] = __builtin_amdgcn_mfma_f32_32x32x2f32(x_[e], v_[e], accv[AC], 0, 0, 0);
-                    accg[AC] = __builtin_amdgcn_mfma_f32_32x32x2f32(x_[e], g_[e], accg[AC], 0, 0, 0);
+                    accv[AC] = __builtin_amdgcn_mfma_f32_32x32x2f32(x_[e], v_[e], (u == 0 && e == 0) ? bvv : accv[AC], 0, 0, 0);
+                    accg[AC] = __builtin_amdgcn_mfma_f32_32x32x2f32(x_[e], g_[e], (u == 0 && e == 0) ? bgv : accg[AC], 0, 0, 0);
                 }
             }
         };
@@ -327,7 +348,7 @@ __global__ __launch_bounds__(256, 1) void gated_conv1d_glu_kernel(const WsConvAr
         auto side = [&](auto UC) {
             constexpr int u = decltype(UC)::value;
             if constexpr (OVERLAP) {
-                if constexpr (u == 0) issue_loads(xp, tile + 2 * tstep);
+                if constexpr (u == 0) { issue_loads(xp, lcur); advance(lcur); }
                 if constexpr (RAW) {
                     if constexpr (u == 0) { put_quad(sw_r, accv[AP], 0); put_quad(sw_r, accv[AP], 1); put_quad(sw_r, accv[AP], 2); put_quad(sw_r, accv[AP], 3); }
                     if constexpr (u == 1) read_plane(sw_r, pl);
@@ -374,7 +395,7 @@ __global__ __launch_bounds__(256, 1) void gated_conv1d_glu_kernel(const WsConvAr
     {
         const int ptile = tile - tstep;
         const int trips = (ptile - tile0) / tstep + 1;
-        const OutPos pp = out_pos(ptile);
+        const OutPos pp = out_pos(scur);
         f32x16 o;
         if (OVERLAP && !(trips & 1)) {
             glu_all(accv[1], accg[1], o);
@@ -387,11 +408,7 @@ __global__ __launch_bounds__(256, 1) void gated_conv1d_glu_kernel(const WsConvAr
 }
 
 // y [G][B][Cout/2][T] = GLU of the gated pair; returns -2 when the geometry is not built
-int launch_gated_conv1d_glu_v1(const WsConvArgs& a, int cin, int kw, int math, float* workspace, hipStream_t s, double flops);
-static thread_local int g_glu_version = 2;                 // A/B hook (round 4): 1 = the round-3 kernel (filter slab in LDS)
-extern "C" int vc_tune_glu_version(int v) { g_glu_version = v == 1 ? 1 : 2; return 0; }
-int launch_gated_conv1d_glu(const WsConvArgs& a, int cin, int kw, int math, float* workspace, hipStream_t s, double flops) {
-    if (g_glu_version == 1) return launch_gated_conv1d_glu_v1(a, cin, kw, math, workspace, s, flops);
+int launch_gated_conv1d_glu(const WsConvArgs& a, int cin, int kw, int math, hipStream_t s, double flops) {
     if (cin != 24 || kw != 15 || (a.Cout & 63) || (a.T & 3)) return -2;
     if ((long)a.B * a.Cout * a.T * 4 >= 0x7ff00000L) return -2;      // 32-bit buffer offsets; VC_OOB_ST must lie beyond every tensor
     const int C = a.Cout / 2, slabs = C / 32;

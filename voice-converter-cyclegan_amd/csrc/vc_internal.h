@@ -168,8 +168,7 @@ struct WsConvArgs {
 };
 int launch_wsconv1d(const WsConvArgs& a, int cin, int kw, int math, hipStream_t s, double flops);   // returns -2 when the geometry is not built
 // the whole gated block in one kernel: y [G][B][Cout/2][T] = (conv_v + b_v) * sigmoid(conv_g + b_g); -2 when not built
-int launch_gated_conv1d_glu(const WsConvArgs& a, int cin, int kw, int math, float* workspace, hipStream_t s, double flops);
-int64_t gated_conv1d_glu_workspace_floats(int G, int cout2);   // packed filter image the kernel reads (rebuilt per call)
+int launch_gated_conv1d_glu(const WsConvArgs& a, int cin, int kw, int math, hipStream_t s, double flops);
 
 struct NormArgs {
     const float* y; const float* res; const float* gamma; const float* beta;
