@@ -21,7 +21,7 @@ extern "C" {
 int  vc_tune_igemm_override(int tile_rows, int k_groups, int splitk);
 int  vc_tune_wgrad_override(int tile_cols, int k_groups, int splitk);
 int  vc_tune_rowskip(int wgrad_on);     /* filter gradients of 2-D layers whose taps reach far into the SAME padding (D.d3) enumerate pixels row-major and
-                                         * skip the output rows a K tile's taps never reach (csrc/vc_api.hip: rowskip_pays); default on; thread-local */
+                                         * skip the output rows a K tile's taps never reach (csrc/vc_ops.hip: rowskip_pays); default on; thread-local */
 int  vc_tune_wgrad_store(int on);       /* tuning only: while on, vc_conv2d_wgrad OVERWRITES dw (the train step's plain-store form) */
 int  vc_tune_conv_bf16_override(int tile_rows, int stages, int splitk);
 /* Which configuration did the calling thread's last conv forward / input-gradient launch (igemm) or filter-gradient launch

@@ -23,13 +23,13 @@ def same_pad(n, k, s):
 
 
 def pad_rows(ntaps, per_tap):
-    """K rows of a table: every tap padded to whole 32-row chunks, the table to whole 64-row tiles (vc_api.hip: upload_table)"""
+    """K rows of a table: every tap padded to whole 32-row chunks, the table to whole 64-row tiles (vc_tables.hip: upload_table)"""
     rows = ntaps * (-(-per_tap // 32) * 32)
     return -(-rows // 64) * 64
 
 
 def launch_keys(op, Cin, H, W, Cout, kh, kw, sh, sw, Bs):
-    """(a_trans, M, Ptot, krows) of every implicit-GEMM launch the op makes (vc_api.hip: conv_fwd / conv_dgrad)"""
+    """(a_trans, M, Ptot, krows) of every implicit-GEMM launch the op makes (vc_ops.hip: conv_fwd / conv_dgrad)"""
     OH, pt = same_pad(H, kh, sh); OW, pl = same_pad(W, kw, sw)
     if op == 'fwd':
         return [(0, Cout, Bs * OH * OW, pad_rows(kh * kw, Cin))]
@@ -44,7 +44,7 @@ def launch_keys(op, Cin, H, W, Cout, kh, kw, sh, sw, Bs):
 
 
 def wgrad_key(Cin, H, W, Cout, kh, kw, sh, sw, batches):
-    """(K tiles, Cout, 32-pixel chunks) of the filter-gradient launch that reduces the applications in `batches` (vc_api.hip:
+    """(K tiles, Cout, 32-pixel chunks) of the filter-gradient launch that reduces the applications in `batches` (vc_ops.hip:
     conv_wgrad; the generator's first hop 2B and cycle hop B go out as ONE launch)"""
     OH, _ = same_pad(H, kh, sh); OW, _ = same_pad(W, kw, sw)
     return (pad_rows(kh * kw, Cin) // 64, Cout, sum(-(-(b * OH * OW) // 32) for b in batches))

@@ -82,7 +82,7 @@ def test_conv_fwd_dgrad_wgrad(built_lib, case):
 @pytest.mark.parametrize('case', [c for c in CONV_CASES if c[4] == 6] + [(16, 5, 7, 32, 6, 3, 1, 2, 2)])
 def test_conv_rowskip_modes(built_lib, case, on):
     """WgradArgs::rowskip (filter gradient: launch pixels enumerated (row, sample, column); a K tile reduces only over the
-    output rows its taps reach): on by default (vc_api.hip: rowskip_pays); both settings are forced here (vc_tune_rowskip) on the
+    output rows its taps reach): on by default (vc_ops.hip: rowskip_pays); both settings are forced here (vc_tune_rowskip) on the
     6-row-kernel geometries it applies to (module.py:208, D.d3)."""
     from voice_converter_cyclegan_amd._lib import lib, check
     check(lib.vc_tune_rowskip(on))

@@ -10,10 +10,15 @@ import __graft_entry__ as ge  # noqa: E402
 ge.build()
 from voice_converter_cyclegan_amd._lib import lib, ptr, check, vp  # noqa: E402
 
+import argparse  # noqa: E402
+ap = argparse.ArgumentParser()
+ap.add_argument('--batches', default='', help='comma-separated batch sizes at T = 128 (default: the standard set incl. a long-utterance shape)')
+args = ap.parse_args()
+SHAPES = [(int(b), 128) for b in args.batches.split(',')] if args.batches else [(256, 128), (4096, 128), (8, 2048), (16, 128)]
 dev = 'cuda:0'
 for ver in (2,):
     for math in ('fp32', 'bf16'):
-        for B, T in ((256, 128), (4096, 128), (8, 2048), (16, 128)):
+        for B, T in SHAPES:
             x = torch.randn((1, B, 24, T), device=dev)
             w = torch.randn((1, 15, 24, 256), device=dev) * 0.05
             b = torch.randn((1, 256), device=dev) * 0.1
@@ -36,4 +41,4 @@ for ver in (2,):
             t = ms.value * 1e-3 / max(n.value, 1)
             algo = B * (24 * T + 128 * T) * 4 + (15 * 24 * 256 + 256) * 4
             flops = 2.0 * B * T * 256 * 15 * 24
-            print('v%d %-4s B=%-4d T=%-4d %8.2f us  HBM %6.3f of 8 TB/s  %7.1f TFLOP/s' % (ver, math, B, T, t * 1e6, algo / t / 8e12, flops / t / 1e12), flush=True)
+            print('r4%s %-4s B=%-4d T=%-4d %8.2f us  HBM %6.3f of 8 TB/s  %7.1f TFLOP/s' % ('' if ver == 2 else '?', math, B, T, t * 1e6, algo / t / 8e12, flops / t / 1e12), flush=True)

@@ -66,7 +66,7 @@ def _pad_rows(ntaps, per_tap):
 
 
 def launch_keys(op, Cin, H, W, Cout, kh, kw, sh, sw, Bs):
-    """(a_trans, M, Ptot, krows) of every implicit-GEMM launch the op makes (vc_api.hip: conv_fwd / conv_dgrad)"""
+    """(a_trans, M, Ptot, krows) of every implicit-GEMM launch the op makes (vc_ops.hip: conv_fwd / conv_dgrad)"""
     OH, pt = _same(H, kh, sh); OW, pl = _same(W, kw, sw)
     if op == 'fwd':
         return [(0, Cout, Bs * OH * OW, _pad_rows(kh * kw, Cin))]

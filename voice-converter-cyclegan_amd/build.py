@@ -11,8 +11,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(CSRC, 'build')
 LIB = os.path.join(CSRC, 'libvcgan_hip.so')
-SOURCES = ['vc_conv_igemm.hip', 'vc_conv_bf16.hip', 'vc_conv_wgrad.hip', 'vc_conv_small.hip', 'vc_conv_glu.hip', 'vc_elementwise.hip', 'vc_api.hip', 'vc_comm.hip']
-HEADERS = ['vc_internal.h', 'vc_device_util.h', 'vc_tuned_igemm.h', 'vc_tuned_wgrad.h', 'vc_tuned_bf16.h', os.path.join('..', '..', 'include', 'vc_cyclegan.h'),
+SOURCES = ['vc_conv_igemm.hip', 'vc_conv_bf16.hip', 'vc_conv_wgrad.hip', 'vc_conv_small.hip', 'vc_conv_glu.hip', 'vc_elementwise.hip', 'vc_tables.hip', 'vc_ops.hip', 'vc_net.hip', 'vc_step.hip', 'vc_comm.hip']
+HEADERS = ['vc_internal.h', 'vc_host.h', 'vc_device_util.h', 'vc_tuned_igemm.h', 'vc_tuned_wgrad.h', 'vc_tuned_bf16.h', os.path.join('..', '..', 'include', 'vc_cyclegan.h'),
            os.path.join('..', '..', 'include', 'vc_cyclegan_testing.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++20', '-munsafe-fp-atomics', '-fPIC',
          '-Wall', '-Wextra', '-Wno-unused-parameter']

@@ -18,7 +18,7 @@
 // Workgroup: 256 threads = 2 x 2 waves, tile 128 or 64 (m) x 128 (pixels), K chunk 64, a ring of 2 or 4 LDS stages of
 // 32 KB; a wave owns 64 x 64 = 2 x 2 MFMA tiles (16 MFMAs of 32 cycles per chunk against 16 ds_read_b128 and 8 LDS-direct
 // copies).  The filter gradient is the same kernel on operands repacked 8 PIXELS to a unit (im2col_bf16_kernel,
-// pack_pixel_octets_bf16_kernel; launch set-up in vc_api.hip: conv_wgrad).
+// pack_pixel_octets_bf16_kernel; launch set-up in vc_ops.hip: conv_wgrad).
 #include "vc_internal.h"
 #include "vc_device_util.h"
 #include <array>
@@ -169,7 +169,7 @@ int launch_pack_filter_multi(const std::vector<PackFilterJob>& jobs, int G, hipS
 // ---- filter gradient (autodiff of model.py:107-108 through module.py:32-40, 54-62) --------------------------------------
 //   dW[k][co] = sum over (application, sample, pixel) of Xg[k][P] * dY[co][P],   k = (tap, cin) in TF's own order
 // is a plain GEMM over the pixel axis, so it runs on conv_bf16_kernel itself: rows = K rows, "pixels" = Cout, K octets =
-// pixel octets (vc_api.hip: conv_wgrad).  What it needs is both operands with 8 consecutive PIXELS to a unit:
+// pixel octets (vc_ops.hip: conv_wgrad).  What it needs is both operands with 8 consecutive PIXELS to a unit:
 // im2col in bf16: Xcol[g][po][k][8] = the 8 consecutive output pixels 8 po .. 8 po + 7 of K row k = tap * Cin + c, read
 // from the channel-octet packed activations.  A thread owns (channel octet, tap, pixel octet): it loads the 8 gathered
 // units (8 pixels x 8 channels, zeros where the tap leaves the image), transposes them in registers (v_perm_b32) and

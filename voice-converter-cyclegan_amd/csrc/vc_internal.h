@@ -1,5 +1,5 @@
 // Internal launch descriptors shared by the device TUs (vc_conv_igemm.hip, vc_conv_wgrad.hip, vc_conv_small.hip,
-// vc_elementwise.hip) and the host orchestration (vc_api.hip, vc_comm.cpp).  gfx950 only.
+// vc_elementwise.hip) and the host orchestration (vc_host.h: vc_tables.hip, vc_ops.hip, vc_net.hip, vc_step.hip; vc_comm.hip).  gfx950 only.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
