@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256, 1) void gated_conv1d_glu_kernel(const WsConvAr
     s = sub(s, '    __syncthreads();                                        // filter fragments and tile 0 are in LDS\n',
             '    __syncthreads();                                        // filter fragments and tile 0 are in LDS\n    VC_GTL(tl1 = __builtin_readcyclecounter());\n')
     s = sub(s, '    f32x16 accv[2], accg[2];\n', '    VC_GTL(tl2 = __builtin_readcyclecounter());\n    f32x16 accv[2], accg[2];\n')
-    s = sub(s, '        const OutPos pp = out_pos(tile - tstep);\n        f32x16 o;\n', '        const OutPos pp = out_pos(tile - tstep);\n        f32x16 o;\n        VC_GTL(ts = __builtin_readcyclecounter());\n')
+    s = sub(s, '        f32x16 o;\n        if constexpr (!OVERLAP) {', '        f32x16 o;\n        VC_GTL(ts = __builtin_readcyclecounter());\n        if constexpr (!OVERLAP) {')
     s = sub(s, '                    store_plane(pl, yrs, pp.yb, pp.ok, 0);\n                    wait_counted(xq);\n',
             '                    store_plane(pl, yrs, pp.yb, pp.ok, 0);\n                    VC_GTL(tw = __builtin_readcyclecounter());\n                    wait_counted(xq);\n')
     s = sub(s, '            wait_counted(xq);\n            [&]<int... J>', '            VC_GTL(tw = __builtin_readcyclecounter());\n            wait_counted(xq);\n            [&]<int... J>')

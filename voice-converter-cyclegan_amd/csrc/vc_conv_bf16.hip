@@ -286,23 +286,32 @@ template <int BM, int NST> __global__ __launch_bounds__(256, NST <= 2 ? 2 : 1) v
     // ---- global -> LDS copies (global_load_lds_dwordx4: lane l of the instruction lands at base + 16 l, no register
     //      staging, no ds_write): a wave moves octets 2 wv and 2 wv + 1 of every chunk, rows [0, 64) and [64, 128) of both
     //      operands = 8 copies of 1 KB per chunk.  The lane's two pixels / two filter rows:
-    unsigned xoffb[2], tapmask[2];
+    unsigned xoffb[2], tapmask[2] = {0u, 0u};
+    {
+        // one vector load brings the whole tap table (lane t holds tap t; at most 32 taps), the loop reads a tap back with
+        // v_readlane -- a scalar load per tap and pixel half was a chain of up to 36 dependent scalar round trips (D.d3: 18 taps)
+        int vdh = 0, vdw = 0;
+        if (lane < p.ntaps) { const Tap tp = p.taps[lane]; vdh = tp.dh; vdw = tp.dw; }
+        int li0[2], lj0[2]; bool pv[2];
 #pragma unroll
-    for (int hf = 0; hf < 2; ++hf) {
-        const int P = nt * BN + hf * 64 + lane;
-        const bool pv = P < p.Ptot;
-        int xb = 0, xi = 0, xj = 0;
-        if (pv) { int r; xb = fast_divmod(P, p.NPB, p.inv_npb, &r); xi = fast_divmod(r, p.OWc, p.inv_ow, &xj); }
-        const int li0 = xi * p.si, lj0 = xj * p.sj;
-        xoffb[hf] = (unsigned)((long)xb * p.x_bs + ((long)li0 * p.xW + lj0) * 16);
-        unsigned tm = 0;
-        c_tap_p taps = (c_tap_p)p.taps;
-        for (int t = 0; t < p.ntaps; ++t) {
-            const int dh = taps[t].dh, dw = taps[t].dw;
-            const bool ok = pv && (unsigned)(li0 + dh) < (unsigned)p.Hl && (unsigned)(lj0 + dw) < (unsigned)p.Wl;
-            tm |= (unsigned)ok << t;
+        for (int hf = 0; hf < 2; ++hf) {
+            const int P = nt * BN + hf * 64 + lane;
+            pv[hf] = P < p.Ptot;
+            int xb = 0, xi = 0, xj = 0;
+            if (pv[hf]) { int r; xb = fast_divmod(P, p.NPB, p.inv_npb, &r); xi = fast_divmod(r, p.OWc, p.inv_ow, &xj); }
+            li0[hf] = xi * p.si; lj0[hf] = xj * p.sj;
+            xoffb[hf] = (unsigned)((long)xb * p.x_bs + ((long)li0[hf] * p.xW + lj0[hf]) * 16);
         }
-        tapmask[hf] = tm;
+        const unsigned Hl = (unsigned)p.Hl, Wl = (unsigned)p.Wl;
+        const int ntaps = p.ntaps;
+        for (int t = 0; t < ntaps; ++t) {
+            const int dh = __builtin_amdgcn_readlane(vdh, t), dw = __builtin_amdgcn_readlane(vdw, t);
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const unsigned ok = (unsigned)pv[hf] & (unsigned)((unsigned)(li0[hf] + dh) < Hl) & (unsigned)((unsigned)(lj0[hf] + dw) < Wl);
+                tapmask[hf] |= ok << t;
+            }
+        }
     }
     // buffer addressing: the lane's pixel (or VC_OOB for a padding tap: the hardware range check returns -- and copies --
     // zeros) in the VGPR offset, the K octet in the SGPR offset; no per-copy address arithmetic on the vector ALU
