@@ -52,7 +52,6 @@ __global__ __launch_bounds__(256, 1) void gated_conv1d_glu_kernel(const WsConvAr
     static_assert(NXL == 16, "operand lists of the counted waits below");
     constexpr int NST = RAW ? 12 : 4;                       // 16-byte output stores per tile and lane
     constexpr bool OVERLAP = BF16;                          // GLU + stores of tile i-1 inside the MFMA loop of tile i
-    constexpr int NCH = BF16 ? 2 : 1;                       // accumulator chains per branch (see the accumulators' declaration)
     __shared__ __attribute__((aligned(16))) T Xs[2 * SLOT];
     __shared__ __attribute__((aligned(16))) frag_t Wf[2 * NU * 64];
     // per-wave 32 x 32 fp32 transposition tiles for the output planes (row = channel, stride 36 floats): the accumulators
@@ -229,41 +228,31 @@ __global__ __launch_bounds__(256, 1) void gated_conv1d_glu_kernel(const WsConvAr
     // SIMD means nobody covers a DEPENDENT chain (mul -> exp -> add -> rcp -> mul: the in-order wave cannot issue the next MFMA
     // pair from behind it), so the chain is cut into STAGES applied to four values at a time: four independent instructions
     // per stage, one stage per K step (bf16), i.e. a stage's inputs are two MFMAs old when it runs.
-    // (the chain sum and the bias ride in the first and the last stage: (g0 + g1) * c + b_g c, (v0 + v1 + b_v) * t)
-    const float bgc = bgl * -1.44269504f;
-    auto vsum = [&](const f32x16 (&c)[NCH], int r) { return NCH == 2 ? c[0][r] + c[NCH - 1][r] : c[0][r]; };
-    auto glu_stage = [&](const f32x16 (&cv)[NCH], const f32x16 (&cg)[NCH], f32x4& t, f32x16& o, int q, int st) {
+    auto glu_stage = [&](const f32x16& sv, const f32x16& sg, f32x4& t, f32x16& o, int q, int st) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int r = 4 * q + j;
-            if (st == 0) t[j] = __builtin_fmaf(vsum(cg, r), -1.44269504f, bgc);
+            if (st == 0) t[j] = sg[4 * q + j] * -1.44269504f;
             else if (st == 1) t[j] = __builtin_amdgcn_exp2f(t[j]);
             else if (st == 2) t[j] = 1.f + t[j];
             else if (st == 3) t[j] = __builtin_amdgcn_rcpf(t[j]);
-            else o[r] = (vsum(cv, r) + bvl) * t[j];
+            else o[4 * q + j] = sv[4 * q + j] * t[j];
         }
     };
-    auto glu_all = [&](const f32x16 (&cv)[NCH], const f32x16 (&cg)[NCH], f32x16& o) {     // outside the MFMA loop: the scheduler interleaves the 16 chains
+    auto glu_all = [&](const f32x16& sv, const f32x16& sg, f32x16& o) {     // outside the MFMA loop: the scheduler interleaves the 16 chains
         f32x4 t[4];
 #pragma unroll
         for (int st = 0; st < 5; ++st)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) glu_stage(cv, cg, t[q], o, q, st);
-    };
-    auto put_sum_quad = [&](float* sw, const f32x16 (&c)[NCH], float bias, int q) {      // a raw plane's quad: chains summed, + bias
-        f32x4 x;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) x[j] = vsum(c, 4 * q + j) + bias;
-        *reinterpret_cast<f32x4*>(sw + l31 * LDS_S + 8 * q + 4 * h) = x;
+            for (int q = 0; q < 4; ++q) glu_stage(sv, sg, t[q], o, q, st);
     };
     // a whole tile's planes, one after the other (fp32 trips, the last tile, the dummy tile): NST stores
-    auto store_tile = [&](const f32x16 (&cv)[NCH], const f32x16 (&cg)[NCH], const f32x16& o, const OutPos& p) {
+    auto store_tile = [&](const f32x16& sv, const f32x16& sg, const f32x16& o, const OutPos& p) {
         if constexpr (RAW) {                                // training: the raw value / gate pair is kept for the backward pass
 #pragma unroll
-            for (int q = 0; q < 4; ++q) put_sum_quad(sw_r, cv, bvl, q);
+            for (int q = 0; q < 4; ++q) put_quad(sw_r, sv, q);
             flush_plane(sw_r, rawrs, p.rb, p.ok, 0);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) put_sum_quad(sw_r, cg, bgl, q);
+            for (int q = 0; q < 4; ++q) put_quad(sw_r, sg, q);
             flush_plane(sw_r, rawrs, p.rb, p.ok, CT4);
         }
 #pragma unroll
@@ -272,10 +261,10 @@ __global__ __launch_bounds__(256, 1) void gated_conv1d_glu_kernel(const WsConvAr
     };
     // dummy "tile -2" stores: with them the first trip sees the same operation count behind its frames as every other
     {
-        f32x16 z, zc[NCH];
+        f32x16 z;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { z[r] = 0.f; zc[0][r] = 0.f; zc[NCH - 1][r] = 0.f; }
-        store_tile(zc, zc, z, out_pos(retreat(cursor_at(tile0))));    // tile0 - tstep < 0: every lane out of range
+        for (int r = 0; r < 16; ++r) z[r] = 0.f;
+        store_tile(z, z, z, out_pos(retreat(cursor_at(tile0))));      // tile0 - tstep < 0: every lane out of range
     }
     __syncthreads();                                        // filter fragments and tile 0 are in LDS
     // bf16: value and gate fragments in registers (184 of the 512).  fp32: 360 fragment registers + accumulators + frames in
@@ -298,20 +287,15 @@ __global__ __launch_bounds__(256, 1) void gated_conv1d_glu_kernel(const WsConvAr
         }
     }
 
+    // the bias as two constant accumulator tuples (a lane's 16 outputs are 16 pixels of ONE channel), kept in the AGPR half
+    f32x16 bvv, bgv;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { bvv[r] = bvl; bgv[r] = bgl; }
+    asm volatile("" : "+a"(bvv)); asm volatile("" : "+a"(bgv));
     Cursor scur = retreat(cursor_at(tile0));             // tile whose planes the next trip stores (the first trip: a dummy in front of tile0)
-    // Accumulators [overlap set][chain].  bf16: TWO chains per branch (even / odd K steps), summed in the epilogue: a wave is
-    // alone on its SIMD, and v_mfma_f32_32x32x16_bf16 issues every 32 cycles but hands its result to a dependent MFMA only
-    // after ~107 (measured: value / gate alternating = 2 chains ran 53.7 cycles per MFMA, whatever else the loop held --
-    // tools/glu_probe.py, profiles/r04_named_kernel_timeline.txt).  Four chains put 128 cycles between dependent MFMAs.
-    // fp32's 64-cycle MFMAs are covered by the value / gate alternation alone.
-    f32x16 accv[2][NCH], accg[2][NCH];
+    f32x16 accv[2], accg[2];
 #pragma unroll
-    for (int r = 0; r < 16; ++r)
-#pragma unroll
-        for (int k = 0; k < 2 * NCH; ++k) { accv[k / NCH][k % NCH][r] = 0.f; accg[k / NCH][k % NCH][r] = 0.f; }
-    f32x16 zero16;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
+    for (int r = 0; r < 16; ++r) { accv[0][r] = accv[1][r] = 0.f; accg[0][r] = accg[1][r] = 0.f; }
 
     // One trip: multiply tile `tile` (LDS slot P) into accumulator set P (bf16) / 0 (fp32); frames of tile + 2 steps -> register
     // set P; frames of tile + 1 step (register set P ^ 1) -> LDS slot P ^ 1; GLU + stores of the previous tile.
@@ -345,15 +329,14 @@ __global__ __launch_bounds__(256, 1) void gated_conv1d_glu_kernel(const WsConvAr
             const frag_t x_ = fx[u % RS];
             if constexpr (BF16) {
                 // step 0 starts the accumulators at the bias: the constant tuples are its C operand (no 32 moves per tile)
-                constexpr int CH = u & 1;               // both chains start at zero (an inline constant as the C operand); the bias joins in the epilogue
-                accv[AC][CH] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x_, wv[u], u < 2 ? zero16 : accv[AC][CH], 0, 0, 0);
-                accg[AC][CH] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x_, wgt[u], u < 2 ? zero16 : accg[AC][CH], 0, 0, 0);
+                accv[AC] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x_, wv[u], u == 0 ? bvv : accv[AC], 0, 0, 0);
+                accg[AC] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x_, wgt[u], u == 0 ? bgv : accg[AC], 0, 0, 0);
             } else {
                 const frag_t v_ = fwv[u % RS], g_ = fwg[u % RS];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    accv[AC][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x_[e], v_[e], (u == 0 && e == 0) ? zero16 : accv[AC][0], 0, 0, 0);
-                    accg[AC][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x_[e], g_[e], (u == 0 && e == 0) ? zero16 : accg[AC][0], 0, 0, 0);
+                    accv[AC] = __builtin_amdgcn_mfma_f32_32x32x2f32(x_[e], v_[e], (u == 0 && e == 0) ? bvv : accv[AC], 0, 0, 0);
+                    accg[AC] = __builtin_amdgcn_mfma_f32_32x32x2f32(x_[e], g_[e], (u == 0 && e == 0) ? bgv : accg[AC], 0, 0, 0);
                 }
             }
         };
@@ -367,10 +350,10 @@ __global__ __launch_bounds__(256, 1) void gated_conv1d_glu_kernel(const WsConvAr
             if constexpr (OVERLAP) {
                 if constexpr (u == 0) { issue_loads(xp, lcur); advance(lcur); }
                 if constexpr (RAW) {
-                    if constexpr (u == 0) { put_sum_quad(sw_r, accv[AP], bvl, 0); put_sum_quad(sw_r, accv[AP], bvl, 1); put_sum_quad(sw_r, accv[AP], bvl, 2); put_sum_quad(sw_r, accv[AP], bvl, 3); }
+                    if constexpr (u == 0) { put_quad(sw_r, accv[AP], 0); put_quad(sw_r, accv[AP], 1); put_quad(sw_r, accv[AP], 2); put_quad(sw_r, accv[AP], 3); }
                     if constexpr (u == 1) read_plane(sw_r, pl);
                     if constexpr (u == 2) { store_plane(pl, rawrs, pp.rb, pp.ok, 0);
-                                            put_sum_quad(sw_r, accg[AP], bgl, 0); put_sum_quad(sw_r, accg[AP], bgl, 1); put_sum_quad(sw_r, accg[AP], bgl, 2); put_sum_quad(sw_r, accg[AP], bgl, 3); }
+                                            put_quad(sw_r, accg[AP], 0); put_quad(sw_r, accg[AP], 1); put_quad(sw_r, accg[AP], 2); put_quad(sw_r, accg[AP], 3); }
                     if constexpr (u == 3) read_plane(sw_r, pl);
                     if constexpr (u == 5) store_plane(pl, rawrs, pp.rb, pp.ok, CT4);
                 }
