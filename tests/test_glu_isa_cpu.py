@@ -68,12 +68,28 @@ def test_trip_issues_the_counted_operations(asm, bf16, raw):
     assert len(body) == 1
     body = body[0]
     nst = 12 if raw else 4
-    # the tile loop's body is two trips (register sets alternate), each ending in the workgroup barrier: the two stretches of
-    # code between consecutive barriers (or the loop header and a barrier) that hold a counted wait
-    cuts = sorted([i for i, l in enumerate(body) if 's_barrier' in l or 'Loop Header' in l])
+    # the tile loop's body is two trips (register sets alternate), each ending in the workgroup barrier.  Block placement is the
+    # compiler's business (prologue blocks may sit behind the loop in the text): keep only the lines of blocks LLVM annotates as
+    # belonging to the tile loop (the one loop of this kernel that holds a barrier), then cut that stream at the barriers.
     want = 's_waitcnt vmcnt(%d)' % (16 + 2 * nst)
-    trips = [(lo, hi) for lo, hi in zip(cuts[:-1], cuts[1:]) if 's_barrier' in body[hi] and any(want in l for l in body[lo:hi])]
-    assert len(trips) == 2, (tag, len(trips))
+    loops = {}
+    cur = None
+    for l in body:
+        m = re.match(r'^(\.LBB\d+_\d+:|; %bb\.\d+:)', l)
+        if m:
+            h = re.search(r'in Loop: Header=(BB\d+_\d+)', l)
+            cur = h.group(1) if h else (l.split(':')[0].lstrip('.L') if 'Loop Header' in l else None)
+        if cur is not None:
+            loops.setdefault(cur, []).append(l)
+    tile_loop = [v for v in loops.values() if any('s_barrier' in l for l in v)]
+    assert len(tile_loop) == 1, (tag, list(loops))
+    stream = tile_loop[0]
+    cuts = [-1] + [i for i, l in enumerate(stream) if 's_barrier' in l]
+    trips_l = [stream[lo + 1:hi + 1] for lo, hi in zip(cuts[:-1], cuts[1:])]
+    assert len(trips_l) == 2 and all(any(want in l for l in t) for t in trips_l), (tag, len(trips_l))
+    body = [l for t in trips_l for l in t]
+    n0 = len(trips_l[0])
+    trips = [(0, n0), (n0, len(body))]
     dests = []
     for lo, hi in trips:
         ins = _instrs(body[lo:hi])
