@@ -101,14 +101,27 @@ def cpu_baseline(leg_timeout_s=150):
                 sample='24x128 MCEP, fp32; ' + '; '.join([l[2] for l in legs] + notes) + '; TF1 reference not runnable (no tensorflow)')
 
 
-def _pmc_traffic(B, F, T, world, math):
-    """HBM-side bytes per igemm launch from the committed PMC summary of the same configuration (None if not profiled)"""
-    try:
-        with open(os.path.join(ROOT, 'profiles', 'r03_pmc_traffic.json' if os.path.exists(os.path.join(ROOT, 'profiles', 'r03_pmc_traffic.json')) else 'r02_pmc_traffic.json')) as f:
-            d = json.load(f)
-        return d.get('%s_b%d_%dx%d' % (math, B, F, T)) if world == 1 else None
-    except Exception:
-        return None
+PMC_FILES = ('r04_pmc_traffic.json', 'r03_pmc_traffic.json')
+
+
+def _pmc_traffic(B, F, T, world, math, role='igemm'):
+    """HBM-side bytes per launch of one roofline entry's kernels (role 'igemm': convolutions + input gradients; 'wgrad': filter
+    gradients) from the committed PMC summary of the same configuration (tools/profile_round.sh -> tools/summarize_pmc.py):
+    (bytes per launch, launches per step the figure averages over, file) or (None, None, None) if not profiled."""
+    if world != 1:
+        return None, None, None
+    key = '%s_b%d_%dx%d' % (math, B, F, T)
+    for fn in PMC_FILES:
+        try:
+            with open(os.path.join(ROOT, 'profiles', fn)) as f:
+                d = json.load(f).get(key)
+        except Exception:
+            continue
+        if isinstance(d, dict) and role in d:
+            return d[role]['bytes_per_launch'], d[role]['launches_per_step'], 'profiles/' + fn
+        if isinstance(d, (int, float)) and role == 'igemm' and math != 'bf16':     # round-3 file: one figure per configuration
+            return d, None, 'profiles/' + fn                                       # (its bf16 figure mixed both roles: not used)
+    return None, None, None
 
 
 def named_kernel_h1(lib, dev, B=256, reps=20, peak=FP32_MFMA_PEAK_TFLOPS, math='fp32'):
@@ -188,13 +201,15 @@ def roofline_leg(eng, lib, A, Bm, hp, math, peak, world, serial, n_prof=3):
     eng.set_overlap(not serial)
     name, ms, n, fl = stats[0]
     ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    tr, tr_n, tr_file = _pmc_traffic(B, F, T, world, math, 'igemm')
     out = {'roofline': {
         'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak,
         # HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
-        # (FETCH_SIZE doubled per MI355X_MICROARCH.md, Infinity-Cache hits included)
-        'traffic': _pmc_traffic(B, F, T, world, math),
-        'traffic_unit': 'bytes/launch (offline rocprofv3 PMC passes of this command, profiles/r03_pmc_traffic.json; '
-                        'FETCH_SIZE doubled per MI355X_MICROARCH.md; upper bound: Infinity-Cache hits counted)',
+        # (FETCH_SIZE doubled per MI355X_MICROARCH.md, Infinity-Cache hits included), over THIS entry's launches
+        'traffic': tr,
+        'traffic_unit': 'bytes/launch, mean over the %s launches per step of this entry\'s kernels (offline rocprofv3 PMC passes of this '
+                        'command, %s; FETCH_SIZE doubled per MI355X_MICROARCH.md; upper bound: Infinity-Cache hits counted)'
+                        % ('%g' % tr_n if tr_n else '?', tr_file),
         'kernel': name, 'launches_per_step': n // n_prof,
         'condition': 'step chains serialised on one stream (no co-running launches); see --serial',
         'avg_launch_us': 1e3 * ms / max(n, 1), 'algorithmic_gflop_per_step': fl / n_prof / 1e9,
@@ -202,7 +217,8 @@ def roofline_leg(eng, lib, A, Bm, hp, math, peak, world, serial, n_prof=3):
     name, ms, n, fl = stats[1]
     ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     out['roofline_wgrad'] = {'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak, 'kernel': name,
-                             'launches_per_step': n // n_prof, 'kernel_ms_per_step': ms / n_prof}
+                             'launches_per_step': n // n_prof, 'kernel_ms_per_step': ms / n_prof,
+                             'traffic': _pmc_traffic(B, F, T, world, math, 'wgrad')[0]}
     # FLOPs the step executes: every MFMA launch carries its algorithmic FLOPs; the Cin = 1 layer (D.h1, vector ALU)
     # is added analytically: forward over 2B samples per D, filter gradient over 2B, input gradient over B
     c1 = 2.0 * 9 * 256 * (F * (T // 2)) * 2 * (2 * B + 2 * B + B)      # 9 taps x 256 filters x F x T/2 pixels, 2 discriminators
@@ -334,7 +350,11 @@ def main():
     ap.add_argument('--serial', action='store_true',
                     help='serialise the step\'s two independent chains on one stream for the WHOLE run (the condition the '
                          'roofline leg always uses; for rocprof summaries that must agree with it)')
+    ap.add_argument('--print-key', action='store_true', help=argparse.SUPPRESS)   # internal: the configuration's key in profiles/*_pmc_traffic.json
     args = ap.parse_args()
+    if args.print_key:
+        print('%s_b%d_%dx%d' % (args.math, args.batch, args.features, args.frames))
+        return 0
     if args.cpu_leg:
         kind, B_, th, bud = args.cpu_leg.split(',')
         return _cpu_leg(kind, int(B_), int(th), float(bud))

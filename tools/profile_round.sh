@@ -16,7 +16,7 @@ timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -o fetch 
 timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -o write -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --serial $EXTRA > $O/write.log 2>&1
 timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/mfma -o mfma -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --serial $EXTRA > $O/mfma.log 2>&1
 F=$(find $O/fetch -name '*counter_collection.csv' | head -1); W=$(find $O/write -name '*counter_collection.csv' | head -1); M=$(find $O/mfma -name '*counter_collection.csv' | head -1)
-python $R/tools/summarize_pmc.py $F $W 4 > $O/pmc_hbm_traffic.txt 2>&1
+python $R/tools/summarize_pmc.py $F $W 4 $O/pmc_traffic.json "$(python $R/bench.py --print-key $EXTRA)" > $O/pmc_hbm_traffic.txt 2>&1
 python $R/tools/summarize_mfma.py $M > $O/pmc_mfma_busy.txt 2>&1
 cp $(find $O/serial -name '*kernel_stats.csv' | head -1) $O/kernel_stats_serial.csv 2>/dev/null
 cp $(find $O/streams -name '*kernel_stats.csv' | head -1) $O/kernel_stats_streams.csv 2>/dev/null

@@ -1,5 +1,5 @@
 """Summarises rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py` into per-kernel HBM traffic per step.
-usage: python tools/summarize_pmc.py <fetch_counter_collection.csv> <write_counter_collection.csv> <steps incl. warm-up>
+usage: python tools/summarize_pmc.py <fetch_counter_collection.csv> <write_counter_collection.csv> <steps incl. warm-up> [<out.json> <key>]
 FETCH_SIZE is doubled: on gfx950 it reports 1/2 of the bytes of a coalesced stream (MI355X_MICROARCH.md, HBM section);
 Infinity-Cache hits are included, so this is an upper bound on HBM bytes."""
 import collections
@@ -23,11 +23,28 @@ for k in sorted(f, key=lambda k: -sum(f[k])):
     tot += fe + wr
     print('%s, %.1f, %.1f, %.1f' % (k, len(f[k]) / steps, fe, wr))
 print('TOTAL MB/step, %.1f' % tot)
-# (bf16 mode: the filter gradient runs on conv_bf16_kernel too, so its launches are counted under igemm here)
-for tag, pats in (('igemm', ('igemm_kernel', 'conv_bf16_kernel')), ('wgrad', ('wgrad_kernel',))):
-    ks = [k for k in f if any(k.startswith(p) for p in pats)]
+# the two roofline entries of bench.py: `roofline` = convolutions + input gradients (igemm_kernel; in bf16 conv_bf16_kernel<.., 0>
+# plus the few launches below its tile size that stay on igemm_kernel), `roofline_wgrad` = filter gradients (wgrad_kernel; in bf16
+# conv_bf16_kernel<.., 1> as a GEMM, + wgrad_kernel for o1)
+def role(k):
+    if k.startswith('conv_bf16_kernel'):
+        return 'wgrad' if k.rstrip('>').replace(' ', '').endswith(',1') else 'igemm'
+    return 'igemm' if k.startswith('igemm_kernel') else 'wgrad' if k.startswith('wgrad_kernel') else None
+
+
+summary = {}
+for tag in ('igemm', 'wgrad'):
+    ks = [k for k in f if role(k) == tag]
     if not ks:
         continue
     n = sum(len(f[k]) for k in ks)
     b = 2 * sum(sum(f[k]) for k in ks) * 1024 + sum(sum(w.get(k, [0])) for k in ks) * 1024
+    summary[tag] = {'launches_per_step': n / steps, 'bytes_per_launch': b / n, 'bytes_per_step': b / steps}
     print('%s: %.1f launches/step, %.2f MB per launch, %.2f GB per step' % (tag, n / steps, b / n / 1e6, b / steps / 1e9))
+if len(sys.argv) > 4:       # machine-readable copy: key -> the summary above (bench.py reads profiles/r04_pmc_traffic.json)
+    import json
+    import os
+    out, key = sys.argv[4], sys.argv[5]
+    d = json.load(open(out)) if os.path.exists(out) else {}
+    d[key] = summary
+    json.dump(d, open(out, 'w'), indent=1)

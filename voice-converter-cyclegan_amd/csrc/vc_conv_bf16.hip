@@ -259,7 +259,9 @@ int launch_pack_filter_bf16(const float* w, long w_gs, void* ap, long ap_gs_byte
 // BM = 256 (round 4): a wave owns 4 x 2 MFMA tiles (128 rows x 64 pixels, 128 accumulator registers): 6 fragment reads feed 8
 // MFMAs (4 feed 4 at BM = 128), a chunk is 32 MFMAs per wave instead of 16 -- the per-chunk barrier, table fetch and LDS
 // round trip weigh half as much -- on a 3-stage ring (48 KB per stage), one workgroup per CU.
-template <int BM, int NST> __global__ __launch_bounds__(256, NST <= 2 ? 2 : 1) void conv_bf16_kernel(const ConvBf16Args p) {
+// ROLE changes no code: 0 = convolution / input gradient, 1 = the filter-gradient GEMM -- two kernel names, so that rocprofv3
+// statistics and PMC counters of a step separate the two uses
+template <int BM, int NST, int ROLE> __global__ __launch_bounds__(256, NST <= 2 ? 2 : 1) void conv_bf16_kernel(const ConvBf16Args p) {
     touch_kernarg(p);
     constexpr int BN = 128, MI = BM / 64;                 // a wave owns MI x 2 MFMA tiles: rows [wm * BM/2, +BM/2), pixels [wn * 64, +64)
     constexpr int ASZ = 8 * BM * 16, XSZ = 8 * BN * 16, STAGE = ASZ + XSZ;      // one K chunk: [octet][row][16 B] for both operands
@@ -532,9 +534,12 @@ int launch_conv_bf16(const ConvBf16Args& a, hipStream_t s, double flops, int pro
     if (a.splitk > 1 && !a.accumulate) { vc_set_error("launch_conv_bf16: split-K requires accumulate semantics"); return -1; }
     dim3 grid(a.mtiles * a.ntiles, 1, a.groups * a.splitk);
     ProfScope ps(prof_kind, flops, s);
-    if (a.bm == 256) conv_bf16_kernel<256, 3><<<grid, 256, 0, s>>>(a);
-    else if (a.bm == 64) { if (a.nst == 4) conv_bf16_kernel<64, 4><<<grid, 256, 0, s>>>(a); else conv_bf16_kernel<64, 2><<<grid, 256, 0, s>>>(a); }
-    else { if (a.nst == 4) conv_bf16_kernel<128, 4><<<grid, 256, 0, s>>>(a); else conv_bf16_kernel<128, 2><<<grid, 256, 0, s>>>(a); }
+#define VC_BF16_LAUNCH(BM, NST) do { if (prof_kind == 1) conv_bf16_kernel<BM, NST, 1><<<grid, 256, 0, s>>>(a); \
+                                     else conv_bf16_kernel<BM, NST, 0><<<grid, 256, 0, s>>>(a); } while (0)
+    if (a.bm == 256) VC_BF16_LAUNCH(256, 3);
+    else if (a.bm == 64) { if (a.nst == 4) VC_BF16_LAUNCH(64, 4); else VC_BF16_LAUNCH(64, 2); }
+    else { if (a.nst == 4) VC_BF16_LAUNCH(128, 4); else VC_BF16_LAUNCH(128, 2); }
+#undef VC_BF16_LAUNCH
     VC_HIP(hipGetLastError());
     return 0;
 }
