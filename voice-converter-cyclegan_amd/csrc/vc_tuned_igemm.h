@@ -1,6 +1,6 @@
 // Measured implicit-GEMM configurations: tools/tune_igemm.py --sweep on MI355X (round 3; profiles/r03_tune_sweep_*.txt), for the
 // launch shapes of the configurations bench.py reports: batch 8 (BASELINE configs[1], the headline), batch 32 (configs[3]'s
-// per-GPU share of global batch 256 on 8 GPUs) and 36x256 at batch 64 (configs[4]'s share).  {a_trans, M, Ptot, krows,
+// per-GPU share of global batch 256 on 8 GPUs), 36x256 at batch 64 (configs[4]'s share) and batch 1 (configs[0]; round 4).  {a_trans, M, Ptot, krows,
 // groups, tile rows, K groups, split-K}.  Shapes not listed go by the cost model in igemm_config.
 static const TunedCfg kTunedIgemm[] = {
     // ---- batch 8 per GPU, 24x128 MCEP
@@ -299,4 +299,101 @@ static const TunedCfg kTunedIgemm[] = {
     // d_d3_2B dgrad: 9861.6 us (automatic choice before this sweep: 10733.2 us)
     {1, 512, 18432, 24576, 2, 128, 2, 1},
     {1, 512, 18432, 12288, 2, 128, 2, 1},
+    // ---- batch 1 per GPU, 24x128 MCEP (BASELINE configs[0], the reference's own mini_batch_size; round-4 sweep, profiles/r04_tune_sweep_b1.txt)
+    // g_d1 fwd: 12.9 us (automatic choice before this sweep: 16.7 us)
+    {0, 512, 64, 640, 2, 64, 2, 8},
+    // g_d1 dgrad: 10.7 us (automatic choice before this sweep: 20.2 us)
+    {1, 128, 64, 1024, 2, 64, 2, 16},
+    {1, 128, 64, 1536, 2, 64, 2, 16},
+    // g_d1_2B fwd: 13.5 us (automatic choice before this sweep: 18.0 us)
+    {0, 512, 128, 640, 2, 64, 2, 8},
+    // g_d1_2B dgrad: 12.5 us (automatic choice before this sweep: 14.4 us)
+    {1, 128, 128, 1024, 2, 64, 1, 8},
+    {1, 128, 128, 1536, 2, 64, 1, 8},
+    // g_d2 fwd: 15.1 us (automatic choice before this sweep: 19.3 us)
+    {0, 1024, 32, 1280, 2, 64, 2, 16},
+    // g_d2 dgrad: 13.0 us (automatic choice before this sweep: 22.0 us)
+    {1, 256, 32, 2048, 2, 64, 1, 16},
+    {1, 256, 32, 3072, 2, 64, 1, 16},
+    // g_d2_2B fwd: 16.1 us (automatic choice before this sweep: 29.6 us)
+    {0, 1024, 64, 1280, 2, 64, 2, 8},
+    // g_d2_2B dgrad: 15.6 us (automatic choice before this sweep: 17.6 us)
+    {1, 256, 64, 2048, 2, 64, 2, 8},
+    {1, 256, 64, 3072, 2, 64, 2, 8},
+    // g_r_h1 fwd: 17.9 us (automatic choice before this sweep: 18.7 us)
+    {0, 2048, 32, 1536, 2, 64, 2, 4},
+    // g_r_h1 dgrad: 16.1 us (automatic choice before this sweep: 15.9 us)
+    {1, 512, 32, 6144, 2, 64, 2, 16},
+    // g_r_h1_2B fwd: 18.9 us (automatic choice before this sweep: 24.0 us)
+    {0, 2048, 64, 1536, 2, 64, 2, 4},
+    // g_r_h1_2B dgrad: 19.0 us (automatic choice before this sweep: 21.2 us)
+    {1, 512, 64, 6144, 2, 64, 2, 16},
+    // g_r_h2 fwd: 15.5 us (automatic choice before this sweep: 17.3 us)
+    {0, 512, 32, 3072, 2, 64, 2, 16},
+    // g_r_h2 dgrad: 12.0 us (automatic choice before this sweep: 12.4 us)
+    {1, 1024, 32, 1536, 2, 64, 1, 8},
+    // g_r_h2_2B fwd: 16.5 us (automatic choice before this sweep: 22.5 us)
+    {0, 512, 64, 3072, 2, 64, 4, 16},
+    // g_r_h2_2B dgrad: 13.9 us (automatic choice before this sweep: 14.7 us)
+    {1, 1024, 64, 1536, 2, 64, 1, 8},
+    // g_u1 fwd: 23.0 us (automatic choice before this sweep: 25.3 us)
+    {0, 2048, 32, 2560, 2, 64, 2, 4},
+    // g_u1 dgrad: 21.3 us (automatic choice before this sweep: 20.7 us)
+    {1, 512, 32, 10240, 2, 64, 2, 16},
+    // g_u1_2B fwd: 24.3 us (automatic choice before this sweep: 32.7 us)
+    {0, 2048, 64, 2560, 2, 64, 2, 4},
+    // g_u1_2B dgrad: 23.8 us (automatic choice before this sweep: 29.8 us)
+    {1, 512, 64, 10240, 2, 64, 2, 16},
+    // g_u2 fwd: 18.7 us (automatic choice before this sweep: 21.2 us)
+    {0, 1024, 64, 2560, 2, 64, 2, 8},
+    // g_u2 dgrad: 16.9 us (automatic choice before this sweep: 16.9 us)
+    {1, 512, 64, 5120, 2, 64, 1, 16},
+    // g_u2_2B fwd: 23.8 us (automatic choice before this sweep: 31.9 us)
+    {0, 1024, 128, 2560, 2, 64, 2, 4},
+    // g_u2_2B dgrad: 21.5 us (automatic choice before this sweep: 21.5 us)
+    {1, 512, 128, 5120, 2, 64, 2, 8},
+    // g_o1 fwd: 12.5 us (automatic choice before this sweep: 18.4 us)
+    {0, 24, 128, 3840, 2, 64, 2, 16},
+    // g_o1 dgrad: 10.4 us (automatic choice before this sweep: 16.2 us)
+    {1, 256, 128, 512, 2, 64, 1, 16},
+    // g_o1_2B fwd: 13.1 us (automatic choice before this sweep: 39.9 us)
+    {0, 24, 256, 3840, 2, 64, 2, 16},
+    // g_o1_2B dgrad: 10.8 us (automatic choice before this sweep: 11.3 us)
+    {1, 256, 256, 512, 2, 64, 1, 4},
+    // g_h1 dgrad: 11.7 us (automatic choice before this sweep: 15.9 us)
+    {1, 24, 128, 3840, 2, 64, 2, 16},
+    // g_h1_2B dgrad: 11.9 us (automatic choice before this sweep: 23.6 us)
+    {1, 24, 256, 3840, 2, 64, 1, 16},
+    // d_d1 dgrad: 21.2 us (automatic choice before this sweep: 58.5 us)
+    {1, 128, 384, 2048, 2, 64, 2, 4},
+    {1, 128, 384, 1024, 2, 64, 2, 4},
+    {1, 128, 384, 1024, 2, 64, 2, 4},
+    {1, 128, 384, 512, 2, 64, 2, 4},
+    // d_d1_2B fwd: 30.6 us (automatic choice before this sweep: 32.8 us)
+    {0, 512, 768, 1152, 2, 64, 4, 1},
+    // d_d1_2B dgrad: 32.2 us (automatic choice before this sweep: 64.9 us)
+    {1, 128, 768, 2048, 2, 64, 2, 2},
+    {1, 128, 768, 1024, 2, 64, 2, 2},
+    {1, 128, 768, 1024, 2, 64, 2, 2},
+    {1, 128, 768, 512, 2, 64, 2, 2},
+    // d_d2 dgrad: 26.1 us (automatic choice before this sweep: 55.4 us)
+    {1, 256, 96, 4096, 2, 64, 4, 4},
+    {1, 256, 96, 2048, 2, 64, 4, 4},
+    {1, 256, 96, 2048, 2, 64, 4, 4},
+    {1, 256, 96, 1024, 2, 64, 4, 4},
+    // d_d2_2B fwd: 32.0 us (automatic choice before this sweep: 35.1 us)
+    {0, 1024, 192, 2304, 2, 64, 1, 4},
+    // d_d2_2B dgrad: 33.3 us (automatic choice before this sweep: 66.8 us)
+    {1, 256, 192, 4096, 2, 64, 2, 4},
+    {1, 256, 192, 2048, 2, 64, 2, 4},
+    {1, 256, 192, 2048, 2, 64, 2, 4},
+    {1, 256, 192, 1024, 2, 64, 2, 4},
+    // d_d3 dgrad: 65.4 us (automatic choice before this sweep: 66.7 us)
+    {1, 512, 48, 24576, 2, 64, 4, 16},
+    {1, 512, 48, 12288, 2, 64, 4, 16},
+    // d_d3_2B fwd: 86.2 us (automatic choice before this sweep: 96.5 us)
+    {0, 2048, 96, 9216, 2, 64, 4, 2},
+    // d_d3_2B dgrad: 100.3 us (automatic choice before this sweep: 100.5 us)
+    {1, 512, 96, 24576, 2, 64, 2, 16},
+    {1, 512, 96, 12288, 2, 64, 2, 16},
 };

@@ -72,4 +72,27 @@ static const TunedWgrad kTunedWgrad[] = {
     {36, 1024, 1152, 2, 1, 128, 1, 8},
     // d_d3_2B: 9540.9 us (automatic choice before this sweep: 9729.3 us)
     {144, 2048, 576, 2, 1, 128, 2, 1},
+    // ---- batch 1 per GPU, 24x128 MCEP (BASELINE configs[0], the reference's own mini_batch_size; round-4 sweep, profiles/r04_tune_sweep_b1.txt)
+    // g_d1_3B: 12.1 us (automatic choice before this sweep: 12.4 us)
+    {10, 512, 6, 2, 1, 64, 1, 1},
+    // g_d2_3B: 16.9 us (automatic choice before this sweep: 17.5 us)
+    {20, 1024, 3, 2, 1, 64, 1, 1},
+    // g_r_h1_3B: 29.1 us (automatic choice before this sweep: 36.3 us)
+    {24, 2048, 3, 2, 1, 64, 1, 1},
+    // g_r_h2_3B: 17.2 us (automatic choice before this sweep: 18.3 us)
+    {48, 512, 3, 2, 1, 64, 1, 1},
+    // g_u1_3B: 39.5 us (automatic choice before this sweep: 56.1 us)
+    {40, 2048, 3, 2, 1, 64, 1, 1},
+    // g_u2_3B: 30.0 us (automatic choice before this sweep: 36.0 us)
+    {40, 1024, 6, 2, 1, 64, 1, 1},
+    // g_o1_3B: 15.0 us (automatic choice before this sweep: 15.4 us)
+    {60, 24, 12, 2, 1, 64, 2, 1},
+    // g_h1_3B: 11.8 us (automatic choice before this sweep: 15.8 us)
+    {8, 256, 12, 2, 1, 64, 2, 8},
+    // d_d1_2B: 33.9 us (automatic choice before this sweep: 33.9 us)
+    {18, 512, 24, 2, 1, 128, 2, 1},
+    // d_d2_2B: 31.0 us (automatic choice before this sweep: 33.9 us)
+    {36, 1024, 6, 2, 1, 64, 1, 1},
+    // d_d3_2B: 115.5 us (automatic choice before this sweep: 120.1 us)
+    {144, 2048, 3, 2, 1, 64, 1, 1},
 };
