@@ -396,4 +396,198 @@ static const TunedCfg kTunedIgemm[] = {
     // d_d3_2B dgrad: 100.3 us (automatic choice before this sweep: 100.5 us)
     {1, 512, 96, 24576, 2, 64, 2, 16},
     {1, 512, 96, 12288, 2, 64, 2, 16},
+    // ---- batch 2 per GPU, 24x128 MCEP (round-4 sweep, profiles/r04_tune_sweep_b2.txt)
+    // g_d1 fwd: 13.7 us (automatic choice before this sweep: 13.9 us)
+    {0, 512, 128, 640, 2, 64, 2, 8},
+    // g_d1 dgrad: 12.3 us (automatic choice before this sweep: 13.1 us)
+    {1, 128, 128, 1024, 2, 64, 1, 8},
+    {1, 128, 128, 1536, 2, 64, 1, 8},
+    // g_d1_2B fwd: 16.2 us (automatic choice before this sweep: 19.1 us)
+    {0, 512, 256, 640, 2, 64, 2, 8},
+    // g_d1_2B dgrad: 14.8 us (automatic choice before this sweep: 15.6 us)
+    {1, 128, 256, 1024, 2, 64, 2, 4},
+    {1, 128, 256, 1536, 2, 64, 2, 4},
+    // g_d2 fwd: 16.0 us (automatic choice before this sweep: 16.9 us)
+    {0, 1024, 64, 1280, 2, 64, 4, 16},
+    // g_d2 dgrad: 15.6 us (automatic choice before this sweep: 15.0 us)
+    {1, 256, 64, 2048, 2, 64, 2, 8},
+    {1, 256, 64, 3072, 2, 64, 2, 8},
+    // g_d2_2B fwd: 19.9 us (automatic choice before this sweep: 30.6 us)
+    {0, 1024, 128, 1280, 2, 64, 2, 4},
+    // g_d2_2B dgrad: 18.8 us (automatic choice before this sweep: 34.1 us)
+    {1, 256, 128, 2048, 2, 64, 4, 8},
+    {1, 256, 128, 3072, 2, 64, 4, 8},
+    // g_r_h1 fwd: 19.1 us (automatic choice before this sweep: 20.0 us)
+    {0, 2048, 64, 1536, 2, 64, 2, 4},
+    // g_r_h1 dgrad: 18.3 us (automatic choice before this sweep: 17.7 us)
+    {1, 512, 64, 6144, 2, 64, 2, 16},
+    // g_r_h1_2B fwd: 24.1 us (automatic choice before this sweep: 26.8 us)
+    {0, 2048, 128, 1536, 2, 64, 4, 2},
+    // g_r_h1_2B dgrad: 24.9 us (automatic choice before this sweep: 23.6 us)
+    {1, 512, 128, 6144, 2, 64, 4, 8},
+    // g_r_h2 fwd: 16.1 us (automatic choice before this sweep: 16.7 us)
+    {0, 512, 64, 3072, 2, 64, 4, 16},
+    // g_r_h2 dgrad: 14.5 us (automatic choice before this sweep: 14.7 us)
+    {1, 1024, 64, 1536, 2, 64, 2, 4},
+    // g_r_h2_2B fwd: 19.5 us (automatic choice before this sweep: 23.9 us)
+    {0, 512, 128, 3072, 2, 64, 2, 8},
+    // g_r_h2_2B dgrad: 16.8 us (automatic choice before this sweep: 16.9 us)
+    {1, 1024, 128, 1536, 2, 64, 2, 4},
+    // g_u1 fwd: 24.2 us (automatic choice before this sweep: 25.4 us)
+    {0, 2048, 64, 2560, 2, 64, 2, 4},
+    // g_u1 dgrad: 24.9 us (automatic choice before this sweep: 23.5 us)
+    {1, 512, 64, 10240, 2, 64, 2, 16},
+    // g_u1_2B fwd: 31.9 us (automatic choice before this sweep: 36.0 us)
+    {0, 2048, 128, 2560, 2, 64, 4, 2},
+    // g_u1_2B dgrad: 34.0 us (automatic choice before this sweep: 32.1 us)
+    {1, 512, 128, 10240, 2, 64, 4, 8},
+    // g_u2 fwd: 23.6 us (automatic choice before this sweep: 26.9 us)
+    {0, 1024, 128, 2560, 2, 64, 2, 4},
+    // g_u2 dgrad: 22.0 us (automatic choice before this sweep: 20.9 us)
+    {1, 512, 128, 5120, 2, 64, 2, 8},
+    // g_u2_2B fwd: 32.1 us (automatic choice before this sweep: 35.7 us)
+    {0, 1024, 256, 2560, 2, 64, 4, 2},
+    // g_u2_2B dgrad: 32.0 us (automatic choice before this sweep: 30.7 us)
+    {1, 512, 256, 5120, 2, 64, 4, 4},
+    // g_o1 fwd: 12.8 us (automatic choice before this sweep: 12.4 us)
+    {0, 24, 256, 3840, 2, 64, 2, 16},
+    // g_o1 dgrad: 10.9 us (automatic choice before this sweep: 10.9 us)
+    {1, 256, 256, 512, 2, 64, 2, 16},
+    // g_o1_2B fwd: 13.7 us (automatic choice before this sweep: 40.8 us)
+    {0, 24, 512, 3840, 2, 64, 2, 16},
+    // g_o1_2B dgrad: 12.4 us (automatic choice before this sweep: 13.0 us)
+    {1, 256, 512, 512, 2, 64, 1, 4},
+    // g_h1 dgrad: 12.1 us (automatic choice before this sweep: 12.1 us)
+    {1, 24, 256, 3840, 2, 64, 2, 16},
+    // g_h1_2B dgrad: 13.1 us (automatic choice before this sweep: 24.9 us)
+    {1, 24, 512, 3840, 2, 64, 1, 16},
+    // d_d1 dgrad: 32.4 us (automatic choice before this sweep: 34.9 us)
+    {1, 128, 768, 2048, 2, 64, 2, 2},
+    {1, 128, 768, 1024, 2, 64, 2, 2},
+    {1, 128, 768, 1024, 2, 64, 2, 2},
+    {1, 128, 768, 512, 2, 64, 2, 2},
+    // d_d1_2B fwd: 45.8 us (automatic choice before this sweep: 62.6 us)
+    {0, 512, 1536, 1152, 2, 64, 1, 2},
+    // d_d1_2B dgrad: 45.9 us (automatic choice before this sweep: 90.6 us)
+    {1, 128, 1536, 2048, 2, 64, 4, 1},
+    {1, 128, 1536, 1024, 2, 64, 4, 1},
+    {1, 128, 1536, 1024, 2, 64, 4, 1},
+    {1, 128, 1536, 512, 2, 64, 4, 1},
+    // d_d2 dgrad: 33.3 us (automatic choice before this sweep: 35.6 us)
+    {1, 256, 192, 4096, 2, 64, 2, 4},
+    {1, 256, 192, 2048, 2, 64, 2, 4},
+    {1, 256, 192, 2048, 2, 64, 2, 4},
+    {1, 256, 192, 1024, 2, 64, 2, 4},
+    // d_d2_2B fwd: 44.4 us (automatic choice before this sweep: 57.0 us)
+    {0, 1024, 384, 2304, 2, 64, 1, 4},
+    // d_d2_2B dgrad: 47.3 us (automatic choice before this sweep: 94.0 us)
+    {1, 256, 384, 4096, 2, 64, 1, 4},
+    {1, 256, 384, 2048, 2, 64, 1, 4},
+    {1, 256, 384, 2048, 2, 64, 1, 4},
+    {1, 256, 384, 1024, 2, 64, 1, 4},
+    // d_d3 dgrad: 100.6 us (automatic choice before this sweep: 108.1 us)
+    {1, 512, 96, 24576, 2, 64, 2, 16},
+    {1, 512, 96, 12288, 2, 64, 2, 16},
+    // d_d3_2B fwd: 127.1 us (automatic choice before this sweep: 181.4 us)
+    {0, 2048, 192, 9216, 2, 64, 1, 4},
+    // d_d3_2B dgrad: 153.3 us (automatic choice before this sweep: 145.4 us)
+    {1, 512, 192, 24576, 2, 64, 1, 16},
+    {1, 512, 192, 12288, 2, 64, 1, 16},
+    // ---- batch 4 per GPU, 24x128 MCEP (round-4 sweep, profiles/r04_tune_sweep_b4.txt)
+    // g_d1 fwd: 16.4 us (automatic choice before this sweep: 18.5 us)
+    {0, 512, 256, 640, 2, 64, 2, 16},
+    // g_d1 dgrad: 14.9 us (automatic choice before this sweep: 14.5 us)
+    {1, 128, 256, 1024, 2, 64, 2, 4},
+    {1, 128, 256, 1536, 2, 64, 2, 4},
+    // g_d1_2B fwd: 19.0 us (automatic choice before this sweep: 19.9 us)
+    {0, 512, 512, 640, 2, 64, 2, 2},
+    // g_d1_2B dgrad: 17.3 us (automatic choice before this sweep: 16.9 us)
+    {1, 128, 512, 1024, 2, 64, 2, 4},
+    {1, 128, 512, 1536, 2, 64, 2, 4},
+    // g_d2 fwd: 19.5 us (automatic choice before this sweep: 30.2 us)
+    {0, 1024, 128, 1280, 2, 64, 2, 4},
+    // g_d2 dgrad: 18.5 us (automatic choice before this sweep: 33.7 us)
+    {1, 256, 128, 2048, 2, 64, 4, 8},
+    {1, 256, 128, 3072, 2, 64, 4, 8},
+    // g_d2_2B fwd: 24.1 us (automatic choice before this sweep: 27.2 us)
+    {0, 1024, 256, 1280, 2, 64, 2, 2},
+    // g_d2_2B dgrad: 23.2 us (automatic choice before this sweep: 22.9 us)
+    {1, 256, 256, 2048, 2, 64, 2, 4},
+    {1, 256, 256, 3072, 2, 64, 2, 4},
+    // g_r_h1 fwd: 24.0 us (automatic choice before this sweep: 26.5 us)
+    {0, 2048, 128, 1536, 2, 64, 4, 2},
+    // g_r_h1 dgrad: 25.1 us (automatic choice before this sweep: 23.2 us)
+    {1, 512, 128, 6144, 2, 64, 2, 8},
+    // g_r_h1_2B fwd: 33.8 us (automatic choice before this sweep: 38.3 us)
+    {0, 2048, 256, 1536, 2, 64, 4, 1},
+    // g_r_h1_2B dgrad: 37.1 us (automatic choice before this sweep: 34.6 us)
+    {1, 512, 256, 6144, 2, 64, 4, 4},
+    // g_r_h2 fwd: 20.1 us (automatic choice before this sweep: 23.7 us)
+    {0, 512, 128, 3072, 2, 64, 2, 8},
+    // g_r_h2 dgrad: 16.1 us (automatic choice before this sweep: 16.6 us)
+    {1, 1024, 128, 1536, 2, 64, 2, 4},
+    // g_r_h2_2B fwd: 25.3 us (automatic choice before this sweep: 26.7 us)
+    {0, 512, 256, 3072, 2, 64, 4, 4},
+    // g_r_h2_2B dgrad: 21.8 us (automatic choice before this sweep: 22.5 us)
+    {1, 1024, 256, 1536, 2, 64, 2, 2},
+    // g_u1 fwd: 32.1 us (automatic choice before this sweep: 35.5 us)
+    {0, 2048, 128, 2560, 2, 64, 4, 2},
+    // g_u1 dgrad: 34.4 us (automatic choice before this sweep: 32.3 us)
+    {1, 512, 128, 10240, 2, 64, 2, 16},
+    // g_u1_2B fwd: 51.0 us (automatic choice before this sweep: 57.3 us)
+    {0, 2048, 256, 2560, 2, 64, 4, 1},
+    // g_u1_2B dgrad: 54.4 us (automatic choice before this sweep: 51.0 us)
+    {1, 512, 256, 10240, 2, 64, 4, 4},
+    // g_u2 fwd: 32.9 us (automatic choice before this sweep: 35.7 us)
+    {0, 1024, 256, 2560, 2, 64, 4, 2},
+    // g_u2 dgrad: 32.3 us (automatic choice before this sweep: 31.3 us)
+    {1, 512, 256, 5120, 2, 64, 4, 4},
+    // g_u2_2B fwd: 49.8 us (automatic choice before this sweep: 57.3 us)
+    {0, 1024, 512, 2560, 2, 64, 4, 1},
+    // g_u2_2B dgrad: 50.4 us (automatic choice before this sweep: 49.0 us)
+    {1, 512, 512, 5120, 2, 64, 2, 4},
+    // g_o1 fwd: 14.1 us (automatic choice before this sweep: 39.4 us)
+    {0, 24, 512, 3840, 2, 64, 2, 16},
+    // g_o1 dgrad: 12.5 us (automatic choice before this sweep: 12.7 us)
+    {1, 256, 512, 512, 2, 64, 2, 16},
+    // g_o1_2B fwd: 18.6 us (automatic choice before this sweep: 19.3 us)
+    {0, 24, 1024, 3840, 2, 64, 4, 8},
+    // g_o1_2B dgrad: 15.0 us (automatic choice before this sweep: 14.7 us)
+    {1, 256, 1024, 512, 2, 64, 2, 2},
+    // g_h1 dgrad: 12.8 us (automatic choice before this sweep: 23.6 us)
+    {1, 24, 512, 3840, 2, 64, 2, 16},
+    // g_h1_2B dgrad: 17.5 us (automatic choice before this sweep: 18.2 us)
+    {1, 24, 1024, 3840, 2, 64, 2, 8},
+    // d_d1 dgrad: 45.7 us (automatic choice before this sweep: 96.8 us)
+    {1, 128, 1536, 2048, 2, 64, 4, 1},
+    {1, 128, 1536, 1024, 2, 64, 4, 1},
+    {1, 128, 1536, 1024, 2, 64, 4, 1},
+    {1, 128, 1536, 512, 2, 64, 4, 1},
+    // d_d1_2B fwd: 70.3 us (automatic choice before this sweep: 91.1 us)
+    {0, 512, 3072, 1152, 2, 64, 1, 1},
+    // d_d1_2B dgrad: 76.5 us (automatic choice before this sweep: 71.8 us)
+    {1, 128, 3072, 2048, 2, 64, 1, 1},
+    {1, 128, 3072, 1024, 2, 64, 1, 1},
+    {1, 128, 3072, 1024, 2, 64, 1, 1},
+    {1, 128, 3072, 512, 2, 64, 1, 1},
+    // d_d2 dgrad: 47.5 us (automatic choice before this sweep: 99.2 us)
+    {1, 256, 384, 4096, 2, 64, 1, 4},
+    {1, 256, 384, 2048, 2, 64, 1, 4},
+    {1, 256, 384, 2048, 2, 64, 1, 4},
+    {1, 256, 384, 1024, 2, 64, 1, 4},
+    // d_d2_2B fwd: 73.1 us (automatic choice before this sweep: 81.0 us)
+    {0, 1024, 768, 2304, 2, 64, 1, 2},
+    // d_d2_2B dgrad: 76.6 us (automatic choice before this sweep: 74.1 us)
+    {1, 256, 768, 4096, 2, 64, 1, 2},
+    {1, 256, 768, 2048, 2, 64, 1, 2},
+    {1, 256, 768, 2048, 2, 64, 1, 2},
+    {1, 256, 768, 1024, 2, 64, 1, 2},
+    // d_d3 dgrad: 154.9 us (automatic choice before this sweep: 169.5 us)
+    {1, 512, 192, 24576, 2, 64, 2, 16},
+    {1, 512, 192, 12288, 2, 64, 2, 16},
+    // d_d3_2B fwd: 239.9 us (automatic choice before this sweep: 309.1 us)
+    {0, 2048, 384, 9216, 2, 64, 1, 4},
+    // d_d3_2B dgrad: 256.3 us (automatic choice before this sweep: 244.4 us)
+    {1, 512, 384, 24576, 2, 64, 1, 8},
+    {1, 512, 384, 12288, 2, 64, 1, 8},
 };

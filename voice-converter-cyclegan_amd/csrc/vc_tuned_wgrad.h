@@ -95,4 +95,50 @@ static const TunedWgrad kTunedWgrad[] = {
     {36, 1024, 6, 2, 1, 64, 1, 1},
     // d_d3_2B: 115.5 us (automatic choice before this sweep: 120.1 us)
     {144, 2048, 3, 2, 1, 64, 1, 1},
+    // ---- batch 2 per GPU, 24x128 MCEP (round-4 sweep, profiles/r04_tune_sweep_b2.txt)
+    // g_d1_3B: 15.6 us (automatic choice before this sweep: 18.2 us)
+    {10, 512, 12, 2, 1, 64, 2, 1},
+    // g_d2_3B: 20.9 us (automatic choice before this sweep: 21.9 us)
+    {20, 1024, 6, 2, 1, 64, 1, 1},
+    // g_r_h1_3B: 34.9 us (automatic choice before this sweep: 37.8 us)
+    {24, 2048, 6, 2, 1, 64, 1, 1},
+    // g_r_h2_3B: 21.4 us (automatic choice before this sweep: 23.1 us)
+    {48, 512, 6, 2, 1, 64, 1, 1},
+    // g_u1_3B: 50.5 us (automatic choice before this sweep: 55.6 us)
+    {40, 2048, 6, 2, 1, 64, 1, 1},
+    // g_u2_3B: 47.6 us (automatic choice before this sweep: 52.4 us)
+    {40, 1024, 12, 2, 1, 64, 1, 1},
+    // g_o1_3B: 18.5 us (automatic choice before this sweep: 23.5 us)
+    {60, 24, 24, 2, 1, 64, 2, 2},
+    // g_h1_3B: 14.3 us (automatic choice before this sweep: 17.4 us)
+    {8, 256, 24, 2, 1, 64, 4, 8},
+    // d_d1_2B: 56.3 us (automatic choice before this sweep: 59.6 us)
+    {18, 512, 48, 2, 1, 64, 1, 4},
+    // d_d2_2B: 48.0 us (automatic choice before this sweep: 47.3 us)
+    {36, 1024, 12, 2, 1, 64, 1, 1},
+    // d_d3_2B: 161.3 us (automatic choice before this sweep: 167.9 us)
+    {144, 2048, 6, 2, 1, 64, 1, 1},
+    // ---- batch 4 per GPU, 24x128 MCEP (round-4 sweep, profiles/r04_tune_sweep_b4.txt)
+    // g_d1_3B: 22.3 us (automatic choice before this sweep: 24.1 us)
+    {10, 512, 24, 2, 1, 64, 4, 1},
+    // g_d2_3B: 31.6 us (automatic choice before this sweep: 34.2 us)
+    {20, 1024, 12, 2, 1, 64, 1, 1},
+    // g_r_h1_3B: 53.8 us (automatic choice before this sweep: 59.6 us)
+    {24, 2048, 12, 2, 1, 64, 1, 1},
+    // g_r_h2_3B: 31.9 us (automatic choice before this sweep: 33.9 us)
+    {48, 512, 12, 2, 1, 64, 1, 1},
+    // g_u1_3B: 83.8 us (automatic choice before this sweep: 93.3 us)
+    {40, 2048, 12, 2, 1, 64, 1, 1},
+    // g_u2_3B: 81.1 us (automatic choice before this sweep: 93.8 us)
+    {40, 1024, 24, 2, 1, 64, 1, 1},
+    // g_o1_3B: 24.7 us (automatic choice before this sweep: 25.2 us)
+    {60, 24, 48, 2, 1, 64, 4, 2},
+    // g_h1_3B: 18.1 us (automatic choice before this sweep: 23.1 us)
+    {8, 256, 48, 2, 1, 64, 2, 4},
+    // d_d1_2B: 90.4 us (automatic choice before this sweep: 89.8 us)
+    {18, 512, 96, 2, 1, 64, 1, 8},
+    // d_d2_2B: 85.0 us (automatic choice before this sweep: 85.9 us)
+    {36, 1024, 24, 2, 1, 64, 1, 1},
+    // d_d3_2B: 238.5 us (automatic choice before this sweep: 240.1 us)
+    {144, 2048, 12, 2, 1, 128, 1, 1},
 };
