@@ -42,7 +42,7 @@ def _np_conv_bwd(O, dy_cl, w, cache, one_d, need_dx=True):
     return dx, dw
 
 
-@pytest.mark.parametrize('F,T,B', [(24, 128, 32), (36, 256, 64), (24, 128, 1), (24, 128, 2), (24, 128, 4)])
+@pytest.mark.parametrize('F,T,B', [(24, 128, 32), (36, 256, 64), (24, 128, 1), (24, 128, 2), (24, 128, 4), (24, 128, 16), (24, 128, 64)])
 def test_every_benched_table_row_against_the_oracle(built_lib, F, T, B):
     from oracle import cyclegan_oracle as O
     from tests import gpu_util as U

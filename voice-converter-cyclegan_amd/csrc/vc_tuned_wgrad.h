@@ -141,4 +141,50 @@ static const TunedWgrad kTunedWgrad[] = {
     {36, 1024, 24, 2, 1, 64, 1, 1},
     // d_d3_2B: 238.5 us (automatic choice before this sweep: 240.1 us)
     {144, 2048, 12, 2, 1, 128, 1, 1},
+    // ---- batch 16 per GPU, 24x128 MCEP (round-4 sweep, profiles/r04_tune_sweep_b16.txt)
+    // g_d1_3B: 59.0 us (automatic choice before this sweep: 69.6 us)
+    {10, 512, 96, 2, 1, 64, 1, 4},
+    // g_d2_3B: 92.8 us (automatic choice before this sweep: 105.2 us)
+    {20, 1024, 48, 2, 1, 64, 2, 2},
+    // g_r_h1_3B: 175.0 us (automatic choice before this sweep: 203.4 us)
+    {24, 2048, 48, 2, 1, 64, 2, 1},
+    // g_r_h2_3B: 92.0 us (automatic choice before this sweep: 105.6 us)
+    {48, 512, 48, 2, 1, 64, 1, 1},
+    // g_u1_3B: 285.4 us (automatic choice before this sweep: 339.3 us)
+    {40, 2048, 48, 2, 1, 64, 2, 1},
+    // g_u2_3B: 281.5 us (automatic choice before this sweep: 354.2 us)
+    {40, 1024, 96, 2, 1, 64, 2, 1},
+    // g_o1_3B: 65.4 us (automatic choice before this sweep: 71.8 us)
+    {60, 24, 192, 2, 1, 64, 4, 2},
+    // g_h1_3B: 39.8 us (automatic choice before this sweep: 37.6 us)
+    {8, 256, 192, 2, 1, 64, 4, 4},
+    // d_d1_2B: 272.2 us (automatic choice before this sweep: 273.6 us)
+    {18, 512, 384, 2, 1, 64, 1, 8},
+    // d_d2_2B: 275.6 us (automatic choice before this sweep: 290.2 us)
+    {36, 1024, 96, 2, 1, 64, 1, 2},
+    // d_d3_2B: 812.2 us (automatic choice before this sweep: 820.9 us)
+    {144, 2048, 48, 2, 1, 128, 1, 1},
+    // ---- batch 64 per GPU, 24x128 MCEP (round-4 sweep, profiles/r04_tune_sweep_b64.txt)
+    // g_d1_3B: 160.4 us (automatic choice before this sweep: 183.7 us)
+    {10, 512, 384, 2, 1, 64, 2, 8},
+    // g_d2_3B: 295.8 us (automatic choice before this sweep: 376.4 us)
+    {20, 1024, 192, 2, 1, 64, 1, 4},
+    // g_r_h1_3B: 631.8 us (automatic choice before this sweep: 747.3 us)
+    {24, 2048, 192, 2, 1, 128, 2, 1},
+    // g_r_h2_3B: 334.5 us (automatic choice before this sweep: 431.4 us)
+    {48, 512, 192, 2, 1, 64, 2, 1},
+    // g_u1_3B: 1050.1 us (automatic choice before this sweep: 1246.6 us)
+    {40, 2048, 192, 2, 1, 128, 2, 1},
+    // g_u2_3B: 1066.6 us (automatic choice before this sweep: 1252.6 us)
+    {40, 1024, 384, 2, 1, 128, 1, 4},
+    // g_o1_3B: 226.1 us (automatic choice before this sweep: 257.7 us)
+    {60, 24, 768, 2, 1, 64, 1, 8},
+    // g_h1_3B: 124.3 us (automatic choice before this sweep: 131.8 us)
+    {8, 256, 768, 2, 1, 64, 1, 16},
+    // d_d1_2B: 1036.3 us (automatic choice before this sweep: 1110.6 us)
+    {18, 512, 1536, 2, 1, 128, 2, 16},
+    // d_d2_2B: 1002.2 us (automatic choice before this sweep: 1042.7 us)
+    {36, 1024, 384, 2, 1, 64, 1, 4},
+    // d_d3_2B: 3522.6 us (automatic choice before this sweep: 4766.5 us)
+    {144, 2048, 192, 2, 1, 128, 2, 1},
 };
