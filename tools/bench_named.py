@@ -13,6 +13,7 @@ from voice_converter_cyclegan_amd._lib import lib, ptr, check, vp  # noqa: E402
 import argparse  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument('--batches', default='', help='comma-separated batch sizes at T = 128 (default: the standard set incl. a long-utterance shape)')
+ap.add_argument('--warm-ms', type=float, default=50.0, help='run the kernel this long before timing it (0: three calls, the rounds 1-3 protocol)')
 args = ap.parse_args()
 SHAPES = [(int(b), 128) for b in args.batches.split(',')] if args.batches else [(256, 128), (4096, 128), (8, 2048), (16, 128)]
 dev = 'cuda:0'
@@ -26,9 +27,16 @@ for ver in (2,):
             s = vp(torch.cuda.current_stream().cuda_stream)
             check(lib.vc_set_math_mode({'fp32': 0, 'bf16': 1}[math]))
             call = lambda: check(lib.vc_gated_conv1d_glu_fwd(ptr(x), 0, ptr(w), 0, ptr(b), 0, ptr(y), 0, 1, B, 24, T, 256, 15, s))
-            for _ in range(3):
-                call()
-            torch.cuda.synchronize()
+            # the GPU drops its clocks while the host builds the tensors above: run the kernel for >= 50 ms before timing it, so
+            # the figure is the kernel at sustained clocks (as inside a training loop), not at whatever the ramp had reached
+            import time
+            t_end = time.perf_counter() + args.warm_ms * 1e-3
+            while True:
+                for _ in range(50):
+                    call()
+                torch.cuda.synchronize()
+                if time.perf_counter() >= t_end:
+                    break
             lib.vc_prof_enable(1)
             reps = 20 if B <= 256 else 10
             for _ in range(reps):

@@ -13,6 +13,7 @@ over 3B samples (first hop 2B + cycle hop B reduce in ONE launch; a single appli
 count), the discriminator's over 2B.  Split-K needs a zeroed dW: its zero-fill is added at 3 TB/s.
 """
 import argparse
+import time
 import ctypes as C
 import os
 import sys
@@ -42,9 +43,11 @@ def layers(F, T):
 
 
 def time_call(f, kind, reps):
-    for _ in range(2):
-        f()
-    torch.cuda.synchronize()
+    t_end = time.perf_counter() + 0.03          # >= 30 ms of the launch itself before timing it: the clocks drop while the host prepares a shape (tools/ab_auto_forced.py: 10 ms left the first measurement of a shape 10 % slow)
+    while time.perf_counter() < t_end:
+        for _ in range(5):
+            f()
+        torch.cuda.synchronize()
     lib.vc_prof_enable(1)
     for _ in range(reps):
         f()
@@ -176,6 +179,11 @@ def main():
                         continue
                     res.append((u + (zero_us if op == 'wgrad' and sk > 1 else 0.0), bm, kg, sk))
                 check(lib.vc_tune_igemm_override(0, 0, 0)); check(lib.vc_tune_wgrad_override(0, 0, 0))
+                # the tables' choice once more, now in the same thermal / clock state as the forced configurations (the first
+                # measurement of a shape follows tens of ms of host work and reads up to 10 % slow: tools/ab_auto_forced.py)
+                us = min(us, time_call(f, kind, args.reps)[0])
+                line = '%-10s %-5s %6.2f GFLOP ideal %6.1f us | auto %7.1f us %6.1f TF (%d launch)' % (
+                    nm, op, flops / 1e9, flops / 157.3e12 * 1e6, us, flops / us / 1e6, nl)
                 res.sort()
                 line += ' | best ' + '  '.join('%dx%d/%d %.1f' % (bm, kg, sk, u) for u, bm, kg, sk in res[:4])
                 if res and op == 'wgrad':

@@ -3,302 +3,301 @@
 // per-GPU share of global batch 256 on 8 GPUs), 36x256 at batch 64 (configs[4]'s share) and batch 1 (configs[0]; round 4).  {a_trans, M, Ptot, krows,
 // groups, tile rows, K groups, split-K}.  Shapes not listed go by the cost model in igemm_config.
 static const TunedCfg kTunedIgemm[] = {
-    // ---- batch 8 per GPU, 24x128 MCEP
-    // g_d1 fwd: 20.8 us (automatic choice before this sweep: 21.4 us)
+    // ---- batch 8 per GPU, 24x128 MCEP (re-measured on the round-4 kernels, profiles/r04_tune_sweep_*.txt)
+    // g_d1 fwd: 19.0 us (automatic choice before this sweep: 19.3 us)
     {0, 512, 512, 640, 2, 64, 2, 2},
-    // g_d1 dgrad: 18.7 us (automatic choice before this sweep: 18.8 us)
+    // g_d1 dgrad: 17.0 us (automatic choice before this sweep: 16.9 us)
     {1, 128, 512, 1024, 2, 64, 2, 4},
     {1, 128, 512, 1536, 2, 64, 2, 4},
-    // g_d1_2B fwd: 22.5 us (automatic choice before this sweep: 23.8 us)
+    // g_d1_2B fwd: 20.1 us (automatic choice before this sweep: 20.1 us)
     {0, 512, 1024, 640, 2, 64, 2, 1},
-    // g_d1_2B dgrad: 23.9 us (automatic choice before this sweep: 23.3 us)
-    {1, 128, 1024, 1024, 2, 64, 4, 2},
-    {1, 128, 1024, 1536, 2, 64, 4, 2},
-    // g_d2 fwd: 25.9 us (automatic choice before this sweep: 26.9 us)
-    {0, 1024, 256, 1280, 2, 64, 4, 2},
-    // g_d2 dgrad: 25.3 us (automatic choice before this sweep: 24.5 us)
+    // g_d1_2B dgrad: 21.6 us (automatic choice before this sweep: 22.2 us)
+    {1, 128, 1024, 1024, 2, 64, 2, 2},
+    {1, 128, 1024, 1536, 2, 64, 2, 2},
+    // g_d2 fwd: 23.6 us (automatic choice before this sweep: 24.3 us)
+    {0, 1024, 256, 1280, 2, 64, 2, 2},
+    // g_d2 dgrad: 22.3 us (automatic choice before this sweep: 22.3 us)
     {1, 256, 256, 2048, 2, 64, 2, 4},
     {1, 256, 256, 3072, 2, 64, 2, 4},
-    // g_d2_2B fwd: 32.7 us (automatic choice before this sweep: 35.8 us)
+    // g_d2_2B fwd: 30.2 us (automatic choice before this sweep: 30.0 us)
     {0, 1024, 512, 1280, 2, 64, 4, 1},
-    // g_d2_2B dgrad: 36.6 us (automatic choice before this sweep: 36.2 us)
+    // g_d2_2B dgrad: 34.8 us (automatic choice before this sweep: 34.7 us)
     {1, 256, 512, 2048, 2, 64, 4, 2},
     {1, 256, 512, 3072, 2, 64, 4, 2},
-    // g_r_h1 fwd: 35.4 us (automatic choice before this sweep: 39.4 us)
+    // g_r_h1 fwd: 33.2 us (automatic choice before this sweep: 32.9 us)
     {0, 2048, 256, 1536, 2, 64, 4, 1},
-    // g_r_h1 dgrad: 38.1 us (automatic choice before this sweep: 38.0 us)
+    // g_r_h1 dgrad: 34.0 us (automatic choice before this sweep: 34.1 us)
     {1, 512, 256, 6144, 2, 64, 4, 4},
-    // g_r_h1_2B fwd: 59.8 us (automatic choice before this sweep: 66.5 us)
+    // g_r_h1_2B fwd: 56.2 us (automatic choice before this sweep: 56.2 us)
     {0, 2048, 512, 1536, 2, 64, 2, 1},
-    // g_r_h1_2B dgrad: 60.5 us (automatic choice before this sweep: 60.5 us)
-    {1, 512, 512, 6144, 2, 64, 4, 2},
-    // g_r_h2 fwd: 26.8 us (automatic choice before this sweep: 28.2 us)
+    // g_r_h1_2B dgrad: 55.5 us (automatic choice before this sweep: 57.0 us)
+    {1, 512, 512, 6144, 2, 64, 2, 4},
+    // g_r_h2 fwd: 23.9 us (automatic choice before this sweep: 24.1 us)
     {0, 512, 256, 3072, 2, 64, 4, 4},
-    // g_r_h2 dgrad: 23.4 us (automatic choice before this sweep: 23.9 us)
+    // g_r_h2 dgrad: 21.5 us (automatic choice before this sweep: 21.5 us)
     {1, 1024, 256, 1536, 2, 64, 2, 2},
-    // g_r_h2_2B fwd: 38.7 us (automatic choice before this sweep: 41.6 us)
+    // g_r_h2_2B fwd: 35.4 us (automatic choice before this sweep: 35.0 us)
     {0, 512, 512, 3072, 2, 64, 4, 2},
-    // g_r_h2_2B dgrad: 34.0 us (automatic choice before this sweep: 33.7 us)
-    {1, 1024, 512, 1536, 2, 64, 2, 1},
-    // g_u1 fwd: 52.5 us (automatic choice before this sweep: 58.1 us)
+    // g_r_h2_2B dgrad: 32.0 us (automatic choice before this sweep: 32.2 us)
+    {1, 1024, 512, 1536, 2, 64, 4, 1},
+    // g_u1 fwd: 49.2 us (automatic choice before this sweep: 49.1 us)
     {0, 2048, 256, 2560, 2, 64, 4, 1},
-    // g_u1 dgrad: 56.3 us (automatic choice before this sweep: 53.2 us)
-    {1, 512, 256, 10240, 2, 64, 4, 4},
-    // g_u1_2B fwd: 90.8 us (automatic choice before this sweep: 103.5 us)
-    {0, 2048, 512, 2560, 2, 64, 2, 1},
-    // g_u1_2B dgrad: 94.7 us (automatic choice before this sweep: 92.6 us)
-    {1, 512, 512, 10240, 2, 64, 4, 2},
-    // g_u2 fwd: 51.9 us (automatic choice before this sweep: 58.3 us)
+    // g_u1 dgrad: 49.5 us (automatic choice before this sweep: 49.8 us)
+    {1, 512, 256, 10240, 2, 64, 2, 8},
+    // g_u1_2B fwd: 86.9 us (automatic choice before this sweep: 87.9 us)
+    {0, 2048, 512, 2560, 2, 128, 2, 1},
+    // g_u1_2B dgrad: 86.1 us (automatic choice before this sweep: 88.5 us)
+    {1, 512, 512, 10240, 2, 64, 2, 4},
+    // g_u2 fwd: 48.9 us (automatic choice before this sweep: 49.1 us)
     {0, 1024, 512, 2560, 2, 64, 4, 1},
-    // g_u2 dgrad: 52.4 us (automatic choice before this sweep: 52.0 us)
+    // g_u2 dgrad: 48.1 us (automatic choice before this sweep: 48.5 us)
     {1, 512, 512, 5120, 2, 64, 2, 4},
-    // g_u2_2B fwd: 90.5 us (automatic choice before this sweep: 103.4 us)
+    // g_u2_2B fwd: 87.6 us (automatic choice before this sweep: 87.4 us)
     {0, 1024, 1024, 2560, 2, 64, 2, 1},
-    // g_u2_2B dgrad: 89.5 us (automatic choice before this sweep: 91.2 us)
+    // g_u2_2B dgrad: 84.8 us (automatic choice before this sweep: 84.4 us)
     {1, 512, 1024, 5120, 2, 64, 2, 2},
-    // g_o1 fwd: 21.0 us (automatic choice before this sweep: 20.6 us)
+    // g_o1 fwd: 17.7 us (automatic choice before this sweep: 17.5 us)
     {0, 24, 1024, 3840, 2, 64, 4, 8},
-    // g_o1 dgrad: 16.8 us (automatic choice before this sweep: 16.7 us)
-    {1, 256, 1024, 512, 2, 64, 2, 2},
-    // g_o1_2B fwd: 29.0 us (automatic choice before this sweep: 30.7 us)
-    {0, 24, 2048, 3840, 2, 64, 2, 8},
-    // g_o1_2B dgrad: 18.7 us (automatic choice before this sweep: 19.7 us)
+    // g_o1 dgrad: 14.3 us (automatic choice before this sweep: 14.2 us)
+    {1, 256, 1024, 512, 2, 64, 1, 2},
+    // g_o1_2B fwd: 24.8 us (automatic choice before this sweep: 25.2 us)
+    {0, 24, 2048, 3840, 2, 64, 1, 16},
+    // g_o1_2B dgrad: 16.6 us (automatic choice before this sweep: 16.2 us)
     {1, 256, 2048, 512, 2, 64, 2, 1},
-    // g_h1 dgrad: 19.6 us (automatic choice before this sweep: 19.0 us)
-    {1, 24, 1024, 3840, 2, 64, 2, 8},
-    // g_h1_2B dgrad: 28.1 us (automatic choice before this sweep: 28.7 us)
-    {1, 24, 2048, 3840, 2, 64, 2, 8},
-    // d_d1 dgrad: 77.6 us (automatic choice before this sweep: 82.3 us)
+    // g_h1 dgrad: 16.4 us (automatic choice before this sweep: 16.2 us)
+    {1, 24, 1024, 3840, 2, 64, 1, 16},
+    // g_h1_2B dgrad: 23.8 us (automatic choice before this sweep: 24.5 us)
+    {1, 24, 2048, 3840, 2, 64, 1, 8},
+    // d_d1 dgrad: 70.8 us (automatic choice before this sweep: 70.5 us)
     {1, 128, 3072, 2048, 2, 64, 1, 1},
     {1, 128, 3072, 1024, 2, 64, 1, 1},
     {1, 128, 3072, 1024, 2, 64, 1, 1},
     {1, 128, 3072, 512, 2, 64, 1, 1},
-    // d_d1_2B fwd: 135.3 us (automatic choice before this sweep: 145.4 us)
-    {0, 512, 6144, 1152, 2, 64, 1, 1},
-    // d_d1_2B dgrad: 134.7 us (automatic choice before this sweep: 129.8 us)
+    // d_d1_2B fwd: 115.1 us (automatic choice before this sweep: 122.0 us)
+    {0, 512, 6144, 1152, 2, 128, 1, 1},
+    // d_d1_2B dgrad: 119.7 us (automatic choice before this sweep: 118.8 us)
     {1, 128, 6144, 2048, 2, 128, 1, 1},
     {1, 128, 6144, 1024, 2, 128, 1, 1},
     {1, 128, 6144, 1024, 2, 128, 1, 1},
     {1, 128, 6144, 512, 2, 128, 1, 1},
-    // d_d2 dgrad: 79.5 us (automatic choice before this sweep: 83.6 us)
+    // d_d2 dgrad: 73.6 us (automatic choice before this sweep: 73.4 us)
     {1, 256, 768, 4096, 2, 64, 1, 2},
     {1, 256, 768, 2048, 2, 64, 1, 2},
     {1, 256, 768, 2048, 2, 64, 1, 2},
     {1, 256, 768, 1024, 2, 64, 1, 2},
-    // d_d2_2B fwd: 125.9 us (automatic choice before this sweep: 145.2 us)
+    // d_d2_2B fwd: 121.0 us (automatic choice before this sweep: 122.7 us)
     {0, 1024, 1536, 2304, 2, 64, 1, 1},
-    // d_d2_2B dgrad: 138.0 us (automatic choice before this sweep: 136.7 us)
+    // d_d2_2B dgrad: 129.5 us (automatic choice before this sweep: 129.8 us)
     {1, 256, 1536, 4096, 2, 64, 2, 1},
     {1, 256, 1536, 2048, 2, 64, 2, 1},
     {1, 256, 1536, 2048, 2, 64, 2, 1},
     {1, 256, 1536, 1024, 2, 64, 2, 1},
-    // d_d3 (forward / input gradient without rowskip: the round-2 sweep, profiles/r02_tune_sweep_b8.txt)
-    // d_d3 dgrad: 254.4 us
+    // d_d3 dgrad: 239.7 us (automatic choice before this sweep: 243.7 us)
     {1, 512, 384, 24576, 2, 64, 1, 8},
     {1, 512, 384, 12288, 2, 64, 1, 8},
-    // d_d3_2B fwd (round-3 re-sweep without rowskip: 64x2/2 471, 64x2/1 478, 128x2/2 481 on a box where 64x1/4 took 490+)
-    {0, 2048, 768, 9216, 2, 64, 2, 2},
-    // d_d3_2B dgrad (re-sweep: 64x1/4 482, 64x2/4 487, 128x1/8 497)
+    // d_d3_2B fwd: 430.0 us (automatic choice before this sweep: 465.2 us)
+    {0, 2048, 768, 9216, 2, 128, 1, 2},
+    // d_d3_2B dgrad: 442.8 us (automatic choice before this sweep: 441.2 us)
     {1, 512, 768, 24576, 2, 64, 1, 4},
     {1, 512, 768, 12288, 2, 64, 1, 4},
-    // ---- batch 32 per GPU, 24x128 MCEP
-    // g_d1 fwd: 34.6 us (automatic choice before this sweep: 37.2 us)
+    // ---- batch 32 per GPU, 24x128 MCEP (re-measured on the round-4 kernels, profiles/r04_tune_sweep_*.txt)
+    // g_d1 fwd: 28.6 us (automatic choice before this sweep: 29.0 us)
     {0, 512, 2048, 640, 2, 128, 2, 1},
-    // g_d1 dgrad: 35.4 us (automatic choice before this sweep: 34.9 us)
+    // g_d1 dgrad: 31.7 us (automatic choice before this sweep: 31.8 us)
     {1, 128, 2048, 1024, 2, 64, 4, 1},
     {1, 128, 2048, 1536, 2, 64, 4, 1},
-    // g_d1_2B fwd: 57.7 us (automatic choice before this sweep: 62.6 us)
+    // g_d1_2B fwd: 48.5 us (automatic choice before this sweep: 47.9 us)
     {0, 512, 4096, 640, 2, 128, 1, 1},
-    // g_d1_2B dgrad: 58.7 us (automatic choice before this sweep: 63.8 us)
-    {1, 128, 4096, 1024, 2, 64, 2, 1},
-    {1, 128, 4096, 1536, 2, 64, 2, 1},
-    // g_d2 fwd: 54.0 us (automatic choice before this sweep: 59.8 us)
-    {0, 1024, 1024, 1280, 2, 64, 2, 1},
-    // g_d2 dgrad: 58.7 us (automatic choice before this sweep: 65.3 us)
-    {1, 256, 1024, 2048, 2, 64, 2, 2},
-    {1, 256, 1024, 3072, 2, 64, 2, 2},
-    // g_d2_2B fwd: 97.4 us (automatic choice before this sweep: 107.0 us)
-    {0, 1024, 2048, 1280, 2, 64, 1, 1},
-    // g_d2_2B dgrad: 103.5 us (automatic choice before this sweep: 113.5 us)
+    // g_d1_2B dgrad: 54.1 us (automatic choice before this sweep: 55.1 us)
+    {1, 128, 4096, 1024, 2, 128, 2, 1},
+    {1, 128, 4096, 1536, 2, 128, 2, 1},
+    // g_d2 fwd: 49.6 us (automatic choice before this sweep: 51.0 us)
+    {0, 1024, 1024, 1280, 2, 128, 2, 1},
+    // g_d2 dgrad: 56.0 us (automatic choice before this sweep: 56.6 us)
+    {1, 256, 1024, 2048, 2, 64, 4, 1},
+    {1, 256, 1024, 3072, 2, 64, 4, 1},
+    // g_d2_2B fwd: 85.4 us (automatic choice before this sweep: 91.6 us)
+    {0, 1024, 2048, 1280, 2, 128, 1, 1},
+    // g_d2_2B dgrad: 97.7 us (automatic choice before this sweep: 97.3 us)
     {1, 256, 2048, 2048, 2, 64, 2, 2},
     {1, 256, 2048, 3072, 2, 64, 2, 2},
-    // g_r_h1 fwd: 109.5 us (automatic choice before this sweep: 121.4 us)
-    {0, 2048, 1024, 1536, 2, 64, 1, 1},
-    // g_r_h1 dgrad: 105.2 us (automatic choice before this sweep: 109.6 us)
-    {1, 512, 1024, 6144, 2, 128, 2, 2},
-    // g_r_h1_2B fwd: 211.0 us (automatic choice before this sweep: 244.3 us)
-    {0, 2048, 2048, 1536, 2, 64, 2, 1},
-    // g_r_h1_2B dgrad: 193.2 us (automatic choice before this sweep: 211.6 us)
-    {1, 512, 2048, 6144, 2, 128, 1, 2},
-    // g_r_h2 fwd: 61.1 us (automatic choice before this sweep: 68.3 us)
+    // g_r_h1 fwd: 100.0 us (automatic choice before this sweep: 101.5 us)
+    {0, 2048, 1024, 1536, 2, 128, 1, 1},
+    // g_r_h1 dgrad: 100.8 us (automatic choice before this sweep: 101.1 us)
+    {1, 512, 1024, 6144, 2, 64, 2, 2},
+    // g_r_h1_2B fwd: 191.9 us (automatic choice before this sweep: 207.1 us)
+    {0, 2048, 2048, 1536, 2, 128, 1, 1},
+    // g_r_h1_2B dgrad: 187.6 us (automatic choice before this sweep: 190.6 us)
+    {1, 512, 2048, 6144, 2, 128, 2, 1},
+    // g_r_h2 fwd: 56.9 us (automatic choice before this sweep: 57.2 us)
     {0, 512, 1024, 3072, 2, 64, 4, 1},
-    // g_r_h2 dgrad: 56.2 us (automatic choice before this sweep: 57.1 us)
-    {1, 1024, 1024, 1536, 2, 64, 2, 1},
-    // g_r_h2_2B fwd: 106.4 us (automatic choice before this sweep: 122.0 us)
+    // g_r_h2 dgrad: 54.1 us (automatic choice before this sweep: 54.2 us)
+    {1, 1024, 1024, 1536, 2, 64, 1, 1},
+    // g_r_h2_2B fwd: 103.5 us (automatic choice before this sweep: 102.3 us)
     {0, 512, 2048, 3072, 2, 64, 2, 1},
-    // g_r_h2_2B dgrad: 103.4 us (automatic choice before this sweep: 105.7 us)
+    // g_r_h2_2B dgrad: 97.3 us (automatic choice before this sweep: 97.4 us)
     {1, 1024, 2048, 1536, 2, 128, 1, 1},
-    // g_u1 fwd: 170.2 us (automatic choice before this sweep: 205.1 us)
-    {0, 2048, 1024, 2560, 2, 64, 1, 1},
-    // g_u1 dgrad: 170.0 us (automatic choice before this sweep: 178.8 us)
+    // g_u1 fwd: 160.3 us (automatic choice before this sweep: 162.1 us)
+    {0, 2048, 1024, 2560, 2, 128, 1, 1},
+    // g_u1 dgrad: 159.9 us (automatic choice before this sweep: 159.7 us)
     {1, 512, 1024, 10240, 2, 128, 2, 2},
-    // g_u1_2B fwd: 336.0 us (automatic choice before this sweep: 424.6 us)
-    {0, 2048, 2048, 2560, 2, 64, 2, 1},
-    // g_u1_2B dgrad: 313.8 us (automatic choice before this sweep: 351.6 us)
-    {1, 512, 2048, 10240, 2, 128, 2, 1},
-    // g_u2 fwd: 170.3 us (automatic choice before this sweep: 206.9 us)
-    {0, 1024, 2048, 2560, 2, 64, 1, 1},
-    // g_u2 dgrad: 161.9 us (automatic choice before this sweep: 171.9 us)
-    {1, 512, 2048, 5120, 2, 128, 2, 1},
-    // g_u2_2B fwd: 337.7 us (automatic choice before this sweep: 421.2 us)
-    {0, 1024, 4096, 2560, 2, 64, 2, 1},
-    // g_u2_2B dgrad: 318.6 us (automatic choice before this sweep: 351.3 us)
-    {1, 512, 4096, 5120, 2, 128, 2, 1},
-    // g_o1 fwd: 46.1 us (automatic choice before this sweep: 48.7 us)
-    {0, 24, 4096, 3840, 2, 64, 4, 2},
-    // g_o1 dgrad: 26.9 us (automatic choice before this sweep: 28.0 us)
-    {1, 256, 4096, 512, 2, 128, 2, 1},
-    // g_o1_2B fwd: 75.1 us (automatic choice before this sweep: 80.4 us)
-    {0, 24, 8192, 3840, 2, 64, 4, 1},
-    // g_o1_2B dgrad: 43.0 us (automatic choice before this sweep: 44.7 us)
+    // g_u1_2B fwd: 313.3 us (automatic choice before this sweep: 332.0 us)
+    {0, 2048, 2048, 2560, 2, 128, 1, 1},
+    // g_u1_2B dgrad: 303.8 us (automatic choice before this sweep: 308.5 us)
+    {1, 512, 2048, 10240, 2, 128, 1, 2},
+    // g_u2 fwd: 161.0 us (automatic choice before this sweep: 163.2 us)
+    {0, 1024, 2048, 2560, 2, 128, 1, 1},
+    // g_u2 dgrad: 158.7 us (automatic choice before this sweep: 159.2 us)
+    {1, 512, 2048, 5120, 2, 128, 1, 2},
+    // g_u2_2B fwd: 316.7 us (automatic choice before this sweep: 330.5 us)
+    {0, 1024, 4096, 2560, 2, 128, 1, 1},
+    // g_u2_2B dgrad: 301.9 us (automatic choice before this sweep: 312.9 us)
+    {1, 512, 4096, 5120, 2, 128, 1, 1},
+    // g_o1 fwd: 39.6 us (automatic choice before this sweep: 40.6 us)
+    {0, 24, 4096, 3840, 2, 64, 1, 4},
+    // g_o1 dgrad: 24.5 us (automatic choice before this sweep: 24.7 us)
+    {1, 256, 4096, 512, 2, 64, 1, 1},
+    // g_o1_2B fwd: 67.0 us (automatic choice before this sweep: 67.6 us)
+    {0, 24, 8192, 3840, 2, 64, 1, 4},
+    // g_o1_2B dgrad: 40.6 us (automatic choice before this sweep: 40.5 us)
     {1, 256, 8192, 512, 2, 128, 1, 1},
-    // g_h1 dgrad: 42.1 us (automatic choice before this sweep: 44.3 us)
-    {1, 24, 4096, 3840, 2, 64, 2, 2},
-    // g_h1_2B dgrad: 68.8 us (automatic choice before this sweep: 71.4 us)
-    {1, 24, 8192, 3840, 2, 64, 4, 1},
-    // d_d1 dgrad: 245.7 us (automatic choice before this sweep: 307.8 us)
+    // g_h1 dgrad: 37.2 us (automatic choice before this sweep: 37.9 us)
+    {1, 24, 4096, 3840, 2, 64, 1, 4},
+    // g_h1_2B dgrad: 64.3 us (automatic choice before this sweep: 65.8 us)
+    {1, 24, 8192, 3840, 2, 64, 1, 2},
+    // d_d1 dgrad: 230.0 us (automatic choice before this sweep: 232.0 us)
     {1, 128, 12288, 2048, 2, 64, 1, 1},
     {1, 128, 12288, 1024, 2, 64, 1, 1},
     {1, 128, 12288, 1024, 2, 64, 1, 1},
     {1, 128, 12288, 512, 2, 64, 1, 1},
-    // d_d1_2B fwd: 510.9 us (automatic choice before this sweep: 651.6 us)
-    {0, 512, 24576, 1152, 2, 128, 2, 1},
-    // d_d1_2B dgrad: 472.7 us (automatic choice before this sweep: 497.0 us)
+    // d_d1_2B fwd: 442.4 us (automatic choice before this sweep: 484.1 us)
+    {0, 512, 24576, 1152, 2, 128, 1, 1},
+    // d_d1_2B dgrad: 441.2 us (automatic choice before this sweep: 440.5 us)
     {1, 128, 24576, 2048, 2, 128, 1, 1},
     {1, 128, 24576, 1024, 2, 128, 1, 1},
     {1, 128, 24576, 1024, 2, 128, 1, 1},
     {1, 128, 24576, 512, 2, 128, 1, 1},
-    // d_d2 dgrad: 237.7 us (automatic choice before this sweep: 349.3 us)
-    {1, 256, 3072, 4096, 2, 64, 1, 1},
-    {1, 256, 3072, 2048, 2, 64, 1, 1},
-    {1, 256, 3072, 2048, 2, 64, 1, 1},
-    {1, 256, 3072, 1024, 2, 64, 1, 1},
-    // d_d2_2B fwd: 485.4 us (automatic choice before this sweep: 619.4 us)
-    {0, 1024, 6144, 2304, 2, 128, 2, 1},
-    // d_d2_2B dgrad: 447.5 us (automatic choice before this sweep: 523.6 us)
+    // d_d2 dgrad: 233.1 us (automatic choice before this sweep: 234.8 us)
+    {1, 256, 3072, 4096, 2, 128, 2, 1},
+    {1, 256, 3072, 2048, 2, 128, 2, 1},
+    {1, 256, 3072, 2048, 2, 128, 2, 1},
+    {1, 256, 3072, 1024, 2, 128, 2, 1},
+    // d_d2_2B fwd: 426.2 us (automatic choice before this sweep: 455.8 us)
+    {0, 1024, 6144, 2304, 2, 128, 1, 1},
+    // d_d2_2B dgrad: 454.4 us (automatic choice before this sweep: 452.6 us)
     {1, 256, 6144, 4096, 2, 128, 1, 1},
     {1, 256, 6144, 2048, 2, 128, 1, 1},
     {1, 256, 6144, 2048, 2, 128, 1, 1},
     {1, 256, 6144, 1024, 2, 128, 1, 1},
-    // d_d3 dgrad: 843.1 us (automatic choice before this sweep: 993.7 us)
-    {1, 512, 1536, 24576, 2, 128, 1, 8},      // (re-sweep without rowskip: 128x1/8 910, 128x1/4 912, 128x2/4 945)
-    {1, 512, 1536, 12288, 2, 128, 1, 8},
-    // d_d3_2B fwd: 1463.5 us (automatic choice before this sweep: 2462.7 us)
-    {0, 2048, 3072, 9216, 2, 128, 2, 1},
-    // d_d3_2B dgrad: 1535.9 us (automatic choice before this sweep: 1643.4 us)
-    {1, 512, 3072, 24576, 2, 128, 2, 2},
-    {1, 512, 3072, 12288, 2, 128, 2, 2},
-    // ---- batch 64 per GPU, 36x256 MCEP
-    // g_d1 fwd: 105.3 us (automatic choice before this sweep: 112.4 us)
-    {0, 512, 8192, 640, 2, 64, 1, 1},
-    // g_d1 dgrad: 94.6 us (automatic choice before this sweep: 98.2 us)
+    // d_d3 dgrad: 859.3 us (automatic choice before this sweep: 875.3 us)
+    {1, 512, 1536, 24576, 2, 64, 1, 4},
+    {1, 512, 1536, 12288, 2, 64, 1, 4},
+    // d_d3_2B fwd: 1634.6 us (automatic choice before this sweep: 1718.2 us)
+    {0, 2048, 3072, 9216, 2, 128, 1, 1},
+    // d_d3_2B dgrad: 1675.5 us (automatic choice before this sweep: 1667.0 us)
+    {1, 512, 3072, 24576, 2, 128, 1, 4},
+    {1, 512, 3072, 12288, 2, 128, 1, 4},
+    // ---- batch 64 per GPU, 36x256 MCEP (re-measured on the round-4 kernels, profiles/r04_tune_sweep_*.txt)
+    // g_d1 fwd: 89.6 us (automatic choice before this sweep: 98.3 us)
+    {0, 512, 8192, 640, 2, 128, 1, 1},
+    // g_d1 dgrad: 88.5 us (automatic choice before this sweep: 86.1 us)
     {1, 128, 8192, 1024, 2, 64, 1, 1},
     {1, 128, 8192, 1536, 2, 64, 1, 1},
-    // g_d1_2B fwd: 205.8 us (automatic choice before this sweep: 237.2 us)
-    {0, 512, 16384, 640, 2, 64, 1, 1},
-    // g_d1_2B dgrad: 179.1 us (automatic choice before this sweep: 180.4 us)
-    {1, 128, 16384, 1024, 2, 64, 1, 1},
-    {1, 128, 16384, 1536, 2, 64, 1, 1},
-    // g_d2 fwd: 191.8 us (automatic choice before this sweep: 228.7 us)
-    {0, 1024, 4096, 1280, 2, 64, 1, 1},
-    // g_d2 dgrad: 180.1 us (automatic choice before this sweep: 182.9 us)
+    // g_d1_2B fwd: 173.9 us (automatic choice before this sweep: 188.8 us)
+    {0, 512, 16384, 640, 2, 128, 1, 1},
+    // g_d1_2B dgrad: 163.6 us (automatic choice before this sweep: 165.5 us)
+    {1, 128, 16384, 1024, 2, 128, 1, 1},
+    {1, 128, 16384, 1536, 2, 128, 1, 1},
+    // g_d2 fwd: 162.7 us (automatic choice before this sweep: 177.9 us)
+    {0, 1024, 4096, 1280, 2, 128, 1, 1},
+    // g_d2 dgrad: 163.6 us (automatic choice before this sweep: 167.8 us)
     {1, 256, 4096, 2048, 2, 64, 1, 1},
     {1, 256, 4096, 3072, 2, 64, 1, 1},
-    // g_d2_2B fwd: 375.0 us (automatic choice before this sweep: 494.8 us)
-    {0, 1024, 8192, 1280, 2, 128, 2, 1},
-    // g_d2_2B dgrad: 343.7 us (automatic choice before this sweep: 351.8 us)
-    {1, 256, 8192, 2048, 2, 128, 2, 1},
-    {1, 256, 8192, 3072, 2, 128, 2, 1},
-    // g_r_h1 fwd: 426.5 us (automatic choice before this sweep: 498.0 us)
-    {0, 2048, 4096, 1536, 2, 128, 2, 1},
-    // g_r_h1 dgrad: 379.5 us (automatic choice before this sweep: 432.5 us)
-    {1, 512, 4096, 6144, 2, 128, 2, 1},
-    // g_r_h1_2B fwd: 809.1 us (automatic choice before this sweep: 976.1 us)
+    // g_d2_2B fwd: 319.7 us (automatic choice before this sweep: 348.2 us)
+    {0, 1024, 8192, 1280, 2, 128, 1, 1},
+    // g_d2_2B dgrad: 317.1 us (automatic choice before this sweep: 323.3 us)
+    {1, 256, 8192, 2048, 2, 128, 1, 1},
+    {1, 256, 8192, 3072, 2, 128, 1, 1},
+    // g_r_h1 fwd: 372.7 us (automatic choice before this sweep: 405.7 us)
+    {0, 2048, 4096, 1536, 2, 128, 1, 1},
+    // g_r_h1 dgrad: 363.1 us (automatic choice before this sweep: 374.8 us)
+    {1, 512, 4096, 6144, 2, 128, 1, 1},
+    // g_r_h1_2B fwd: 750.2 us (automatic choice before this sweep: 745.6 us)
     {0, 2048, 8192, 1536, 2, 128, 1, 1},
-    // g_r_h1_2B dgrad: 758.5 us (automatic choice before this sweep: 838.6 us)
-    {1, 512, 8192, 6144, 2, 128, 2, 1},
-    // g_r_h2 fwd: 203.7 us (automatic choice before this sweep: 257.8 us)
-    {0, 512, 4096, 3072, 2, 64, 1, 1},
-    // g_r_h2 dgrad: 208.1 us (automatic choice before this sweep: 209.7 us)
-    {1, 1024, 4096, 1536, 2, 64, 1, 1},
-    // g_r_h2_2B fwd: 411.0 us (automatic choice before this sweep: 504.9 us)
-    {0, 512, 8192, 3072, 2, 64, 2, 1},
-    // g_r_h2_2B dgrad: 408.1 us (automatic choice before this sweep: 422.1 us)
+    // g_r_h1_2B dgrad: 715.3 us (automatic choice before this sweep: 737.0 us)
+    {1, 512, 8192, 6144, 2, 128, 1, 1},
+    // g_r_h2 fwd: 189.1 us (automatic choice before this sweep: 197.9 us)
+    {0, 512, 4096, 3072, 2, 128, 1, 1},
+    // g_r_h2 dgrad: 189.4 us (automatic choice before this sweep: 192.6 us)
+    {1, 1024, 4096, 1536, 2, 128, 1, 1},
+    // g_r_h2_2B fwd: 371.2 us (automatic choice before this sweep: 399.4 us)
+    {0, 512, 8192, 3072, 2, 128, 1, 1},
+    // g_r_h2_2B dgrad: 372.7 us (automatic choice before this sweep: 376.6 us)
     {1, 1024, 8192, 1536, 2, 128, 1, 1},
-    // g_u1 fwd: 673.4 us (automatic choice before this sweep: 822.3 us)
-    {0, 2048, 4096, 2560, 2, 64, 2, 1},
-    // g_u1 dgrad: 618.1 us (automatic choice before this sweep: 713.5 us)
-    {1, 512, 4096, 10240, 2, 128, 2, 1},
-    // g_u1_2B fwd: 1285.0 us (automatic choice before this sweep: 1490.2 us)
+    // g_u1 fwd: 612.6 us (automatic choice before this sweep: 657.1 us)
+    {0, 2048, 4096, 2560, 2, 128, 1, 1},
+    // g_u1 dgrad: 594.8 us (automatic choice before this sweep: 609.8 us)
+    {1, 512, 4096, 10240, 2, 128, 1, 1},
+    // g_u1_2B fwd: 1206.4 us (automatic choice before this sweep: 1221.1 us)
     {0, 2048, 8192, 2560, 2, 128, 1, 1},
-    // g_u1_2B dgrad: 1235.5 us (automatic choice before this sweep: 1371.8 us)
-    {1, 512, 8192, 10240, 2, 128, 1, 2},
-    // g_u2 fwd: 681.4 us (automatic choice before this sweep: 822.7 us)
-    {0, 1024, 8192, 2560, 2, 64, 2, 1},
-    // g_u2 dgrad: 633.2 us (automatic choice before this sweep: 700.0 us)
-    {1, 512, 8192, 5120, 2, 128, 1, 2},
-    // g_u2_2B fwd: 1288.2 us (automatic choice before this sweep: 1494.1 us)
+    // g_u1_2B dgrad: 1181.9 us (automatic choice before this sweep: 1189.2 us)
+    {1, 512, 8192, 10240, 2, 128, 1, 1},
+    // g_u2 fwd: 608.9 us (automatic choice before this sweep: 667.2 us)
+    {0, 1024, 8192, 2560, 2, 128, 1, 1},
+    // g_u2 dgrad: 593.2 us (automatic choice before this sweep: 613.3 us)
+    {1, 512, 8192, 5120, 2, 128, 1, 1},
+    // g_u2_2B fwd: 1220.5 us (automatic choice before this sweep: 1222.2 us)
     {0, 1024, 16384, 2560, 2, 128, 1, 1},
-    // g_u2_2B dgrad: 1244.5 us (automatic choice before this sweep: 1364.2 us)
+    // g_u2_2B dgrad: 1188.6 us (automatic choice before this sweep: 1192.0 us)
     {1, 512, 16384, 5120, 2, 128, 1, 1},
-    // g_o1 fwd: 140.9 us (automatic choice before this sweep: 150.8 us)
-    {0, 36, 16384, 3840, 2, 64, 4, 1},
-    // g_o1 dgrad: 131.1 us (automatic choice before this sweep: 134.7 us)
+    // g_o1 fwd: 124.3 us (automatic choice before this sweep: 131.3 us)
+    {0, 36, 16384, 3840, 2, 64, 1, 2},
+    // g_o1 dgrad: 124.8 us (automatic choice before this sweep: 124.5 us)
     {1, 256, 16384, 960, 2, 128, 1, 1},
-    // g_o1_2B fwd: 258.0 us (automatic choice before this sweep: 300.8 us)
-    {0, 36, 32768, 3840, 2, 64, 2, 1},
-    // g_o1_2B dgrad: 251.1 us (automatic choice before this sweep: 254.5 us)
+    // g_o1_2B fwd: 240.3 us (automatic choice before this sweep: 243.6 us)
+    {0, 36, 32768, 3840, 2, 64, 1, 1},
+    // g_o1_2B dgrad: 241.8 us (automatic choice before this sweep: 242.4 us)
     {1, 256, 32768, 960, 2, 128, 1, 1},
-    // g_h1 fwd: 137.1 us (automatic choice before this sweep: 155.1 us)
-    {0, 256, 16384, 960, 2, 64, 1, 1},
-    // g_h1 dgrad: 126.0 us (automatic choice before this sweep: 128.8 us)
-    {1, 36, 16384, 3840, 2, 64, 2, 1},
-    // g_h1_2B fwd: 265.3 us (automatic choice before this sweep: 304.2 us)
-    {0, 256, 32768, 960, 2, 64, 1, 1},
-    // g_h1_2B dgrad: 244.8 us (automatic choice before this sweep: 251.2 us)
-    {1, 36, 32768, 3840, 2, 64, 2, 1},
-    // d_d1 dgrad: 1394.4 us (automatic choice before this sweep: 1615.3 us)
+    // g_h1 fwd: 126.9 us (automatic choice before this sweep: 130.0 us)
+    {0, 256, 16384, 960, 2, 128, 1, 1},
+    // g_h1 dgrad: 121.0 us (automatic choice before this sweep: 121.3 us)
+    {1, 36, 16384, 3840, 2, 64, 1, 1},
+    // g_h1_2B fwd: 245.3 us (automatic choice before this sweep: 247.8 us)
+    {0, 256, 32768, 960, 2, 128, 1, 1},
+    // g_h1_2B dgrad: 235.2 us (automatic choice before this sweep: 235.4 us)
+    {1, 36, 32768, 3840, 2, 64, 1, 2},
+    // d_d1 dgrad: 1335.1 us (automatic choice before this sweep: 1353.4 us)
     {1, 128, 73728, 2048, 2, 128, 1, 1},
     {1, 128, 73728, 1024, 2, 128, 1, 1},
     {1, 128, 73728, 1024, 2, 128, 1, 1},
     {1, 128, 73728, 512, 2, 128, 1, 1},
-    // d_d1_2B fwd: 2757.6 us (automatic choice before this sweep: 3167.2 us)
+    // d_d1_2B fwd: 2671.1 us (automatic choice before this sweep: 2665.6 us)
     {0, 512, 147456, 1152, 2, 128, 1, 1},
-    // d_d1_2B dgrad: 2810.9 us (automatic choice before this sweep: 2971.5 us)
+    // d_d1_2B dgrad: 2905.1 us (automatic choice before this sweep: 2771.9 us)
     {1, 128, 147456, 2048, 2, 128, 1, 1},
     {1, 128, 147456, 1024, 2, 128, 1, 1},
     {1, 128, 147456, 1024, 2, 128, 1, 1},
     {1, 128, 147456, 512, 2, 128, 1, 1},
-    // d_d2 dgrad: 1321.8 us (automatic choice before this sweep: 1629.6 us)
+    // d_d2 dgrad: 1251.0 us (automatic choice before this sweep: 1283.2 us)
     {1, 256, 18432, 4096, 2, 128, 1, 1},
     {1, 256, 18432, 2048, 2, 128, 1, 1},
     {1, 256, 18432, 2048, 2, 128, 1, 1},
     {1, 256, 18432, 1024, 2, 128, 1, 1},
-    // d_d2_2B fwd: 2733.6 us (automatic choice before this sweep: 3075.5 us)
+    // d_d2_2B fwd: 2588.8 us (automatic choice before this sweep: 2583.9 us)
     {0, 1024, 36864, 2304, 2, 128, 1, 1},
-    // d_d2_2B dgrad: 2585.7 us (automatic choice before this sweep: 2790.8 us)
+    // d_d2_2B dgrad: 2624.7 us (automatic choice before this sweep: 2603.7 us)
     {1, 256, 36864, 4096, 2, 128, 1, 1},
     {1, 256, 36864, 2048, 2, 128, 1, 1},
     {1, 256, 36864, 2048, 2, 128, 1, 1},
     {1, 256, 36864, 1024, 2, 128, 1, 1},
-    // d_d3 dgrad: 4732.0 us (automatic choice before this sweep: 4960.6 us)
+    // d_d3 dgrad: 4916.2 us (automatic choice before this sweep: 4914.4 us)
     {1, 512, 9216, 24576, 2, 128, 1, 4},
     {1, 512, 9216, 12288, 2, 128, 1, 4},
-    // d_d3_2B fwd: 8907.2 us (automatic choice before this sweep: 9951.6 us)
+    // d_d3_2B fwd: 9859.5 us (automatic choice before this sweep: 9849.6 us)
     {0, 2048, 18432, 9216, 2, 128, 1, 1},
-    // d_d3_2B dgrad: 9861.6 us (automatic choice before this sweep: 10733.2 us)
-    {1, 512, 18432, 24576, 2, 128, 2, 1},
-    {1, 512, 18432, 12288, 2, 128, 2, 1},
+    // d_d3_2B dgrad: 9712.4 us (automatic choice before this sweep: 9827.8 us)
+    {1, 512, 18432, 24576, 2, 128, 1, 2},
+    {1, 512, 18432, 12288, 2, 128, 1, 2},
     // ---- batch 1 per GPU, 24x128 MCEP (BASELINE configs[0], the reference's own mini_batch_size; round-4 sweep, profiles/r04_tune_sweep_b1.txt)
     // g_d1 fwd: 12.9 us (automatic choice before this sweep: 16.7 us)
     {0, 512, 64, 640, 2, 64, 2, 8},

@@ -3,74 +3,74 @@
 // Cout, pixel chunks (all applications), groups, plain stores?, tile columns, K groups, split-K}.  Shapes not listed go by the
 // cost model in wgrad_config.
 static const TunedWgrad kTunedWgrad[] = {
-    // ---- batch 8 per GPU, 24x128 MCEP
-    // g_d1_3B: 35.9 us (automatic choice before this sweep: 39.2 us)
-    {10, 512, 48, 2, 1, 64, 4, 1},
-    // g_d2_3B: 53.0 us (automatic choice before this sweep: 57.2 us)
+    // ---- batch 8 per GPU, 24x128 MCEP (re-measured on the round-4 kernels, profiles/r04_tune_sweep_*.txt)
+    // g_d1_3B: 35.5 us (automatic choice before this sweep: 36.0 us)
+    {10, 512, 48, 2, 1, 64, 1, 4},
+    // g_d2_3B: 50.9 us (automatic choice before this sweep: 50.7 us)
     {20, 1024, 24, 2, 1, 64, 1, 1},
-    // g_r_h1_3B: 95.2 us (automatic choice before this sweep: 109.7 us)
+    // g_r_h1_3B: 91.2 us (automatic choice before this sweep: 91.2 us)
     {24, 2048, 24, 2, 1, 64, 1, 1},
-    // g_r_h2_3B: 52.0 us (automatic choice before this sweep: 57.7 us)
+    // g_r_h2_3B: 50.6 us (automatic choice before this sweep: 49.8 us)
     {48, 512, 24, 2, 1, 64, 1, 1},
-    // g_u1_3B: 153.1 us (automatic choice before this sweep: 184.4 us)
+    // g_u1_3B: 145.4 us (automatic choice before this sweep: 145.0 us)
     {40, 2048, 24, 2, 1, 64, 1, 1},
-    // g_u2_3B: 153.4 us (automatic choice before this sweep: 189.9 us)
+    // g_u2_3B: 146.4 us (automatic choice before this sweep: 146.9 us)
     {40, 1024, 48, 2, 1, 64, 2, 1},
-    // g_o1_3B: 37.8 us (automatic choice before this sweep: 40.7 us)
+    // g_o1_3B: 36.6 us (automatic choice before this sweep: 36.0 us)
     {60, 24, 96, 2, 1, 64, 4, 2},
-    // g_h1_3B: 24.7 us (automatic choice before this sweep: 24.8 us)
+    // g_h1_3B: 23.4 us (automatic choice before this sweep: 23.0 us)
     {8, 256, 96, 2, 1, 64, 4, 4},
-    // d_d1_2B: 149.1 us (automatic choice before this sweep: 178.7 us)
+    // d_d1_2B: 147.0 us (automatic choice before this sweep: 144.5 us)
     {18, 512, 192, 2, 1, 64, 1, 8},
-    // d_d2_2B: 152.9 us (automatic choice before this sweep: 172.4 us)
+    // d_d2_2B: 149.3 us (automatic choice before this sweep: 149.3 us)
     {36, 1024, 48, 2, 1, 64, 2, 1},
-    // d_d3_2B: 419.5 us (automatic choice before this sweep: 423.4 us)
+    // d_d3_2B: 424.5 us (automatic choice before this sweep: 422.3 us)
     {144, 2048, 24, 2, 1, 128, 1, 1},
-    // ---- batch 32 per GPU, 24x128 MCEP
-    // g_d1_3B: 93.4 us (automatic choice before this sweep: 107.7 us)
-    {10, 512, 192, 2, 1, 64, 2, 8},
-    // g_d2_3B: 162.2 us (automatic choice before this sweep: 208.9 us)
+    // ---- batch 32 per GPU, 24x128 MCEP (re-measured on the round-4 kernels, profiles/r04_tune_sweep_*.txt)
+    // g_d1_3B: 88.8 us (automatic choice before this sweep: 88.5 us)
+    {10, 512, 192, 2, 1, 64, 1, 8},
+    // g_d2_3B: 158.5 us (automatic choice before this sweep: 156.2 us)
     {20, 1024, 96, 2, 1, 64, 2, 2},
-    // g_r_h1_3B: 335.5 us (automatic choice before this sweep: 390.3 us)
-    {24, 2048, 96, 2, 1, 128, 2, 1},
-    // g_r_h2_3B: 175.3 us (automatic choice before this sweep: 209.6 us)
+    // g_r_h1_3B: 324.3 us (automatic choice before this sweep: 324.7 us)
+    {24, 2048, 96, 2, 1, 128, 1, 1},
+    // g_r_h2_3B: 173.7 us (automatic choice before this sweep: 173.0 us)
     {48, 512, 96, 2, 1, 64, 1, 1},
-    // g_u1_3B: 552.2 us (automatic choice before this sweep: 644.7 us)
-    {40, 2048, 96, 2, 1, 64, 2, 1},
-    // g_u2_3B: 552.1 us (automatic choice before this sweep: 690.4 us)
+    // g_u1_3B: 527.6 us (automatic choice before this sweep: 548.3 us)
+    {40, 2048, 96, 2, 1, 128, 1, 1},
+    // g_u2_3B: 544.7 us (automatic choice before this sweep: 544.0 us)
     {40, 1024, 192, 2, 1, 64, 2, 1},
-    // g_o1_3B: 121.2 us (automatic choice before this sweep: 133.0 us)
-    {60, 24, 384, 2, 1, 64, 4, 2},
-    // g_h1_3B: 69.3 us (automatic choice before this sweep: 68.9 us)
+    // g_o1_3B: 116.8 us (automatic choice before this sweep: 116.9 us)
+    {60, 24, 384, 2, 1, 64, 2, 4},
+    // g_h1_3B: 63.2 us (automatic choice before this sweep: 62.9 us)
     {8, 256, 384, 2, 1, 64, 4, 4},
-    // d_d1_2B: 532.8 us (automatic choice before this sweep: 577.0 us)
-    {18, 512, 768, 2, 1, 64, 2, 8},
-    // d_d2_2B: 526.3 us (automatic choice before this sweep: 597.2 us)
-    {36, 1024, 192, 2, 1, 64, 2, 2},
-    // d_d3_2B: 1635.7 us (automatic choice before this sweep: 1688.1 us)
+    // d_d1_2B: 519.8 us (automatic choice before this sweep: 516.7 us)
+    {18, 512, 768, 2, 1, 64, 1, 8},
+    // d_d2_2B: 520.9 us (automatic choice before this sweep: 517.1 us)
+    {36, 1024, 192, 2, 1, 64, 1, 2},
+    // d_d3_2B: 1663.8 us (automatic choice before this sweep: 1679.9 us)
     {144, 2048, 96, 2, 1, 128, 1, 1},
-    // ---- batch 64 per GPU, 36x256 MCEP
-    // g_d1_3B: 305.0 us (automatic choice before this sweep: 386.9 us)
-    {10, 512, 768, 2, 1, 64, 2, 8},
-    // g_d2_3B: 573.4 us (automatic choice before this sweep: 681.8 us)
-    {20, 1024, 384, 2, 1, 64, 1, 4},
-    // g_r_h1_3B: 1247.3 us (automatic choice before this sweep: 1360.1 us)
-    {24, 2048, 384, 2, 1, 128, 1, 2},
-    // g_r_h2_3B: 652.6 us (automatic choice before this sweep: 756.4 us)
+    // ---- batch 64 per GPU, 36x256 MCEP (re-measured on the round-4 kernels, profiles/r04_tune_sweep_*.txt)
+    // g_d1_3B: 295.1 us (automatic choice before this sweep: 296.2 us)
+    {10, 512, 768, 2, 1, 64, 1, 16},
+    // g_d2_3B: 575.1 us (automatic choice before this sweep: 573.5 us)
+    {20, 1024, 384, 2, 1, 128, 2, 4},
+    // g_r_h1_3B: 1244.6 us (automatic choice before this sweep: 1240.0 us)
+    {24, 2048, 384, 2, 1, 128, 2, 1},
+    // g_r_h2_3B: 651.1 us (automatic choice before this sweep: 646.8 us)
     {48, 512, 384, 2, 1, 128, 1, 4},
-    // g_u1_3B: 2064.8 us (automatic choice before this sweep: 2209.4 us)
-    {40, 2048, 384, 2, 1, 128, 1, 2},
-    // g_u2_3B: 2054.8 us (automatic choice before this sweep: 2216.0 us)
+    // g_u1_3B: 2071.6 us (automatic choice before this sweep: 2062.8 us)
+    {40, 2048, 384, 2, 1, 128, 2, 1},
+    // g_u2_3B: 2060.7 us (automatic choice before this sweep: 2052.8 us)
     {40, 1024, 768, 2, 1, 128, 1, 4},
-    // g_o1_3B: 435.5 us (automatic choice before this sweep: 501.9 us)
-    {60, 36, 1536, 2, 1, 64, 2, 8},
-    // g_h1_3B: 421.1 us (automatic choice before this sweep: 493.4 us)
-    {15, 256, 1536, 2, 1, 128, 1, 16},
-    // d_d1_2B: 2929.2 us (automatic choice before this sweep: 2925.8 us)
+    // g_o1_3B: 432.2 us (automatic choice before this sweep: 430.9 us)
+    {60, 36, 1536, 2, 1, 64, 1, 8},
+    // g_h1_3B: 412.8 us (automatic choice before this sweep: 423.0 us)
+    {15, 256, 1536, 2, 1, 128, 1, 8},
+    // d_d1_2B: 2943.3 us (automatic choice before this sweep: 2941.7 us)
     {18, 512, 4608, 2, 1, 128, 2, 16},
-    // d_d2_2B: 2846.8 us (automatic choice before this sweep: 2915.0 us)
+    // d_d2_2B: 2847.3 us (automatic choice before this sweep: 2837.4 us)
     {36, 1024, 1152, 2, 1, 128, 1, 8},
-    // d_d3_2B: 9540.9 us (automatic choice before this sweep: 9729.3 us)
+    // d_d3_2B: 9615.7 us (automatic choice before this sweep: 9643.3 us)
     {144, 2048, 576, 2, 1, 128, 2, 1},
     // ---- batch 1 per GPU, 24x128 MCEP (BASELINE configs[0], the reference's own mini_batch_size; round-4 sweep, profiles/r04_tune_sweep_b1.txt)
     // g_d1_3B: 12.1 us (automatic choice before this sweep: 12.4 us)
