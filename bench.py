@@ -288,7 +288,7 @@ def dp_selftest(eng, lib, A, Bm, hp, steps, warmup):
 
 
 def workload_text(math, B, F, T, global_batch):
-    idx = 4 if (F, T) == (36, 256) else 3 if global_batch else 1 if math == 'fp32' else 2
+    idx = 4 if (F, T) == (36, 256) else 3 if global_batch else 2 if math != 'fp32' else 0 if B == 1 else 1
     return ('BASELINE configs[%d]: full CycleGAN-VC train step (2G+2D fwd/bwd + losses + TF-Adam), %s, batch %d per GPU, '
             '%dx%d MCEP, random-init weights' % (idx, MATH_TEXT[math], B, F, T))
 
@@ -297,7 +297,7 @@ def extra_config(lib, dev, math, B, F, T, steps, warmup, note, constant_operands
     """one more BASELINE configuration on this GPU, measured like the headline: wall time of `steps` steps + its own roofline leg.
     constant_operands: every parameter and every input 0 (activations and weight gradients stay 0, only biases move) -- the
     same launches on zero-entropy data (a DIAGNOSTIC of the
-    chip's data-dependent power management, DESIGN 4.1 / profiles/r03_data_dependent_power.txt; never a performance figure)"""
+    chip's data-dependent power management, profiles/HISTORY.md 4.1 / profiles/r03_data_dependent_power.txt; never a performance figure)"""
     import numpy as np
     import torch
     from voice_converter_cyclegan_amd.engine import CycleGANEngine
@@ -479,7 +479,7 @@ def main():
         r4k = named_kernel_h1(lib, dev, B=4096, reps=10, peak=BF16_MFMA_PEAK_TFLOPS, math='bf16')
         out['named_kernel']['bf16_mode'] = {'us': r['us'], 'hbm_frac': r['hbm']['frac'], 'achieved_TFLOPs': r['mfma']['achieved_TFLOPs'],
                                             'B4096': {'us': r4k['us'], 'hbm_frac': r4k['hbm']['frac'], 'algorithmic_bytes': r4k['algorithmic_bytes']}}
-        out['named_kernel']['timed'] = 'everything one vc_gated_conv1d_glu_fwd call launches (filter-image pack + the kernel), HIP events on the call\'s stream'
+        out['named_kernel']['timed'] = 'everything one vc_gated_conv1d_glu_fwd call launches (one kernel), HIP events on the call\'s stream, after 50 ms of the same call (sustained clocks)'
 
     dp = None
     if rank == 0 and world == 1 and (args.dp_selftest or (default_workload and not args.no_extra and not args.no_roofline)):
@@ -492,6 +492,7 @@ def main():
         eng.close()
         torch.cuda.empty_cache()
         out['extra'] = {'configs': [
+            extra_config(lib, dev, 'fp32', 1, 24, 128, 40, 10, 'configs[0]: batch 1, the reference\'s own mini_batch_size (train.py:16)'),
             extra_config(lib, dev, 'bf16', 64, 24, 128, 10, 3, 'configs[2]: batch 64, bf16'),
             extra_config(lib, dev, 'fp32', 32, 24, 128, 10, 3, 'configs[3]: the per-GPU share (32) of global batch 256 on an 8-GPU node, measured on one GPU without the exchange'),
             extra_config(lib, dev, 'fp32', 64, 36, 256, 5, 2, 'configs[4]: the per-GPU share (64) of global batch 512 at 36x256, measured on one GPU without the exchange'),

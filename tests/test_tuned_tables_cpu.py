@@ -10,7 +10,7 @@ import pytest
 
 from tests.step_shapes import step_launches, launch_keys, wgrad_key
 
-BENCHED = [(24, 128, 8), (24, 128, 32), (36, 256, 64), (24, 128, 1), (24, 128, 2), (24, 128, 4), (24, 128, 16), (24, 128, 64)]       # bench.py: headline, extra.configs[1], extra.configs[2]; the reference's own batch (BASELINE configs[0])
+BENCHED = [(24, 128, 8), (24, 128, 32), (36, 256, 64), (24, 128, 1), (24, 128, 2), (24, 128, 4), (24, 128, 16), (24, 128, 64)]       # bench.py: headline and its extra.configs (batch 32, 36x256 batch 64, batch 1 = the reference's own); 2, 4, 16, 64: the sizes between
 SRC = {0: 'cost model', 1: 'exact row', 2: 'nearest measured size', 3: 'forced', 4: 'bf16 rule'}
 
 
