@@ -492,7 +492,7 @@ def main():
         eng.close()
         torch.cuda.empty_cache()
         out['extra'] = {'configs': [
-            extra_config(lib, dev, 'fp32', 1, 24, 128, 40, 10, 'configs[0]: batch 1, the reference\'s own mini_batch_size (train.py:16)'),
+            extra_config(lib, dev, 'fp32', 1, 24, 128, 60, 40, 'configs[0]: batch 1, the reference\'s own mini_batch_size (train.py:16); 40 warm-up steps = 0.1 s: a latency-bound step reads the clock ramp after the engine set-up'),
             extra_config(lib, dev, 'bf16', 64, 24, 128, 10, 3, 'configs[2]: batch 64, bf16'),
             extra_config(lib, dev, 'fp32', 32, 24, 128, 10, 3, 'configs[3]: the per-GPU share (32) of global batch 256 on an 8-GPU node, measured on one GPU without the exchange'),
             extra_config(lib, dev, 'fp32', 64, 36, 256, 5, 2, 'configs[4]: the per-GPU share (64) of global batch 512 at 36x256, measured on one GPU without the exchange'),
