@@ -124,6 +124,18 @@ int vc_conv2d_wgrad(const float* x, int64_t x_gs, const float* dy, int64_t dy_gs
 int vc_gated_conv1d_glu_fwd(const float* x, int64_t x_gs, const float* w, int64_t w_gs,
                             const float* bias, int64_t b_gs, float* out, int64_t out_gs,
                             int G, int B, int Cin, int T, int Cout2, int k, void* stream);
+/* The same block with the filters pre-packed (weights that do not change between calls: CycleGAN.test / convert.py, model.py:128-137,
+ * or once per weight update).  vc_gated_conv1d_glu_prepack writes, per group, the MFMA fragment image of w for the calling
+ * thread's math mode (bf16: rounded once, 16-bit; fp32: exact) -- vc_gated_conv1d_glu_image_bytes(Cin, k, Cout2) bytes, 16-byte
+ * aligned, group stride in bytes; -1: geometry not built.  vc_gated_conv1d_glu_fwd_packed is vc_gated_conv1d_glu_fwd reading
+ * that image instead of w: a workgroup fetches its filter fragments with 16-byte coalesced loads straight into registers.
+ * The image must have been built in the math mode of the call. */
+int64_t vc_gated_conv1d_glu_image_bytes(int Cin, int k, int Cout2);
+int vc_gated_conv1d_glu_prepack(const float* w, int64_t w_gs, void* image, int64_t image_gs_bytes,
+                                int G, int Cin, int k, int Cout2, void* stream);
+int vc_gated_conv1d_glu_fwd_packed(const float* x, int64_t x_gs, const void* image, int64_t image_gs_bytes,
+                                   const float* bias, int64_t b_gs, float* out, int64_t out_gs,
+                                   int G, int B, int Cin, int T, int Cout2, int k, void* stream);
 /* BiasAddGrad: db[c] += sum_{b,l} dy[g][b][c][l]  (dy [G][B][C][L]). */
 int vc_bias_grad(const float* dy, int64_t dy_gs, float* db, int64_t db_gs,
                  int G, int B, int C, int L, void* stream);

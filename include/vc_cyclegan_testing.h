@@ -44,6 +44,11 @@ int  vc_prof_collect(int kind, double* ms, long long* launches, double* flops);
 /* Per-launch records (in launch order) since enable: fills ms[i], flops[i] for i < max_n; returns the record count. */
 int  vc_prof_records(int kind, double* ms, double* flops, int max_n);
 
+/* Measurement control for the north-star kernel (bench.py named_kernel.copy_roof): ONE launch on vc_gated_conv1d_glu_fwd_packed's grid
+ * (G = 1) that performs that kernel's memory operations only -- every workgroup reads its slab's bf16 fragment image and its tiles'
+ * frames and writes its output rows with the same dword stores -- and no arithmetic.  Recorded under profiling kind 2. */
+int  vc_prof_glu_copy_roof(const float* x, const void* image_bf16, float* out, int B, int T, int Cout2, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,10 +1,12 @@
 """CPU: the generated ISA of gated_conv1d_glu_kernel (csrc/vc_conv_glu.hip; reference module.py:161-163) keeps the promises its
 hand-counted waits rely on.  The kernel issues the frames of the next-but-one tile with inline-asm buffer loads into registers
-the compiler knows nothing about until a counted `s_waitcnt vmcnt(16 + 2 NST)` one trip later; that is only correct if
-  * every trip issues exactly 16 such loads and exactly NST output stores (4 inference, 12 training) -- no merged, split or
-    branch-skipped store --, with no other vector-memory operation in between,
+the compiler knows nothing about until a counted `s_waitcnt vmcnt(8 + 2 NST)` one trip later; that is only correct if
+  * every trip issues exactly 8 such loads and exactly NST output stores (8 inference, 24 training: dword stores of two full
+    128-byte lines each) -- no merged, split or branch-skipped store --, with no other vector-memory operation in between,
   * nothing reads or overwrites the destination registers between the loads and the wait that retires them,
-  * no register is spilled (scratch would add vector-memory operations of its own) and the loop holds no vmcnt(0).
+  * no register is spilled (scratch would add vector-memory operations of its own) and the loop holds no vmcnt(0),
+  * the two bodies of a kernel (K set 0 / 1: a wave-uniform branch at entry picks one) execute the same number of workgroup
+    barriers per trip -- waves of both sets meet at every one of them.
 A compiler or flag change that breaks one of these would stage garbage frames silently; this test reads the
 assembly hipcc produces for gfx950 and fails instead."""
 import os
@@ -50,28 +52,31 @@ def _instrs(body):
 
 
 def test_no_scratch_and_register_budget(asm):
-    metas = re.findall(r'\.name:\s+(_Z23gated_conv1d_glu_kernel\w+).*?\.private_segment_fixed_size:\s+(\d+)', asm, flags=re.S)
     seen = {}
     for blk in re.split(r'\n  - \.agpr_count', asm)[1:]:
         n = re.search(r'\.name:\s+(\S+)', blk); s = re.search(r'\.private_segment_fixed_size:\s+(\d+)', blk)
+        v = re.search(r'\.vgpr_count:\s+(\d+)', blk)
         if n and s and 'gated_conv1d_glu_kernel' in n.group(1):
-            seen[n.group(1)] = int(s.group(1))
-    assert len(seen) == 4 or len(metas) >= 4, (seen, metas)
-    assert all(v == 0 for v in seen.values()), 'scratch in use: %s' % seen
+            seen[n.group(1)] = (int(s.group(1)), int(v.group(1)) if v else 0)
+    assert len(seen) == 8, seen
+    assert all(v[0] == 0 for v in seen.values()), 'scratch in use: %s' % seen
+    # two waves per SIMD: the unified register file gives each 256 registers (VGPR + AGPR)
+    assert all(0 < v[1] <= 256 for v in seen.values()), seen
     assert 'scratch_' not in asm
 
 
+@pytest.mark.parametrize('pre', [False, True])
 @pytest.mark.parametrize('bf16,raw', [(True, False), (True, True), (False, False), (False, True)])
-def test_trip_issues_the_counted_operations(asm, bf16, raw):
-    tag = 'ILi24ELi15ELb%dELb%dEE' % (int(bf16), int(raw))
+def test_trip_issues_the_counted_operations(asm, bf16, raw, pre):
+    tag = 'ILi24ELi15ELb%dELb%dELb%dEE' % (int(bf16), int(raw), int(pre))
     body = [b for n, b in _kernels(asm) if tag in n]
     assert len(body) == 1
     body = body[0]
-    nst = 12 if raw else 4
-    # the tile loop's body is two trips (register sets alternate), each ending in the workgroup barrier.  Block placement is the
-    # compiler's business (prologue blocks may sit behind the loop in the text): keep only the lines of blocks LLVM annotates as
-    # belonging to the tile loop (the one loop of this kernel that holds a barrier), then cut that stream at the barriers.
-    want = 's_waitcnt vmcnt(%d)' % (16 + 2 * nst)
+    nst = 24 if raw else 8
+    want = 's_waitcnt vmcnt(%d)' % (8 + 2 * nst)
+    # The kernel holds two tile loops (K set 0 / 1), each two trips long (register sets alternate), each trip ending in the
+    # workgroup barrier(s).  Block placement is the compiler's business: keep the lines of blocks LLVM annotates as belonging
+    # to a loop that holds a barrier, then cut each loop's stream at its barriers (fp32: two per trip).
     loops = {}
     cur = None
     for l in body:
@@ -81,44 +86,51 @@ def test_trip_issues_the_counted_operations(asm, bf16, raw):
             cur = h.group(1) if h else (l.split(':')[0].lstrip('.L') if 'Loop Header' in l else None)
         if cur is not None:
             loops.setdefault(cur, []).append(l)
-    tile_loop = [v for v in loops.values() if any('s_barrier' in l for l in v)]
-    assert len(tile_loop) == 1, (tag, list(loops))
-    stream = tile_loop[0]
-    cuts = [-1] + [i for i, l in enumerate(stream) if 's_barrier' in l]
-    trips_l = [stream[lo + 1:hi + 1] for lo, hi in zip(cuts[:-1], cuts[1:])]
-    assert len(trips_l) == 2 and all(any(want in l for l in t) for t in trips_l), (tag, len(trips_l))
-    body = [l for t in trips_l for l in t]
-    n0 = len(trips_l[0])
-    trips = [(0, n0), (n0, len(body))]
-    dests = []
-    for lo, hi in trips:
-        ins = _instrs(body[lo:hi])
-        loads = [x for x in ins if x.startswith('buffer_load_dword ')]
-        stores = [x for x in ins if x.startswith('buffer_store_dwordx4')]
-        other_vm = [x for x in ins if re.match(r'(buffer_|global_|flat_|scratch_)', x) and x not in loads and x not in stores]
-        waits = [x for x in ins if 'vmcnt' in x]
-        assert len(loads) == 16, (len(loads), tag)
-        assert len(stores) == nst, (len(stores), tag)
-        assert not other_vm, other_vm[:3]
-        assert waits == ['s_waitcnt vmcnt(%d)' % (16 + 2 * nst)], waits
-        assert len([x for x in ins if x.startswith('v_mfma')]) == (46 if bf16 else 360)
-        # program order inside the trip: loads of the next-but-one tile, then the previous tile's stores, then the wait
-        order = [x.split()[0] if 'vmcnt' not in x else 'wait' for x in ins if x in loads or x in stores or 'vmcnt' in x]
-        assert order.index('wait') == len(order) - 1, 'a vector-memory operation behind the counted wait of its trip'
-        dests.append({re.match(r'buffer_load_dword (v\d+),', x).group(1) for x in loads})
-    assert not (dests[0] & dests[1]), 'the two register sets overlap'
-    # a trip's load destinations are retired by the OTHER trip's wait: until then no instruction may touch them
-    for k, (lo, hi) in enumerate(trips):
-        mine, others = dests[k], dests[1 - k]
-        ins = _instrs(body[lo:hi])
-        w = [i for i, x in enumerate(ins) if 'vmcnt' in x][0]
-        last_load = max(i for i, x in enumerate(ins) if x.startswith('buffer_load_dword '))
-        for i, x in enumerate(ins):
-            regs = set(re.findall(r'\bv(\d+)\b', x))
-            for a, b in re.findall(r'v\[(\d+):(\d+)\]', x):
-                regs |= {str(r) for r in range(int(a), int(b) + 1)}
-            regs = {'v' + r for r in regs}
-            if i < w and not x.startswith('buffer_load_dword '):
-                assert not (regs & others), 'trip %d touches frames in flight before its wait: %s' % (k, x)
-            if i > last_load:
-                assert not (regs & mine), 'trip %d touches its own loads before the next trip\'s wait: %s' % (k, x)
+    tile_loops = [v for v in loops.values() if any('s_barrier' in l for l in v)]
+    assert len(tile_loops) == 2, (tag, list(loops))
+    bars_per_trip = 1 if bf16 else 2
+    mfmas = set()
+    for stream in tile_loops:
+        bars = [i for i, l in enumerate(stream) if 's_barrier' in l]
+        assert len(bars) == 2 * bars_per_trip, (tag, len(bars))
+        ends = bars[bars_per_trip - 1::bars_per_trip]
+        cuts = [-1] + ends
+        trips_l = [stream[lo + 1:hi + 1] for lo, hi in zip(cuts[:-1], cuts[1:])]
+        assert len(trips_l) == 2 and all(any(want in l for l in t) for t in trips_l), (tag, len(trips_l))
+        body2 = [l for t in trips_l for l in t]
+        n0 = len(trips_l[0])
+        trips = [(0, n0), (n0, len(body2))]
+        dests = []
+        for lo, hi in trips:
+            ins = _instrs(body2[lo:hi])
+            loads = [x for x in ins if x.startswith('buffer_load_dword ')]
+            stores = [x for x in ins if x.startswith('buffer_store_dword ')]
+            other_vm = [x for x in ins if re.match(r'(buffer_|global_|flat_|scratch_)', x) and x not in loads and x not in stores]
+            waits = [x for x in ins if 'vmcnt' in x]
+            assert len(loads) == 8, (len(loads), tag)
+            assert len(stores) == nst, (len(stores), tag)
+            assert not other_vm, other_vm[:3]
+            assert waits == [want], waits
+            mfmas.add(len([x for x in ins if x.startswith('v_mfma')]))
+            # program order inside the trip: loads of the next-but-one tile, then the previous tile's stores, then the wait
+            order = [x.split()[0] if 'vmcnt' not in x else 'wait' for x in ins if x in loads or x in stores or 'vmcnt' in x]
+            assert order.index('wait') == len(order) - 1, 'a vector-memory operation behind the counted wait of its trip'
+            dests.append({re.match(r'buffer_load_dword (v\d+),', x).group(1) for x in loads})
+        assert not (dests[0] & dests[1]), 'the two register sets overlap'
+        # a trip's load destinations are retired by the OTHER trip's wait: until then no instruction may touch them
+        for k, (lo, hi) in enumerate(trips):
+            mine, others = dests[k], dests[1 - k]
+            ins = _instrs(body2[lo:hi])
+            w = [i for i, x in enumerate(ins) if 'vmcnt' in x][0]
+            last_load = max(i for i, x in enumerate(ins) if x.startswith('buffer_load_dword '))
+            for i, x in enumerate(ins):
+                regs = set(re.findall(r'\bv(\d+)\b', x))
+                for a, b in re.findall(r'v\[(\d+):(\d+)\]', x):
+                    regs |= {str(r) for r in range(int(a), int(b) + 1)}
+                regs = {'v' + r for r in regs}
+                if i < w and not x.startswith('buffer_load_dword '):
+                    assert not (regs & others), 'trip %d touches frames in flight before its wait: %s' % (k, x)
+                if i > last_load:
+                    assert not (regs & mine), 'trip %d touches its own loads before the next trip\'s wait: %s' % (k, x)
+    # the K axis is split 12 / 11 steps (bf16: two MFMAs per step) or 23 / 22 (fp32: eight per step) between the two bodies
+    assert mfmas == ({24, 22} if bf16 else {184, 176}), mfmas

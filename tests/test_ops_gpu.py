@@ -253,12 +253,14 @@ def _conv_check(case):
     assert e < TOL, 'wgrad accumulate rel err %g' % e
 
 
+@pytest.mark.parametrize('packed', [False, True])
 @pytest.mark.parametrize('mode', ['fp32', 'bf16'])
-@pytest.mark.parametrize('B,T', [(2, 128), (256, 128), (3, 132), (8, 2048), (1, 4)])
-def test_gated_conv1d_glu_fused(built_lib, B, T, mode):
-    """vc_gated_conv1d_glu_fwd: the generator's h1 block (module.py:161-163) in one kernel, against conv1d + conv1d +
-    gated_linear_layer of the oracle.  (256, 128) is the shape bench.py times as the north-star kernel; (8, 2048) an
-    inference batch; T = 132 / 4: ragged last tile, tile smaller than the kernel."""
+@pytest.mark.parametrize('B,T', [(2, 128), (256, 128), (3, 132), (8, 2048), (1, 4), (5, 260)])
+def test_gated_conv1d_glu_fused(built_lib, B, T, mode, packed):
+    """vc_gated_conv1d_glu_fwd / vc_gated_conv1d_glu_prepack + vc_gated_conv1d_glu_fwd_packed: the generator's h1 block
+    (module.py:161-163) in one kernel, against conv1d + conv1d + gated_linear_layer of the oracle.  (256, 128) is the shape
+    bench.py times as the north-star kernel; (8, 2048) an inference batch; T = 132 / 260 / 4: ragged last tile (a partial
+    32-pixel block), tile smaller than the kernel."""
     from tests import gpu_util as U
     from voice_converter_cyclegan_amd._lib import lib, ptr, check
     O = _oracle()
@@ -278,8 +280,16 @@ def test_gated_conv1d_glu_fused(built_lib, B, T, mode):
         x_d = U.dev(np.ascontiguousarray(np.transpose(x, (0, 1, 3, 2))))
         w_d, b_d = U.dev(w), U.dev(b)
         out = torch.full((G, B, C, T), float('nan'), device=U.DEV)
-        check(lib.vc_gated_conv1d_glu_fwd(ptr(x_d), x_d[0].numel(), ptr(w_d), w_d[0].numel(), ptr(b_d), 2 * C,
-                                          ptr(out), out[0].numel(), G, B, 24, T, 2 * C, 15, U.stream()))
+        if packed:
+            nb = lib.vc_gated_conv1d_glu_image_bytes(24, 15, 2 * C)
+            assert nb > 0 and nb % 16 == 0
+            img = torch.zeros((G, nb), dtype=torch.uint8, device=U.DEV)
+            check(lib.vc_gated_conv1d_glu_prepack(ptr(w_d), w_d[0].numel(), ptr(img), nb, G, 24, 15, 2 * C, U.stream()))
+            check(lib.vc_gated_conv1d_glu_fwd_packed(ptr(x_d), x_d[0].numel(), ptr(img), nb, ptr(b_d), 2 * C,
+                                                     ptr(out), out[0].numel(), G, B, 24, T, 2 * C, 15, U.stream()))
+        else:
+            check(lib.vc_gated_conv1d_glu_fwd(ptr(x_d), x_d[0].numel(), ptr(w_d), w_d[0].numel(), ptr(b_d), 2 * C,
+                                              ptr(out), out[0].numel(), G, B, 24, T, 2 * C, 15, U.stream()))
         e = U.rel_err(out.cpu().numpy(), np.stack(ref))
     finally:
         O.set_operand_rounding(None)

@@ -1,7 +1,16 @@
-"""The north-star kernel (vc_gated_conv1d_glu_fwd) at several sizes, fp32 and bf16, HIP events around every call.  Run on the GPU box."""
+"""The north-star kernel (vc_gated_conv1d_glu_fwd / _fwd_packed) at several sizes, fp32 and bf16.  Run on the GPU box.
+
+Per (math, shape) three launches are timed with the same protocol (>= 50 ms of the same call first: sustained clocks):
+  plain   vc_gated_conv1d_glu_fwd         filters in TF layout, converted by every workgroup
+  packed  vc_gated_conv1d_glu_fwd_packed  filters as the pre-packed fragment image (vc_gated_conv1d_glu_prepack, outside the timed region)
+  roof    vc_prof_glu_copy_roof           the same grid performing the kernel's memory operations only (bf16 image): the copy roof
+and two clocks: `ev` = HIP events around every single call (launch + kernel + event overhead), `b2b` = N calls back to back between two
+events / N (the average launch duration in a stream of launches: what a caller that does not synchronise per call sees)."""
+import argparse
 import ctypes as C
 import os
 import sys
+import time
 
 import torch
 
@@ -10,43 +19,67 @@ import __graft_entry__ as ge  # noqa: E402
 ge.build()
 from voice_converter_cyclegan_amd._lib import lib, ptr, check, vp  # noqa: E402
 
-import argparse  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument('--batches', default='', help='comma-separated batch sizes at T = 128 (default: the standard set incl. a long-utterance shape)')
 ap.add_argument('--warm-ms', type=float, default=50.0, help='run the kernel this long before timing it (0: three calls, the rounds 1-3 protocol)')
+ap.add_argument('--maths', default='fp32,bf16')
 args = ap.parse_args()
 SHAPES = [(int(b), 128) for b in args.batches.split(',')] if args.batches else [(256, 128), (4096, 128), (8, 2048), (16, 128)]
 dev = 'cuda:0'
-for ver in (2,):
-    for math in ('fp32', 'bf16'):
-        for B, T in SHAPES:
-            x = torch.randn((1, B, 24, T), device=dev)
-            w = torch.randn((1, 15, 24, 256), device=dev) * 0.05
-            b = torch.randn((1, 256), device=dev) * 0.1
-            y = torch.empty((1, B, 128, T), device=dev)
-            s = vp(torch.cuda.current_stream().cuda_stream)
-            check(lib.vc_set_math_mode({'fp32': 0, 'bf16': 1}[math]))
-            call = lambda: check(lib.vc_gated_conv1d_glu_fwd(ptr(x), 0, ptr(w), 0, ptr(b), 0, ptr(y), 0, 1, B, 24, T, 256, 15, s))
-            # the GPU drops its clocks while the host builds the tensors above: run the kernel for >= 50 ms before timing it, so
-            # the figure is the kernel at sustained clocks (as inside a training loop), not at whatever the ramp had reached
-            import time
-            t_end = time.perf_counter() + args.warm_ms * 1e-3
-            while True:
-                for _ in range(50):
-                    call()
-                torch.cuda.synchronize()
-                if time.perf_counter() >= t_end:
-                    break
-            lib.vc_prof_enable(1)
-            reps = 20 if B <= 256 else 10
-            for _ in range(reps):
-                call()
-            torch.cuda.synchronize()
-            ms, n, fl = C.c_double(0), C.c_longlong(0), C.c_double(0)
-            lib.vc_prof_collect(2, C.byref(ms), C.byref(n), C.byref(fl))
-            lib.vc_prof_enable(0)
-            check(lib.vc_set_math_mode(0))
-            t = ms.value * 1e-3 / max(n.value, 1)
-            algo = B * (24 * T + 128 * T) * 4 + (15 * 24 * 256 + 256) * 4
-            flops = 2.0 * B * T * 256 * 15 * 24
-            print('r4%s %-4s B=%-4d T=%-4d %8.2f us  HBM %6.3f of 8 TB/s  %7.1f TFLOP/s' % ('' if ver == 2 else '?', math, B, T, t * 1e6, algo / t / 8e12, flops / t / 1e12), flush=True)
+
+
+def timed(call, B):
+    t_end = time.perf_counter() + args.warm_ms * 1e-3
+    while True:
+        for _ in range(50):
+            call()
+        torch.cuda.synchronize()
+        if time.perf_counter() >= t_end:
+            break
+    lib.vc_prof_enable(1)
+    reps = 20 if B <= 256 else 10
+    for _ in range(reps):
+        call()
+    torch.cuda.synchronize()
+    ms, n, fl = C.c_double(0), C.c_longlong(0), C.c_double(0)
+    lib.vc_prof_collect(2, C.byref(ms), C.byref(n), C.byref(fl))
+    lib.vc_prof_enable(0)
+    ev = ms.value * 1e-3 / max(n.value, 1)
+    nb = 200 if B <= 256 else 40
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(20):
+        call()
+    e0.record()
+    for _ in range(nb):
+        call()
+    e1.record()
+    torch.cuda.synchronize()
+    return ev, e0.elapsed_time(e1) * 1e-3 / nb
+
+
+for math in args.maths.split(','):
+    for B, T in SHAPES:
+        x = torch.randn((1, B, 24, T), device=dev)
+        w = torch.randn((1, 15, 24, 256), device=dev) * 0.05
+        b = torch.randn((1, 256), device=dev) * 0.1
+        y = torch.empty((1, B, 128, T), device=dev)
+        s = vp(torch.cuda.current_stream().cuda_stream)
+        check(lib.vc_set_math_mode({'fp32': 0, 'bf16': 1}[math]))
+        nb_img = lib.vc_gated_conv1d_glu_image_bytes(24, 15, 256)
+        img = torch.empty((nb_img,), dtype=torch.uint8, device=dev)
+        check(lib.vc_gated_conv1d_glu_prepack(ptr(w), 0, ptr(img), 0, 1, 24, 15, 256, s))
+        check(lib.vc_set_math_mode(1))
+        img16 = torch.empty((lib.vc_gated_conv1d_glu_image_bytes(24, 15, 256),), dtype=torch.uint8, device=dev)
+        check(lib.vc_gated_conv1d_glu_prepack(ptr(w), 0, ptr(img16), 0, 1, 24, 15, 256, s))
+        check(lib.vc_set_math_mode({'fp32': 0, 'bf16': 1}[math]))
+        calls = [('plain ', lambda: check(lib.vc_gated_conv1d_glu_fwd(ptr(x), 0, ptr(w), 0, ptr(b), 0, ptr(y), 0, 1, B, 24, T, 256, 15, s))),
+                 ('packed', lambda: check(lib.vc_gated_conv1d_glu_fwd_packed(ptr(x), 0, ptr(img), 0, ptr(b), 0, ptr(y), 0, 1, B, 24, T, 256, 15, s)))]
+        if math == 'bf16':
+            calls.append(('roof  ', lambda: check(lib.vc_prof_glu_copy_roof(ptr(x), ptr(img16), ptr(y), B, T, 256, s))))
+        algo = B * (24 * T + 128 * T) * 4 + (15 * 24 * 256 + 256) * 4
+        flops = 2.0 * B * T * 256 * 15 * 24
+        for name, call in calls:
+            ev, b2b = timed(call, B)
+            print('r5 %-4s %s B=%-4d T=%-4d  ev %8.2f us (HBM %5.3f, %7.1f TFLOP/s)   b2b %8.2f us (HBM %5.3f, %7.1f TFLOP/s)' % (
+                math, name, B, T, ev * 1e6, algo / ev / 8e12, flops / ev / 1e12, b2b * 1e6, algo / b2b / 8e12, flops / b2b / 1e12), flush=True)
+        check(lib.vc_set_math_mode(0))

@@ -1,5 +1,7 @@
 """Regenerates tools/glu_timeline.patch: in-kernel phase stamps for csrc/vc_conv_glu.hip (gated_conv1d_glu_kernel), kept OUT of
-the product source.  Apply, build with VC_EXTRA_FLAGS=-DVC_GLU_TIMELINE, run tools/glu_probe.py, `git checkout` the file."""
+the product source.  Apply (`git apply tools/glu_timeline.patch`), build with VC_EXTRA_FLAGS=-DVC_GLU_TIMELINE, run
+tools/glu_probe.py, `git checkout` the file.  Stamps: s_memtime (shader cycles) AND s_memrealtime (100 MHz): the ratio is the clock
+the kernel actually ran at."""
 import os
 import subprocess
 
@@ -7,54 +9,63 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = 'voice-converter-cyclegan_amd/csrc/vc_conv_glu.hip'
 
 
-def sub(s, a, b):
-    assert s.count(a) == 1, (s.count(a), a)
-    return s.replace(a, b, 1)
+def sub(s, a, b, count=1):
+    assert s.count(a) == count, (s.count(a), a)
+    return s.replace(a, b)
 
 
 def main():
     path = os.path.join(ROOT, P)
     orig = open(path).read()
     s = orig
-    s = sub(s, 'template <int CIN, int KW, bool BF16, bool RAW>\n__global__ __launch_bounds__(256, 1) void gated_conv1d_glu_kernel(const WsConvArgs a) {',
+    s = sub(s, '// LDS map of the kernel (one allocation, shared by the two bodies)\n',
             '''#ifdef VC_GLU_TIMELINE
-// workgroup (0,0,0), thread 0: [0] entry -> fragments + tile 0 in LDS, [1] -> fragments in registers, [2] sum of trips: start ->
-// counted wait reached, [3] sum of trips: wait -> barrier passed, [4] loop end -> kernel end, [5] launches, [6] trips
-__device__ unsigned long long g_glu_tl[8];
+// slot = 2 * which + S (which: 0 = workgroup (0,0,0), 1 = the last workgroup of the grid; S: K set, lane 0 of waves 0 / 4); per slot:
+// [0] entry -> prologue barrier passed, [1] sum over trips: start -> K loop done, [2] sum: -> hand-over barrier passed, [3] sum: ->
+// trip end, [4] loop end -> kernel end, [5] launches, [6] trips, [7] kernel cycles, [8] kernel real-time ticks (100 MHz)
+__device__ unsigned long long g_glu_tl[4][16];
 extern "C" int vc_debug_glu_timeline(unsigned long long* out, int reset) {
-    if (reset) { unsigned long long z[8] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_glu_tl), z, sizeof z); return 0; }
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_glu_tl), 8 * sizeof(unsigned long long));
+    if (reset) { unsigned long long z[4][16] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_glu_tl), z, sizeof z); return 0; }
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_glu_tl), sizeof(unsigned long long) * 64);
 }
 #define VC_GTL(x) do { if (tl_on) { x; } } while (0)
 #else
 #define VC_GTL(x) do { } while (0)
 #endif
-template <int CIN, int KW, bool BF16, bool RAW>
-__global__ __launch_bounds__(256, 1) void gated_conv1d_glu_kernel(const WsConvArgs a) {
-#ifdef VC_GLU_TIMELINE
-    const bool tl_on = threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0;
-    unsigned long long tl0 = __builtin_readcyclecounter(), tl1 = 0, tl2 = 0, tl3 = 0, tla = 0, tlb = 0, ts = 0, tw = 0, ntr = 0;
-#endif''')
-    s = sub(s, '    __syncthreads();                                        // filter fragments and tile 0 are in LDS\n',
-            '    __syncthreads();                                        // filter fragments and tile 0 are in LDS\n    VC_GTL(tl1 = __builtin_readcyclecounter());\n')
-    s = sub(s, '    f32x16 accv[2], accg[2];\n', '    VC_GTL(tl2 = __builtin_readcyclecounter());\n    f32x16 accv[2], accg[2];\n')
-    s = sub(s, '        f32x16 o;\n        if constexpr (!OVERLAP) {', '        f32x16 o;\n        VC_GTL(ts = __builtin_readcyclecounter());\n        if constexpr (!OVERLAP) {')
-    s = sub(s, '                    store_plane(pl, yrs, pp.yb, pp.ok, 0);\n                    wait_counted(xq);\n',
-            '                    store_plane(pl, yrs, pp.yb, pp.ok, 0);\n                    VC_GTL(tw = __builtin_readcyclecounter());\n                    wait_counted(xq);\n')
-    s = sub(s, '            wait_counted(xq);\n            [&]<int... J>', '            VC_GTL(tw = __builtin_readcyclecounter());\n            wait_counted(xq);\n            [&]<int... J>')
-    s = sub(s, '        __syncthreads();                                    // slot P ^ 1 is complete; slot P may be overwritten by the next trip\n',
-            '        __syncthreads();                                    // slot P ^ 1 is complete; slot P may be overwritten by the next trip\n        VC_GTL(tla += tw - ts; tlb += __builtin_readcyclecounter() - tw; ++ntr);\n')
-    s = sub(s, '    // ---- the last tile\'s GLU + stores', '    VC_GTL(tl3 = __builtin_readcyclecounter());\n    // ---- the last tile\'s GLU + stores')
-    # end of kernel: before the launcher declaration
-    s = sub(s, '            store_tile(accv[0], accg[0], o, pp);\n        }\n    }\n}\n',
-            '''            store_tile(accv[0], accg[0], o, pp);
+// LDS map of the kernel (one allocation, shared by the two bodies)
+''')
+    s = sub(s, '    typedef GluGeo<CIN, KW, BF16> GG;\n    typedef typename std::conditional<BF16, __bf16, float>::type T;\n',
+            '''#ifdef VC_GLU_TIMELINE
+    const int tl_which = (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) ? 0 :
+                         (blockIdx.x == gridDim.x - 1 && blockIdx.y == gridDim.y - 1 && blockIdx.z == gridDim.z - 1) ? 1 : -1;
+    const bool tl_on = (threadIdx.x & 255) == 0 && tl_which >= 0;
+    unsigned long long tl0 = __builtin_readcyclecounter(), tr0 = __builtin_amdgcn_s_memrealtime(), tl1 = 0, tl3 = 0, ta = 0, tb = 0, tc = 0, sa = 0, sb = 0, sc = 0, ntr = 0;
+#endif
+    typedef GluGeo<CIN, KW, BF16> GG;
+    typedef typename std::conditional<BF16, __bf16, float>::type T;
+''')
+    s = sub(s, '    __syncthreads();                                        // fragment image (if any) and tile 0 are in LDS\n',
+            '    __syncthreads();                                        // fragment image (if any) and tile 0 are in LDS\n    VC_GTL(tl1 = __builtin_readcyclecounter());\n')
+    s = sub(s, '            const OutPos pp = out_pos(scur); advance(scur);   // the previous tile\'s output position\n            f32x4 o[2], gt[2];\n',
+            '            VC_GTL(ta = __builtin_readcyclecounter());\n            const OutPos pp = out_pos(scur); advance(scur);   // the previous tile\'s output position\n            f32x4 o[2], gt[2];\n')
+    s = sub(s, '            // hand-over: the half of the partial sums the partner finishes\n',
+            '            VC_GTL(tb = __builtin_readcyclecounter());\n            // hand-over: the half of the partial sums the partner finishes\n')
+    s = sub(s, '            __syncthreads();                                // hand-over written; slot P ^ 1 is complete; slot P may be overwritten by the next trip\n',
+            '            __syncthreads();                                // hand-over written; slot P ^ 1 is complete; slot P may be overwritten by the next trip\n            VC_GTL(tc = __builtin_readcyclecounter());\n')
+    s = sub(s, '            fg[0] = quad(accg, OWN) + ex_in[128]; fg[1] = quad(accg, OWN + 1) + ex_in[192];\n',
+            '            fg[0] = quad(accg, OWN) + ex_in[128]; fg[1] = quad(accg, OWN + 1) + ex_in[192];\n            VC_GTL(sa += tb - ta; sb += tc - tb; sc += __builtin_readcyclecounter() - tc; ++ntr);\n')
+    s = sub(s, '        // ---- the last tile\'s GLU + stores\n', '        VC_GTL(tl3 = __builtin_readcyclecounter());\n        // ---- the last tile\'s GLU + stores\n')
+    s = sub(s, '            glu_all(o);\n            store_tile(o, pp);\n        }\n    }\n}\n',
+            '''            glu_all(o);
+            store_tile(o, pp);
         }
     }
 #ifdef VC_GLU_TIMELINE
     if (tl_on) {
-        const unsigned long long te = __builtin_readcyclecounter();
-        atomicAdd(&g_glu_tl[0], tl1 - tl0); atomicAdd(&g_glu_tl[1], tl2 - tl1); atomicAdd(&g_glu_tl[2], tla); atomicAdd(&g_glu_tl[3], tlb);
-        atomicAdd(&g_glu_tl[4], te - tl3); atomicAdd(&g_glu_tl[5], 1ull); atomicAdd(&g_glu_tl[6], ntr);
+        const unsigned long long te = __builtin_readcyclecounter(), tre = __builtin_amdgcn_s_memrealtime();
+        unsigned long long* o_ = g_glu_tl[2 * tl_which + S];
+        atomicAdd(&o_[0], tl1 - tl0); atomicAdd(&o_[1], sa); atomicAdd(&o_[2], sb); atomicAdd(&o_[3], sc);
+        atomicAdd(&o_[4], te - tl3); atomicAdd(&o_[5], 1ull); atomicAdd(&o_[6], ntr); atomicAdd(&o_[7], te - tl0); atomicAdd(&o_[8], tre - tr0);
     }
 #endif
 }
@@ -64,8 +75,8 @@ __global__ __launch_bounds__(256, 1) void gated_conv1d_glu_kernel(const WsConvAr
         d = subprocess.run(['git', 'diff', '--', P], cwd=ROOT, capture_output=True, text=True, check=True).stdout
     finally:
         open(path, 'w').write(orig)
-    hdr = ('Timing probe for csrc/vc_conv_glu.hip (never ship a build with it): -DVC_GLU_TIMELINE makes workgroup (0,0,0) of every launch\n'
-           'add its phase durations to a device array (vc_debug_glu_timeline), read by tools/glu_probe.py.  Regenerate with\n'
+    hdr = ('Timing probe for csrc/vc_conv_glu.hip (never ship a build with it): -DVC_GLU_TIMELINE makes two workgroups of every launch\n'
+           'add their phase durations to a device array (vc_debug_glu_timeline), read by tools/glu_probe.py.  Regenerate with\n'
            'tools/make_glu_timeline_patch.py.\n\n')
     open(os.path.join(ROOT, 'tools', 'glu_timeline.patch'), 'w').write(hdr + d)
     print('tools/glu_timeline.patch: %d lines' % (hdr + d).count('\n'))

@@ -58,6 +58,10 @@ SIGNATURES = [
     ('vc_conv2d_dgrad', i32, [vp, i64, vp, i64, vp, i64, vp, i64, i32] + [i32] * 10 + [vp]),
     ('vc_conv2d_wgrad', i32, [vp, i64, vp, i64, vp, i64] + [i32] * 10 + [vp]),
     ('vc_gated_conv1d_glu_fwd', i32, [vp, i64, vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, i32, i32, vp]),
+    ('vc_gated_conv1d_glu_image_bytes', i64, [i32, i32, i32]),
+    ('vc_gated_conv1d_glu_prepack', i32, [vp, i64, vp, i64, i32, i32, i32, i32, vp]),
+    ('vc_gated_conv1d_glu_fwd_packed', i32, [vp, i64, vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, i32, i32, vp]),
+    ('vc_prof_glu_copy_roof', i32, [vp, vp, vp, i32, i32, i32, vp]),
     ('vc_bias_grad', i32, [vp, i64, vp, i64, i32, i32, i32, i32, vp]),
     ('vc_instnorm_glu_fwd', i32, [i32, i32, vp, i64, vp, i64, vp, vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, vp]),
     ('vc_instnorm_glu_bwd', i32, [i32, i32, vp, i64, vp, i64, vp, vp, i64, vp, i64, vp, i64, vp, vp, i64, vp, i64,

@@ -3,44 +3,103 @@
 // the kernel BASELINE.json's north_star names ("gated-conv1d forward at B=256").  HBM sees the frames once and the
 // activation once (12 KB in + 64 KB out per sample).
 //
-// Design (round 4).  D[pixel][channel] = sum_k X[pixel][k] * W[k][channel], k = tap * 24 + cin:
-//   * the FILTERS are the MFMA's B operand and live in REGISTERS for the whole life of the workgroup: a lane owns channel
-//     (lane & 31) of the slab's 32 value and 32 gate channels and keeps its 8-k (bf16) / 4-k (fp32) fragments of every K
-//     step -- 184 / 360 VGPRs, hence one 4-wave workgroup per CU with the 512-register budget (launch bounds (256, 1)).
-//     Round 3 kept them in LDS and re-read them for every tile: 3 ds_read_b128 per MFMA pair put the LDS pipe beside
-//     the MFMA pipe on the critical path; now the K loop issues ONE ds_read_b128 (the frames) per MFMA pair.
-//   * the FRAMES are the A operand: a 128-pixel tile (+ halo) sits in LDS pixel-major ([pixel][24 cin], no row padding:
-//     run q of 8 (4) consecutive k of the K axis starts q * 16 bytes after the pixel's row start, because consecutive
-//     taps are consecutive rows), converted to bf16 ONCE and written with one 16-byte ds_write per (pixel, channel octet)
-//     -- round 3 wrote 2 bytes at a time.  48-byte rows make both the writes and the fragment reads conflict-free.
-//   * pixels are the MFMA's M axis, so a lane ends up with 4 CONSECUTIVE pixels of one channel in 4 consecutive
-//     accumulator registers: bias + GLU happen in registers and go out as 16-byte stores with no LDS staging at all.
+// Design (round 5).  D[channel][pixel] = sum_k W[channel][k] * X[k][pixel], k = tap * 24 + cin, per workgroup a slab of 32
+// value + 32 gate channels and a stream of 128-pixel tiles:
+//   * EIGHT waves, two per SIMD, split the K axis (round 4: four waves, one per SIMD, 184 filter registers each; counters:
+//     ~6.5 other instructions between two MFMAs of the lone in-order wave, matrix pipe 38 % busy).  Wave (pb, S): pixel
+//     block pb of the tile, K steps of set S (12 / 11 of the 23 bf16 steps).  The FILTERS of its K steps are the MFMA's A
+//     operand and live in REGISTERS for the life of the workgroup (96 / 88 of the wave's 256); the FRAMES are the B operand,
+//     one ds_read_b128 per MFMA pair, out of a pixel-major LDS tile ([pixel][24 cin], 48-byte rows: run q of 8 consecutive
+//     k starts 16 q bytes after the pixel's row start because consecutive taps are consecutive rows; writes and fragment
+//     reads conflict-free).  Operand reuse is the round-4 kernel's: every frame fragment and every filter fragment is read
+//     once per tile and CU.
+//   * the two K sets of a pixel block meet through LDS once per tile: each wave hands over the half of its partial sums
+//     that the partner finishes (16 registers out, 16 in, register index = channel group, so the split needs no shuffle)
+//     -- the igemm kernel's K-group scheme.  fp32: same structure, filters in LDS (360 fragment registers do not fit),
+//     exact v_mfma_f32_32x32x2_f32; bf16: operands rounded RNE once, v_mfma_f32_32x32x16_bf16.
+//   * channels are the MFMA's M axis: a lane ends up with ONE pixel of 16 channels, value and gate of a channel in the same
+//     register index -> bias (the first MFMA's C operand) + GLU happen in registers, and register i of the 32 lanes of a
+//     half-wave is 128 contiguous bytes of one channel row: outputs leave as dword stores of two full 128-byte lines per
+//     instruction.  (Round 4 had pixels on M: 16-byte stores touched 32 rows x 32 bytes, cured with an LDS transposition
+//     of every plane; that LDS traffic is gone.)
+//   * filters arrive PRE-PACKED (vc_gated_conv1d_glu_prepack: the fragment image [slab][K step][value|gate][lane][16 B],
+//     built once per weight update): a lane fetches its fragments with 16-byte coalesced loads straight into registers
+//     while tile 0's frames travel.  Round 4 re-read 92 KB of fp32 filters per workgroup with 4-byte loads, converted them
+//     and bounced them through LDS: 4.7 + 0.7 us in front of the first MFMA.  The unpacked entry point keeps that path
+//     (PRE = false) for callers whose weights change before every call (the train step).
 //   * software pipeline over the workgroup's tiles (one barrier per tile): while tile i is multiplied, the frames of
 //     tile i+2 are in flight (inline-asm buffer loads retired by a COUNTED s_waitcnt: gfx950 has one in-order counter for
 //     loads and stores, and the compiler would wait vmcnt(0), i.e. for the previous tile's output stores to complete),
-//     the frames of tile i+1 are converted and written to the other LDS slot, and -- bf16 -- the GLU + stores of tile
-//     i-1 are interleaved with the MFMAs (second accumulator set).  Every trip issues the same number of loads and
-//     stores (out-of-tensor lanes carry an out-of-range buffer offset), which is what makes the wait countable.
-//   MATH fp32 : v_mfma_f32_32x32x2_f32, exact;  MATH bf16 : operands rounded RNE once, v_mfma_f32_32x32x16_bf16.
+//     the frames of tile i+1 are converted and written to the other LDS slot, and -- bf16 -- the GLU + stores of the wave's
+//     half of tile i-1 ride between the MFMAs.  Every trip issues the same number of loads and stores (out-of-tensor
+//     lanes carry an out-of-range buffer offset), which is what makes the wait countable.
 #include "vc_internal.h"
 #include "vc_device_util.h"
 #include <type_traits>
 #include <utility>
 
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 #define VC_OOB_ST 0x80000000u      // store offset beyond every buffer this kernel accepts (< 2 GiB); adding an immediate cannot wrap
 
-template <int CIN, int KW, bool BF16, bool RAW>
-__global__ __launch_bounds__(256, 1) void gated_conv1d_glu_kernel(const WsConvArgs a) {
-    touch_kernarg(a);
+// geometry of the fragment image, shared by the kernel, the pre-pack kernel and the host
+template <int CIN, int KW, bool BF16> struct GluGeo {
+    static constexpr int R = BF16 ? 8 : 4;                 // k values per lane and K step (one 16-byte fragment)
+    static constexpr int RPT = CIN / R;                    // runs per tap
+    static constexpr int NRUN = KW * RPT, NU = (NRUN + 1) / 2;   // K steps: lane half h multiplies run 2u + h
+    static constexpr int NU0 = (NU + 1) / 2, NU1 = NU - NU0;     // K steps of wave set 0 / 1
+    static constexpr int K = CIN * KW;
+    static constexpr long SLAB_BYTES = 2L * NU * 64 * 16;  // fragment unit U = 2u + vg: 64 lanes x 16 bytes
+};
+
+// image[g][slab][U = 2u + vg][lane] (16 bytes): lane (channel l31 of the slab, half h) holds W[k = R (2u + h) + e][channel], e < R
+template <int CIN, int KW, bool BF16>
+__global__ __launch_bounds__(256) void glu_prepack_kernel(const float* __restrict__ w, long w_gs, char* __restrict__ img, long img_gs, int Cout) {
+    typedef GluGeo<CIN, KW, BF16> GG;
+    const int C = Cout >> 1, slabs = C / 32, g = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= slabs * 2 * GG::NU * 64) return;
+    const int lane = i & 63, U = (i >> 6) % (2 * GG::NU), slab = (i >> 6) / (2 * GG::NU);
+    const int u = U >> 1, vg = U & 1, l31 = lane & 31, h = lane >> 5;
+    const int ch = (vg ? C : 0) + slab * 32 + l31;
+    const float* wg_ = w + (long)g * w_gs;
+    float v[GG::R];
+#pragma unroll
+    for (int e = 0; e < GG::R; ++e) {
+        const int k = GG::R * (2 * u + h) + e;
+        v[e] = k < GG::K ? wg_[(long)k * Cout + ch] : 0.f;
+    }
+    char* dst = img + (long)g * img_gs + (long)i * 16;
+    if constexpr (BF16) {
+        bf16x8 f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = (__bf16)v[e];
+        *reinterpret_cast<bf16x8*>(dst) = f;
+    } else {
+        *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
+    }
+}
+
+// LDS map of the kernel (one allocation, shared by the two bodies)
+template <int CIN, int KW, bool BF16, bool PRE> struct GluLds {
+    typedef GluGeo<CIN, KW, BF16> GG;
+    static constexpr int CS = BF16 ? CIN : CIN + 4, SLOT = (144 + 1) * CS, ESZ = BF16 ? 2 : 4;
+    static constexpr bool W_LDS = !BF16 || !PRE;
+    static constexpr int NXB = BF16 ? 2 : 1;
+    static constexpr int WF_OFF = (2 * SLOT * ESZ + 15) & ~15;
+    static constexpr int EX_OFF = WF_OFF + (W_LDS ? 2 * GG::NU * 64 * 16 : 0);
+    static constexpr int BYTES = EX_OFF + NXB * 8 * 4 * 64 * 16;
+};
+
+// the kernel's body for the waves of K set S (a wave-uniform branch at the kernel's entry picks one: the set's K steps, which half of
+// the accumulators it hands over and which half it finishes are compile-time constants, and no register is live across a join
+// of the two).  Both bodies execute the same sequence of workgroup barriers.
+template <int CIN, int KW, bool BF16, bool RAW, bool PRE, int S>
+__device__ __forceinline__ void gated_conv1d_glu_body(const WsConvArgs& a, char* lds) {
+    typedef GluGeo<CIN, KW, BF16> GG;
     typedef typename std::conditional<BF16, __bf16, float>::type T;
     typedef typename std::conditional<BF16, bf16x8, f32x4>::type frag_t;
-    constexpr int R = BF16 ? 8 : 4;                         // k values per lane and K step (one 16-byte fragment)
-    constexpr int RPT = CIN / R;                            // runs per tap
+    constexpr int R = GG::R, RPT = GG::RPT, NU = GG::NU, NU0 = GG::NU0, K = GG::K;
     static_assert(CIN % R == 0 && (BF16 || RPT % 2 == 0), "runs of R channels inside one tap; fp32: both lane halves in the same tap");
-    constexpr int NRUN = KW * RPT, NU = (NRUN + 1) / 2;     // K steps: lane half h multiplies run 2u + h
-    constexpr int K = CIN * KW;
     constexpr int TP = 128, PADL = (KW - 1) / 2;
     constexpr int XR = 144;                                 // staged rows: TP + KW - 1 frames + the row the zero-weight pad run touches
     static_assert(TP + KW <= XR && (KW & 1), "tile + halo fits the staged rows; odd kernel width");
@@ -48,35 +107,33 @@ __global__ __launch_bounds__(256, 1) void gated_conv1d_glu_kernel(const WsConvAr
     // (112 B, conflict-free 16-byte reads across pixels); run q = (tap, quad o) starts at tap * 28 + 4 o floats.
     constexpr int CS = BF16 ? CIN : CIN + 4;
     constexpr int SLOT = (XR + 1) * CS;                     // + one dummy row for the threads that have no staging task
-    constexpr int NTASK = XR * RPT, NTPT = (NTASK + 255) / 256, NXL = NTPT * R;   // staging tasks (pixel row, run), per thread, loads per thread
-    static_assert(NXL == 16, "operand lists of the counted waits below");
-    constexpr int NST = RAW ? 12 : 4;                       // 16-byte output stores per tile and lane
-    constexpr bool OVERLAP = BF16;                          // GLU + stores of tile i-1 inside the MFMA loop of tile i
-    __shared__ __attribute__((aligned(16))) T Xs[2 * SLOT];
-    __shared__ __attribute__((aligned(16))) frag_t Wf[2 * NU * 64];
-    // per-wave 32 x 32 fp32 transposition tiles for the output planes (row = channel, stride 36 floats): the accumulators
-    // hold 4 consecutive pixels of ONE channel per lane; stored straight from there an instruction touched 32 channel rows
-    // with 32 bytes each -- 512 partial-line transactions per tile and CU, measured 2.0 us per tile against 0.64 us of MFMA
-    // time.  Through the tile an instruction writes 8 rows x 128 contiguous bytes.
-    constexpr int LDS_S = 36, NSTT = (BF16 && RAW) ? 2 : 1;
-    __shared__ __attribute__((aligned(16))) float Ss[4 * NSTT * 32 * LDS_S];
+    constexpr int NTASK = XR * RPT, NTPT = (NTASK + 511) / 512, NXL = NTPT * R;   // staging tasks (pixel row, run), per thread, loads per thread
+    static_assert(NXL == 8, "operand lists of the counted waits below");
+    constexpr int NST = RAW ? 24 : 8;                       // dword output stores per tile and lane
+    constexpr bool OVERLAP = BF16;                          // GLU + stores of tile i-1 between the MFMAs of tile i
+    constexpr bool W_LDS = !BF16 || !PRE;                   // fragment image in LDS: fp32 reads it in the K loop, un-packed bf16 bounces through it
+    constexpr int NXB = BF16 ? 2 : 1;                       // exchange buffers (fp32: one, behind a second barrier per 10-us trip)
+    typedef GluLds<CIN, KW, BF16, PRE> L;
+    static_assert(L::SLOT == SLOT && L::NXB == NXB && L::W_LDS == W_LDS, "LDS map");
+    T* const Xs = reinterpret_cast<T*>(lds);                                   // [2][SLOT]
+    frag_t* const Wf = reinterpret_cast<frag_t*>(lds + L::WF_OFF);             // [2 NU][64] (if W_LDS)
+    f32x4* const Ex = reinterpret_cast<f32x4*>(lds + L::EX_OFF);               // [buffer][sending wave][quad][lane]
 
     const int tid = threadIdx.x, lane = tid & 63;
-    const int w4 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int w8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pb = w8 & 3;
+    constexpr int kset = S;
     const int l31 = lane & 31, h = lane >> 5;
     const int g = blockIdx.z, slab = blockIdx.y;
     const int C = a.Cout >> 1;
     const int tps = (a.T + TP - 1) / TP, ntiles = a.B * tps;
     const int T4 = a.T * 4;
-    const int c = slab * 32 + l31;                          // this lane's channel (column of the MFMA tile)
-    const float bvl = a.bias ? a.bias[(long)g * a.b_gs + c] : 0.f;
-    const float bgl = a.bias ? a.bias[(long)g * a.b_gs + C + c] : 0.f;
 
     // ---- frame staging, per-thread constants: task j of a thread is (row r, run o) of EVERY tile
     unsigned goff[NTPT], ldsb[NTPT]; int rpos[NTPT];
 #pragma unroll
     for (int j = 0; j < NTPT; ++j) {
-        const int i = tid + 256 * j, o = i / XR, r = i - o * XR;
+        const int i = tid + 512 * j, o = i / XR, r = i - o * XR;
         const bool in = i < NTASK;
         goff[j] = (unsigned)((o * R * a.T + r) * 4);
         rpos[j] = in ? r : 0x40000000;                      // no task: always fails the range check below
@@ -91,9 +148,6 @@ __global__ __launch_bounds__(256, 1) void gated_conv1d_glu_kernel(const WsConvAr
         xrs_[3] = 0x00020000;
     }
     float xr0[NXL], xr1[NXL];                               // two register sets of frames in flight
-    // frames of `tile` -> a register set: R channels x NTPT rows per thread, lanes along time (coalesced); the channel's offset
-    // rides in the load's SGPR offset.  Positions outside the sample (SAME padding) and tiles past the end get an out-of-
-    // range VGPR offset: the hardware returns 0.  Always NXL load instructions.
     // tile -> (sample, tile inside the sample) without a division per trip: a cursor that advances by the workgroup's tile
     // step (tstep = qs * tps + rs, decomposed once)
     struct Cursor { int tile, b, tt; };
@@ -109,6 +163,9 @@ __global__ __launch_bounds__(256, 1) void gated_conv1d_glu_kernel(const WsConvAr
         if (c.tt < 0) { c.tt += tps; --c.b; }
         return c;
     };
+    // frames of `tile` -> a register set: R channels x NTPT rows per thread, lanes along time (coalesced); the channel's offset
+    // rides in the load's SGPR offset.  Positions outside the sample (SAME padding) and tiles past the end get an out-of-
+    // range VGPR offset: the hardware returns 0.  Always NXL load instructions.
     auto issue_loads = [&](float (&x)[NXL], const Cursor& cu) {
         const bool tv = cu.tile < ntiles;
         const int b = tv ? cu.b : 0, t0 = (tv ? cu.tt : 0) * TP - PADL;
@@ -123,14 +180,13 @@ __global__ __launch_bounds__(256, 1) void gated_conv1d_glu_kernel(const WsConvAr
     };
     // The counter retires in order: "at most N younger operations outstanding" means the register set has arrived.  The
     // compiler sees the registers pass through the asm, so no use can move above the wait.
-#define VC_XR_OPS "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]), \
-                  "+v"(x[8]), "+v"(x[9]), "+v"(x[10]), "+v"(x[11]), "+v"(x[12]), "+v"(x[13]), "+v"(x[14]), "+v"(x[15])
+#define VC_XR_OPS "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7])
     auto wait_all = [&](float (&x)[NXL]) { asm volatile("s_waitcnt vmcnt(0)" : VC_XR_OPS :: "memory"); };
     // younger operations at the point of use: the next-but-one tile's NXL loads + two tiles' output stores
-    static_assert(16 + 2 * NST == 24 || 16 + 2 * NST == 40, "the two counted waits below");
+    static_assert(NXL + 2 * NST == 24 || NXL + 2 * NST == 56, "the two counted waits below");
     auto wait_counted = [&](float (&x)[NXL]) {
-        if constexpr (NST == 4) asm volatile("s_waitcnt vmcnt(24)" : VC_XR_OPS :: "memory");
-        else asm volatile("s_waitcnt vmcnt(40)" : VC_XR_OPS :: "memory");
+        if constexpr (NST == 8) asm volatile("s_waitcnt vmcnt(24)" : VC_XR_OPS :: "memory");
+        else asm volatile("s_waitcnt vmcnt(56)" : VC_XR_OPS :: "memory");
     };
 #undef VC_XR_OPS
     // task j of a register set -> LDS slot: R values converted once, one 16-byte write
@@ -141,21 +197,70 @@ __global__ __launch_bounds__(256, 1) void gated_conv1d_glu_kernel(const WsConvAr
         for (int e = 0; e < R; ++e) f[e] = (T)x[j * R + e];
         *reinterpret_cast<frag_t*>(reinterpret_cast<char*>(slot) + ldsb[j]) = f;
     };
+    auto stage_all = [&](const float (&x)[NXL], T* slot) {
+        [&]<int... J>(std::integer_sequence<int, J...>) { (stage_task(x, std::integral_constant<int, J>{}, slot), ...); }
+            (std::make_integer_sequence<int, NTPT>{});
+    };
 
-    // ---- prologue: first tile's frames travel while the filter fragments are built
+    // ---- prologue: first tile's frames travel while the filter fragments arrive
     const int tile0 = blockIdx.x, tstep = gridDim.x;
     Cursor lcur = cursor_at(tile0);                      // next tile whose frames are requested
     issue_loads(xr0, lcur); advance(lcur);
-    {
-        // Fragment unit U = 2u + vg (K step u; value / gate): lane (channel l31, half h) holds W[k = R (2u + h) + e][channel],
-        // e < R.  Wave w builds units w, w + 4, ..: R coalesced loads each (32 channels = 128 bytes per k row), all issued
-        // before the first conversion (ONE memory round trip), one conflict-free 16-byte LDS write per unit.
-        constexpr int NB = (2 * NU + 3) / 4;
+    const char* const wimg = PRE ? (const char*)a.wimg + (long)g * a.wimg_gs + (long)slab * GG::SLAB_BYTES : nullptr;
+    // bf16: the wave's filter fragments, value and gate, of its K steps.  Pre-packed:
+    // 16-byte coalesced loads straight into the registers, in flight together with tile 0's frames.
+    constexpr bool W_REGS = BF16;
+    constexpr int NUS = S ? GG::NU1 : GG::NU0, U0 = S ? GG::NU0 : 0;
+    frag_t wv[W_REGS ? NUS : 1], wgt[W_REGS ? NUS : 1];
+    if constexpr (W_REGS && PRE) {
+        // inline asm: the gate fragments land in the ACCUMULATOR half of the register file directly (the compiler would land all of them
+        // in the VGPR half -- 128 of the wave's 256 -- and spill); retired by the wait_all below, handed to the compiler by the
+        // pins behind it.  One SGPR base per fragment unit (1 KB apart), the lane's 16 bytes in the VGPR offset.
+        const unsigned lo16 = (unsigned)lane * 16u;
+#pragma unroll
+        for (int j = 0; j < NUS; ++j) {
+            const int u = U0 + j;
+            const char* pv = wimg + (long)(2 * u) * 1024;
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(wv[j]) : "v"(lo16), "s"(pv) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=a"(wgt[j]) : "v"(lo16), "s"(pv) : "memory");
+        }
+    }
+    // the bias as the first MFMA's C operand: register i of a lane is channel row 8 (i / 4) + 4 h + i % 4.  Set 1 starts from 0.
+    f32x16 bvv, bgv;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { bvv[i] = 0.f; bgv[i] = 0.f; }
+    if constexpr (S == 0) {
+        if (a.bias) {                                       // one uniform branch around all 32 loads
+            const float* bp = a.bias + (long)g * a.b_gs + slab * 32 + 4 * h;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { bvv[i] = bp[8 * (i >> 2) + (i & 3)]; bgv[i] = bp[C + 8 * (i >> 2) + (i & 3)]; }
+        }
+    }
+    if constexpr (W_LDS && PRE) {
+        // fp32: the slab's image -> LDS as it lies (coalesced 16-byte loads, all in flight before the first write)
+        constexpr int NC = (2 * NU * 64 + 511) / 512;
+        frag_t v[NC];
+#pragma unroll
+        for (int it = 0; it < NC; ++it) {
+            const int i = tid + 512 * it;
+            v[it] = *reinterpret_cast<const frag_t*>(wimg + (long)(i < 2 * NU * 64 ? i : 0) * 16);
+        }
+#pragma unroll
+        for (int it = 0; it < NC; ++it) {
+            const int i = tid + 512 * it;
+            if (i < 2 * NU * 64) Wf[i] = v[it];
+        }
+    }
+    if constexpr (W_LDS && !PRE) {
+        // Fragment unit U = 2u + vg straight from the TF-layout filters: wave w builds units w, w + 8, ..: R coalesced loads
+        // each (32 channels = 128 bytes per k row), all issued before the first conversion (ONE memory round trip), one
+        // conflict-free 16-byte LDS write per unit.
+        constexpr int NB = (2 * NU + 7) / 8;
         const float* wg_ = a.w + (long)g * a.w_gs;
         float v[NB][R];
 #pragma unroll
         for (int it = 0; it < NB; ++it) {
-            const int U = w4 + 4 * it, u = U >> 1, vg = U & 1;
+            const int U = w8 + 8 * it, u = U >> 1, vg = U & 1;
             const int ch = (vg ? C : 0) + slab * 32 + l31;
 #pragma unroll
             for (int e = 0; e < R; ++e) {
@@ -167,7 +272,7 @@ __global__ __launch_bounds__(256, 1) void gated_conv1d_glu_kernel(const WsConvAr
         }
 #pragma unroll
         for (int it = 0; it < NB; ++it) {
-            const int U = w4 + 4 * it;
+            const int U = w8 + 8 * it;
             if (U < 2 * NU) {
                 frag_t f;
 #pragma unroll
@@ -177,249 +282,300 @@ __global__ __launch_bounds__(256, 1) void gated_conv1d_glu_kernel(const WsConvAr
         }
     }
     wait_all(xr0);
-    [&]<int... J>(std::integer_sequence<int, J...>) { (stage_task(xr0, std::integral_constant<int, J>{}, Xs), ...); }
-        (std::make_integer_sequence<int, NTPT>{});
+    if constexpr (W_REGS && PRE) {
+#pragma unroll
+        for (int j = 0; j < NUS; ++j) { asm volatile("" : "+v"(wv[j])); asm volatile("" : "+a"(wgt[j])); }
+    }
+    // the bias tuples are consumed HERE (everything issued so far has landed): a first use behind the next tile's asm loads would make
+    // the compiler's own wait for the bias loads -- it cannot see that the wait above retired them -- drain those frames too
+    if constexpr (S == 0) { asm volatile("" : "+a"(bvv)); asm volatile("" : "+a"(bgv)); }
+    stage_all(xr0, Xs);
     issue_loads(xr1, lcur); advance(lcur);
 
-    // output addressing: an accumulator quad (4 consecutive pixels of the lane's channel) goes into the wave's transposition
-    // tile; flushing a plane, lane l stores pixels 4 (l & 7) .. + 3 of rows (l >> 3) + 8 i, i < 4: 16 bytes per lane
+    // output addressing: accumulator register i of a lane is pixel l31 of channel row 8 (i / 4) + 4 h + i % 4 of the slab: the
+    // lane's byte offset carries (sample, slab, 4 h, pixel), the register's row rides in the store's SGPR offset
     const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(a.y + (long)g * a.y_gs), 0, (int)((unsigned)a.B * (unsigned)C * (unsigned)a.T * 4u), 0x00020000);
     const __amdgpu_buffer_rsrc_t rawrs = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(RAW ? a.raw + (long)g * a.raw_gs : a.y), 0, (int)((unsigned)a.B * (unsigned)a.Cout * (unsigned)a.T * 4u), 0x00020000);
     const int CT4 = C * T4;
-    // where the wave's 32 x 32 output tile of `tile` goes: the lane's byte offsets for flush row 0 (tile < 0 or past the end, or
-    // pixels past the end of the sample: invalid -> an out-of-range offset, dropped by the hardware)
-    struct OutPos { bool ok; unsigned yb, rb; };
+    // where the wave's 32 x 32 output tile of `tile` goes (tile < 0 or past the end, or pixels past the end of the sample:
+    // invalid -> an out-of-range offset, dropped by the hardware)
+    struct OutPos { unsigned yb, rb; };
     auto out_pos = [&](const Cursor& cu) {
         OutPos p;
         const bool tv = cu.tile >= 0 && cu.tile < ntiles;
         const int b = tv ? cu.b : 0;
-        const int t = (tv ? cu.tt : 0) * TP + w4 * 32 + 4 * (lane & 7), row = slab * 32 + (lane >> 3);
-        p.ok = tv && t < a.T;
-        p.yb = (unsigned)(((b * C + row) * a.T + t) * 4);
-        p.rb = (unsigned)(((b * 2 * C + row) * a.T + t) * 4);
+        const int t = (tv ? cu.tt : 0) * TP + pb * 32 + l31, row = slab * 32 + 4 * h;
+        const bool ok = tv && t < a.T;
+        p.yb = ok ? (unsigned)(((b * C + row) * a.T + t) * 4) : VC_OOB_ST;
+        p.rb = ok ? (unsigned)(((b * 2 * C + row) * a.T + t) * 4) : VC_OOB_ST;
         return p;
     };
-    float* const sw_y = Ss + (w4 * NSTT) * 32 * LDS_S;                      // GLU output plane
-    float* const sw_r = Ss + (w4 * NSTT + (NSTT - 1)) * 32 * LDS_S;         // raw value / gate planes, one after the other
-    auto put_quad = [&](float* sw, const f32x16& v, int q) {                // quad q: pixels 8 q + 4 h .. + 3 of channel row l31
-        const f32x4 x = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
-        *reinterpret_cast<f32x4*>(sw + l31 * LDS_S + 8 * q + 4 * h) = x;
-    };
-    // A plane leaves in two halves: 4 reads of the tile (lane l: pixels 4 (l & 7) .. + 3 of rows (l >> 3) + 8 i), then -- a K
-    // step later in the bf16 schedule, so that the LDS round trip hides behind MFMAs -- 4 stores, always issued.  Wave-private
-    // tile and the LDS queue is in order within a wave: no barrier between the quads' writes and these reads, nor between
-    // these reads and the next plane's writes.
-    auto read_plane = [&](const float* sw, f32x4 (&r)[4]) {
+    // dummy "tile -2" stores: with them the first trip sees the same operation count behind its frames as every other
 #pragma unroll
-        for (int i = 0; i < 4; ++i) r[i] = *reinterpret_cast<const f32x4*>(sw + ((lane >> 3) + 8 * i) * LDS_S + 4 * (lane & 7));
-    };
-    auto store_plane = [&](const f32x4 (&r)[4], __amdgpu_buffer_rsrc_t rs, unsigned base, bool ok, int plane_off) {
-        const unsigned off = ok ? base : VC_OOB_ST;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, r[i]), rs, (int)off, plane_off + i * 8 * T4, 0);
-    };
-    auto flush_plane = [&](const float* sw, __amdgpu_buffer_rsrc_t rs, unsigned base, bool ok, int plane_off) {
-        f32x4 r[4];
-        read_plane(sw, r); store_plane(r, rs, base, ok, plane_off);
-    };
-    // value * sigmoid(gate) = value * rcp(1 + exp2(-log2(e) gate)): hardware exp2 and reciprocal (1 ulp each).  One wave per
-    // SIMD means nobody covers a DEPENDENT chain (mul -> exp -> add -> rcp -> mul: the in-order wave cannot issue the next MFMA
-    // pair from behind it), so the chain is cut into STAGES applied to four values at a time: four independent instructions
-    // per stage, one stage per K step (bf16), i.e. a stage's inputs are two MFMAs old when it runs.
-    auto glu_stage = [&](const f32x16& sv, const f32x16& sg, f32x4& t, f32x16& o, int q, int st) {
+    for (int i = 0; i < NST; ++i) __builtin_amdgcn_raw_buffer_store_b32(0u, yrs, (int)VC_OOB_ST, 0, 0);
+    __syncthreads();                                        // fragment image (if any) and tile 0 are in LDS
+
+    // value * sigmoid(gate) = value * rcp(1 + exp2(-log2(e) gate)): hardware exp2 and reciprocal (1 ulp each), cut into STAGES
+    // of four independent instructions (a dependent chain would stall the in-order wave and the MFMAs behind it)
+    auto glu_stage = [&](const f32x4& sv, const f32x4& sg, f32x4& t, f32x4& o, int st) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            if (st == 0) t[j] = sg[4 * q + j] * -1.44269504f;
+            if (st == 0) t[j] = sg[j] * -1.44269504f;
             else if (st == 1) t[j] = __builtin_amdgcn_exp2f(t[j]);
             else if (st == 2) t[j] = 1.f + t[j];
             else if (st == 3) t[j] = __builtin_amdgcn_rcpf(t[j]);
-            else o[4 * q + j] = sv[4 * q + j] * t[j];
+            else o[j] = sv[j] * t[j];
         }
     };
-    auto glu_all = [&](const f32x16& sv, const f32x16& sg, f32x16& o) {     // outside the MFMA loop: the scheduler interleaves the 16 chains
-        f32x4 t[4];
-#pragma unroll
-        for (int st = 0; st < 5; ++st)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) glu_stage(sv, sg, t[q], o, q, st);
-    };
-    // a whole tile's planes, one after the other (fp32 trips, the last tile, the dummy tile): NST stores
-    auto store_tile = [&](const f32x16& sv, const f32x16& sg, const f32x16& o, const OutPos& p) {
-        if constexpr (RAW) {                                // training: the raw value / gate pair is kept for the backward pass
-#pragma unroll
-            for (int q = 0; q < 4; ++q) put_quad(sw_r, sv, q);
-            flush_plane(sw_r, rawrs, p.rb, p.ok, 0);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) put_quad(sw_r, sg, q);
-            flush_plane(sw_r, rawrs, p.rb, p.ok, CT4);
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) put_quad(sw_y, o, q);
-        flush_plane(sw_y, yrs, p.yb, p.ok, 0);
-    };
-    // dummy "tile -2" stores: with them the first trip sees the same operation count behind its frames as every other
+
     {
-        f32x16 z;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) z[r] = 0.f;
-        store_tile(z, z, z, out_pos(retreat(cursor_at(tile0))));      // tile0 - tstep < 0: every lane out of range
-    }
-    __syncthreads();                                        // filter fragments and tile 0 are in LDS
-    // bf16: value and gate fragments in registers (184 of the 512).  fp32: 360 fragment registers + accumulators + frames in
-    // flight do not fit, and a register allocator under pressure parks the in-flight frame registers in AGPRs -- which copies
-    // them BEFORE their loads have landed (tests/test_glu_isa_cpu.py caught exactly that on the first fp32 build).  fp32 is
-    // bound by its 64-cycle MFMAs (8 per K step), so it re-reads both fragments from LDS behind them: two 16-byte reads per
-    // 512 cycles of matrix work, nowhere near the LDS pipe's capacity, and ~130 registers in all.
-    constexpr bool W_REGS = BF16;
-    frag_t wv[W_REGS ? NU : 1], wgt[W_REGS ? NU : 1];
-    if constexpr (W_REGS) {
-#pragma unroll
-        for (int u = 0; u < NU; ++u) {
-            wv[u] = Wf[(2 * u) * 64 + lane];
-            wgt[u] = Wf[(2 * u + 1) * 64 + lane];
-            // Pin the gate fragments in ACCUMULATOR registers (gfx950: one 512-entry file; an MFMA reads its B operand from
-            // either half).  Left alone the allocator keeps all 184 fragment registers in the VGPR half, runs out, "spills"
-            // a third of them to AGPRs and copies each back (4 v_accvgpr_mov) in front of every use -- 8 extra issue slots
-            // per MFMA pair.  Defined through an "a" constraint they are AGPR values from the start and are used in place.
-            asm volatile("" : "+a"(wgt[u]));
-        }
-    }
+        constexpr int OWN = S ? 2 : 0, SEND = S ? 0 : 2;   // first accumulator quad (of 4) the wave finishes / hands over
+        // store rows of the wave's 8 own registers: register 4 q + r of quad OWN + q
+        const int srow0 = (8 * OWN) * T4, srow1 = (8 * (OWN + 1)) * T4;
 
-    // the bias as two constant accumulator tuples (a lane's 16 outputs are 16 pixels of ONE channel), kept in the AGPR half
-    f32x16 bvv, bgv;
+        if constexpr (W_REGS) {
+            if constexpr (!PRE) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { bvv[r] = bvl; bgv[r] = bgl; }
-    asm volatile("" : "+a"(bvv)); asm volatile("" : "+a"(bgv));
-    Cursor scur = retreat(cursor_at(tile0));             // tile whose planes the next trip stores (the first trip: a dummy in front of tile0)
-    f32x16 accv[2], accg[2];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { accv[0][r] = accv[1][r] = 0.f; accg[0][r] = accg[1][r] = 0.f; }
-
-    // One trip: multiply tile `tile` (LDS slot P) into accumulator set P (bf16) / 0 (fp32); frames of tile + 2 steps -> register
-    // set P; frames of tile + 1 step (register set P ^ 1) -> LDS slot P ^ 1; GLU + stores of the previous tile.
-    auto trip = [&](auto PC, int tile) {
-        constexpr int P = decltype(PC)::value, AC = OVERLAP ? P : 0, AP = OVERLAP ? P ^ 1 : 0;
-        float (&xp)[NXL] = P ? xr1 : xr0;                   // set that receives tile + 2 steps
-        float (&xq)[NXL] = P ? xr0 : xr1;                   // set that holds tile + 1 step
-        const T* xrow = Xs + P * SLOT + (w4 * 32 + l31) * CS + h * R;
-        T* nslot = Xs + (P ^ 1) * SLOT;
-        const OutPos pp = out_pos(scur); advance(scur);   // the previous tile's output position
-        f32x16 o;
-        if constexpr (!OVERLAP) {
-            // fp32: the K loop is 360 MFMAs of 64 cycles; the previous tile's epilogue in front of it is < 2 % of a trip
-            issue_loads(xp, lcur); advance(lcur);
-            glu_all(accv[0], accg[0], o);
-            store_tile(accv[0], accg[0], o, pp);
-        }
-        // fragment ring RD steps deep, reads pinned ahead of the MFMAs that use them
-        constexpr int RD = 3, RS = RD + 1;
-        frag_t fx[RS], fwv[W_REGS ? 1 : RS], fwg[W_REGS ? 1 : RS];
-        auto rd = [&](auto UC) {
-            constexpr int u = decltype(UC)::value;
-            if constexpr (u < NU) {
-                constexpr int off = BF16 ? 2 * R * u : (u / (RPT / 2)) * CS + (u % (RPT / 2)) * 2 * R;
-                fx[u % RS] = *reinterpret_cast<const frag_t*>(xrow + off);
-                if constexpr (!W_REGS) { fwv[u % RS] = Wf[(2 * u) * 64 + lane]; fwg[u % RS] = Wf[(2 * u + 1) * 64 + lane]; }
-            }
-        };
-        auto mm = [&](auto UC) {
-            constexpr int u = decltype(UC)::value;
-            const frag_t x_ = fx[u % RS];
-            if constexpr (BF16) {
-                // step 0 starts the accumulators at the bias: the constant tuples are its C operand (no 32 moves per tile)
-                accv[AC] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x_, wv[u], u == 0 ? bvv : accv[AC], 0, 0, 0);
-                accg[AC] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x_, wgt[u], u == 0 ? bgv : accg[AC], 0, 0, 0);
-            } else {
-                const frag_t v_ = fwv[u % RS], g_ = fwg[u % RS];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    accv[AC] = __builtin_amdgcn_mfma_f32_32x32x2f32(x_[e], v_[e], (u == 0 && e == 0) ? bvv : accv[AC], 0, 0, 0);
-                    accg[AC] = __builtin_amdgcn_mfma_f32_32x32x2f32(x_[e], g_[e], (u == 0 && e == 0) ? bgv : accg[AC], 0, 0, 0);
+                for (int j = 0; j < NUS; ++j) {
+                    wv[j] = Wf[(2 * (U0 + j)) * 64 + lane];
+                    wgt[j] = Wf[(2 * (U0 + j) + 1) * 64 + lane];
                 }
             }
-        };
-        // bf16: what rides behind the MFMAs of step u.  Step 0: the next-but-one tile's loads; steps 0-3 (training): the previous
-        // tile's raw value / gate planes through the transposition tile; steps 0-19: stage (u % 5) of its GLU quad (u / 5), the
-        // finished quad into the tile; step 20: the GLU plane back out of the tile, step 21: its stores; steps 21-22: the next
-        // tile's frames -> LDS.
-        f32x4 gt, pl[4];
-        auto side = [&](auto UC) {
-            constexpr int u = decltype(UC)::value;
-            if constexpr (OVERLAP) {
-                if constexpr (u == 0) { issue_loads(xp, lcur); advance(lcur); }
-                if constexpr (RAW) {
-                    if constexpr (u == 0) { put_quad(sw_r, accv[AP], 0); put_quad(sw_r, accv[AP], 1); put_quad(sw_r, accv[AP], 2); put_quad(sw_r, accv[AP], 3); }
-                    if constexpr (u == 1) read_plane(sw_r, pl);
-                    if constexpr (u == 2) { store_plane(pl, rawrs, pp.rb, pp.ok, 0);
-                                            put_quad(sw_r, accg[AP], 0); put_quad(sw_r, accg[AP], 1); put_quad(sw_r, accg[AP], 2); put_quad(sw_r, accg[AP], 3); }
-                    if constexpr (u == 3) read_plane(sw_r, pl);
-                    if constexpr (u == 5) store_plane(pl, rawrs, pp.rb, pp.ok, CT4);
-                }
-                if constexpr (u < 20) {
-                    glu_stage(accv[AP], accg[AP], gt, o, u / 5, u % 5);
-                    if constexpr (u % 5 == 4) put_quad(sw_y, o, u / 5);
-                }
-                if constexpr (u == 20) read_plane(sw_y, pl);
-                if constexpr (u == 21) {
-                    store_plane(pl, yrs, pp.yb, pp.ok, 0);
-                    wait_counted(xq);
-                    stage_task(xq, std::integral_constant<int, 0>{}, nslot);
-                }
-                if constexpr (u == 22) stage_task(xq, std::integral_constant<int, 1>{}, nslot);
+            // Pin the gate fragments in ACCUMULATOR registers (gfx950: one register file; an MFMA reads its A operand from either
+            // half).  Left alone the allocator keeps every fragment in the VGPR half, runs out, parks some in AGPRs and
+            // copies each back in front of every use.  Defined through an "a" constraint they are used in place.
+#pragma unroll
+            for (int j = 0; j < NUS; ++j) asm volatile("" : "+a"(wgt[j]));
+        }
+        f32x16 zero16;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) zero16[i] = 0.f;
+        Cursor scur = retreat(cursor_at(tile0));         // tile whose outputs the next trip stores (the first trip: a dummy in front of tile0)
+        f32x16 accv, accg;
+        f32x4 fv[2], fg[2];                                  // the wave's half of the previous tile, both K sets summed
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { accv[r] = 0.f; accg[r] = 0.f; }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) { fv[q] = f32x4{0.f, 0.f, 0.f, 0.f}; fg[q] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+        auto store_quad = [&](const f32x4& v, __amdgpu_buffer_rsrc_t rs, unsigned off, int srow) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float xr = v[r];                      // (a bit_cast of the vector-element lvalue itself reads element 0: clang)
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, xr), rs, (int)off, srow + r * T4, 0);
             }
         };
-        [&]<int... U>(std::integer_sequence<int, U...>) { (rd(std::integral_constant<int, U>{}), ...); }(std::make_integer_sequence<int, RD>{});
-        [&]<int... U>(std::integer_sequence<int, U...>) {
-            ((rd(std::integral_constant<int, U + RD>{}), __builtin_amdgcn_sched_barrier(0),
-              mm(std::integral_constant<int, U>{}), side(std::integral_constant<int, U>{}), __builtin_amdgcn_sched_barrier(0)), ...);
-        }(std::make_integer_sequence<int, NU>{});
-        if constexpr (!OVERLAP) {
-            wait_counted(xq);
-            [&]<int... J>(std::integer_sequence<int, J...>) { (stage_task(xq, std::integral_constant<int, J>{}, nslot), ...); }
-                (std::make_integer_sequence<int, NTPT>{});
-        }
-        __syncthreads();                                    // slot P ^ 1 is complete; slot P may be overwritten by the next trip
-    };
-    static_assert(!OVERLAP || (NU >= 23 && NTPT == 2), "the bf16 side schedule places its work on steps 0-22");
+        auto glu_all = [&](f32x4 (&o)[2]) {                  // outside the MFMA loop: the scheduler interleaves the chains
+            f32x4 t[2];
+#pragma unroll
+            for (int st = 0; st < 5; ++st)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) glu_stage(fv[q], fg[q], t[q], o[q], st);
+        };
+        auto store_tile = [&](const f32x4 (&o)[2], const OutPos& p) {        // NST stores
+            if constexpr (RAW) {                            // training: the raw value / gate pair is kept for the backward pass
+                store_quad(fv[0], rawrs, p.rb, srow0); store_quad(fv[1], rawrs, p.rb, srow1);
+                store_quad(fg[0], rawrs, p.rb, srow0 + CT4); store_quad(fg[1], rawrs, p.rb, srow1 + CT4);
+            }
+            store_quad(o[0], yrs, p.yb, srow0); store_quad(o[1], yrs, p.yb, srow1);
+        };
+        auto quad = [](const f32x16& v, int q) { return f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]}; };
 
-    int tile = tile0;
-    for (;;) {
-        if (tile >= ntiles) break;
-        trip(std::integral_constant<int, 0>{}, tile); tile += tstep;
-        if (tile >= ntiles) break;
-        trip(std::integral_constant<int, 1>{}, tile); tile += tstep;
-    }
-    // ---- the last tile's GLU + stores (its accumulators: set ((trips - 1) & 1) in bf16 mode, set 0 in fp32)
-    {
-        const int ptile = tile - tstep;
-        const int trips = (ptile - tile0) / tstep + 1;
-        const OutPos pp = out_pos(scur);
-        f32x16 o;
-        if (OVERLAP && !(trips & 1)) {
-            glu_all(accv[1], accg[1], o);
-            store_tile(accv[1], accg[1], o, pp);
-        } else {
-            glu_all(accv[0], accg[0], o);
-            store_tile(accv[0], accg[0], o, pp);
+        // One trip: multiply tile `tile` (LDS slot P); frames of tile + 2 steps -> register set P; frames of tile + 1 step
+        // (register set P ^ 1) -> LDS slot P ^ 1; GLU + stores of the wave's half of the previous tile; hand-over.
+        auto trip = [&](auto PC) {
+            constexpr int P = decltype(PC)::value;
+            float (&xp)[NXL] = P ? xr1 : xr0;               // set that receives tile + 2 steps
+            float (&xq)[NXL] = P ? xr0 : xr1;               // set that holds tile + 1 step
+            const T* xrow = Xs + P * SLOT + (pb * 32 + l31) * CS + h * R;
+            T* nslot = Xs + (P ^ 1) * SLOT;
+            const OutPos pp = out_pos(scur); advance(scur);   // the previous tile's output position
+            f32x4 o[2], gt[2];
+            if constexpr (!OVERLAP) {
+                // fp32: the K loop is 180 MFMAs of 64 cycles per wave; the previous tile's epilogue in front of it is < 2 % of a trip
+                issue_loads(xp, lcur); advance(lcur);
+                glu_all(o);
+                store_tile(o, pp);
+            }
+            // fragment ring RD steps deep, reads pinned ahead of the MFMAs that use them
+            constexpr int RD = 3, RS = RD + 1;
+            frag_t fx[RS], fwv[W_REGS ? 1 : RS], fwg[W_REGS ? 1 : RS];
+            auto rd = [&](auto JC) {
+                constexpr int j = decltype(JC)::value;
+                if constexpr (j < NUS) {
+                    constexpr int u = U0 + j;
+                    constexpr int off = BF16 ? 2 * R * u : (u / (RPT / 2)) * CS + (u % (RPT / 2)) * 2 * R;
+                    fx[j % RS] = *reinterpret_cast<const frag_t*>(xrow + off);
+                    if constexpr (!W_REGS) { fwv[j % RS] = Wf[(2 * u) * 64 + lane]; fwg[j % RS] = Wf[(2 * u + 1) * 64 + lane]; }
+                }
+            };
+            auto mm = [&](auto JC) {
+                constexpr int j = decltype(JC)::value;
+                const frag_t x_ = fx[j % RS];
+                if constexpr (BF16) {
+                    // step 0 starts the accumulators at the bias (set 0) / zero (set 1): a constant tuple is its C operand
+                    accv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv[j], x_, j == 0 ? (S ? zero16 : bvv) : accv, 0, 0, 0);
+                    accg = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wgt[j], x_, j == 0 ? (S ? zero16 : bgv) : accg, 0, 0, 0);
+                } else {
+                    const frag_t v_ = fwv[j % RS], g_ = fwg[j % RS];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        accv = __builtin_amdgcn_mfma_f32_32x32x2f32(v_[e], x_[e], (j == 0 && e == 0) ? (S ? zero16 : bvv) : accv, 0, 0, 0);
+                        accg = __builtin_amdgcn_mfma_f32_32x32x2f32(g_[e], x_[e], (j == 0 && e == 0) ? (S ? zero16 : bgv) : accg, 0, 0, 0);
+                    }
+                }
+            };
+            // bf16: what rides behind the MFMAs of step j.  Step 0: the next-but-one tile's loads; steps 1-4 (training): the
+            // previous tile's raw value / gate quads; steps 1-5: GLU stage j - 1 of both quads; steps 6-7: its stores; step 8:
+            // the next tile's frames -> LDS.
+            auto side = [&](auto JC) {
+                constexpr int j = decltype(JC)::value;
+                if constexpr (OVERLAP) {
+                    if constexpr (j == 0) { issue_loads(xp, lcur); advance(lcur); }
+                    if constexpr (RAW) {
+                        if constexpr (j == 1) store_quad(fv[0], rawrs, pp.rb, srow0);
+                        if constexpr (j == 2) store_quad(fv[1], rawrs, pp.rb, srow1);
+                        if constexpr (j == 3) store_quad(fg[0], rawrs, pp.rb, srow0 + CT4);
+                        if constexpr (j == 4) store_quad(fg[1], rawrs, pp.rb, srow1 + CT4);
+                    }
+                    if constexpr (j >= 1 && j <= 5) { glu_stage(fv[0], fg[0], gt[0], o[0], j - 1); glu_stage(fv[1], fg[1], gt[1], o[1], j - 1); }
+                    if constexpr (j == 6) store_quad(o[0], yrs, pp.yb, srow0);
+                    if constexpr (j == 7) store_quad(o[1], yrs, pp.yb, srow1);
+                    if constexpr (j == 8) { wait_counted(xq); stage_all(xq, nslot); }
+                }
+            };
+            [&]<int... J>(std::integer_sequence<int, J...>) { (rd(std::integral_constant<int, J>{}), ...); }(std::make_integer_sequence<int, RD>{});
+            [&]<int... J>(std::integer_sequence<int, J...>) {
+                ((rd(std::integral_constant<int, J + RD>{}), __builtin_amdgcn_sched_barrier(0),
+                  mm(std::integral_constant<int, J>{}), side(std::integral_constant<int, J>{}), __builtin_amdgcn_sched_barrier(0)), ...);
+            }(std::make_integer_sequence<int, NUS>{});
+            if constexpr (!OVERLAP) {
+                wait_counted(xq);
+                stage_all(xq, nslot);
+                __syncthreads();                            // the partner has read the previous tile's hand-over (single exchange buffer)
+            }
+            // hand-over: the half of the partial sums the partner finishes
+            f32x4* ex_out = Ex + (((NXB > 1 ? P : 0) * 8 + w8) * 4) * 64 + lane;
+            const f32x4* ex_in = Ex + (((NXB > 1 ? P : 0) * 8 + (w8 ^ 4)) * 4) * 64 + lane;
+            ex_out[0] = quad(accv, SEND); ex_out[64] = quad(accv, SEND + 1);
+            ex_out[128] = quad(accg, SEND); ex_out[192] = quad(accg, SEND + 1);
+            __syncthreads();                                // hand-over written; slot P ^ 1 is complete; slot P may be overwritten by the next trip
+            fv[0] = quad(accv, OWN) + ex_in[0]; fv[1] = quad(accv, OWN + 1) + ex_in[64];
+            fg[0] = quad(accg, OWN) + ex_in[128]; fg[1] = quad(accg, OWN + 1) + ex_in[192];
+        };
+        static_assert(!OVERLAP || NUS >= 9, "the bf16 side schedule places its work on steps 0-8");
+
+        int tile = tile0;
+        for (;;) {
+            if (tile >= ntiles) break;
+            trip(std::integral_constant<int, 0>{}); tile += tstep;
+            if (tile >= ntiles) break;
+            trip(std::integral_constant<int, 1>{}); tile += tstep;
+        }
+        // ---- the last tile's GLU + stores
+        {
+            const OutPos pp = out_pos(scur);
+            f32x4 o[2];
+            glu_all(o);
+            store_tile(o, pp);
         }
     }
 }
 
-// y [G][B][Cout/2][T] = GLU of the gated pair; returns -2 when the geometry is not built
-int launch_gated_conv1d_glu(const WsConvArgs& a, int cin, int kw, int math, hipStream_t s, double flops) {
-    if (cin != 24 || kw != 15 || (a.Cout & 63) || (a.T & 3)) return -2;
-    if ((long)a.B * a.Cout * a.T * 4 >= 0x7ff00000L) return -2;      // 32-bit buffer offsets; VC_OOB_ST must lie beyond every tensor
+template <int CIN, int KW, bool BF16, bool RAW, bool PRE>
+__global__ __launch_bounds__(512, 1) void gated_conv1d_glu_kernel(const WsConvArgs a) {
+    touch_kernarg(a);
+    __shared__ __attribute__((aligned(16))) char lds[GluLds<CIN, KW, BF16, PRE>::BYTES];
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 8) == 0) gated_conv1d_glu_body<CIN, KW, BF16, RAW, PRE, 0>(a, lds);
+    else gated_conv1d_glu_body<CIN, KW, BF16, RAW, PRE, 1>(a, lds);
+}
+
+// same grid, same frame and fragment-image reads, same output stores, no arithmetic: what the memory system alone allows a launch of
+// this shape (bench.py named_kernel.copy_roof; include/vc_cyclegan_testing.h: vc_prof_glu_copy_roof)
+__global__ __launch_bounds__(512, 1) void glu_copy_roof_kernel(const WsConvArgs a) {
+    constexpr int CIN = 24, TP = 128;
+    const int tid = threadIdx.x, lane = tid & 63, w8 = tid >> 6, pb = w8 & 3, kset = w8 >> 2, l31 = lane & 31, h = lane >> 5;
+    const int g = blockIdx.z, slab = blockIdx.y, C = a.Cout >> 1;
+    const int tps = (a.T + TP - 1) / TP, ntiles = a.B * tps;
+    const float* x = a.x + (long)g * a.x_gs;
+    float* y = a.y + (long)g * a.y_gs;
+    float acc = 0.f;
+    {   // the slab's fragment image: 46 KB (bf16 form), 16 bytes per lane and step
+        const f32x4* img = reinterpret_cast<const f32x4*>((const char*)a.wimg + (long)g * a.wimg_gs + (long)slab * GluGeo<24, 15, true>::SLAB_BYTES);
+        for (int i = tid; i < 46 * 64; i += 512) { const f32x4 v = img[i]; acc += v[0] + v[1] + v[2] + v[3]; }
+    }
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int b = tile / tps, tt = tile - b * tps;
+        // the tile's frames: 24 channels x 128 frames, one dword per thread and pass (lanes along time)
+        for (int i = tid; i < CIN * TP; i += 512) {
+            const int c = i >> 7, t = tt * TP + (i & 127);
+            if (t < a.T) acc += x[((long)b * CIN + c) * a.T + t];
+        }
+        const float v = acc * 1e-30f;
+        const int t = tt * TP + pb * 32 + l31;
+        if (t < a.T) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int row = slab * 32 + 8 * (2 * kset + (i >> 2)) + 4 * h + (i & 3);
+                y[((long)b * C + row) * a.T + t] = v;
+            }
+        }
+    }
+}
+
+long gated_conv1d_glu_image_bytes(int cin, int kw, int cout, int math) {
+    if (cin != 24 || kw != 15 || (cout & 63)) return -1;
+    const long slabs = cout / 64;
+    return slabs * (math == VC_MATH_BF16 ? GluGeo<24, 15, true>::SLAB_BYTES : GluGeo<24, 15, false>::SLAB_BYTES);
+}
+
+int launch_gated_conv1d_glu_prepack(const float* w, long w_gs, void* img, long img_gs_bytes, int G, int cin, int kw, int cout, int math, hipStream_t s) {
+    if (gated_conv1d_glu_image_bytes(cin, kw, cout, math) < 0) return -2;
+    const int slabs = cout / 64;
+    if (math == VC_MATH_BF16) {
+        const int n = slabs * 2 * GluGeo<24, 15, true>::NU * 64;
+        glu_prepack_kernel<24, 15, true><<<dim3((n + 255) / 256, G), dim3(256), 0, s>>>(w, w_gs, (char*)img, img_gs_bytes, cout);
+    } else {
+        const int n = slabs * 2 * GluGeo<24, 15, false>::NU * 64;
+        glu_prepack_kernel<24, 15, false><<<dim3((n + 255) / 256, G), dim3(256), 0, s>>>(w, w_gs, (char*)img, img_gs_bytes, cout);
+    }
+    VC_HIP(hipGetLastError());
+    return 0;
+}
+
+static bool glu_grid(const WsConvArgs& a, int cin, int kw, dim3* grid) {
+    if (cin != 24 || kw != 15 || (a.Cout & 63) || (a.T & 3)) return false;
+    if ((long)a.B * a.Cout * a.T * 4 >= 0x7ff00000L) return false;   // 32-bit buffer offsets; VC_OOB_ST must lie beyond every tensor
     const int C = a.Cout / 2, slabs = C / 32;
     const int ntiles = a.B * ((a.T + 127) / 128);
     int parts = 256 / (slabs * a.G); if (parts < 1) parts = 1; if (parts > ntiles) parts = ntiles;   // one workgroup per CU, persistent over its tiles
-    dim3 grid(parts, slabs, a.G);
+    *grid = dim3(parts, slabs, a.G);
+    return true;
+}
+
+// y [G][B][Cout/2][T] = GLU of the gated pair; a.wimg != null: the filters as a pre-packed fragment image of `math`; returns -2
+// when the geometry is not built
+int launch_gated_conv1d_glu(const WsConvArgs& a, int cin, int kw, int math, hipStream_t s, double flops) {
+    dim3 grid;
+    if (!glu_grid(a, cin, kw, &grid)) return -2;
     ProfScope ps(2, flops, s);
-#define VC_GLU(BF) { if (a.raw) gated_conv1d_glu_kernel<24, 15, BF, true><<<grid, dim3(256), 0, s>>>(a); \
-                     else gated_conv1d_glu_kernel<24, 15, BF, false><<<grid, dim3(256), 0, s>>>(a); }
+#define VC_GLU2(BF, RW) { if (a.wimg) gated_conv1d_glu_kernel<24, 15, BF, RW, true><<<grid, dim3(512), 0, s>>>(a); \
+                          else gated_conv1d_glu_kernel<24, 15, BF, RW, false><<<grid, dim3(512), 0, s>>>(a); }
+#define VC_GLU(BF) { if (a.raw) VC_GLU2(BF, true) else VC_GLU2(BF, false) }
     if (math == VC_MATH_BF16) VC_GLU(true) else VC_GLU(false)
 #undef VC_GLU
+#undef VC_GLU2
+    VC_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_glu_copy_roof(const WsConvArgs& a, int cin, int kw, hipStream_t s) {
+    dim3 grid;
+    if (!glu_grid(a, cin, kw, &grid) || !a.wimg) return -2;
+    ProfScope ps(2, 0.0, s);
+    glu_copy_roof_kernel<<<grid, dim3(512), 0, s>>>(a);
     VC_HIP(hipGetLastError());
     return 0;
 }

@@ -165,10 +165,16 @@ struct WsConvArgs {
     long x_gs, w_gs, b_gs, y_gs;          // signed group strides (floats)
     int B, T, Cout, G;
     float* raw; long raw_gs;              // gated_conv1d_glu only, optional: the raw (value, gate) pair [G][B][Cout][T] for a backward pass
+    const void* wimg; long wimg_gs;       // gated_conv1d_glu only, optional: the filters as a pre-packed fragment image (group stride in BYTES); w unused then
 };
 int launch_wsconv1d(const WsConvArgs& a, int cin, int kw, int math, hipStream_t s, double flops);   // returns -2 when the geometry is not built
 // the whole gated block in one kernel: y [G][B][Cout/2][T] = (conv_v + b_v) * sigmoid(conv_g + b_g); -2 when not built
 int launch_gated_conv1d_glu(const WsConvArgs& a, int cin, int kw, int math, hipStream_t s, double flops);
+// the fragment image of a gated filter pair w [kw][cin][cout] for `math` (fp32 / bf16): bytes per group (-1: geometry not built), builder
+long gated_conv1d_glu_image_bytes(int cin, int kw, int cout, int math);
+int launch_gated_conv1d_glu_prepack(const float* w, long w_gs, void* img, long img_gs_bytes, int G, int cin, int kw, int cout, int math, hipStream_t s);
+// measurement control: the launch of the gated kernel with its memory operations only (a.wimg = a bf16 image, a.y written)
+int launch_glu_copy_roof(const WsConvArgs& a, int cin, int kw, hipStream_t s);
 
 struct NormArgs {
     const float* y; const float* res; const float* gamma; const float* beta;

@@ -471,6 +471,37 @@ extern "C" int vc_gated_conv1d_glu_fwd(const float* x, int64_t x_gs, const float
     VC_ARG(r != -2, "vc_gated_conv1d_glu_fwd: built for Cin = 24, k = 15, Cout2 %% 64 == 0, T %% 4 == 0, tensors < 2 GiB (the generator's h1 block)");
     return r;
 }
+extern "C" int64_t vc_gated_conv1d_glu_image_bytes(int Cin, int k, int Cout2) {
+    return gated_conv1d_glu_image_bytes(Cin, k, Cout2, vc_thread_math() == VC_MATH_BF16 ? VC_MATH_BF16 : VC_MATH_FP32);
+}
+extern "C" int vc_gated_conv1d_glu_prepack(const float* w, int64_t w_gs, void* image, int64_t image_gs_bytes,
+                                           int G, int Cin, int k, int Cout2, void* stream) {
+    VC_ARG(w && image && G > 0, "vc_gated_conv1d_glu_prepack: bad args");
+    VC_ARG(aligned16(image) && image_gs_bytes % 16 == 0, "vc_gated_conv1d_glu_prepack: image must be 16-byte aligned");
+    const int math = vc_thread_math() == VC_MATH_BF16 ? VC_MATH_BF16 : VC_MATH_FP32;
+    const int r = launch_gated_conv1d_glu_prepack(w, w_gs, image, image_gs_bytes, G, Cin, k, Cout2, math, (hipStream_t)stream);
+    VC_ARG(r != -2, "vc_gated_conv1d_glu_prepack: built for Cin = 24, k = 15, Cout2 %% 64 == 0");
+    return r;
+}
+extern "C" int vc_gated_conv1d_glu_fwd_packed(const float* x, int64_t x_gs, const void* image, int64_t image_gs_bytes,
+                                              const float* bias, int64_t b_gs, float* out, int64_t out_gs,
+                                              int G, int B, int Cin, int T, int Cout2, int k, void* stream) {
+    VC_ARG(x && image && out && G > 0 && B > 0 && Cin > 0 && T > 0 && Cout2 > 0 && k > 0, "vc_gated_conv1d_glu_fwd_packed: bad args");
+    VC_ARG(aligned16(image) && image_gs_bytes % 16 == 0, "vc_gated_conv1d_glu_fwd_packed: image must be 16-byte aligned");
+    WsConvArgs c{}; c.x = x; c.wimg = image; c.wimg_gs = image_gs_bytes; c.bias = bias; c.y = out; c.x_gs = x_gs; c.b_gs = b_gs; c.y_gs = out_gs;
+    c.B = B; c.T = T; c.Cout = Cout2; c.G = G;
+    const int math = vc_thread_math() == VC_MATH_BF16 ? VC_MATH_BF16 : VC_MATH_FP32;
+    const int r = launch_gated_conv1d_glu(c, Cin, k, math, (hipStream_t)stream, 2.0 * G * B * T * (double)Cout2 * k * Cin);
+    VC_ARG(r != -2, "vc_gated_conv1d_glu_fwd_packed: built for Cin = 24, k = 15, Cout2 %% 64 == 0, T %% 4 == 0, tensors < 2 GiB (the generator's h1 block)");
+    return r;
+}
+extern "C" int vc_prof_glu_copy_roof(const float* x, const void* image_bf16, float* out, int B, int T, int Cout2, void* stream) {
+    VC_ARG(x && image_bf16 && out, "vc_prof_glu_copy_roof: bad args");
+    WsConvArgs c{}; c.x = x; c.wimg = image_bf16; c.y = out; c.B = B; c.T = T; c.Cout = Cout2; c.G = 1;
+    const int r = launch_glu_copy_roof(c, 24, 15, (hipStream_t)stream);
+    VC_ARG(r != -2, "vc_prof_glu_copy_roof: geometry not built");
+    return r;
+}
 extern "C" int vc_bias_grad(const float* dy, int64_t dy_gs, float* db, int64_t db_gs,
                             int G, int B, int C, int L, void* stream) {
     VC_ARG(dy && db, "vc_bias_grad: bad args");

@@ -238,9 +238,12 @@ extern "C" int vc_train_step_graph(vc_plan* p, float* params, float* grads, floa
     VC_ARG(p && params && grads && m && v && A && Bm && losses && ws && batch > 0, "vc_train_step_graph: bad args");
     VC_ARG(!p->inference, "this plan was created for inference only (vc_plan_create_inference)");
     hipStream_t user = (hipStream_t)stream;
+    // the key carries the CALLER's overlap setting: the capture below masks use_side, and a key built from the masked value would never
+    // match the next call's lookup (every graph step re-captured)
+    const int overlap_key = p->use_side & 7;
     auto make_key = [&]() {
         return std::array<const void*, 12>{params, grads, m, v, A, Bm, losses, gen_A, gen_B, ws,
-                                           (const void*)(intptr_t)(batch * 16 + (lambda_identity == 0.0f ? 1 : 0) * 8 + (p->use_side & 7)),
+                                           (const void*)(intptr_t)(batch * 16 + (lambda_identity == 0.0f ? 1 : 0) * 8 + overlap_key),
                                            (const void*)(intptr_t)(p->math + 16 * p->det +
                                                                    64 * ws_generation({p->gstream, p->side, p->wstream, p->wstream_d, p->ustream}))};
     };
@@ -291,6 +294,7 @@ extern "C" int vc_train_step_graph(vc_plan* p, float* params, float* grads, floa
     return 0;
 }
 
+extern "C" int vc_plan_num_step_graphs(const vc_plan* p) { return p ? (int)p->graphs.size() : -1; }
 extern "C" int vc_plan_set_overlap(vc_plan* p, int enabled) {
     VC_ARG(p, "vc_plan_set_overlap: bad plan");
     p->use_side = enabled == 1 ? 7 : ((enabled >> 3) & 7);   // 0 / 1: the documented switch; 8 * bits selects single mechanisms (debugging)
