@@ -41,5 +41,5 @@ for math in ('bf16', 'fp32'):
                 o = out[16 * slot:16 * slot + 16]
                 n, tr = max(o[5], 1), max(o[6], 1)
                 ghz = o[7] / max(o[8], 1) / 10.0
-                print('   wg %s set %d: clock %.2f GHz  kernel %6.0f cyc (%.2f us) | prologue %5.0f | per trip (%4.1f): K loop %5.0f  hand-over+barrier %4.0f  sum %4.0f | tail %5.0f' % (
+                print('   wg %s set %d: clock %.2f GHz  kernel %6.0f cyc (%.2f us) | prologue %5.0f | per trip (%4.1f): K loop %5.0f  hand-over out %4.0f  barrier %4.0f | tail %5.0f' % (
                     'first' if slot < 2 else 'last ', slot & 1, ghz, o[7] / n, o[8] / n * 0.01, o[0] / n, o[6] / n, o[1] / tr, o[2] / tr, o[3] / tr, o[4] / n), flush=True)

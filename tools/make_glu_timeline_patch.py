@@ -21,8 +21,8 @@ def main():
     s = sub(s, '// LDS map of the kernel (one allocation, shared by the two bodies)\n',
             '''#ifdef VC_GLU_TIMELINE
 // slot = 2 * which + S (which: 0 = workgroup (0,0,0), 1 = the last workgroup of the grid; S: K set, lane 0 of waves 0 / 4); per slot:
-// [0] entry -> prologue barrier passed, [1] sum over trips: start -> K loop done, [2] sum: -> hand-over barrier passed, [3] sum: ->
-// trip end, [4] loop end -> kernel end, [5] launches, [6] trips, [7] kernel cycles, [8] kernel real-time ticks (100 MHz)
+// [0] entry -> prologue barrier passed, [1] sum over trips: start -> K loop done, [2] sum: -> hand-over out, own half copied, [3] sum: ->
+// barrier passed, [4] loop end -> kernel end, [5] launches, [6] trips, [7] kernel cycles, [8] kernel real-time ticks (100 MHz)
 __device__ unsigned long long g_glu_tl[4][16];
 extern "C" int vc_debug_glu_timeline(unsigned long long* out, int reset) {
     if (reset) { unsigned long long z[4][16] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_glu_tl), z, sizeof z); return 0; }
@@ -46,19 +46,15 @@ extern "C" int vc_debug_glu_timeline(unsigned long long* out, int reset) {
 ''')
     s = sub(s, '    __syncthreads();                                        // fragment image (if any) and tile 0 are in LDS\n',
             '    __syncthreads();                                        // fragment image (if any) and tile 0 are in LDS\n    VC_GTL(tl1 = __builtin_readcyclecounter());\n')
-    s = sub(s, '            const OutPos pp = out_pos(scur); advance(scur);   // the previous tile\'s output position\n            f32x4 o[2], gt[2];\n',
-            '            VC_GTL(ta = __builtin_readcyclecounter());\n            const OutPos pp = out_pos(scur); advance(scur);   // the previous tile\'s output position\n            f32x4 o[2], gt[2];\n')
-    s = sub(s, '            // hand-over: the half of the partial sums the partner finishes\n',
-            '            VC_GTL(tb = __builtin_readcyclecounter());\n            // hand-over: the half of the partial sums the partner finishes\n')
+    s = sub(s, '            const OutPos pp = out_pos(scur); advance(scur);   // the previous tile\'s output position\n',
+            '            VC_GTL(ta = __builtin_readcyclecounter());\n            const OutPos pp = out_pos(scur); advance(scur);   // the previous tile\'s output position\n')
+    s = sub(s, '            // hand-over: the half of the partial sums the partner finishes goes to LDS',
+            '            VC_GTL(tb = __builtin_readcyclecounter());\n            // hand-over: the half of the partial sums the partner finishes goes to LDS')
     s = sub(s, '            __syncthreads();                                // hand-over written; slot P ^ 1 is complete; slot P may be overwritten by the next trip\n',
-            '            __syncthreads();                                // hand-over written; slot P ^ 1 is complete; slot P may be overwritten by the next trip\n            VC_GTL(tc = __builtin_readcyclecounter());\n')
-    s = sub(s, '            fg[0] = quad(accg, OWN) + ex_in[128]; fg[1] = quad(accg, OWN + 1) + ex_in[192];\n',
-            '            fg[0] = quad(accg, OWN) + ex_in[128]; fg[1] = quad(accg, OWN + 1) + ex_in[192];\n            VC_GTL(sa += tb - ta; sb += tc - tb; sc += __builtin_readcyclecounter() - tc; ++ntr);\n')
-    s = sub(s, '        // ---- the last tile\'s GLU + stores\n', '        VC_GTL(tl3 = __builtin_readcyclecounter());\n        // ---- the last tile\'s GLU + stores\n')
-    s = sub(s, '            glu_all(o);\n            store_tile(o, pp);\n        }\n    }\n}\n',
-            '''            glu_all(o);
-            store_tile(o, pp);
-        }
+            '            VC_GTL(tc = __builtin_readcyclecounter());\n            __syncthreads();                                // hand-over written; slot P ^ 1 is complete; slot P may be overwritten by the next trip\n            VC_GTL(sa += tb - ta; sb += tc - tb; sc += __builtin_readcyclecounter() - tc; ++ntr);\n')
+    s = sub(s, '        // ---- the last tile: the partner\'s half lies in the buffer of the last trip\'s parity\n', '        VC_GTL(tl3 = __builtin_readcyclecounter());\n        // ---- the last tile: the partner\'s half lies in the buffer of the last trip\'s parity\n')
+    s = sub(s, '        if constexpr (S == 1) __builtin_amdgcn_s_setprio(0);\n    }\n}\n',
+            '''        if constexpr (S == 1) __builtin_amdgcn_s_setprio(0);
     }
 #ifdef VC_GLU_TIMELINE
     if (tl_on) {

@@ -7,8 +7,8 @@
 // value + 32 gate channels and a stream of 128-pixel tiles:
 //   * EIGHT waves, two per SIMD, split the K axis (round 4: four waves, one per SIMD, 184 filter registers each; counters:
 //     ~6.5 other instructions between two MFMAs of the lone in-order wave, matrix pipe 38 % busy).  Wave (pb, S): pixel
-//     block pb of the tile, K steps of set S (12 / 11 of the 23 bf16 steps).  The FILTERS of its K steps are the MFMA's A
-//     operand and live in REGISTERS for the life of the workgroup (96 / 88 of the wave's 256); the FRAMES are the B operand,
+//     block pb of the tile, K steps of set S (11 / 12 of the 23 bf16 steps).  The FILTERS of its K steps are the MFMA's A
+//     operand and live in REGISTERS for the life of the workgroup (88 / 96 of the wave's 256); the FRAMES are the B operand,
 //     one ds_read_b128 per MFMA pair, out of a pixel-major LDS tile ([pixel][24 cin], 48-byte rows: run q of 8 consecutive
 //     k starts 16 q bytes after the pixel's row start because consecutive taps are consecutive rows; writes and fragment
 //     reads conflict-free).  Operand reuse is the round-4 kernel's: every frame fragment and every filter fragment is read
@@ -46,7 +46,7 @@ template <int CIN, int KW, bool BF16> struct GluGeo {
     static constexpr int R = BF16 ? 8 : 4;                 // k values per lane and K step (one 16-byte fragment)
     static constexpr int RPT = CIN / R;                    // runs per tap
     static constexpr int NRUN = KW * RPT, NU = (NRUN + 1) / 2;   // K steps: lane half h multiplies run 2u + h
-    static constexpr int NU0 = (NU + 1) / 2, NU1 = NU - NU0;     // K steps of wave set 0 / 1
+    static constexpr int NU0 = NU / 2, NU1 = NU - NU0;           // K steps of wave set 0 / 1 (set 0, which also carries the bias tuples, gets the smaller share)
     static constexpr int K = CIN * KW;
     static constexpr long SLAB_BYTES = 2L * NU * 64 * 16;  // fragment unit U = 2u + vg: 64 lanes x 16 bytes
 };
@@ -98,7 +98,7 @@ __device__ __forceinline__ void gated_conv1d_glu_body(const WsConvArgs& a, char*
     typedef GluGeo<CIN, KW, BF16> GG;
     typedef typename std::conditional<BF16, __bf16, float>::type T;
     typedef typename std::conditional<BF16, bf16x8, f32x4>::type frag_t;
-    constexpr int R = GG::R, RPT = GG::RPT, NU = GG::NU, NU0 = GG::NU0, K = GG::K;
+    constexpr int R = GG::R, RPT = GG::RPT, NU = GG::NU, K = GG::K;
     static_assert(CIN % R == 0 && (BF16 || RPT % 2 == 0), "runs of R channels inside one tap; fp32: both lane halves in the same tap");
     constexpr int TP = 128, PADL = (KW - 1) / 2;
     constexpr int XR = 144;                                 // staged rows: TP + KW - 1 frames + the row the zero-weight pad run touches
@@ -122,7 +122,6 @@ __device__ __forceinline__ void gated_conv1d_glu_body(const WsConvArgs& a, char*
     const int tid = threadIdx.x, lane = tid & 63;
     const int w8 = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pb = w8 & 3;
-    constexpr int kset = S;
     const int l31 = lane & 31, h = lane >> 5;
     const int g = blockIdx.z, slab = blockIdx.y;
     const int C = a.Cout >> 1;
@@ -212,6 +211,8 @@ __device__ __forceinline__ void gated_conv1d_glu_body(const WsConvArgs& a, char*
     constexpr bool W_REGS = BF16;
     constexpr int NUS = S ? GG::NU1 : GG::NU0, U0 = S ? GG::NU0 : 0;
     frag_t wv[W_REGS ? NUS : 1], wgt[W_REGS ? NUS : 1];
+    constexpr int NVV = NUS - 4;                            // value fragments [NVV, NUS) live in the accumulator half as well: the VGPR half (128 of the
+                                                            // wave's 256) also holds the frames in flight, the fragment ring and the previous tile's GLU
     if constexpr (W_REGS && PRE) {
         // inline asm: the gate fragments land in the ACCUMULATOR half of the register file directly (the compiler would land all of them
         // in the VGPR half -- 128 of the wave's 256 -- and spill); retired by the wait_all below, handed to the compiler by the
@@ -221,7 +222,8 @@ __device__ __forceinline__ void gated_conv1d_glu_body(const WsConvArgs& a, char*
         for (int j = 0; j < NUS; ++j) {
             const int u = U0 + j;
             const char* pv = wimg + (long)(2 * u) * 1024;
-            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(wv[j]) : "v"(lo16), "s"(pv) : "memory");
+            if (j < NVV) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(wv[j]) : "v"(lo16), "s"(pv) : "memory");
+            else asm volatile("global_load_dwordx4 %0, %1, %2" : "=a"(wv[j]) : "v"(lo16), "s"(pv) : "memory");
             asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=a"(wgt[j]) : "v"(lo16), "s"(pv) : "memory");
         }
     }
@@ -284,7 +286,10 @@ __device__ __forceinline__ void gated_conv1d_glu_body(const WsConvArgs& a, char*
     wait_all(xr0);
     if constexpr (W_REGS && PRE) {
 #pragma unroll
-        for (int j = 0; j < NUS; ++j) { asm volatile("" : "+v"(wv[j])); asm volatile("" : "+a"(wgt[j])); }
+        for (int j = 0; j < NUS; ++j) {
+            if (j < NVV) asm volatile("" : "+v"(wv[j])); else asm volatile("" : "+a"(wv[j]));
+            asm volatile("" : "+a"(wgt[j]));
+        }
     }
     // the bias tuples are consumed HERE (everything issued so far has landed): a first use behind the next tile's asm loads would make
     // the compiler's own wait for the bias loads -- it cannot see that the wait above retired them -- drain those frames too
@@ -319,14 +324,14 @@ __device__ __forceinline__ void gated_conv1d_glu_body(const WsConvArgs& a, char*
 
     // value * sigmoid(gate) = value * rcp(1 + exp2(-log2(e) gate)): hardware exp2 and reciprocal (1 ulp each), cut into STAGES
     // of four independent instructions (a dependent chain would stall the in-order wave and the MFMAs behind it)
-    auto glu_stage = [&](const f32x4& sv, const f32x4& sg, f32x4& t, f32x4& o, int st) {
+    auto glu_stage = [&](const f32x4& sv, const f32x4& sg, f32x4& t, int st) {     // the result replaces t
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if (st == 0) t[j] = sg[j] * -1.44269504f;
             else if (st == 1) t[j] = __builtin_amdgcn_exp2f(t[j]);
             else if (st == 2) t[j] = 1.f + t[j];
             else if (st == 3) t[j] = __builtin_amdgcn_rcpf(t[j]);
-            else o[j] = sv[j] * t[j];
+            else t[j] = sv[j] * t[j];
         }
     };
 
@@ -347,18 +352,27 @@ __device__ __forceinline__ void gated_conv1d_glu_body(const WsConvArgs& a, char*
             // half).  Left alone the allocator keeps every fragment in the VGPR half, runs out, parks some in AGPRs and
             // copies each back in front of every use.  Defined through an "a" constraint they are used in place.
 #pragma unroll
-            for (int j = 0; j < NUS; ++j) asm volatile("" : "+a"(wgt[j]));
+            for (int j = 0; j < NUS; ++j) {
+                asm volatile("" : "+a"(wgt[j]));
+                if (j >= NVV) asm volatile("" : "+a"(wv[j]));
+            }
         }
         f32x16 zero16;
 #pragma unroll
         for (int i = 0; i < 16; ++i) zero16[i] = 0.f;
         Cursor scur = retreat(cursor_at(tile0));         // tile whose outputs the next trip stores (the first trip: a dummy in front of tile0)
         f32x16 accv, accg;
-        f32x4 fv[2], fg[2];                                  // the wave's half of the previous tile, both K sets summed
+        // the wave's own half of the previous tile's partial sums (copied out of the accumulators behind the K loop); the partner's
+        // contribution waits in the exchange buffer and is added inside the NEXT trip, between its MFMAs
+        f32x4 ownv[2], owng[2];
 #pragma unroll
         for (int r = 0; r < 16; ++r) { accv[r] = 0.f; accg[r] = 0.f; }
 #pragma unroll
-        for (int q = 0; q < 2; ++q) { fv[q] = f32x4{0.f, 0.f, 0.f, 0.f}; fg[q] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        for (int q = 0; q < 2; ++q) { ownv[q] = f32x4{0.f, 0.f, 0.f, 0.f}; owng[q] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        // The second-dispatched half of the workgroup (waves 4-7 = K set 1) loses every issue arbitration against its older partner
+        // on the same SIMD (measured: set 0 finished its K loop after 1430 cycles and then idled 1240 at the barrier while set 1
+        // needed 2150): raise it once, no per-segment flips (MI355X_MICROARCH.md, two waves per SIMD, item 4).
+        if constexpr (S == 1) __builtin_amdgcn_s_setprio(1);
 
         auto store_quad = [&](const f32x4& v, __amdgpu_buffer_rsrc_t rs, unsigned off, int srow) {
 #pragma unroll
@@ -367,24 +381,26 @@ __device__ __forceinline__ void gated_conv1d_glu_body(const WsConvArgs& a, char*
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, xr), rs, (int)off, srow + r * T4, 0);
             }
         };
-        auto glu_all = [&](f32x4 (&o)[2]) {                  // outside the MFMA loop: the scheduler interleaves the chains
-            f32x4 t[2];
+        auto quad = [](const f32x16& v, int q) { return f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]}; };
+        // exchange buffer of trip parity P: [sending wave][quad: value 0, value 1, gate 0, gate 1][lane]
+        auto ex_of = [&](int P, int wave) { return Ex + (((NXB > 1 ? P : 0) * 8 + wave) * 4) * 64 + lane; };
+        // previous tile, finished outside the MFMA loop (fp32 trips, the last tile): partner's half + own half, GLU, NST stores
+        auto finish_tile = [&](const f32x4* ex_in, const OutPos& p) {
+            f32x4 fv[2], fg[2], t[2];
+            fv[0] = ownv[0] + ex_in[0]; fv[1] = ownv[1] + ex_in[64]; fg[0] = owng[0] + ex_in[128]; fg[1] = owng[1] + ex_in[192];
 #pragma unroll
             for (int st = 0; st < 5; ++st)
 #pragma unroll
-                for (int q = 0; q < 2; ++q) glu_stage(fv[q], fg[q], t[q], o[q], st);
-        };
-        auto store_tile = [&](const f32x4 (&o)[2], const OutPos& p) {        // NST stores
+                for (int q = 0; q < 2; ++q) glu_stage(fv[q], fg[q], t[q], st);
             if constexpr (RAW) {                            // training: the raw value / gate pair is kept for the backward pass
                 store_quad(fv[0], rawrs, p.rb, srow0); store_quad(fv[1], rawrs, p.rb, srow1);
                 store_quad(fg[0], rawrs, p.rb, srow0 + CT4); store_quad(fg[1], rawrs, p.rb, srow1 + CT4);
             }
-            store_quad(o[0], yrs, p.yb, srow0); store_quad(o[1], yrs, p.yb, srow1);
+            store_quad(t[0], yrs, p.yb, srow0); store_quad(t[1], yrs, p.yb, srow1);
         };
-        auto quad = [](const f32x16& v, int q) { return f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]}; };
 
         // One trip: multiply tile `tile` (LDS slot P); frames of tile + 2 steps -> register set P; frames of tile + 1 step
-        // (register set P ^ 1) -> LDS slot P ^ 1; GLU + stores of the wave's half of the previous tile; hand-over.
+        // (register set P ^ 1) -> LDS slot P ^ 1; the previous tile's hand-over, GLU and stores; this tile's hand-over out.
         auto trip = [&](auto PC) {
             constexpr int P = decltype(PC)::value;
             float (&xp)[NXL] = P ? xr1 : xr0;               // set that receives tile + 2 steps
@@ -392,12 +408,14 @@ __device__ __forceinline__ void gated_conv1d_glu_body(const WsConvArgs& a, char*
             const T* xrow = Xs + P * SLOT + (pb * 32 + l31) * CS + h * R;
             T* nslot = Xs + (P ^ 1) * SLOT;
             const OutPos pp = out_pos(scur); advance(scur);   // the previous tile's output position
-            f32x4 o[2], gt[2];
+            const f32x4* ex_in = ex_of(P ^ 1, w8 ^ 4);       // what the partner handed over behind the previous trip's K loop (first trip: never
+                                                            // written -- whatever it holds goes to an out-of-range store offset)
+            f32x4 xin[2], fv[2], fg[2], gt[2];
             if constexpr (!OVERLAP) {
                 // fp32: the K loop is 180 MFMAs of 64 cycles per wave; the previous tile's epilogue in front of it is < 2 % of a trip
                 issue_loads(xp, lcur); advance(lcur);
-                glu_all(o);
-                store_tile(o, pp);
+                finish_tile(ex_in, pp);
+                __syncthreads();                            // single exchange buffer: every wave has read the previous hand-over before this trip's overwrites it
             }
             // fragment ring RD steps deep, reads pinned ahead of the MFMAs that use them
             constexpr int RD = 3, RS = RD + 1;
@@ -411,14 +429,14 @@ __device__ __forceinline__ void gated_conv1d_glu_body(const WsConvArgs& a, char*
                     if constexpr (!W_REGS) { fwv[j % RS] = Wf[(2 * u) * 64 + lane]; fwg[j % RS] = Wf[(2 * u + 1) * 64 + lane]; }
                 }
             };
-            auto mm = [&](auto JC) {
-                constexpr int j = decltype(JC)::value;
+            // step 0 starts the accumulators at the bias (set 0) / zero (set 1): a constant tuple is its C operand
+            auto mm = [&](auto JC, auto HC) {                // HC: 0 = the value MFMA(s) of step j, 1 = the gate MFMA(s)
+                constexpr int j = decltype(JC)::value, half = decltype(HC)::value;
                 const frag_t x_ = fx[j % RS];
                 if constexpr (BF16) {
-                    // step 0 starts the accumulators at the bias (set 0) / zero (set 1): a constant tuple is its C operand
-                    accv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv[j], x_, j == 0 ? (S ? zero16 : bvv) : accv, 0, 0, 0);
-                    accg = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wgt[j], x_, j == 0 ? (S ? zero16 : bgv) : accg, 0, 0, 0);
-                } else {
+                    if constexpr (half == 0) accv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv[j], x_, j == 0 ? (S ? zero16 : bvv) : accv, 0, 0, 0);
+                    else accg = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wgt[j], x_, j == 0 ? (S ? zero16 : bgv) : accg, 0, 0, 0);
+                } else if constexpr (half == 0) {
                     const frag_t v_ = fwv[j % RS], g_ = fwg[j % RS];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -427,60 +445,60 @@ __device__ __forceinline__ void gated_conv1d_glu_body(const WsConvArgs& a, char*
                     }
                 }
             };
-            // bf16: what rides behind the MFMAs of step j.  Step 0: the next-but-one tile's loads; steps 1-4 (training): the
-            // previous tile's raw value / gate quads; steps 1-5: GLU stage j - 1 of both quads; steps 6-7: its stores; step 8:
-            // the next tile's frames -> LDS.
-            auto side = [&](auto JC) {
-                constexpr int j = decltype(JC)::value;
+            // bf16: what rides behind the value MFMA (half 0) and the gate MFMA (half 1) of step j -- four instructions or so each, so
+            // that neither wave of the SIMD holds the issue port for long.  Step 0: the next-but-one tile's loads; 1-3: the partner's
+            // half of the previous tile out of the exchange buffer + the own half (value, then gate, through the same registers);
+            // 4-8: GLU stage j - 4 (quad 0 | quad 1); 4-5 (training): raw value / gate stores; 9: output stores; 10: the next
+            // tile's frames -> LDS.
+            auto side = [&](auto JC, auto HC) {
+                constexpr int j = decltype(JC)::value, half = decltype(HC)::value;
                 if constexpr (OVERLAP) {
-                    if constexpr (j == 0) { issue_loads(xp, lcur); advance(lcur); }
+                    if constexpr (j == 0 && half == 0) { issue_loads(xp, lcur); advance(lcur); }
+                    if constexpr (j == 1 && half == 0) { xin[0] = ex_in[0]; xin[1] = ex_in[64]; }
+                    if constexpr (j == 2 && half == 0) { fv[0] = ownv[0] + xin[0]; fv[1] = ownv[1] + xin[1]; }
+                    if constexpr (j == 2 && half == 1) { xin[0] = ex_in[128]; xin[1] = ex_in[192]; }
+                    if constexpr (j == 3 && half == 1) { fg[0] = owng[0] + xin[0]; fg[1] = owng[1] + xin[1]; }
                     if constexpr (RAW) {
-                        if constexpr (j == 1) store_quad(fv[0], rawrs, pp.rb, srow0);
-                        if constexpr (j == 2) store_quad(fv[1], rawrs, pp.rb, srow1);
-                        if constexpr (j == 3) store_quad(fg[0], rawrs, pp.rb, srow0 + CT4);
-                        if constexpr (j == 4) store_quad(fg[1], rawrs, pp.rb, srow1 + CT4);
+                        if constexpr (j == 4) store_quad(fv[half], rawrs, pp.rb, half ? srow1 : srow0);
+                        if constexpr (j == 5) store_quad(fg[half], rawrs, pp.rb, (half ? srow1 : srow0) + CT4);
                     }
-                    if constexpr (j >= 1 && j <= 5) { glu_stage(fv[0], fg[0], gt[0], o[0], j - 1); glu_stage(fv[1], fg[1], gt[1], o[1], j - 1); }
-                    if constexpr (j == 6) store_quad(o[0], yrs, pp.yb, srow0);
-                    if constexpr (j == 7) store_quad(o[1], yrs, pp.yb, srow1);
-                    if constexpr (j == 8) { wait_counted(xq); stage_all(xq, nslot); }
+                    if constexpr (j >= 4 && j <= 8) glu_stage(fv[half], fg[half], gt[half], j - 4);
+                    if constexpr (j == 9) store_quad(gt[half], yrs, pp.yb, half ? srow1 : srow0);
+                    if constexpr (j == 10 && half == 0) { wait_counted(xq); stage_all(xq, nslot); }
                 }
             };
             [&]<int... J>(std::integer_sequence<int, J...>) { (rd(std::integral_constant<int, J>{}), ...); }(std::make_integer_sequence<int, RD>{});
             [&]<int... J>(std::integer_sequence<int, J...>) {
                 ((rd(std::integral_constant<int, J + RD>{}), __builtin_amdgcn_sched_barrier(0),
-                  mm(std::integral_constant<int, J>{}), side(std::integral_constant<int, J>{}), __builtin_amdgcn_sched_barrier(0)), ...);
+                  mm(std::integral_constant<int, J>{}, std::integral_constant<int, 0>{}), side(std::integral_constant<int, J>{}, std::integral_constant<int, 0>{}),
+                  __builtin_amdgcn_sched_barrier(0),
+                  mm(std::integral_constant<int, J>{}, std::integral_constant<int, 1>{}), side(std::integral_constant<int, J>{}, std::integral_constant<int, 1>{}),
+                  __builtin_amdgcn_sched_barrier(0)), ...);
             }(std::make_integer_sequence<int, NUS>{});
             if constexpr (!OVERLAP) {
                 wait_counted(xq);
                 stage_all(xq, nslot);
-                __syncthreads();                            // the partner has read the previous tile's hand-over (single exchange buffer)
             }
-            // hand-over: the half of the partial sums the partner finishes
-            f32x4* ex_out = Ex + (((NXB > 1 ? P : 0) * 8 + w8) * 4) * 64 + lane;
-            const f32x4* ex_in = Ex + (((NXB > 1 ? P : 0) * 8 + (w8 ^ 4)) * 4) * 64 + lane;
+            // hand-over: the half of the partial sums the partner finishes goes to LDS, the own half out of the accumulators (the next
+            // trip's first MFMAs overwrite them)
+            f32x4* ex_out = ex_of(P, w8);
             ex_out[0] = quad(accv, SEND); ex_out[64] = quad(accv, SEND + 1);
             ex_out[128] = quad(accg, SEND); ex_out[192] = quad(accg, SEND + 1);
+            ownv[0] = quad(accv, OWN); ownv[1] = quad(accv, OWN + 1); owng[0] = quad(accg, OWN); owng[1] = quad(accg, OWN + 1);
             __syncthreads();                                // hand-over written; slot P ^ 1 is complete; slot P may be overwritten by the next trip
-            fv[0] = quad(accv, OWN) + ex_in[0]; fv[1] = quad(accv, OWN + 1) + ex_in[64];
-            fg[0] = quad(accg, OWN) + ex_in[128]; fg[1] = quad(accg, OWN + 1) + ex_in[192];
         };
-        static_assert(!OVERLAP || NUS >= 9, "the bf16 side schedule places its work on steps 0-8");
+        static_assert(!OVERLAP || NUS >= 11, "the bf16 side schedule places its work on steps 0-10");
 
-        int tile = tile0;
+        int tile = tile0, par = 0;                          // par: parity of the NEXT trip = which exchange buffer the last trip did not use
         for (;;) {
             if (tile >= ntiles) break;
-            trip(std::integral_constant<int, 0>{}); tile += tstep;
+            trip(std::integral_constant<int, 0>{}); tile += tstep; par = 1;
             if (tile >= ntiles) break;
-            trip(std::integral_constant<int, 1>{}); tile += tstep;
+            trip(std::integral_constant<int, 1>{}); tile += tstep; par = 0;
         }
-        // ---- the last tile's GLU + stores
-        {
-            const OutPos pp = out_pos(scur);
-            f32x4 o[2];
-            glu_all(o);
-            store_tile(o, pp);
-        }
+        // ---- the last tile: the partner's half lies in the buffer of the last trip's parity
+        finish_tile(ex_of(par ^ 1, w8 ^ 4), out_pos(scur));
+        if constexpr (S == 1) __builtin_amdgcn_s_setprio(0);
     }
 }
 
