@@ -23,6 +23,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--batches', default='', help='comma-separated batch sizes at T = 128 (default: the standard set incl. a long-utterance shape)')
 ap.add_argument('--warm-ms', type=float, default=50.0, help='run the kernel this long before timing it (0: three calls, the rounds 1-3 protocol)')
 ap.add_argument('--maths', default='fp32,bf16')
+ap.add_argument('--data', default='rand', help='rand | zero | one: operand fill (the chip\'s power management is data dependent)')
 args = ap.parse_args()
 SHAPES = [(int(b), 128) for b in args.batches.split(',')] if args.batches else [(256, 128), (4096, 128), (8, 2048), (16, 128)]
 dev = 'cuda:0'
@@ -62,6 +63,8 @@ for math in args.maths.split(','):
         x = torch.randn((1, B, 24, T), device=dev)
         w = torch.randn((1, 15, 24, 256), device=dev) * 0.05
         b = torch.randn((1, 256), device=dev) * 0.1
+        if args.data != 'rand':
+            x.fill_(0.0 if args.data == 'zero' else 1.0); w.fill_(0.0 if args.data == 'zero' else 1.0); b.zero_()
         y = torch.empty((1, B, 128, T), device=dev)
         s = vp(torch.cuda.current_stream().cuda_stream)
         check(lib.vc_set_math_mode({'fp32': 0, 'bf16': 1}[math]))
@@ -80,6 +83,6 @@ for math in args.maths.split(','):
         flops = 2.0 * B * T * 256 * 15 * 24
         for name, call in calls:
             ev, b2b = timed(call, B)
-            print('r5 %-4s %s B=%-4d T=%-4d  ev %8.2f us (HBM %5.3f, %7.1f TFLOP/s)   b2b %8.2f us (HBM %5.3f, %7.1f TFLOP/s)' % (
-                math, name, B, T, ev * 1e6, algo / ev / 8e12, flops / ev / 1e12, b2b * 1e6, algo / b2b / 8e12, flops / b2b / 1e12), flush=True)
+            print('r5%s %-4s %s B=%-4d T=%-4d  ev %8.2f us (HBM %5.3f, %7.1f TFLOP/s)   b2b %8.2f us (HBM %5.3f, %7.1f TFLOP/s)' % (
+                '' if args.data == 'rand' else '[' + args.data + ']', math, name, B, T, ev * 1e6, algo / ev / 8e12, flops / ev / 1e12, b2b * 1e6, algo / b2b / 8e12, flops / b2b / 1e12), flush=True)
         check(lib.vc_set_math_mode(0))

@@ -22,7 +22,8 @@ def main():
             '''#ifdef VC_GLU_TIMELINE
 // slot = 2 * which + S (which: 0 = workgroup (0,0,0), 1 = the last workgroup of the grid; S: K set, lane 0 of waves 0 / 4); per slot:
 // [0] entry -> prologue barrier passed, [1] sum over trips: start -> K loop done, [2] sum: -> hand-over out, own half copied, [3] sum: ->
-// barrier passed, [4] loop end -> kernel end, [5] launches, [6] trips, [7] kernel cycles, [8] kernel real-time ticks (100 MHz)
+// barrier passed, [4] loop end -> kernel end, [5] launches, [6] trips, [7] kernel cycles, [8] kernel real-time ticks (100 MHz),
+// [9] entry -> prologue loads issued, [10] -> landed (vmcnt 0), [11] -> tile 0 staged, tile 1 requested, [12] -> barrier passed
 __device__ unsigned long long g_glu_tl[4][16];
 extern "C" int vc_debug_glu_timeline(unsigned long long* out, int reset) {
     if (reset) { unsigned long long z[4][16] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_glu_tl), z, sizeof z); return 0; }
@@ -39,11 +40,13 @@ extern "C" int vc_debug_glu_timeline(unsigned long long* out, int reset) {
     const int tl_which = (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) ? 0 :
                          (blockIdx.x == gridDim.x - 1 && blockIdx.y == gridDim.y - 1 && blockIdx.z == gridDim.z - 1) ? 1 : -1;
     const bool tl_on = (threadIdx.x & 255) == 0 && tl_which >= 0;
-    unsigned long long tl0 = __builtin_readcyclecounter(), tr0 = __builtin_amdgcn_s_memrealtime(), tl1 = 0, tl3 = 0, ta = 0, tb = 0, tc = 0, sa = 0, sb = 0, sc = 0, ntr = 0;
+    unsigned long long tl0 = __builtin_readcyclecounter(), tr0 = __builtin_amdgcn_s_memrealtime(), tl1 = 0, tl3 = 0, tp1 = 0, tp2 = 0, tp3 = 0, ta = 0, tb = 0, tc = 0, sa = 0, sb = 0, sc = 0, ntr = 0;
 #endif
     typedef GluGeo<CIN, KW, BF16> GG;
     typedef typename std::conditional<BF16, __bf16, float>::type T;
 ''')
+    s = sub(s, '    wait_all(xr0);\n', '    VC_GTL(tp1 = __builtin_readcyclecounter());\n    wait_all(xr0);\n    VC_GTL(tp2 = __builtin_readcyclecounter());\n')
+    s = sub(s, '    // dummy "tile -2" stores:', '    VC_GTL(tp3 = __builtin_readcyclecounter());\n    // dummy "tile -2" stores:')
     s = sub(s, '    __syncthreads();                                        // fragment image (if any) and tile 0 are in LDS\n',
             '    __syncthreads();                                        // fragment image (if any) and tile 0 are in LDS\n    VC_GTL(tl1 = __builtin_readcyclecounter());\n')
     s = sub(s, '            const OutPos pp = out_pos(scur); advance(scur);   // the previous tile\'s output position\n',
@@ -62,6 +65,7 @@ extern "C" int vc_debug_glu_timeline(unsigned long long* out, int reset) {
         unsigned long long* o_ = g_glu_tl[2 * tl_which + S];
         atomicAdd(&o_[0], tl1 - tl0); atomicAdd(&o_[1], sa); atomicAdd(&o_[2], sb); atomicAdd(&o_[3], sc);
         atomicAdd(&o_[4], te - tl3); atomicAdd(&o_[5], 1ull); atomicAdd(&o_[6], ntr); atomicAdd(&o_[7], te - tl0); atomicAdd(&o_[8], tre - tr0);
+        atomicAdd(&o_[9], tp1 - tl0); atomicAdd(&o_[10], tp2 - tp1); atomicAdd(&o_[11], tp3 - tp2); atomicAdd(&o_[12], tl1 - tp3);
     }
 #endif
 }

@@ -372,7 +372,7 @@ __device__ __forceinline__ void gated_conv1d_glu_body(const WsConvArgs& a, char*
         // The second-dispatched half of the workgroup (waves 4-7 = K set 1) loses every issue arbitration against its older partner
         // on the same SIMD (measured: set 0 finished its K loop after 1430 cycles and then idled 1240 at the barrier while set 1
         // needed 2150): raise it once, no per-segment flips (MI355X_MICROARCH.md, two waves per SIMD, item 4).
-        if constexpr (S == 1) __builtin_amdgcn_s_setprio(1);
+        if constexpr (S == 1) { if (a.flags & 1) __builtin_amdgcn_s_setprio(1); }
 
         auto store_quad = [&](const f32x4& v, __amdgpu_buffer_rsrc_t rs, unsigned off, int srow) {
 #pragma unroll
@@ -511,7 +511,9 @@ __global__ __launch_bounds__(512, 1) void gated_conv1d_glu_kernel(const WsConvAr
 }
 
 // same grid, same frame and fragment-image reads, same output stores, no arithmetic: what the memory system alone allows a launch of
-// this shape (bench.py named_kernel.copy_roof; include/vc_cyclegan_testing.h: vc_prof_glu_copy_roof)
+// this shape (bench.py named_kernel.copy_roof; include/vc_cyclegan_testing.h: vc_prof_glu_copy_roof).  A streaming kernel: the loads of
+// tile i + 1 are in flight while tile i's stores are issued, nothing waits on a store, the stored value does not depend on the tile's
+// loads (they are summed into a value that leaves once, at the end).
 __global__ __launch_bounds__(512, 1) void glu_copy_roof_kernel(const WsConvArgs a) {
     constexpr int CIN = 24, TP = 128;
     const int tid = threadIdx.x, lane = tid & 63, w8 = tid >> 6, pb = w8 & 3, kset = w8 >> 2, l31 = lane & 31, h = lane >> 5;
@@ -520,27 +522,42 @@ __global__ __launch_bounds__(512, 1) void glu_copy_roof_kernel(const WsConvArgs 
     const float* x = a.x + (long)g * a.x_gs;
     float* y = a.y + (long)g * a.y_gs;
     float acc = 0.f;
-    {   // the slab's fragment image: 46 KB (bf16 form), 16 bytes per lane and step
+    f32x4 iv[6];
+    {   // the slab's fragment image: 46 KB (bf16 form), 16 bytes per lane and unit, all loads in flight together
         const f32x4* img = reinterpret_cast<const f32x4*>((const char*)a.wimg + (long)g * a.wimg_gs + (long)slab * GluGeo<24, 15, true>::SLAB_BYTES);
-        for (int i = tid; i < 46 * 64; i += 512) { const f32x4 v = img[i]; acc += v[0] + v[1] + v[2] + v[3]; }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) iv[i] = img[(tid + 512 * i) < 46 * 64 ? tid + 512 * i : 0];
     }
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int b = tile / tps, tt = tile - b * tps;
-        // the tile's frames: 24 channels x 128 frames, one dword per thread and pass (lanes along time)
-        for (int i = tid; i < CIN * TP; i += 512) {
-            const int c = i >> 7, t = tt * TP + (i & 127);
-            if (t < a.T) acc += x[((long)b * CIN + c) * a.T + t];
+    // a tile's frames: 24 channels x 128 frames = 768 x 16 bytes: threads < 384 carry two 16-byte loads each
+    auto load_tile = [&](int tile, f32x4 (&v)[2]) {
+        const int tcl = tile < ntiles ? tile : 0;
+        const int b = tcl / tps, tt = tcl - b * tps;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int i = tid + 384 * j, c = i >> 5, t = tt * TP + 4 * (i & 31);
+            const bool ok = tid < 384 && tile < ntiles && t < a.T;
+            v[j] = ok ? *reinterpret_cast<const f32x4*>(x + ((long)b * CIN + c) * a.T + t) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        const float v = acc * 1e-30f;
+    };
+    f32x4 cur[2], nxt[2];
+    load_tile(blockIdx.x, cur);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        load_tile(tile + gridDim.x, nxt);
+        const int b = tile / tps, tt = tile - b * tps;
         const int t = tt * TP + pb * 32 + l31;
         if (t < a.T) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int row = slab * 32 + 8 * (2 * kset + (i >> 2)) + 4 * h + (i & 3);
-                y[((long)b * C + row) * a.T + t] = v;
+                y[((long)b * C + row) * a.T + t] = 1.f;
             }
         }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { acc += cur[j][0] + cur[j][1] + cur[j][2] + cur[j][3]; cur[j] = nxt[j]; }
     }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) acc += iv[i][0] + iv[i][1] + iv[i][2] + iv[i][3];
+    if (acc == 1.2345e-30f) y[0] = acc;                     // keeps the loads alive
 }
 
 long gated_conv1d_glu_image_bytes(int cin, int kw, int cout, int math) {
@@ -575,9 +592,11 @@ static bool glu_grid(const WsConvArgs& a, int cin, int kw, dim3* grid) {
 
 // y [G][B][Cout/2][T] = GLU of the gated pair; a.wimg != null: the filters as a pre-packed fragment image of `math`; returns -2
 // when the geometry is not built
-int launch_gated_conv1d_glu(const WsConvArgs& a, int cin, int kw, int math, hipStream_t s, double flops) {
+int glu_tune_flags();       // vc_ops.hip: the calling thread's vc_tune_glu switches
+int launch_gated_conv1d_glu(const WsConvArgs& a_, int cin, int kw, int math, hipStream_t s, double flops) {
     dim3 grid;
-    if (!glu_grid(a, cin, kw, &grid)) return -2;
+    if (!glu_grid(a_, cin, kw, &grid)) return -2;
+    WsConvArgs a = a_; a.flags = glu_tune_flags();
     ProfScope ps(2, flops, s);
 #define VC_GLU2(BF, RW) { if (a.wimg) gated_conv1d_glu_kernel<24, 15, BF, RW, true><<<grid, dim3(512), 0, s>>>(a); \
                           else gated_conv1d_glu_kernel<24, 15, BF, RW, false><<<grid, dim3(512), 0, s>>>(a); }

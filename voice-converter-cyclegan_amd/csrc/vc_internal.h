@@ -165,6 +165,7 @@ struct WsConvArgs {
     long x_gs, w_gs, b_gs, y_gs;          // signed group strides (floats)
     int B, T, Cout, G;
     float* raw; long raw_gs;              // gated_conv1d_glu only, optional: the raw (value, gate) pair [G][B][Cout][T] for a backward pass
+    int flags;                            // gated_conv1d_glu only: tuning switches (vc_tune_glu; 0 in production)
     const void* wimg; long wimg_gs;       // gated_conv1d_glu only, optional: the filters as a pre-packed fragment image (group stride in BYTES); w unused then
 };
 int launch_wsconv1d(const WsConvArgs& a, int cin, int kw, int math, hipStream_t s, double flops);   // returns -2 when the geometry is not built

@@ -471,6 +471,9 @@ extern "C" int vc_gated_conv1d_glu_fwd(const float* x, int64_t x_gs, const float
     VC_ARG(r != -2, "vc_gated_conv1d_glu_fwd: built for Cin = 24, k = 15, Cout2 %% 64 == 0, T %% 4 == 0, tensors < 2 GiB (the generator's h1 block)");
     return r;
 }
+static thread_local int t_glu_flags = 0;
+extern "C" int vc_tune_glu(int flags) { t_glu_flags = flags; return 0; }
+int glu_tune_flags() { return t_glu_flags; }
 extern "C" int64_t vc_gated_conv1d_glu_image_bytes(int Cin, int k, int Cout2) {
     return gated_conv1d_glu_image_bytes(Cin, k, Cout2, vc_thread_math() == VC_MATH_BF16 ? VC_MATH_BF16 : VC_MATH_FP32);
 }
