@@ -23,6 +23,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--batches', default='', help='comma-separated batch sizes at T = 128 (default: the standard set incl. a long-utterance shape)')
 ap.add_argument('--warm-ms', type=float, default=50.0, help='run the kernel this long before timing it (0: three calls, the rounds 1-3 protocol)')
 ap.add_argument('--maths', default='fp32,bf16')
+ap.add_argument('--flags', type=int, default=0, help='vc_tune_glu switches for the timed launches')
 ap.add_argument('--data', default='rand', help='rand | zero | one: operand fill (the chip\'s power management is data dependent)')
 args = ap.parse_args()
 SHAPES = [(int(b), 128) for b in args.batches.split(',')] if args.batches else [(256, 128), (4096, 128), (8, 2048), (16, 128)]
@@ -67,6 +68,7 @@ for math in args.maths.split(','):
             x.fill_(0.0 if args.data == 'zero' else 1.0); w.fill_(0.0 if args.data == 'zero' else 1.0); b.zero_()
         y = torch.empty((1, B, 128, T), device=dev)
         s = vp(torch.cuda.current_stream().cuda_stream)
+        lib.vc_tune_glu(args.flags)
         check(lib.vc_set_math_mode({'fp32': 0, 'bf16': 1}[math]))
         nb_img = lib.vc_gated_conv1d_glu_image_bytes(24, 15, 256)
         img = torch.empty((nb_img,), dtype=torch.uint8, device=dev)

@@ -23,10 +23,10 @@
 //     instruction.  (Round 4 had pixels on M: 16-byte stores touched 32 rows x 32 bytes, cured with an LDS transposition
 //     of every plane; that LDS traffic is gone.)
 //   * filters arrive PRE-PACKED (vc_gated_conv1d_glu_prepack: the fragment image [slab][K step][value|gate][lane][16 B],
-//     built once per weight update): a lane fetches its fragments with 16-byte coalesced loads straight into registers
-//     while tile 0's frames travel.  Round 4 re-read 92 KB of fp32 filters per workgroup with 4-byte loads, converted them
-//     and bounced them through LDS: 4.7 + 0.7 us in front of the first MFMA.  The unpacked entry point keeps that path
-//     (PRE = false) for callers whose weights change before every call (the train step).
+//     built once per weight update): a workgroup copies its slab's image global -> LDS once, without registers (LDS-DMA), while
+//     tile 0's frames travel, and every wave reads the fragments of its K steps out of LDS into registers.  Round 4 re-read
+//     92 KB of fp32 filters per workgroup with 4-byte loads and converted them: 4.7 + 0.7 us in front of the first MFMA.  The
+//     unpacked entry point keeps that path (PRE = false) for callers whose weights change before every call (the train step).
 //   * software pipeline over the workgroup's tiles (one barrier per tile): while tile i is multiplied, the frames of
 //     tile i+2 are in flight (inline-asm buffer loads retired by a COUNTED s_waitcnt: gfx950 has one in-order counter for
 //     loads and stores, and the compiler would wait vmcnt(0), i.e. for the previous tile's output stores to complete),
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void glu_prepack_kernel(const float* __restric
 template <int CIN, int KW, bool BF16, bool PRE> struct GluLds {
     typedef GluGeo<CIN, KW, BF16> GG;
     static constexpr int CS = BF16 ? CIN : CIN + 4, SLOT = (144 + 1) * CS, ESZ = BF16 ? 2 : 4;
-    static constexpr bool W_LDS = !BF16 || !PRE;
+    static constexpr bool W_LDS = true;                    // the slab's fragment image always passes through (bf16) or stays in (fp32) LDS
     static constexpr int NXB = BF16 ? 2 : 1;
     static constexpr int WF_OFF = (2 * SLOT * ESZ + 15) & ~15;
     static constexpr int EX_OFF = WF_OFF + (W_LDS ? 2 * GG::NU * 64 * 16 : 0);
@@ -111,7 +111,7 @@ __device__ __forceinline__ void gated_conv1d_glu_body(const WsConvArgs& a, char*
     static_assert(NXL == 8, "operand lists of the counted waits below");
     constexpr int NST = RAW ? 24 : 8;                       // dword output stores per tile and lane
     constexpr bool OVERLAP = BF16;                          // GLU + stores of tile i-1 between the MFMAs of tile i
-    constexpr bool W_LDS = !BF16 || !PRE;                   // fragment image in LDS: fp32 reads it in the K loop, un-packed bf16 bounces through it
+    constexpr bool W_LDS = true;                            // fragment image in LDS: fp32 reads it in the K loop, bf16 passes through it on its way into registers
     constexpr int NXB = BF16 ? 2 : 1;                       // exchange buffers (fp32: one, behind a second barrier per 10-us trip)
     typedef GluLds<CIN, KW, BF16, PRE> L;
     static_assert(L::SLOT == SLOT && L::NXB == NXB && L::W_LDS == W_LDS, "LDS map");
@@ -206,27 +206,12 @@ __device__ __forceinline__ void gated_conv1d_glu_body(const WsConvArgs& a, char*
     Cursor lcur = cursor_at(tile0);                      // next tile whose frames are requested
     issue_loads(xr0, lcur); advance(lcur);
     const char* const wimg = PRE ? (const char*)a.wimg + (long)g * a.wimg_gs + (long)slab * GG::SLAB_BYTES : nullptr;
-    // bf16: the wave's filter fragments, value and gate, of its K steps.  Pre-packed:
-    // 16-byte coalesced loads straight into the registers, in flight together with tile 0's frames.
+    // bf16: the wave's filter fragments, value and gate, of its K steps (read out of the LDS image behind the prologue's barrier)
     constexpr bool W_REGS = BF16;
     constexpr int NUS = S ? GG::NU1 : GG::NU0, U0 = S ? GG::NU0 : 0;
     frag_t wv[W_REGS ? NUS : 1], wgt[W_REGS ? NUS : 1];
     constexpr int NVV = NUS - 4;                            // value fragments [NVV, NUS) live in the accumulator half as well: the VGPR half (128 of the
                                                             // wave's 256) also holds the frames in flight, the fragment ring and the previous tile's GLU
-    if constexpr (W_REGS && PRE) {
-        // inline asm: the gate fragments land in the ACCUMULATOR half of the register file directly (the compiler would land all of them
-        // in the VGPR half -- 128 of the wave's 256 -- and spill); retired by the wait_all below, handed to the compiler by the
-        // pins behind it.  One SGPR base per fragment unit (1 KB apart), the lane's 16 bytes in the VGPR offset.
-        const unsigned lo16 = (unsigned)lane * 16u;
-#pragma unroll
-        for (int j = 0; j < NUS; ++j) {
-            const int u = U0 + j;
-            const char* pv = wimg + (long)(2 * u) * 1024;
-            if (j < NVV) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(wv[j]) : "v"(lo16), "s"(pv) : "memory");
-            else asm volatile("global_load_dwordx4 %0, %1, %2" : "=a"(wv[j]) : "v"(lo16), "s"(pv) : "memory");
-            asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=a"(wgt[j]) : "v"(lo16), "s"(pv) : "memory");
-        }
-    }
     // the bias as the first MFMA's C operand: register i of a lane is channel row 8 (i / 4) + 4 h + i % 4.  Set 1 starts from 0.
     f32x16 bvv, bgv;
 #pragma unroll
@@ -238,20 +223,21 @@ __device__ __forceinline__ void gated_conv1d_glu_body(const WsConvArgs& a, char*
             for (int i = 0; i < 16; ++i) { bvv[i] = bp[8 * (i >> 2) + (i & 3)]; bgv[i] = bp[C + 8 * (i >> 2) + (i & 3)]; }
         }
     }
-    if constexpr (W_LDS && PRE) {
-        // fp32: the slab's image -> LDS as it lies (coalesced 16-byte loads, all in flight before the first write)
-        constexpr int NC = (2 * NU * 64 + 511) / 512;
-        frag_t v[NC];
+    if constexpr (PRE) {
+        // the slab's pre-packed image -> LDS as it lies, ONCE per workgroup, global -> LDS without registers (buffer_load_dwordx4 ... lds:
+        // lane l's 16 bytes land at the wave-uniform LDS address + 16 l; wave w copies units w, w + 8, ..).  Round 5's first build
+        // let every wave fetch its own fragments straight into registers: the four waves of a K set fetch the same 24 KB, 188 KB per
+        // CU through the vector L1 -- the probe put 3.0 - 5.5 k cycles on just ISSUING those loads.
+#if defined(__HIP_DEVICE_COMPILE__)
+        const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc((void*)wimg, 0, (int)GG::SLAB_BYTES, 0x00020000);
+        constexpr int NB = (2 * NU + 7) / 8;
 #pragma unroll
-        for (int it = 0; it < NC; ++it) {
-            const int i = tid + 512 * it;
-            v[it] = *reinterpret_cast<const frag_t*>(wimg + (long)(i < 2 * NU * 64 ? i : 0) * 16);
+        for (int it = 0; it < NB; ++it) {
+            const int U = w8 + 8 * it;
+            if (U < 2 * NU)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(irs, (__attribute__((address_space(3))) void*)(Wf + U * 64), 16, (unsigned)lane * 16u, U * 1024, 0, 0);
         }
-#pragma unroll
-        for (int it = 0; it < NC; ++it) {
-            const int i = tid + 512 * it;
-            if (i < 2 * NU * 64) Wf[i] = v[it];
-        }
+#endif
     }
     if constexpr (W_LDS && !PRE) {
         // Fragment unit U = 2u + vg straight from the TF-layout filters: wave w builds units w, w + 8, ..: R coalesced loads
@@ -284,13 +270,6 @@ __device__ __forceinline__ void gated_conv1d_glu_body(const WsConvArgs& a, char*
         }
     }
     wait_all(xr0);
-    if constexpr (W_REGS && PRE) {
-#pragma unroll
-        for (int j = 0; j < NUS; ++j) {
-            if (j < NVV) asm volatile("" : "+v"(wv[j])); else asm volatile("" : "+a"(wv[j]));
-            asm volatile("" : "+a"(wgt[j]));
-        }
-    }
     // the bias tuples are consumed HERE (everything issued so far has landed): a first use behind the next tile's asm loads would make
     // the compiler's own wait for the bias loads -- it cannot see that the wait above retired them -- drain those frames too
     if constexpr (S == 0) { asm volatile("" : "+a"(bvv)); asm volatile("" : "+a"(bgv)); }
@@ -341,12 +320,10 @@ __device__ __forceinline__ void gated_conv1d_glu_body(const WsConvArgs& a, char*
         const int srow0 = (8 * OWN) * T4, srow1 = (8 * (OWN + 1)) * T4;
 
         if constexpr (W_REGS) {
-            if constexpr (!PRE) {
 #pragma unroll
-                for (int j = 0; j < NUS; ++j) {
-                    wv[j] = Wf[(2 * (U0 + j)) * 64 + lane];
-                    wgt[j] = Wf[(2 * (U0 + j) + 1) * 64 + lane];
-                }
+            for (int j = 0; j < NUS; ++j) {
+                wv[j] = Wf[(2 * (U0 + j)) * 64 + lane];
+                wgt[j] = Wf[(2 * (U0 + j) + 1) * 64 + lane];
             }
             // Pin the gate fragments in ACCUMULATOR registers (gfx950: one register file; an MFMA reads its A operand from either
             // half).  Left alone the allocator keeps every fragment in the VGPR half, runs out, parks some in AGPRs and
