@@ -124,21 +124,36 @@ def _pmc_traffic(B, F, T, world, math, role='igemm'):
     return None, None, None
 
 
-def named_kernel_h1(lib, dev, B=256, reps=20, peak=FP32_MFMA_PEAK_TFLOPS, math='fp32'):
+def named_kernel_h1(lib, dev, B=256, reps=20, peak=FP32_MFMA_PEAK_TFLOPS, math='fp32', variant='packed', data='rand'):
     """The north star's named kernel: the generator's gated conv1d block (module.py:161-163: h1 value + gate convolutions +
-    GLU) forward at B=256, as ONE kernel (vc_gated_conv1d_glu_fwd).  SURVEY 8d: algorithmic bytes 20.29 MB (frames in,
-    GLU output out, weights once), algorithmic FLOPs 6.04 G; exact fp32 caps the HBM fraction at ~6.6 %."""
-    import numpy as np
+    GLU) forward at B=256, as ONE kernel.  SURVEY 8d: algorithmic bytes 20.29 MB (frames in, GLU output out, weights once),
+    algorithmic FLOPs 6.04 G; exact fp32 caps the HBM fraction at ~6.6 %.
+      variant 'packed': vc_gated_conv1d_glu_fwd_packed (filters as the pre-packed fragment image, built outside the timed region by
+                        vc_gated_conv1d_glu_prepack: once per weight update);  'plain': vc_gated_conv1d_glu_fwd (TF-layout filters,
+                        converted by every workgroup);  'roof': vc_prof_glu_copy_roof -- the same grid performing the kernel's
+                        memory operations only (the measured roof of a launch of this shape).
+      two clocks: us = HIP events around every single call (launch + kernel + event overhead, the round 1-4 protocol);
+                  us_back_to_back = N calls between two events / N (average launch duration in a stream of launches)."""
     import torch
     from voice_converter_cyclegan_amd._lib import ptr, check, vp
     from voice_converter_cyclegan_amd.engine import CycleGANEngine
     x = torch.randn((1, B, 24, 128), device=dev)
     w = torch.randn((1, 15, 24, 256), device=dev) * 0.05
     b = torch.randn((1, 256), device=dev) * 0.1
+    if data == 'zero':
+        x.zero_(); w.zero_(); b.zero_()
     y = torch.empty((1, B, 128, 128), device=dev)
     s = vp(torch.cuda.current_stream().cuda_stream)
+    check(lib.vc_set_math_mode(1 if (math == 'bf16' or variant == 'roof') else 0))
+    img = torch.empty((lib.vc_gated_conv1d_glu_image_bytes(24, 15, 256),), dtype=torch.uint8, device=dev)
+    check(lib.vc_gated_conv1d_glu_prepack(ptr(w), 0, ptr(img), 0, 1, 24, 15, 256, s))
     check(lib.vc_set_math_mode({'fp32': 0, 'bf16': 1}[math]))
-    call = lambda: check(lib.vc_gated_conv1d_glu_fwd(ptr(x), 0, ptr(w), 0, ptr(b), 0, ptr(y), 0, 1, B, 24, 128, 256, 15, s))
+    if variant == 'packed':
+        call = lambda: check(lib.vc_gated_conv1d_glu_fwd_packed(ptr(x), 0, ptr(img), 0, ptr(b), 0, ptr(y), 0, 1, B, 24, 128, 256, 15, s))
+    elif variant == 'plain':
+        call = lambda: check(lib.vc_gated_conv1d_glu_fwd(ptr(x), 0, ptr(w), 0, ptr(b), 0, ptr(y), 0, 1, B, 24, 128, 256, 15, s))
+    else:
+        call = lambda: check(lib.vc_prof_glu_copy_roof(ptr(x), ptr(img), ptr(y), B, 128, 256, s))
     try:
         # sustained clocks first: the GPU has idled while the host built the tensors (see tools/bench_named.py)
         t_end = time.perf_counter() + 0.05
@@ -153,17 +168,58 @@ def named_kernel_h1(lib, dev, B=256, reps=20, peak=FP32_MFMA_PEAK_TFLOPS, math='
         ms, n, fl = C.c_double(0), C.c_longlong(0), C.c_double(0)
         lib.vc_prof_collect(2, C.byref(ms), C.byref(n), C.byref(fl))
         CycleGANEngine.profiling(False)
+        nb = 200 if B <= 256 else 40
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(20):
+            call()
+        e0.record()
+        for _ in range(nb):
+            call()
+        e1.record()
+        torch.cuda.synchronize()
+        t_b2b = e0.elapsed_time(e1) * 1e-3 / nb
     finally:
         check(lib.vc_set_math_mode(0))
     t = ms.value * 1e-3 / max(n.value, 1)
     algo = B * (24 * 128 + 128 * 128) * 4 + (15 * 24 * 256 + 256) * 4         # 20.29 MB at B=256; also what the kernel moves
     flops = 2.0 * B * 128 * 256 * 15 * 24
-    return {'kernel': 'gated_conv1d_glu_kernel: G.h1 value + gate conv1d + GLU forward in one kernel, B=%d, %s' % (B, math),
-            'us': t * 1e6, 'algorithmic_bytes': algo,
-            'hbm': {'achieved_GBs': algo / t / 1e9, 'peak_GBs': HBM_PEAK_GBS, 'frac': algo / t / 1e9 / HBM_PEAK_GBS},
-            'mfma': {'achieved_TFLOPs': flops / t / 1e12, 'peak_TFLOPs': peak, 'frac': flops / t / 1e12 / peak},
+    return {'kernel': 'gated_conv1d_glu_kernel: G.h1 value + gate conv1d + GLU forward in one kernel, B=%d, %s, %s' % (B, math, variant),
+            'us': t * 1e6, 'us_back_to_back': t_b2b * 1e6, 'algorithmic_bytes': algo,
+            'hbm': {'achieved_GBs': algo / t / 1e9, 'peak_GBs': HBM_PEAK_GBS, 'frac': algo / t / 1e9 / HBM_PEAK_GBS,
+                    'frac_back_to_back': algo / t_b2b / 1e9 / HBM_PEAK_GBS},
+            'mfma': {'achieved_TFLOPs': flops / t / 1e12, 'peak_TFLOPs': peak, 'frac': flops / t / 1e12 / peak,
+                     'frac_back_to_back': flops / t_b2b / 1e12 / peak},
             'note': ('exact-fp32 MFMA makes this kernel FLOP-bound: 38.4 us at the fp32 peak vs 2.5 us of HBM time' if math == 'fp32'
                      else 'bf16 MFMA operands (rounded once on their way into LDS), fp32 tensors in HBM, fp32 accumulate')}
+
+
+def named_kernel_report(lib, dev):
+    """BASELINE north_star: the gated-conv1d forward at B = 256 (and B = 4096: the asymptote), exact fp32 and bf16 operands, each against
+    (a) the 8 TB/s / MFMA roofs the north star names and (b) the MEASURED copy roof: a streaming kernel on the same grid that performs
+    the same reads and the same stores and nothing else."""
+    nk = named_kernel_h1(lib, dev, peak=FP32_MFMA_PEAK_TFLOPS, math='fp32', variant='packed')
+    nk['plain'] = {k: named_kernel_h1(lib, dev, peak=FP32_MFMA_PEAK_TFLOPS, math='fp32', variant='plain')[k] for k in ('us', 'us_back_to_back')}
+    bf = {}
+    for B, reps in ((256, 20), (4096, 10)):
+        r = named_kernel_h1(lib, dev, B=B, reps=reps, peak=BF16_MFMA_PEAK_TFLOPS, math='bf16', variant='packed')
+        pl = named_kernel_h1(lib, dev, B=B, reps=reps, peak=BF16_MFMA_PEAK_TFLOPS, math='bf16', variant='plain')
+        rf = named_kernel_h1(lib, dev, B=B, reps=reps, peak=BF16_MFMA_PEAK_TFLOPS, math='bf16', variant='roof')
+        z = named_kernel_h1(lib, dev, B=B, reps=reps, peak=BF16_MFMA_PEAK_TFLOPS, math='bf16', variant='packed', data='zero')
+        bf[B] = {'us': r['us'], 'us_back_to_back': r['us_back_to_back'], 'hbm_frac': r['hbm']['frac'], 'hbm_frac_back_to_back': r['hbm']['frac_back_to_back'],
+                 'achieved_TFLOPs': r['mfma']['achieved_TFLOPs'], 'algorithmic_bytes': r['algorithmic_bytes'],
+                 'plain_us': pl['us'], 'plain_us_back_to_back': pl['us_back_to_back'],
+                 'copy_roof': {'us': rf['us'], 'us_back_to_back': rf['us_back_to_back'], 'GBs_back_to_back': rf['algorithmic_bytes'] / rf['us_back_to_back'] / 1e3,
+                               'kernel_frac_of_copy_roof': rf['us'] / r['us'], 'kernel_frac_of_copy_roof_back_to_back': rf['us_back_to_back'] / r['us_back_to_back'],
+                               'what': 'vc_prof_glu_copy_roof: same grid (256 workgroups x 512 threads), every workgroup reads its slab\'s 46 KB fragment image and its '
+                                       'tiles\' frames (16-byte loads, next tile in flight) and writes its 32 x 128 output block per tile with the kernel\'s own dword '
+                                       'stores (two full 128-byte lines per instruction); no arithmetic, no LDS'},
+                 'zero_operands_us_back_to_back': z['us_back_to_back']}
+    nk['bf16_mode'] = dict(bf[256]); nk['bf16_mode']['B4096'] = bf[4096]
+    nk['timed'] = ('one vc_gated_conv1d_glu_fwd_packed call = one kernel (plain_*: vc_gated_conv1d_glu_fwd, filters converted in the kernel); us = HIP events '
+                   'around every call on the call\'s stream, us_back_to_back = 200 (40) calls between two events / N; each after 50 ms of the same call '
+                   '(sustained clocks).  zero_operands_*: the same launch on all-zero operands -- the gap to the headline is the chip\'s data-dependent '
+                   'clock management (in-kernel probe: 1.7-2.1 GHz on random bf16 operands, 2.4 GHz fp32), not the kernel')
+    return nk
 
 
 def time_steps(eng, A, Bm, hp, steps, warmup, barrier):
@@ -473,13 +529,7 @@ def main():
 
     # ---- the kernel the north_star names: gated-conv1d forward (G.h1: 24 -> 2x128, k=15) at B=256 (and B=4096: the asymptote)
     if rank == 0 and not args.no_roofline:
-        out['named_kernel'] = named_kernel_h1(lib, dev, peak=FP32_MFMA_PEAK_TFLOPS, math='fp32')
-        # the same kernel with bf16 MFMA operands (BASELINE configs[2] arithmetic): the HBM-roofline view the north star asks for
-        r = named_kernel_h1(lib, dev, peak=BF16_MFMA_PEAK_TFLOPS, math='bf16')
-        r4k = named_kernel_h1(lib, dev, B=4096, reps=10, peak=BF16_MFMA_PEAK_TFLOPS, math='bf16')
-        out['named_kernel']['bf16_mode'] = {'us': r['us'], 'hbm_frac': r['hbm']['frac'], 'achieved_TFLOPs': r['mfma']['achieved_TFLOPs'],
-                                            'B4096': {'us': r4k['us'], 'hbm_frac': r4k['hbm']['frac'], 'algorithmic_bytes': r4k['algorithmic_bytes']}}
-        out['named_kernel']['timed'] = 'everything one vc_gated_conv1d_glu_fwd call launches (one kernel), HIP events on the call\'s stream, after 50 ms of the same call (sustained clocks)'
+        out['named_kernel'] = named_kernel_report(lib, dev)
 
     dp = None
     if rank == 0 and world == 1 and (args.dp_selftest or (default_workload and not args.no_extra and not args.no_roofline)):

@@ -44,8 +44,8 @@ int  vc_prof_collect(int kind, double* ms, long long* launches, double* flops);
 /* Per-launch records (in launch order) since enable: fills ms[i], flops[i] for i < max_n; returns the record count. */
 int  vc_prof_records(int kind, double* ms, double* flops, int max_n);
 
-/* Tuning switches of the gated conv1d + GLU kernel for the calling thread's following launches (0 = production).  bit 0: raise the
- * issue priority of the younger K set's waves (s_setprio 1). */
+/* Tuning switches of the gated conv1d + GLU kernel for the calling thread's following launches (0 = production).  bit 0: do NOT raise
+ * the issue priority of the younger K set's waves (s_setprio 1 is the production setting). */
 int  vc_tune_glu(int flags);
 /* Measurement control for the north-star kernel (bench.py named_kernel.copy_roof): ONE launch on vc_gated_conv1d_glu_fwd_packed's grid
  * (G = 1) that performs that kernel's memory operations only -- every workgroup reads its slab's bf16 fragment image and its tiles'

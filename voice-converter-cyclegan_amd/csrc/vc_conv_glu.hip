@@ -349,7 +349,7 @@ __device__ __forceinline__ void gated_conv1d_glu_body(const WsConvArgs& a, char*
         // The second-dispatched half of the workgroup (waves 4-7 = K set 1) loses every issue arbitration against its older partner
         // on the same SIMD (measured: set 0 finished its K loop after 1430 cycles and then idled 1240 at the barrier while set 1
         // needed 2150): raise it once, no per-segment flips (MI355X_MICROARCH.md, two waves per SIMD, item 4).
-        if constexpr (S == 1) { if (a.flags & 1) __builtin_amdgcn_s_setprio(1); }
+        if constexpr (S == 1) { if (!(a.flags & 1)) __builtin_amdgcn_s_setprio(1); }   // vc_tune_glu bit 0 switches it off (A/B: 1 % at B = 256)
 
         auto store_quad = [&](const f32x4& v, __amdgpu_buffer_rsrc_t rs, unsigned off, int srow) {
 #pragma unroll
