@@ -410,6 +410,9 @@ def main():
                     help='serialise the step\'s two independent chains on one stream for the WHOLE run (the condition the '
                          'roofline leg always uses; for rocprof summaries that must agree with it)')
     ap.add_argument('--print-key', action='store_true', help=argparse.SUPPRESS)   # internal: the configuration's key in profiles/*_pmc_traffic.json
+    ap.add_argument('--launch-selftest', action='store_true',
+                    help='exercise ONLY the launch path: spawn the ranks if needed, build the process group (RCCL on GPUs, gloo without), '
+                         'all-reduce one number, print {"launch_selftest": ...} and exit (tests/test_dp_gloo.py drives it on CPU)')
     args = ap.parse_args()
     if args.print_key:
         print('%s_b%d_%dx%d' % (args.math, args.batch, args.features, args.frames))
@@ -432,18 +435,54 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # `python bench.py --gpus N` with no launcher around it: become the launcher.  One rank per GPU through torch.distributed.run
+        # on this node (the command the driver itself documents); the ranks re-enter this file with RANK / WORLD_SIZE set, rank 0
+        # prints the JSON line on the inherited stdout.  (this used to exit 2 at the argument check.)
+        import socket
+        with socket.socket() as so:
+            so.bind(('127.0.0.1', 0))
+            port = so.getsockname()[1]
+        os.dup2(json_fd, 1)
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+               '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        print('[bench] --gpus %d without a launcher: ' % args.gpus + ' '.join(cmd), file=sys.stderr, flush=True)
+        os.execv(sys.executable, cmd)
     if world != args.gpus:
         if rank == 0:
-            print('bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N>1)'
-                  % (args.gpus, world), file=sys.stderr)
+            print('bench.py: --gpus %d but the launcher set WORLD_SIZE=%d: pass the same number to both' % (args.gpus, world), file=sys.stderr)
         sys.exit(2)
+    have_gpu = torch.cuda.is_available()
+    if have_gpu and torch.cuda.device_count() < world and not args.launch_selftest:
+        # device selection, not argument parsing, is where a too-large N fails -- and it says so
+        print('bench.py rank %d: %d ranks on this node but only %d GPU(s) visible (LOCAL_RANK %d has no device): one process per GPU is the '
+              'only layout this step supports (DESIGN.md 9)' % (rank, world, torch.cuda.device_count(), local_rank), file=sys.stderr, flush=True)
+        sys.exit(3)
+    if not have_gpu and not args.launch_selftest:
+        print('bench.py: no GPU visible (the hot path has no CPU fallback)', file=sys.stderr, flush=True)
+        sys.exit(3)
     if rank == 0:
         ge.build()
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))   # RCCL
+        if have_gpu and torch.cuda.device_count() >= world:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))   # RCCL
+        else:
+            dist.init_process_group('gloo')                                                # --launch-selftest without GPUs
         dist.barrier()
+    if args.launch_selftest:
+        backend = dist.get_backend() if world > 1 else 'none'
+        t = torch.ones(1, device=('cuda:%d' % local_rank) if backend == 'nccl' else 'cpu') * (rank + 1)
+        if world > 1:
+            dist.all_reduce(t)
+        if rank == 0:
+            os.write(json_fd, (json.dumps({'launch_selftest': True, 'n_gpus': world, 'backend': backend, 'sum_of_rank_plus_1': float(t.item()),
+                                           'launched_by': 'torch.distributed.run' if 'TORCHELASTIC_RUN_ID' in os.environ or world > 1 else 'python'}) + '\n').encode())
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return 0
     ge.build()
     from voice_converter_cyclegan_amd.engine import CycleGANEngine
     from voice_converter_cyclegan_amd._lib import lib
@@ -502,6 +541,8 @@ def main():
             'config': {'workload': workload_text(args.math, B, F, T, args.global_batch),
                        'global_batch': world * B, 'frames_per_step_per_domain': world * B * T,
                        'parallelism': 'dp%d' % world,
+                       'rccl_ranks': int(lib.vc_comm_world(eng.sync.comm)) if eng.sync.comm is not None else (1 if world == 1 else None),
+                       'build_id': lib.vc_build_id().decode(),
                        'launch': 'one hipGraph replay per step (vc_train_step_graph)' if (eng.use_graph and world == 1 and not args.serial)
                        else 'launch by launch',
                        'deterministic': bool(args.deterministic),
@@ -545,6 +586,7 @@ def main():
             extra_config(lib, dev, 'fp32', 1, 24, 128, 60, 40, 'configs[0]: batch 1, the reference\'s own mini_batch_size (train.py:16); 40 warm-up steps = 0.1 s: a latency-bound step reads the clock ramp after the engine set-up'),
             extra_config(lib, dev, 'bf16', 64, 24, 128, 10, 3, 'configs[2]: batch 64, bf16'),
             extra_config(lib, dev, 'fp32', 32, 24, 128, 10, 3, 'configs[3]: the per-GPU share (32) of global batch 256 on an 8-GPU node, measured on one GPU without the exchange'),
+            extra_config(lib, dev, 'fp32', 256, 24, 128, 3, 1, 'configs[3] on ONE GPU: global batch 256, the N = 1 end of the strong-scaling curve (`--gpus 1 --global-batch 256`; golden-backed: tests/golden/golden_f32_b256.npz)'),
             extra_config(lib, dev, 'fp32', 64, 36, 256, 5, 2, 'configs[4]: the per-GPU share (64) of global batch 512 at 36x256, measured on one GPU without the exchange'),
         ]}
         # diagnostic, not a result: the headline configuration's launches on constant operands (data-dependent power management)

@@ -11,6 +11,9 @@ and give the GPU tests an oracle-free comparison target; they are not reference 
                          (train_log/*.csv row 2, step 167) that pin model.py:72's loss weights.
  golden_f32_b32.npz / golden_f32_36x256_b8.npz / golden_bf16_b64_lam0.npz : the same record at the other sizes
                          bench.py reports (`make_golden.py b32|36x256|b64lam0`); lam0 = lambda_cycle = lambda_identity = 0.
+ golden_f32_b256.npz   : the same at BASELINE configs[3]'s global batch (256: the single-GPU end of the strong-scaling curve), generations by the
+                         first 4 samples + norm / projection; b32 / b256 also hold two COMPLETE gradient tensors (one generator, one
+                         discriminator filter) and every 64th element of the largest one (`make_golden.py b32|b256`).
  golden_f32_b64.npz    : one train step (model.py:110-125) at the batch bench.py times as BASELINE configs[2]
  golden_bf16_b64.npz     (B=64, 24x128), fp32 and with bf16 operand rounding (O.set_operand_rounding): the 8 logged
                          scalars, generation_A/B, per-tensor gradient L2 + projection, and the cumulative
@@ -77,7 +80,13 @@ LOSS_KEYS = ('cycle_loss', 'identity_loss', 'generator_loss_A2B', 'generator_los
 L1_CDF_X = np.logspace(-7, -1, 49)          # distances of an L1 element from a tie at which the CDF is recorded
 
 
-def step_golden(batch, rounding, F=24, T=128, lam=(10.0, 5.0), name=None, keep_samples=0):
+# complete gradient tensors kept in the large-batch records (everything else is pinned by two numbers per tensor): one generator
+# and one discriminator filter gradient element by element, the largest one (D.d3, 9.4 M floats) by every 64th element
+FULL_TENSORS = ('generator_A2B/o1_conv/kernel', 'discriminator_A/downsample2d_block1_h1_conv/kernel')
+STRIDED_TENSORS = (('discriminator_B/downsample2d_block3_h1_conv/kernel', 64),)
+
+
+def step_golden(batch, rounding, F=24, T=128, lam=(10.0, 5.0), name=None, keep_samples=0, keep_full=False):
     """One step (model.py:110-125) at `batch` x F x T with the weights / batch generator of full(); rounding None or 'bf16';
     lam = (lambda_cycle, lambda_identity)."""
     P = O.init_params(seed=42, num_features=F, randomize_affine=True)
@@ -101,6 +110,11 @@ def step_golden(batch, rounding, F=24, T=128, lam=(10.0, 5.0), name=None, keep_s
     out['grad_names'] = np.array(names)
     out['grad_l2'] = np.array([np.linalg.norm(G[n].astype(np.float64)) for n in names])
     out['grad_proj'] = np.array([probe(G[n], i) for i, n in enumerate(names)])
+    if keep_full:
+        for n in FULL_TENSORS:
+            out['full/' + n] = G[n].astype(np.float32)
+        for n, st in STRIDED_TENSORS:
+            out['strided%d/' % st + n] = G[n].astype(np.float32).reshape(-1)[::st].copy()
     d = np.sort(orc.last_l1_dist.astype(np.float64))
     out['l1_cdf_x'] = L1_CDF_X
     out['l1_cdf_y'] = np.searchsorted(d, L1_CDF_X, side='right') / float(d.size)
@@ -124,7 +138,9 @@ if __name__ == '__main__':
     if sys.argv[1:] == ['b64']:
         full_b64(None); full_b64('bf16')
     elif sys.argv[1:] == ['b32']:              # BASELINE configs[3]'s per-GPU share (bench.py extra.configs): fp32, B=32, 24x128
-        step_golden(32, None, name='golden_f32_b32.npz')
+        step_golden(32, None, name='golden_f32_b32.npz', keep_full=True)
+    elif sys.argv[1:] == ['b256']:             # BASELINE configs[3]: global batch 256 -- the N = 1 end of the strong-scaling curve (~8 min of CPU)
+        step_golden(256, None, name='golden_f32_b256.npz', keep_samples=4, keep_full=True)
     elif sys.argv[1:] == ['36x256']:           # BASELINE configs[4]'s geometry at a batch the oracle finishes in minutes
         step_golden(8, None, F=36, T=256, name='golden_f32_36x256_b8.npz')
     elif sys.argv[1:] == ['36x256b64']:        # ... and at configs[4]'s per-GPU share itself (the size bench.py times; ~4 min of CPU)

@@ -36,7 +36,48 @@ def test_header_symbols_exported_and_bound(built_lib):
         assert hasattr(built_lib.lib, n), 'symbol %s declared in include/*.h is not exported' % n
         assert n in bound, 'symbol %s has no ctypes signature in _lib.SIGNATURES' % n
     assert bound <= set(names), 'python binds symbols the header does not declare: %s' % (bound - set(names))
-    assert built_lib.lib.vc_version() >= 100
+    assert built_lib.lib.vc_version() == built_lib.ABI_VERSION == 110
+
+
+def test_library_is_stamped_with_the_hash_of_its_sources(built_lib, tmp_path, monkeypatch):
+    """freshness by content, not by mtime.  The library reports the hash of the sources + flags it was built
+    from; it equals the hash of the tree (else _lib would have refused to load); the hash moves with any source byte or flag;
+    and a library whose id differs from the tree's is refused at import."""
+    import importlib.util
+    import subprocess
+    import sys
+    spec = importlib.util.spec_from_file_location('_vcb_id', os.path.join(ROOT, 'voice-converter-cyclegan_amd', 'build.py'))
+    b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
+    bid = built_lib.lib.vc_build_id().decode()
+    assert re.fullmatch(r'[0-9a-f]{16}', bid), bid
+    assert bid == b.build_id() == built_lib.BUILD_ID
+    assert not b.needs_build()
+    assert b.build_id(['-DX']) != bid                      # flags are part of the identity
+    # an older-but-different source (mtime BEFORE the library's) still invalidates: emulate by hashing a modified copy
+    src = os.path.join(b.CSRC, b.SOURCES[0])
+    orig = open(src, 'rb').read()
+    monkeypatch.setattr(b, 'CSRC', str(tmp_path))
+    for f in b.SOURCES + b.HEADERS:
+        dst = os.path.join(str(tmp_path), f)
+        os.makedirs(os.path.dirname(os.path.abspath(dst)), exist_ok=True)
+        with open(os.path.abspath(dst), 'wb') as fh:
+            fh.write(open(os.path.join(os.path.dirname(src), f), 'rb').read())
+    assert b.build_id() == bid
+    with open(os.path.join(str(tmp_path), b.SOURCES[0]), 'wb') as fh:
+        fh.write(orig + b'\n// touched\n')
+    os.utime(os.path.join(str(tmp_path), b.SOURCES[0]), (1, 1))      # far older than the library
+    assert b.build_id() != bid
+    # ... and the loader refuses a library whose id is not the tree's (a sub-process: the module is already imported here)
+    # (VC_EXTRA_FLAGS is part of the identity the loader expects: with it set, the tree's id is no longer the library's)
+    code = ('import sys, os; sys.path.insert(0, %r); import vcgan_pkg\n'
+            'os.environ["VC_EXTRA_FLAGS"] = "-DSOMETHING_ELSE"\n'
+            'try:\n'
+            '    from voice_converter_cyclegan_amd import _lib\n'
+            '    print("LOADED")\n'
+            'except ImportError as e:\n'
+            '    print("REFUSED", e)\n') % (ROOT,)
+    out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, cwd=ROOT).stdout
+    assert 'REFUSED' in out and 'build id' in out, out
 
 
 def test_library_is_gfx950_only(built_lib):

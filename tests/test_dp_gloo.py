@@ -79,3 +79,29 @@ def test_two_rank_gradient_exchange_equals_full_batch():
     assert np.array_equal(res[0][2], res[1][2]), 'replicas diverged after Adam'
     assert np.abs(res[0][1] - full).max() < 1e-12 * np.abs(full).max() + 1e-15
     assert abs(res[0][3][0] - Sg['generator_loss']) < 1e-12 and abs(res[0][3][1] - Sd['discriminator_loss']) < 1e-12
+
+
+def test_bench_gpus_n_spawns_its_own_ranks():
+    """bench.py --gpus N without a launcher around it (it exited 2 at the argument check, so a driver command
+    `python bench.py --gpus 8` would have died before the first kernel): the process becomes the launcher -- one rank per GPU
+    through torch.distributed.run on 127.0.0.1 -- and rank 0 prints the one JSON line.  --launch-selftest stops behind the
+    process group (gloo here, RCCL on GPUs) and an all-reduce: the launch path without the GPU step (model.py:110-125 is
+    single-process in the reference)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--launch-selftest'], capture_output=True, text=True,
+                       cwd=root, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout                      # the contract: exactly one JSON line on stdout
+    d = json.loads(lines[0])
+    assert d['launch_selftest'] is True and d['n_gpus'] == 2 and d['sum_of_rank_plus_1'] == 3.0, d
+    assert 'torch.distributed.run' in r.stderr            # it says what it launched
+    # a launcher that disagrees with --gpus is refused with the reason (exit 2), not silently run at another size
+    env2 = dict(env, RANK='0', LOCAL_RANK='0', WORLD_SIZE='4', MASTER_ADDR='127.0.0.1', MASTER_PORT='29999')
+    r2 = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--launch-selftest'], capture_output=True, text=True,
+                        cwd=root, env=env2, timeout=600)
+    assert r2.returncode == 2 and 'WORLD_SIZE=4' in r2.stderr, (r2.returncode, r2.stderr[-500:])

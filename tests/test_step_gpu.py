@@ -523,6 +523,18 @@ def _check_step_golden(mode, B, F, T, fname, lam=(10.0, 5.0)):
         assert abs(proj - z['grad_proj'][i]) <= 3.0 * tol * z['grad_l2'][i], (n_, proj, float(z['grad_proj'][i]), tol)
         worst = max(worst, abs(l2 - z['grad_l2'][i]) / z['grad_l2'][i])
     print('worst gradient L2 mismatch %.3g' % worst)
+    # complete tensors where the record holds them (b32 / b256: one generator and one discriminator filter gradient element by
+    # element, the largest tensor by every 64th element): two numbers per tensor cannot hide a wrong element here
+    for k in z.files:
+        if k.startswith('full/') or k.startswith('strided'):
+            n_ = k.split('/', 1)[1]
+            st = 1 if k.startswith('full/') else int(k.split('/')[0][len('strided'):])
+            got = G[n_].astype(np.float32).reshape(-1)[::st]
+            ref = z[k].reshape(-1)
+            tol = tol_w + (flip if 'generator' in n_ else 0.0)
+            e = float(np.abs(got - ref).max() / (np.abs(ref).max() + 1e-30))
+            print('complete tensor %s (stride %d, %d elements): max err / max |ref| = %.3g' % (n_, st, ref.size, e))
+            assert e < tol, (n_, e, tol)
     eng.close()
 
 
@@ -536,11 +548,13 @@ def test_step_b64_against_committed_golden(built_lib, mode):
 
 
 @pytest.mark.parametrize('case', [('fp32', 32, 24, 128, 'golden_f32_b32.npz'),
+                                  ('fp32', 256, 24, 128, 'golden_f32_b256.npz'),
                                   ('fp32', 8, 36, 256, 'golden_f32_36x256_b8.npz'),
                                   ('fp32', 64, 36, 256, 'golden_f32_36x256_b64.npz')])
 def test_step_at_the_other_benched_sizes_against_committed_goldens(built_lib, case):
     """The sizes bench.py reports under extra.configs, whole step (model.py:110-125 over module.py:148-213) against oracle
-    records: fp32 B = 32 at 24x128 (BASELINE configs[3]'s per-GPU share) and 36x256 at B = 8 and at B = 64 (configs[4]'s share
+    records: fp32 B = 32 at 24x128 (BASELINE configs[3]'s per-GPU share), B = 256 (configs[3]'s global batch on ONE GPU: the N = 1
+    end of the strong-scaling curve; both with complete gradient tensors in the record) and 36x256 at B = 8 and at B = 64 (configs[4]'s share
     ITSELF) -- the step then runs the batch-32 / 36x256-batch-64 rows of the measured tables, nearest-neighbour entries and
     all (tests/test_tuned_tables_gpu.py holds every such row to the oracle at operator level)."""
     _check_step_golden(*case)

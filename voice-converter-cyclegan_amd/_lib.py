@@ -20,7 +20,27 @@ if not os.path.exists(LIB_PATH):
         'libvcgan_hip.so not built: run `python -c "import __graft_entry__ as g; g.build()"` '
         '(hipcc --offload-arch=gfx950).  There is no CPU or eager fallback for the hot path.')
 
+
+def _expected_build_id():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('_vcgan_build_id', os.path.join(HERE, 'build.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod, mod.build_id(os.environ.get('VC_EXTRA_FLAGS', '').split())
+
+
+ABI_VERSION = 110
 lib = C.CDLL(LIB_PATH)
+lib.vc_build_id.restype = C.c_char_p
+BUILD_ID = lib.vc_build_id().decode()
+_bmod, _want = _expected_build_id()
+if BUILD_ID != _want and not os.environ.get('VC_ALLOW_STALE_LIB'):
+    # a library built from other sources than the ones next to it must never be tested or benched: rebuild if a compiler is
+    # here, refuse otherwise.  (VC_ALLOW_STALE_LIB=1: instrumented builds of tools/, which patch a source temporarily.)
+    if os.path.exists(os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')):
+        raise ImportError('libvcgan_hip.so was built from other sources (build id %s, tree %s): run '
+                          '`python -c "import __graft_entry__ as g; g.build()"` before importing the package' % (BUILD_ID, _want))
+    raise ImportError('libvcgan_hip.so is stale (build id %s, tree %s) and no hipcc is available to rebuild it' % (BUILD_ID, _want))
 
 i32, i64, f32, vp = C.c_int, C.c_int64, C.c_float, C.c_void_p
 
@@ -33,6 +53,7 @@ class ParamRec(C.Structure):
 # (name, restype, argtypes) -- every symbol declared in include/vc_cyclegan.h
 SIGNATURES = [
     ('vc_version', i32, []),
+    ('vc_build_id', C.c_char_p, []),
     ('vc_last_error', C.c_char_p, []),
     ('vc_crc32c', C.c_uint32, [vp, C.c_uint64, C.c_uint32]),
     ('vc_set_math_mode', i32, [i32]),
@@ -110,6 +131,10 @@ for _n, _r, _a in SIGNATURES:
     _f = getattr(lib, _n)          # AttributeError here == header/library mismatch
     _f.restype = _r
     _f.argtypes = _a
+
+
+if lib.vc_version() != ABI_VERSION:
+    raise ImportError('libvcgan_hip.so speaks ABI revision %d, this binding was written against %d' % (lib.vc_version(), ABI_VERSION))
 
 
 class VcError(RuntimeError):

@@ -15,7 +15,13 @@ void vc_set_error(const char* fmt, ...) {
     va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
 }
 extern "C" const char* vc_last_error(void) { return g_err; }
-extern "C" int vc_version(void) { return 100; }
+// 110: vc_gated_conv1d_glu_prepack / _fwd_packed / _image_bytes, vc_build_id (round 5; round 4 changed vc_gated_conv1d_glu_fwd's
+// arity without a bump -- ADVICE r4).  _lib.py asserts the version it was written against.
+extern "C" int vc_version(void) { return 110; }
+#ifndef VC_BUILD_ID
+#define VC_BUILD_ID "unstamped"
+#endif
+extern "C" const char* vc_build_id(void) { return VC_BUILD_ID; }
 // CRC-32C (Castagnoli), slicing-by-8: the checksum of TensorFlow's checkpoint bundles and event files
 // (model.py:21,26-29 tf.train.Saver / tf.summary.FileWriter); host-only utility for the checkpoint / summary writers.
 extern "C" uint32_t vc_crc32c(const void* data, uint64_t n, uint32_t crc) {
