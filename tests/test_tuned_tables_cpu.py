@@ -42,3 +42,20 @@ def test_unmeasured_sizes_fall_back_in_order(built_lib):
     assert lib.vc_tune_query_igemm(0, 96, 4096, 320, 1, out) == 0 and out[3] == 0
     assert out[0] in (64, 128) and out[1] in (1, 2, 4) and out[2] >= 1
     assert lib.vc_tune_query_igemm(0, 96, 4096, 321, 1, out) != 0                   # K rows must be whole chunks
+
+
+def test_table_keys_are_unique():
+    """igemm_config / wgrad_config take the FIRST row whose key matches: a second row with the same key is dead, and which
+    measurement wins would depend on section order (172 duplicated keys, 61 with conflicting configurations)."""
+    import os
+    import re
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'voice-converter-cyclegan_amd', 'csrc')
+    for fn in ('vc_tuned_igemm.h', 'vc_tuned_wgrad.h'):
+        keys = []
+        for l in open(os.path.join(root, fn)):
+            m = re.match(r'^\s*\{([-\d,\s]+)\},\s*$', l)
+            if m:
+                keys.append(tuple(int(x) for x in m.group(1).split(','))[:5])
+        assert len(keys) > 50, fn
+        dup = {k for k in keys if keys.count(k) > 1}
+        assert not dup, (fn, sorted(dup)[:5])

@@ -21,6 +21,7 @@
 // FUSE = true (forward, 64-row tiles): the instance norm + GLU that follow a gated convolution pair (module.py:85-98) run
 // in the epilogue -- see the FUSE branch below; every other launch runs the FUSE = false instantiation, unchanged.
 #include "vc_internal.h"
+#include <cstddef>
 #include "vc_device_util.h"
 #include <algorithm>
 #include <cmath>
@@ -44,7 +45,8 @@ template <int BM, bool AT, int KG, int MATH, bool FUSE = false>
 __global__ __launch_bounds__(64 * (BM / 32) * 2 * KG, (64 * (BM / 32) * 2 * KG >= 1024) ? 4 : 2) void igemm_kernel(const IgemmMulti mm) {
     static_assert(!FUSE || (BM == 64 && !AT), "the fused instance-norm epilogue exists for forward launches with 64-row tiles");
     const IgemmArgs& p = mm.c[blockIdx.y];                    // blockIdx.y: which fused launch (parity class)
-    touch_kernarg(p);
+    static_assert(offsetof(IgemmMulti, c) == 0, "touch_kernarg below addresses c[blockIdx.y] from the kernarg segment's base");
+    touch_kernarg(p, blockIdx.y * (unsigned)sizeof(IgemmArgs));
     if (blockIdx.x >= (unsigned)(p.mtiles * p.ntiles) || blockIdx.z >= (unsigned)(p.groups * p.splitk)) return;
     constexpr int BN = 64, KC = VC_KC, LDK = KC + 4;
     constexpr int WMG = BM / 32, WNG = 2, GT = 64 * WMG * WNG, NT = GT * KG;   // GT: threads of one K group

@@ -8,9 +8,12 @@
 // (round-4 ISA reading of igemm_kernel's prologue: ~12 scalar-load waits in a row; the round-3 probe put 3.8 us between a
 // workgroup's entry and its first operand load).  touch_kernarg reads one dword of every line side by side and makes the
 // kernel wait for them once: one round trip, after which every field is a scalar-cache hit.
-template <class T> __device__ __forceinline__ void touch_kernarg(const T& a) {
+// The address comes from the kernarg segment's base register pair plus the argument's byte offset (every user passes its kernel's
+// first -- only -- argument, offset 0; igemm_kernel the element of its argument array it works on), NOT from the C++ object: a
+// by-value argument the optimiser materialised in private memory would turn `&a` into a scratch address.
+template <class T> __device__ __forceinline__ void touch_kernarg(const T&, unsigned byte_offset = 0) {
     typedef const __attribute__((address_space(4))) int* cint_p;
-    cint_p q = (cint_p)(const void*)&a;
+    cint_p q = (cint_p)__builtin_amdgcn_kernarg_segment_ptr() + (byte_offset >> 2);
     int x = 0;
 #pragma unroll
     for (unsigned o = 0; o < sizeof(T) / 4; o += 16) x |= q[o];

@@ -36,8 +36,17 @@ def _drain_pending_plans():
         lib.vc_plan_destroy(C.c_void_p(_pending_destroy.pop()))
 
 
+def _drain_at_exit():
+    # interpreter teardown: the HIP runtime may already be shutting down -- a failed synchronise must not turn into a traceback
+    try:
+        if torch.cuda.is_available():
+            _drain_pending_plans()
+    except Exception:
+        pass
+
+
 import atexit  # noqa: E402
-atexit.register(lambda: _drain_pending_plans() if torch.cuda.is_available() else None)
+atexit.register(_drain_at_exit)
 
 
 class _PlanHandle(C.c_void_p):
@@ -90,6 +99,7 @@ class VariableStore:
             return h
         while len(self._plans) >= self.PLAN_CAPACITY:
             self._plans.popitem(last=False)        # queued for destruction once no pending backward refers to it (_PlanHandle.__del__)
+        _drain_pending_plans()                     # ... and destroyed NOW if nothing does (this is a safe point): never PLAN_CAPACITY + 1 plans alive
         h = _PlanHandle()
         check(lib.vc_plan_create(F, int(T), C.byref(h)), 'vc_plan_create')
         self._plans[key] = h
