@@ -44,6 +44,9 @@ int  vc_prof_collect(int kind, double* ms, long long* launches, double* flops);
 /* Per-launch records (in launch order) since enable: fills ms[i], flops[i] for i < max_n; returns the record count. */
 int  vc_prof_records(int kind, double* ms, double* flops, int max_n);
 
+/* How many captured step graphs does the plan hold (vc_train_step_graph's cache)?  Tests: N identical graph steps must leave ONE
+ * (a key built after the capture's own masking never matched, every step re-captured). */
+int  vc_plan_num_step_graphs(const struct vc_plan* p);
 /* Tuning switches of the gated conv1d + GLU kernel for the calling thread's following launches (0 = production).  bit 0: do NOT raise
  * the issue priority of the younger K set's waves (s_setprio 1 is the production setting). */
 int  vc_tune_glu(int flags);

@@ -779,6 +779,10 @@ def test_graph_step_equals_launch_by_launch(built_lib):
         g2, d2 = eng_e.train_step(a, b, *hp, gen_A=hA, gen_B=hB)
         assert g1 == g2 and d1 == d2, (step, g1, g2, d1, d2)
         same('fp32', step)
+    # five steps, two schedules (lambda_identity > 0 / == 0): exactly two captured graphs, every other step was a REPLAY
+    # (the cache key was built after the capture had masked use_side and never matched -- every step re-captured)
+    from voice_converter_cyclegan_amd._lib import lib as _l
+    assert _l.vc_plan_num_step_graphs(eng_g.plan(128)) == 2, _l.vc_plan_num_step_graphs(eng_g.plan(128))
     eng_g.set_math('bf16'); eng_e.set_math('bf16')
     try:
         for step in range(2):

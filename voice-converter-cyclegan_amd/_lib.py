@@ -82,6 +82,7 @@ SIGNATURES = [
     ('vc_gated_conv1d_glu_image_bytes', i64, [i32, i32, i32]),
     ('vc_gated_conv1d_glu_prepack', i32, [vp, i64, vp, i64, i32, i32, i32, i32, vp]),
     ('vc_gated_conv1d_glu_fwd_packed', i32, [vp, i64, vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, i32, i32, vp]),
+    ('vc_plan_num_step_graphs', i32, [vp]),
     ('vc_tune_glu', i32, [i32]),
     ('vc_prof_glu_copy_roof', i32, [vp, vp, vp, i32, i32, i32, vp]),
     ('vc_bias_grad', i32, [vp, i64, vp, i64, i32, i32, i32, i32, vp]),
