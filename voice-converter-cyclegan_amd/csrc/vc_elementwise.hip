@@ -248,6 +248,7 @@ template <int LPR> __device__ __forceinline__ float rowv_sum(float v) {
 }
 __device__ __forceinline__ float hsum4(const f32x4 v) { return (v[0] + v[1]) + (v[2] + v[3]); }
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // 4 consecutive logical positions starting at pos4 of (sample b, branch br, channel c) in the raw conv layout
 template <int NB, bool PS> struct RowV4 {
     long even, odd; int C, L;      // float offsets of the row (PS: of conv channels c and C + c, rows of L / 2)
@@ -270,75 +271,120 @@ template <int NB, bool PS> struct RowV4 {
     }
 };
 
+// The bf16 mode's convolutions read their gathered operand as channel octets, [b][C/8][position][8] bf16 (16-byte units: 8 channels of
+// one position; csrc/vc_conv_bf16.hip).  Round 4 wrote every activation as fp32 and re-read it in a separate launch to build that
+// form (pack_act_bf16_kernel: 77 launches and 1.06 ms of the batch-64 step, 6 bytes of HBM traffic per element).  The kernels that
+// PRODUCE a tensor now emit it: a block's 256 / LPR rows are consecutive channels of one sample -- whole octets --, each lane drops
+// its 4 NV values as bf16 (RNE, the conversion the pack kernel did) into an LDS tile [octet][position][8], and the block writes the
+// tile out as 16-byte units, lanes along the positions.  `rowv` = the lane's row exists; rows of a block are all or nothing per octet.
+// One PLANE of a block: its 256 / LPR rows as consecutive channels of a channel-octet tensor with Lc positions a row.  SHUF = false:
+// a lane's value j holds positions 4 (sub + j LPR) .. + 3.  SHUF = true (the gradient of a pixel-shuffled layer, written in the
+// convolution's own layout): the plane is the even (which = 0) or odd (which = 1) positions -- conv channel c or C + c --, a lane's
+// value j holds positions 2 (sub + j LPR), + 1 of it in elements which and which + 2.
+template <int LPR, int NV, bool SHUF>
+__device__ __forceinline__ void emit_channel_octets(const f32x4 (&o)[NV], const bool (&ok)[NV], bool rowv, int which, int Lc,
+                                                    u32x4* dst /* unit of (sample, first octet of the block, position 0) */, int octs_valid) {
+    constexpr int R = 256 / LPR, OCTS = R / 8, LMAX = LPR * 4 * NV;
+    __shared__ __attribute__((aligned(16))) unsigned short tile[OCTS * LMAX * 8];
+    const int r = threadIdx.x / LPR, sub = threadIdx.x % LPR;
+    __syncthreads();                                        // an earlier plane of this block has left the tile
+    if (rowv) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) if (ok[j]) {
+            if constexpr (SHUF) {
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+                    tile[((r >> 3) * LMAX + (sub + j * LPR) * 2 + k) * 8 + (r & 7)] = __builtin_bit_cast(unsigned short, (__bf16)o[j][which + 2 * k]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    tile[((r >> 3) * LMAX + (sub + j * LPR) * 4 + e) * 8 + (r & 7)] = __builtin_bit_cast(unsigned short, (__bf16)o[j][e]);
+            }
+        }
+    }
+    __syncthreads();
+    for (int u = threadIdx.x; u < octs_valid * Lc; u += 256) {
+        const int oc = u / Lc, pos = u - oc * Lc;
+        dst[(long)oc * Lc + pos] = *reinterpret_cast<const u32x4*>(tile + (oc * LMAX + pos) * 8);
+    }
+}
+
 template <int MODE, int LPR, int NV, bool PS>
 __global__ __launch_bounds__(256) void norm_fwd_v4_kernel(const NormArgs p) {
     touch_kernarg(p);
     constexpr int NB = (MODE == 2) ? 1 : 2;
-    const int unit = blockIdx.x * (256 / LPR) + threadIdx.x / LPR, sub = threadIdx.x % LPR;
-    if (unit >= p.G * p.B * p.C) return;
-    const int g = unit / (p.B * p.C); const int rem = unit - g * (p.B * p.C);
+    const int unit0 = blockIdx.x * (256 / LPR);
+    const int unit = unit0 + threadIdx.x / LPR, sub = threadIdx.x % LPR;
+    const int total = p.G * p.B * p.C;
+    const bool rowv = unit < total;
+    if (!rowv && !p.outp) return;                           // (with a packed output every thread meets the block's barrier)
+    const int uu = rowv ? unit : 0;
+    const int g = uu / (p.B * p.C); const int rem = uu - g * (p.B * p.C);
     const int b = rem / p.C, c = rem - b * p.C;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     const float* y = p.y + (long)g * p.y_gs;
     float* out = p.out + (long)g * p.out_gs + ((long)b * p.C + c) * p.L;
     const float invL = 1.f / (float)p.L;
     const RowV4<NB, PS> r0(p, b, 0, c), r1(p, b, NB - 1, c);
-    f32x4 v[NV], gt[NV]; bool ok[NV];
+    f32x4 v[NV], gt[NV], o[NV]; bool ok[NV];
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
         const int pos4 = (sub + j * LPR) * 4;
-        ok[j] = pos4 < p.L;
+        ok[j] = rowv && pos4 < p.L;
         v[j] = ok[j] ? r0.load(y, pos4) : zero;
         gt[j] = (NB == 2 && ok[j]) ? r1.load(y, pos4) : zero;
+        o[j] = zero;
     }
     if (MODE == 1) {
 #pragma unroll
-        for (int j = 0; j < NV; ++j) if (ok[j]) {
-            f32x4 o;
+        for (int j = 0; j < NV; ++j)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = v[j][e] * sigmoidf_(gt[j][e]);
-            *reinterpret_cast<f32x4*>(out + (sub + j * LPR) * 4) = o;
+            for (int e = 0; e < 4; ++e) o[j][e] = v[j][e] * sigmoidf_(gt[j][e]);
+    } else {
+        const float* gam = p.gamma + (long)g * p.par_gs;
+        const float* bet = p.beta + (long)g * p.par_gs;
+        float* st = p.stats + (long)g * p.st_gs + ((long)b * NB * p.C) * 2;
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) s += hsum4(v[j]);
+        const float mu = rowv_sum<LPR>(s) * invL;
+        float q = 0.f; f32x4 d[NV];
+#pragma unroll
+        for (int j = 0; j < NV; ++j) { d[j] = ok[j] ? v[j] - mu : zero; q += hsum4(d[j] * d[j]); }
+        const float rs = rsqrtf(rowv_sum<LPR>(q) * invL + IN_EPS);
+        const float ga = gam[c], be = bet[c];
+        if (sub == 0 && rowv) { st[2 * c] = mu; st[2 * c + 1] = rs; }
+        if (MODE == 2) {
+            const float* res = p.res + (long)g * p.res_gs + ((long)b * p.C + c) * p.L;
+#pragma unroll
+            for (int j = 0; j < NV; ++j) if (ok[j]) o[j] = *reinterpret_cast<const f32x4*>(res + (sub + j * LPR) * 4) + (d[j] * rs * ga + be);
+        } else {
+            float s2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < NV; ++j) s2 += hsum4(gt[j]);
+            const float mu2 = rowv_sum<LPR>(s2) * invL;
+            float q2 = 0.f; f32x4 d2[NV];
+#pragma unroll
+            for (int j = 0; j < NV; ++j) { d2[j] = ok[j] ? gt[j] - mu2 : zero; q2 += hsum4(d2[j] * d2[j]); }
+            const float rs2 = rsqrtf(rowv_sum<LPR>(q2) * invL + IN_EPS);
+            const float ga2 = gam[p.C + c], be2 = bet[p.C + c];
+            if (sub == 0 && rowv) { st[2 * (p.C + c)] = mu2; st[2 * (p.C + c) + 1] = rs2; }
+#pragma unroll
+            for (int j = 0; j < NV; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[j][e] = (d[j][e] * rs * ga + be) * sigmoidf_(d2[j][e] * rs2 * ga2 + be2);
         }
-        return;
     }
-    const float* gam = p.gamma + (long)g * p.par_gs;
-    const float* bet = p.beta + (long)g * p.par_gs;
-    float* st = p.stats + (long)g * p.st_gs + ((long)b * NB * p.C) * 2;
-    float s = 0.f;
 #pragma unroll
-    for (int j = 0; j < NV; ++j) s += hsum4(v[j]);
-    const float mu = rowv_sum<LPR>(s) * invL;
-    float q = 0.f; f32x4 d[NV];
-#pragma unroll
-    for (int j = 0; j < NV; ++j) { d[j] = ok[j] ? v[j] - mu : zero; q += hsum4(d[j] * d[j]); }
-    const float rs = rsqrtf(rowv_sum<LPR>(q) * invL + IN_EPS);
-    const float ga = gam[c], be = bet[c];
-    if (sub == 0) { st[2 * c] = mu; st[2 * c + 1] = rs; }
-    if (MODE == 2) {
-        const float* res = p.res + (long)g * p.res_gs + ((long)b * p.C + c) * p.L;
-#pragma unroll
-        for (int j = 0; j < NV; ++j) if (ok[j]) {
-            const int pos4 = (sub + j * LPR) * 4;
-            *reinterpret_cast<f32x4*>(out + pos4) = *reinterpret_cast<const f32x4*>(res + pos4) + (d[j] * rs * ga + be);
-        }
-        return;
-    }
-    float s2 = 0.f;
-#pragma unroll
-    for (int j = 0; j < NV; ++j) s2 += hsum4(gt[j]);
-    const float mu2 = rowv_sum<LPR>(s2) * invL;
-    float q2 = 0.f; f32x4 d2[NV];
-#pragma unroll
-    for (int j = 0; j < NV; ++j) { d2[j] = ok[j] ? gt[j] - mu2 : zero; q2 += hsum4(d2[j] * d2[j]); }
-    const float rs2 = rsqrtf(rowv_sum<LPR>(q2) * invL + IN_EPS);
-    const float ga2 = gam[p.C + c], be2 = bet[p.C + c];
-    if (sub == 0) { st[2 * (p.C + c)] = mu2; st[2 * (p.C + c) + 1] = rs2; }
-#pragma unroll
-    for (int j = 0; j < NV; ++j) if (ok[j]) {
-        f32x4 o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (d[j][e] * rs * ga + be) * sigmoidf_(d2[j][e] * rs2 * ga2 + be2);
-        *reinterpret_cast<f32x4*>(out + (sub + j * LPR) * 4) = o;
+    for (int j = 0; j < NV; ++j) if (ok[j]) *reinterpret_cast<f32x4*>(out + (sub + j * LPR) * 4) = o[j];
+    if (p.outp) {
+        // the block's rows: units unit0 .. unit0 + 256 / LPR - 1 = consecutive channels of ONE (group, sample) (the launcher checks C % (256 / LPR) == 0)
+        const int u0 = unit0 < total ? unit0 : 0;
+        const int g0 = u0 / (p.B * p.C); const int rem0 = u0 - g0 * (p.B * p.C);
+        const int b0 = rem0 / p.C, c0 = rem0 - b0 * p.C;
+        const int left = (total - unit0) / 8;
+        u32x4* dst = reinterpret_cast<u32x4*>(reinterpret_cast<char*>(p.outp) + (long)g0 * p.outp_gs) + ((long)b0 * (p.C / 8) + c0 / 8) * p.L;
+        emit_channel_octets<LPR, NV, false>(o, ok, rowv, 0, p.L, dst, left < (256 / LPR) / 8 ? (left > 0 ? left : 0) : (256 / LPR) / 8);
     }
 }
 
@@ -346,14 +392,33 @@ template <int MODE, int LPR, int NV, bool PS>
 __global__ __launch_bounds__(256) void norm_bwd_v4_kernel(const NormArgs p) {
     touch_kernarg(p);
     constexpr int NB = (MODE == 2) ? 1 : 2;
-    const int unit = blockIdx.x * (256 / LPR) + threadIdx.x / LPR, sub = threadIdx.x % LPR;
-    if (unit >= p.G * p.B * p.C) return;
-    const int g = unit / (p.B * p.C); const int rem = unit - g * (p.B * p.C);
+    const int unit0 = blockIdx.x * (256 / LPR);
+    const int unit = unit0 + threadIdx.x / LPR, sub = threadIdx.x % LPR;
+    const int total = p.G * p.B * p.C;
+    const bool rowv = unit < total;
+    if (!rowv && !p.outp) return;                           // (with a packed output every thread meets the block's barriers)
+    const int uu = rowv ? unit : 0;
+    const int g = uu / (p.B * p.C); const int rem = uu - g * (p.B * p.C);
     const int b = rem / p.C, c = rem - b * p.C;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     const float* y = p.y + (long)g * p.y_gs;
     float* dy = p.dy + (long)g * p.dy_gs;
     const float* dout = p.dout + (long)g * p.do_gs + ((long)b * p.C + c) * p.L;
+    // dy once more as bf16 channel octets in the convolution's layout [b][Cout / 8][OH OW][8] (what its input gradient gathers): branch br
+    // = conv channels [br Cc, (br + 1) Cc), Cc = C (2 C when shuffled: even positions channel c, odd ones C + c)
+    auto emit_dy = [&](const f32x4 (&val)[NV], const bool (&okv)[NV], int br) {
+        const int Cc = PS ? 2 * p.C : p.C, Lc = PS ? p.L >> 1 : p.L, Cout8 = NB * Cc / 8;
+        const int u0 = unit0 < total ? unit0 : 0;
+        const int g0 = u0 / (p.B * p.C); const int rem0 = u0 - g0 * (p.B * p.C);
+        const int b0 = rem0 / p.C, c0 = rem0 - b0 * p.C;
+        const int left = (total - unit0) / 8, nv = left < (256 / LPR) / 8 ? (left > 0 ? left : 0) : (256 / LPR) / 8;
+        u32x4* base = reinterpret_cast<u32x4*>(reinterpret_cast<char*>(p.outp) + (long)g0 * p.outp_gs);
+#pragma unroll
+        for (int which = 0; which < (PS ? 2 : 1); ++which) {
+            const int chb = br * Cc + which * p.C + c0;
+            emit_channel_octets<LPR, NV, PS>(val, okv, rowv, which, Lc, base + ((long)b0 * Cout8 + chb / 8) * Lc, nv);
+        }
+    };
     const float invL = 1.f / (float)p.L;
     const RowV4<NB, PS> r0(p, b, 0, c), r1(p, b, NB - 1, c);
     float* dbias = p.dbias ? p.dbias + (long)g * p.dbias_gs : nullptr;
@@ -363,7 +428,7 @@ __global__ __launch_bounds__(256) void norm_bwd_v4_kernel(const NormArgs p) {
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
         const int pos4 = (sub + j * LPR) * 4;
-        ok[j] = pos4 < p.L;
+        ok[j] = rowv && pos4 < p.L;
         v[j] = ok[j] ? r0.load(y, pos4) : zero;
         gt[j] = (NB == 2 && ok[j]) ? r1.load(y, pos4) : zero;
         dO[j] = ok[j] ? *reinterpret_cast<const f32x4*>(dout + pos4) : zero;
@@ -373,7 +438,7 @@ __global__ __launch_bounds__(256) void norm_bwd_v4_kernel(const NormArgs p) {
 #pragma unroll
         for (int j = 0; j < NV; ++j) { se += PS ? dv[j][0] + dv[j][2] : hsum4(dv[j]); so += PS ? dv[j][1] + dv[j][3] : 0.f; }
         se = rowv_sum<LPR>(se); if (PS) so = rowv_sum<LPR>(so);
-        if (sub == 0) { atomicAdd(dbias + br * brs + c, se); if (PS) atomicAdd(dbias + br * brs + p.C + c, so); }
+        if (sub == 0 && rowv) { atomicAdd(dbias + br * brs + c, se); if (PS) atomicAdd(dbias + br * brs + p.C + c, so); }
     };
     if (MODE == 1) {
         f32x4 dv[NV], dg[NV];
@@ -384,6 +449,7 @@ __global__ __launch_bounds__(256) void norm_bwd_v4_kernel(const NormArgs p) {
             if (ok[j]) { r0.store(dy, (sub + j * LPR) * 4, dv[j]); r1.store(dy, (sub + j * LPR) * 4, dg[j]); }
         }
         if (dbias) { bias_sums(dv, 0); bias_sums(dg, 1); }
+        if (p.outp) { emit_dy(dv, ok, 0); emit_dy(dg, ok, 1); }
         return;
     }
     const float* gam = p.gamma + (long)g * p.par_gs;
@@ -407,7 +473,8 @@ __global__ __launch_bounds__(256) void norm_bwd_v4_kernel(const NormArgs p) {
             if (ok[j]) r0.store(dy, (sub + j * LPR) * 4, d[j]);
         }
         if (dbias) bias_sums(d, 0);
-        if (sub == 0 && dgam) { atomicAdd(dgam + c, s2); atomicAdd(dbet + c, s1); }
+        if (sub == 0 && dgam && rowv) { atomicAdd(dgam + c, s2); atomicAdd(dbet + c, s1); }
+        if (p.outp) emit_dy(d, ok, 0);
         return;
     }
     const float mu2 = st[2 * (p.C + c)], rs2 = st[2 * (p.C + c) + 1], ga2 = gam[p.C + c], be2 = bet[p.C + c];
@@ -433,10 +500,11 @@ __global__ __launch_bounds__(256) void norm_bwd_v4_kernel(const NormArgs p) {
         if (ok[j]) { r0.store(dy, (sub + j * LPR) * 4, dv[j]); r1.store(dy, (sub + j * LPR) * 4, dg[j]); }
     }
     if (dbias) { bias_sums(dv, 0); bias_sums(dg, 1); }
-    if (sub == 0 && dgam) {
+    if (sub == 0 && dgam && rowv) {
         atomicAdd(dgam + c, s2v); atomicAdd(dbet + c, s1v);
         atomicAdd(dgam + p.C + c, s2g); atomicAdd(dbet + p.C + c, s1g);
     }
+    if (p.outp) { emit_dy(dv, ok, 0); emit_dy(dg, ok, 1); }
 }
 
 // GLU backward without norm (module.py:201-203 / 161-163: the two h1 blocks) for rows of ANY length that is a multiple of 4
@@ -967,6 +1035,10 @@ static int norm_dispatch(const NormArgs& a, hipStream_t s) {
         bool ok = !det && (a.L & 3) == 0 && al(a.y, a.y_gs);
         if (FWD) ok = ok && al(a.out, a.out_gs) && (MODE != 2 || al(a.res, a.res_gs));
         else ok = ok && al(a.dy, a.dy_gs) && al(a.dout, a.do_gs);
+        if (a.outp && !(ok && a.L <= 512 && a.C % 32 == 0 && al(a.outp, a.outp_gs / 4))) {
+            vc_set_error("norm forward / backward: a packed bf16 output was requested for a launch the 16-byte kernels do not serve (ask norm_fwd_emits_packed / norm_bwd_emits_packed first)");
+            return -1;
+        }
         if (ok && MODE == 1 && !FWD && !a.ps && a.L > 512) {          // long GLU rows (D.h1): streamed
             glu_bwd_v4_kernel<<<dim3((units + 7) / 8), block, 0, s>>>(a);
             VC_HIP(hipGetLastError());
@@ -1004,6 +1076,16 @@ static int norm_dispatch(const NormArgs& a, hipStream_t s) {
 #undef VC_NORM_CASE
     VC_HIP(hipGetLastError());
     return 0;
+}
+// would launch_norm_fwd honour NormArgs::outp for this launch?  (rows of up to 512 positions in multiples of 4, 16-byte aligned tensors,
+// channel counts whose blocks of 8 / 16 / 32 rows hold whole octets of one sample)
+bool norm_fwd_emits_packed(const NormArgs& a) {
+    auto al = [](const void* q, long gs) { return ((uintptr_t)q & 15) == 0 && (gs & 3) == 0; };
+    return (a.L & 3) == 0 && a.L <= 512 && a.C % 32 == 0 && al(a.y, a.y_gs) && al(a.out, a.out_gs) && (!a.res || al(a.res, a.res_gs));
+}
+bool norm_bwd_emits_packed(const NormArgs& a) {             // same question for the backward's dy (not in deterministic mode: its kernels walk the batch)
+    auto al = [](const void* q, long gs) { return ((uintptr_t)q & 15) == 0 && (gs & 3) == 0; };
+    return !a.det && (a.L & 3) == 0 && a.L <= 512 && a.C % 32 == 0 && al(a.y, a.y_gs) && al(a.dy, a.dy_gs) && al(a.dout, a.do_gs);
 }
 int launch_norm_fwd(int mode, const NormArgs& a, hipStream_t s) {
     if (a.ps && (a.L & 1)) { vc_set_error("pixel shuffle needs even L"); return -1; }

@@ -57,10 +57,12 @@ struct WgradApp { const float* x; long x_gs; const float* dy; long dy_gs; int B;
 int conv_fwd(const float* x, long x_gs, const float* w, long w_gs, const float* bias, long b_gs,
              float* y, long y_gs, int G, int B, const Geom& g, int math, hipStream_t s,
              bool prezeroed = false, bool* query = nullptr, const char* packed_w = nullptr,
-             char* xp_keep = nullptr, long xp_keep_gs = 0, FuseNorm* fuse = nullptr);
+             char* xp_keep = nullptr, long xp_keep_gs = 0, FuseNorm* fuse = nullptr, bool x_prepacked = false);   // x_prepacked: xp_keep already holds x's channel octets (its producer wrote them)
 int conv_dgrad(const float* dy, long dy_gs, const float* w, long w_gs, float* dx, long dx_gs,
                const float* addend, long add_gs, int accumulate, int G, int B, const Geom& g, int math, hipStream_t s,
-               bool prezeroed = false, bool* query = nullptr, const char* const* packed_w = nullptr);
+               bool prezeroed = false, bool* query = nullptr, const char* const* packed_w = nullptr,
+               const char* dy_packed = nullptr, long dy_packed_gs = 0);   // dy_packed: dy already as bf16 channel octets (its producer wrote them; group stride in bytes)
+bool conv_dgrad_packs_input(const Geom& g, int B, int math);          // the input gradient of this geometry at batch B runs on the 16-bit data path
 int conv_wgrad(const WgradApp* apps, int napps, float* dw, long dw_gs, int G, const Geom& g, int math, hipStream_t s,
                bool store, bool* query = nullptr);
 void drop_pack_spaces(std::initializer_list<hipStream_t> streams);

@@ -181,6 +181,7 @@ struct NormArgs {
     const float* y; const float* res; const float* gamma; const float* beta;
     const float* dout; const float* stats_in;
     float* out; float* stats; float* dy; float* dgamma; float* dbeta; float* dbias;
+    void* outp; long outp_gs;             // optional: the output (forward) / dy (backward) once more as bf16 channel octets [b][channels / 8][positions][8] (group stride in BYTES)
     long y_gs, res_gs, par_gs, out_gs, st_gs, do_gs, dy_gs, dpar_gs, dbias_gs;
     int G, B, C, L, ps;
     int det;                              // backward: reduce dgamma / dbeta / dbias over the batch inside one lane group (fixed order, no atomics)
@@ -197,6 +198,8 @@ struct CopyItem { float* dst; const float* src; long n; };
 int launch_copy_list(const std::vector<CopyItem>& items, hipStream_t s);      // dst[i][0..n) = src[i][0..n), one launch per 8 items
 int launch_add(float* dst, const float* src, long n, hipStream_t s);   // dst += src
 int launch_norm_fwd(int mode, const NormArgs& a, hipStream_t s);
+bool norm_fwd_emits_packed(const NormArgs& a);     // NormArgs::outp is honoured for this launch (else: leave it null)
+bool norm_bwd_emits_packed(const NormArgs& a);     // ... by launch_norm_bwd: dy as channel octets in the convolution's layout
 int launch_norm_bwd(int mode, const NormArgs& a, hipStream_t s);
 int launch_bias_grad(const float* dy, long dy_gs, float* db, long db_gs, int G, int B, int C, int L, hipStream_t s);
 int launch_head_fwd(const float* x, long x_gs, const float* w, const float* b, long par_gs,

@@ -239,10 +239,17 @@ extern "C" int64_t vc_discriminator_save_floats(const vc_plan* p, int B) { retur
 // backward scratch of one group: for every layer i [dY_i: gradient w.r.t. its raw conv output][dA_i: gradient w.r.t. its
 // activation].  Per-layer buffers (not a rotating pair) so a filter gradient on the side stream can still read dY_i
 // while the chain has moved on.
+// + one region for the bf16 channel-octet copy of the dY in flight (bf16 data path: norm backward emits it, the layer's input gradient
+// reads it, the next layer's norm backward overwrites it -- all on one stream): half the floats of the largest dY
+static long scratch_dyp_floats(const std::vector<LayerGeo>& geo, int B) {
+    long m = 0;
+    for (const LayerGeo& l : geo) m = std::max(m, align64((l.raw_ps * B + 1) / 2));
+    return m;
+}
 long scratch_floats_net(const std::vector<LayerGeo>& geo, int B) {
     long o = 0;
     for (const LayerGeo& l : geo) o += align64(l.raw_ps * B) + align64(l.act_ps * B);
-    return o;
+    return o + scratch_dyp_floats(geo, B);
 }
 extern "C" int64_t vc_scratch_floats(const vc_plan* p, int B) {
     if (!p) return 0;
@@ -271,9 +278,10 @@ struct NetCtx {
     const hipEvent_t* ev_free = nullptr;                                            // ... and ev_free[k] after its input gradient is issued
 };
 // scratch map of one group: dY[i], dA[i] per layer (dA[i] = gradient w.r.t. the activation (output) of layer i)
-static void scratch_map(const std::vector<LayerGeo>& geo, int B, long* dY, long* dA) {
+static long scratch_map(const std::vector<LayerGeo>& geo, int B, long* dY, long* dA) {      // returns the offset of the packed-dY region
     long o = 0;
     for (size_t i = 0; i < geo.size(); ++i) { dY[i] = o; o += align64(geo[i].raw_ps * B); dA[i] = o; o += align64(geo[i].act_ps * B); }
+    return o;
 }
 
 static int net_forward(NetCtx& c, const float* x, long x_gs, float* y_plain, long y_plain_gs) {
@@ -298,6 +306,7 @@ static int net_forward(NetCtx& c, const float* x, long x_gs, float* y_plain, lon
     }
     const float* in = x; long in_gs = x_gs;
     const float* blk_in = nullptr; long blk_in_gs = 0;
+    bool in_packed = false;               // bf16 data path: layer i's input already lies in actp[i - 1] as channel octets (its producer emitted them)
     for (size_t i = 0; i < c.n->layers.size(); ++i) {
         const Layer& L = c.n->layers[i]; const LayerGeo& lg = (*c.geo)[i];
         float* raw = (L.mode == M_PLAIN) ? y_plain : c.save + c.sm.raw[i];
@@ -330,7 +339,8 @@ static int net_forward(NetCtx& c, const float* x, long x_gs, float* y_plain, lon
         VC_CHECK(conv_fwd(in, in_gs, c.params + L.w, c.par_gs, c.params + L.b, c.par_gs, raw, raw_gs, c.G, c.B, lg.g, c.math, c.s,
                           /*prezeroed=*/L.mode != M_PLAIN || plain_zeroed, nullptr, c.images ? (*c.images)[i].fwd : nullptr,
                           (c.keep_packed && i > 0) ? (char*)(c.save + c.sm.actp[i - 1]) : nullptr, c.save_gs * 4,
-                          fn.act ? &fn : nullptr));
+                          fn.act ? &fn : nullptr, in_packed));
+        in_packed = false;
         if (L.mode == M_PLAIN) break;
         if (fn.done) { in = fn.act; in_gs = c.save_gs; continue; }
         NormArgs a{};
@@ -342,6 +352,12 @@ static int net_forward(NetCtx& c, const float* x, long x_gs, float* y_plain, lon
             a.stats = c.save + c.sm.st[i]; a.st_gs = c.save_gs;
         }
         if (L.mode == M_IN_RES) { a.res = blk_in; a.res_gs = blk_in_gs; }
+        // the next layer's convolution reads this activation as bf16 channel octets out of actp[i]: let the kernel that produces it write
+        // them (round 4: a pack launch per convolution re-read the fp32 tensor)
+        if (c.keep_packed && i + 1 < c.n->layers.size() && conv_fwd_packs_input((*c.geo)[i + 1].g, c.B, c.math) && norm_fwd_emits_packed(a)) {
+            a.outp = (char*)(c.save + c.sm.actp[i]); a.outp_gs = c.save_gs * 4;
+            in_packed = true;
+        }
         VC_CHECK(launch_norm_fwd(L.mode, a, c.s));
         in = a.out; in_gs = c.save_gs;
     }
@@ -355,7 +371,7 @@ static int net_backward(NetCtx& c, const float* x, long x_gs, const float* dtop,
     const int nl = (int)c.n->layers.size();
     VC_ARG(nl <= 24, "net_backward: more than 24 layers");
     long dYo[24], dAo[24];
-    scratch_map(*c.geo, c.B, dYo, dAo);
+    const long dYp_off = scratch_map(*c.geo, c.B, dYo, dAo);
     long dYd[24], dAd[24];
     if (c.deferred) scratch_map(*c.geo, c.deferred->B, dYd, dAd);
     hipStream_t ws = c.ws ? c.ws : c.s;       // the plan sizes its event pools for its own networks (18 / 4 layers)
@@ -376,6 +392,7 @@ static int net_backward(NetCtx& c, const float* x, long x_gs, const float* dtop,
         const float* in = (i == 0) ? x : c.save + c.sm.act[i - 1];
         const long in_gs = (i == 0) ? x_gs : c.save_gs;
         const float* dyp; long dy_gs;
+        const char* dy_packed = nullptr;                 // dy of this layer as bf16 channel octets in the scratch's packed region, if its producer emitted them
         if (L.mode == M_PLAIN) {
             dyp = dcur; dy_gs = dcur_gs;
             if (c.dparams) {
@@ -394,6 +411,12 @@ static int net_backward(NetCtx& c, const float* x, long x_gs, const float* dtop,
                 if (c.dparams) { a.dgamma = c.dparams + L.gamma; a.dbeta = c.dparams + L.beta; a.dpar_gs = c.dpar_gs; }
             }
             if (c.dparams) { a.dbias = c.dparams + L.b; a.dbias_gs = c.dpar_gs; }
+            // bf16 data path: this layer's input gradient gathers dy as bf16 channel octets -- the kernel that produces dy writes them
+            // (round 4: a pack launch per input gradient re-read the fp32 tensor).  i == 0 without dx: nobody reads them.
+            if ((i > 0 || dx) && conv_dgrad_packs_input(lg.g, c.B, c.math) && norm_bwd_emits_packed(a)) {
+                a.outp = (char*)(scratch + dYp_off); a.outp_gs = scr_gs * 4;
+                dy_packed = (const char*)a.outp;
+            }
             VC_CHECK(launch_norm_bwd(L.mode, a, c.s));
             dyp = scratch + dYo[i]; dy_gs = scr_gs;
             if (c.dparams && c.wmode != W_NONE && ws != c.s) { VC_HIP(hipEventRecord(c.ev_layer[i], c.s)); VC_HIP(hipStreamWaitEvent(ws, c.ev_layer[i], 0)); }
@@ -417,7 +440,7 @@ static int net_backward(NetCtx& c, const float* x, long x_gs, const float* dtop,
         for (int k = 0; k < c.n_ev; ++k) if (c.ev_first[k] == i) VC_HIP(hipEventRecord(c.ev[k], ws));
         if (i == 0) {
             if (dx) VC_CHECK(conv_dgrad(dyp, dy_gs, c.params + L.w, c.par_gs, dx, dx_gs, nullptr, 0, dx_acc, c.G, c.B, lg.g, c.math, c.s,
-                                        false, nullptr, (c.images && (*c.images)[i].has_dg) ? (*c.images)[i].dg : nullptr));
+                                        false, nullptr, (c.images && (*c.images)[i].has_dg) ? (*c.images)[i].dg : nullptr, dy_packed, scr_gs * 4));
             for (int k = 0; k < c.n_ev; ++k) if (c.ev_free && c.ev_first[k] == i) VC_HIP(hipEventRecord(c.ev_free[k], c.s));
             break;        // falls through to the join below
         }
@@ -425,7 +448,7 @@ static int net_backward(NetCtx& c, const float* x, long x_gs, const float* dtop,
         const bool block_head = (L.mode == M_GATED_IN && i + 1 < nl && c.n->layers[i + 1].mode == M_IN_RES);
         VC_CHECK(conv_dgrad(dyp, dy_gs, c.params + L.w, c.par_gs, scratch + dAo[i - 1], scr_gs,
                             block_head ? skip : nullptr, block_head ? skip_gs : 0, 0, c.G, c.B, lg.g, c.math, c.s, /*prezeroed=*/true,
-                            nullptr, (c.images && (*c.images)[i].has_dg) ? (*c.images)[i].dg : nullptr));
+                            nullptr, (c.images && (*c.images)[i].has_dg) ? (*c.images)[i].dg : nullptr, dy_packed, scr_gs * 4));
         if (block_head) skip = nullptr;
         for (int k = 0; k < c.n_ev; ++k) if (c.ev_free && c.ev_first[k] == i) VC_HIP(hipEventRecord(c.ev_free[k], c.s));
         dcur = scratch + dAo[i - 1]; dcur_gs = scr_gs;

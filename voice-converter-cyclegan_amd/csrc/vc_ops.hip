@@ -125,6 +125,16 @@ bool conv_fwd_packs_input(const Geom& g, int B, int math) {
     Table t; if (get_fwd_table(g, &t, nullptr)) return false;
     return bf16_path(t, math, g.Cout, (long)B * g.OH * g.OW);
 }
+// the decision conv_dgrad takes: every stride-parity class of the input gradient has an octet table and the launch fills the tiles
+bool conv_dgrad_packs_input(const Geom& g, int B, int math) {
+    if (math != VC_MATH_BF16 || c1_path(g) || g.Cin % 4) return false;
+    Table t0; if (get_dgrad_table(g, 0, 0, &t0)) return false;
+    if (!bf16_path(t0, math, g.Cin, (long)B * ((g.H + g.sh - 1) / g.sh) * ((g.W + g.sw - 1) / g.sw))) return false;
+    for (int ph = 0; ph < g.sh; ++ph) for (int pw = 0; pw < g.sw; ++pw) {
+        Table t; if (get_dgrad_table(g, ph, pw, &t) || t.koct <= 0) return false;
+    }
+    return true;
+}
 static void bf16_set_vec4(ConvBf16Args& a) {
     a.vec4 = a.so_w == 1 && a.OWc % 4 == 0 && a.o_w0 % 4 == 0 && a.yW % 4 == 0 && a.yHW % 4 == 0 && a.y_bs % 4 == 0 &&
              a.y_gs % 4 == 0 && aligned16(a.Y) && (!a.addend || (aligned16(a.addend) && a.add_gs % 4 == 0));
@@ -133,7 +143,7 @@ static void bf16_set_vec4(ConvBf16Args& a) {
 // query != nullptr: do not launch, only report whether the launch would use split-K atomics (needs a zeroed y)
 int conv_fwd(const float* x, long x_gs, const float* w, long w_gs, const float* bias, long b_gs,
                     float* y, long y_gs, int G, int B, const Geom& g, int math, hipStream_t s,
-                    bool prezeroed, bool* query, const char* packed_w, char* xp_keep, long xp_keep_gs, FuseNorm* fuse) {
+                    bool prezeroed, bool* query, const char* packed_w, char* xp_keep, long xp_keep_gs, FuseNorm* fuse, bool x_prepacked) {
     // fuse: the caller would like instance norm + GLU done in the epilogue; fuse->done tells whether this launch did it
     // xp_keep: where the packed bf16 copy of x is left for the layer's filter gradient (16-bit data path; group stride in bytes)
     VC_CHECK(check_conv_geom(g, B));
@@ -171,7 +181,7 @@ int conv_fwd(const float* x, long x_gs, const float* w, long w_gs, const float* 
         char* xp = xp_keep ? xp_keep : wsp;
         if (xp_keep) a.x_gs = xp_keep_gs;
         a.X = xp; a.A = packed_w ? packed_w : wsp + (xp_keep ? 0 : xp_g * G);
-        VC_CHECK(launch_pack_act_bf16(x, x_gs, xp, a.x_gs, G, B, g.Cin, g.H * g.W, s));
+        if (!(x_prepacked && xp_keep)) VC_CHECK(launch_pack_act_bf16(x, x_gs, xp, a.x_gs, G, B, g.Cin, g.H * g.W, s));
         if (!packed_w) VC_CHECK(launch_pack_filter_bf16(w, w_gs, const_cast<void*>(a.A), (long)ap_g, t.wsrc, 1, G, g.Cout, t.koct * 8, s));
         if (a.splitk > 1) {
             if (!prezeroed)
@@ -211,7 +221,7 @@ int conv_fwd(const float* x, long x_gs, const float* w, long w_gs, const float* 
 
 int conv_dgrad(const float* dy, long dy_gs, const float* w, long w_gs, float* dx, long dx_gs,
                       const float* addend, long add_gs, int accumulate, int G, int B, const Geom& g, int math, hipStream_t s,
-                      bool prezeroed, bool* query, const char* const* packed_w) {
+                      bool prezeroed, bool* query, const char* const* packed_w, const char* dy_packed, long dy_packed_gs) {
     VC_CHECK(check_conv_geom(g, B));
     if (c1_path(g)) {
         if (query) { *query = false; return 0; }      // zeroes dx itself when it has to
@@ -264,7 +274,7 @@ int conv_dgrad(const float* dy, long dy_gs, const float* w, long w_gs, float* dx
             }
             if (query) { *query = split; return 0; }
             char* wsp; VC_CHECK(pack_space(s, xp_g * G + (packed_w ? 0 : ap_tot), &wsp));
-            VC_CHECK(launch_pack_act_bf16(dy, dy_gs, wsp, (long)xp_g, G, B, g.Cout, g.OH * g.OW, s));
+            if (!dy_packed) VC_CHECK(launch_pack_act_bf16(dy, dy_gs, wsp, (long)xp_g, G, B, g.Cout, g.OH * g.OW, s));
             if (split && !accumulate) {
                 if (!prezeroed)
                     for (int gi = 0; gi < G; ++gi)
@@ -272,7 +282,8 @@ int conv_dgrad(const float* dy, long dy_gs, const float* w, long w_gs, float* dx
                 for (int i = 0; i < nc; ++i) cl[i].accumulate = 1;
             }
             for (int i = 0; i < nc; ++i) {
-                cl[i].X = wsp; cl[i].A = packed_w ? packed_w[i] : wsp + xp_g * G + ap_off[i];
+                cl[i].X = dy_packed ? dy_packed : wsp; if (dy_packed) cl[i].x_gs = dy_packed_gs;
+                cl[i].A = packed_w ? packed_w[i] : wsp + xp_g * G + ap_off[i];
                 if (!packed_w) VC_CHECK(launch_pack_filter_bf16(w, w_gs, wsp + xp_g * G + ap_off[i], cl[i].a_gs, wsrc[i], g.Cout, G, g.Cin, cl[i].koct * 8, s));
                 VC_CHECK(launch_conv_bf16(cl[i], s, flb[i]));
             }
