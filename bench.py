@@ -101,7 +101,7 @@ def cpu_baseline(leg_timeout_s=150):
                 sample='24x128 MCEP, fp32; ' + '; '.join([l[2] for l in legs] + notes) + '; TF1 reference not runnable (no tensorflow)')
 
 
-PMC_FILES = ('r04_pmc_traffic.json', 'r03_pmc_traffic.json')
+PMC_FILES = ('r05_pmc_traffic.json', 'r04_pmc_traffic.json', 'r03_pmc_traffic.json')
 
 
 def _pmc_traffic(B, F, T, world, math, role='igemm'):
