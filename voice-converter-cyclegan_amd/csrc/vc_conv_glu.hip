@@ -205,7 +205,7 @@ __device__ __forceinline__ void gated_conv1d_glu_body(const WsConvArgs& a, char*
     const int tile0 = blockIdx.x, tstep = gridDim.x;
     Cursor lcur = cursor_at(tile0);                      // next tile whose frames are requested
     issue_loads(xr0, lcur); advance(lcur);
-    const char* const wimg = PRE ? (const char*)a.wimg + (long)g * a.wimg_gs + (long)slab * GG::SLAB_BYTES : nullptr;
+    [[maybe_unused]] const char* const wimg = PRE ? (const char*)a.wimg + (long)g * a.wimg_gs + (long)slab * GG::SLAB_BYTES : nullptr;
     // bf16: the wave's filter fragments, value and gate, of its K steps (read out of the LDS image behind the prologue's barrier)
     constexpr bool W_REGS = BF16;
     constexpr int NUS = S ? GG::NU1 : GG::NU0, U0 = S ? GG::NU0 : 0;
