@@ -180,7 +180,10 @@ __device__ __forceinline__ void gated_conv1d_glu_body(const WsConvArgs& a, char*
     // The counter retires in order: "at most N younger operations outstanding" means the register set has arrived.  The
     // compiler sees the registers pass through the asm, so no use can move above the wait.
 #define VC_XR_OPS "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7])
-    auto wait_all = [&](float (&x)[NXL]) { asm volatile("s_waitcnt vmcnt(0)" : VC_XR_OPS :: "memory"); };
+    // prologue: everything issued so far has landed; BOTH register sets pass through the asm (see below)
+    auto wait_all2 = [&](float (&x)[NXL], float (&z)[NXL]) {
+        asm volatile("s_waitcnt vmcnt(0)" : VC_XR_OPS, "+v"(z[0]), "+v"(z[1]), "+v"(z[2]), "+v"(z[3]), "+v"(z[4]), "+v"(z[5]), "+v"(z[6]), "+v"(z[7]) :: "memory");
+    };
     // younger operations at the point of use: the next-but-one tile's NXL loads + two tiles' output stores
     static_assert(NXL + 2 * NST == 24 || NXL + 2 * NST == 56, "the two counted waits below");
     auto wait_counted = [&](float (&x)[NXL]) {
@@ -201,16 +204,23 @@ __device__ __forceinline__ void gated_conv1d_glu_body(const WsConvArgs& a, char*
             (std::make_integer_sequence<int, NTPT>{});
     };
 
-    // ---- prologue: first tile's frames travel while the filter fragments arrive
+    // ---- prologue: the first TWO tiles' frames travel while the filter fragments arrive, and BOTH are retired by the one wait below.
+    // Nothing may be in flight when control leaves the prologue: at the loop's entry the compiler is free to shuffle registers (it
+    // did: v_mov copies of the second set's registers in front of the first trip's wait in every bf16 instantiation), and a copy of a
+    // register whose load has not landed is a copy of garbage -- 0.1 - 0.4 % of the launches of the un-packed bf16 kernel at
+    // B >= 512 staged such frames for their second tile (round 5, tools/stress_glu.py; the ISA test only policed the loop body).
+    // Inside the loop the in-flight set crosses trip boundaries only, where tests/test_glu_isa_cpu.py reads every instruction.
     const int tile0 = blockIdx.x, tstep = gridDim.x;
     Cursor lcur = cursor_at(tile0);                      // next tile whose frames are requested
     issue_loads(xr0, lcur); advance(lcur);
+    issue_loads(xr1, lcur); advance(lcur);
     [[maybe_unused]] const char* const wimg = PRE ? (const char*)a.wimg + (long)g * a.wimg_gs + (long)slab * GG::SLAB_BYTES : nullptr;
     // bf16: the wave's filter fragments, value and gate, of its K steps (read out of the LDS image behind the prologue's barrier)
     constexpr bool W_REGS = BF16;
     constexpr int NUS = S ? GG::NU1 : GG::NU0, U0 = S ? GG::NU0 : 0;
     frag_t wv[W_REGS ? NUS : 1], wgt[W_REGS ? NUS : 1];
-    constexpr int NVV = NUS - 4;                            // value fragments [NVV, NUS) live in the accumulator half as well: the VGPR half (128 of the
+    constexpr int NVV = S ? NUS - 8 : NUS - 5;                            // value fragments [NVV, NUS) live in the accumulator half as well (set 0: 5 of them, which fills its 128 AGPRs beside gate fragments, accumulators and
+                                                            // bias tuples; set 1: 8): the VGPR half (128 of the
                                                             // wave's 256) also holds the frames in flight, the fragment ring and the previous tile's GLU
     // the bias as the first MFMA's C operand: register i of a lane is channel row 8 (i / 4) + 4 h + i % 4.  Set 1 starts from 0.
     f32x16 bvv, bgv;
@@ -223,6 +233,7 @@ __device__ __forceinline__ void gated_conv1d_glu_body(const WsConvArgs& a, char*
             for (int i = 0; i < 16; ++i) { bvv[i] = bp[8 * (i >> 2) + (i & 3)]; bgv[i] = bp[C + 8 * (i >> 2) + (i & 3)]; }
         }
     }
+
     if constexpr (PRE) {
         // the slab's pre-packed image -> LDS as it lies, ONCE per workgroup, global -> LDS without registers (buffer_load_dwordx4 ... lds:
         // lane l's 16 bytes land at the wave-uniform LDS address + 16 l; wave w copies units w, w + 8, ..).  Round 5's first build
@@ -269,13 +280,10 @@ __device__ __forceinline__ void gated_conv1d_glu_body(const WsConvArgs& a, char*
             }
         }
     }
-    wait_all(xr0);
-    // the bias tuples are consumed HERE (everything issued so far has landed): a first use behind the next tile's asm loads would make
-    // the compiler's own wait for the bias loads -- it cannot see that the wait above retired them -- drain those frames too
+    wait_all2(xr0, xr1);
+    // the bias tuples are consumed HERE (everything issued so far has landed)
     if constexpr (S == 0) { asm volatile("" : "+a"(bvv)); asm volatile("" : "+a"(bgv)); }
     stage_all(xr0, Xs);
-    issue_loads(xr1, lcur); advance(lcur);
-
     // output addressing: accumulator register i of a lane is pixel l31 of channel row 8 (i / 4) + 4 h + i % 4 of the slab: the
     // lane's byte offset carries (sample, slab, 4 h, pixel), the register's row rides in the store's SGPR offset
     const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
@@ -286,14 +294,17 @@ __device__ __forceinline__ void gated_conv1d_glu_body(const WsConvArgs& a, char*
     // where the wave's 32 x 32 output tile of `tile` goes (tile < 0 or past the end, or pixels past the end of the sample:
     // invalid -> an out-of-range offset, dropped by the hardware)
     struct OutPos { unsigned yb, rb; };
+    // lane part (row 4 h of the slab, pixel pb * 32 + l31 of the tile) + uniform part (sample, tile) of the byte offset: the same lane
+    // constant serves the GLU output and the raw pair (their rows differ by the uniform sample stride only)
+    const int lane_t = pb * 32 + l31;
+    const unsigned lane_off = (unsigned)(((slab * 32 + 4 * h) * a.T + lane_t) * 4);
     auto out_pos = [&](const Cursor& cu) {
         OutPos p;
         const bool tv = cu.tile >= 0 && cu.tile < ntiles;
-        const int b = tv ? cu.b : 0;
-        const int t = (tv ? cu.tt : 0) * TP + pb * 32 + l31, row = slab * 32 + 4 * h;
-        const bool ok = tv && t < a.T;
-        p.yb = ok ? (unsigned)(((b * C + row) * a.T + t) * 4) : VC_OOB_ST;
-        p.rb = ok ? (unsigned)(((b * 2 * C + row) * a.T + t) * 4) : VC_OOB_ST;
+        const int b = tv ? cu.b : 0, t0 = (tv ? cu.tt : 0) * TP;
+        const bool ok = tv && t0 + lane_t < a.T;
+        p.yb = ok ? lane_off + (unsigned)((b * C * a.T + t0) * 4) : VC_OOB_ST;
+        p.rb = ok ? lane_off + (unsigned)((b * 2 * C * a.T + t0) * 4) : VC_OOB_ST;
         return p;
     };
     // dummy "tile -2" stores: with them the first trip sees the same operation count behind its frames as every other
@@ -395,7 +406,7 @@ __device__ __forceinline__ void gated_conv1d_glu_body(const WsConvArgs& a, char*
                 __syncthreads();                            // single exchange buffer: every wave has read the previous hand-over before this trip's overwrites it
             }
             // fragment ring RD steps deep, reads pinned ahead of the MFMAs that use them
-            constexpr int RD = 3, RS = RD + 1;
+            constexpr int RD = BF16 ? 2 : 3, RS = RD + 1;   // (bf16: two steps ahead are 4 MFMAs = 128+ cycles of cover; a third costs the 4 registers that tip the VGPR half into scratch)
             frag_t fx[RS], fwv[W_REGS ? 1 : RS], fwg[W_REGS ? 1 : RS];
             auto rd = [&](auto JC) {
                 constexpr int j = decltype(JC)::value;
