@@ -45,7 +45,7 @@ extern "C" int vc_debug_glu_timeline(unsigned long long* out, int reset) {
     typedef GluGeo<CIN, KW, BF16> GG;
     typedef typename std::conditional<BF16, __bf16, float>::type T;
 ''')
-    s = sub(s, '    wait_all(xr0);\n', '    VC_GTL(tp1 = __builtin_readcyclecounter());\n    wait_all(xr0);\n    VC_GTL(tp2 = __builtin_readcyclecounter());\n')
+    s = sub(s, '    wait_all2(xr0, xr1);\n', '    VC_GTL(tp1 = __builtin_readcyclecounter());\n    wait_all2(xr0, xr1);\n    VC_GTL(tp2 = __builtin_readcyclecounter());\n')
     s = sub(s, '    // dummy "tile -2" stores:', '    VC_GTL(tp3 = __builtin_readcyclecounter());\n    // dummy "tile -2" stores:')
     s = sub(s, '    __syncthreads();                                        // fragment image (if any) and tile 0 are in LDS\n',
             '    __syncthreads();                                        // fragment image (if any) and tile 0 are in LDS\n    VC_GTL(tl1 = __builtin_readcyclecounter());\n')
