@@ -633,6 +633,37 @@ def test_deterministic_mode_is_bitwise_reproducible(built_lib):
             assert torch.equal(r[0], runs[0][0]) and torch.equal(r[1], runs[0][1]) and torch.equal(r[2], runs[0][2]), (B, mode)
 
 
+def test_deterministic_train_step_repeats_bit_for_bit_many_times(built_lib):
+    """The whole deterministic train step (model.py:110-125: gradients, exchange-less update on the update stream, both Adams), repeated
+    60 times from the SAME parameters / Adam state / inputs at B = 2 in fp32 and 30 times at B = 8 in bf16: losses, generations, gradients
+    and updated parameters equal the first repetition bit for bit.  The two-run test above cannot see a fault that strikes one launch in
+    a few hundred -- round 5 found such a one in the named kernel (tests/test_ops_gpu.py::test_gated_conv1d_glu_is_bitwise_repeatable) --
+    and a missing dependency between the step's five streams would look exactly like that.  (tools/stress_step.py runs thousands.)"""
+    from tests import gpu_util as U
+    from voice_converter_cyclegan_amd.engine import CycleGANEngine
+    for B, mode, reps in ((2, 'fp32', 60), (8, 'bf16', 30)):
+        eng = CycleGANEngine(num_features=24, device='cuda:0', seed=42)
+        eng.set_math(mode); eng.set_deterministic(True)
+        rng = np.random.default_rng(7)
+        A = torch.from_numpy(rng.standard_normal((B, 24, 128)).astype(np.float32)).to(U.DEV)
+        Bm = torch.from_numpy(rng.standard_normal((B, 24, 128)).astype(np.float32)).to(U.DEV)
+        gA = torch.empty((B, 24, 128), device=U.DEV); gB = torch.empty_like(gA)
+        p0, m0, v0 = eng.params.clone(), eng.m.clone(), eng.v.clone()
+        b1, b2 = list(eng.b1p), list(eng.b2p)
+        ref = None
+        for i in range(reps + 1):
+            eng.params.copy_(p0); eng.m.copy_(m0); eng.v.copy_(v0); eng.b1p, eng.b2p = list(b1), list(b2)
+            eng.train_step(A, Bm, 10.0, 5.0, 2e-4, 1e-4, sync=False, gen_A=gA, gen_B=gB)
+            torch.cuda.synchronize()
+            cur = (eng.losses.clone(), gA.clone(), gB.clone(), eng.grads.clone(), eng.params.clone())
+            if ref is None:
+                ref = cur
+                continue
+            same = [bool(torch.equal(x, y)) for x, y in zip(cur, ref)]
+            assert all(same), (B, mode, i, dict(zip(('losses', 'gen_A', 'gen_B', 'grads', 'params'), same)))
+        eng.close()
+
+
 @pytest.mark.parametrize('mode', ['bf16', 'bf16x3'])
 def test_train_step_bf16_modes(built_lib, mode):
     """BASELINE configs[2] arithmetic (vc_plan_set_math_mode): one whole train step.
