@@ -8,7 +8,8 @@
 //   * EIGHT waves, two per SIMD, split the K axis (round 4: four waves, one per SIMD, 184 filter registers each; counters:
 //     ~6.5 other instructions between two MFMAs of the lone in-order wave, matrix pipe 38 % busy).  Wave (pb, S): pixel
 //     block pb of the tile, K steps of set S (11 / 12 of the 23 bf16 steps).  The FILTERS of its K steps are the MFMA's A
-//     operand and live in REGISTERS for the life of the workgroup (88 / 96 of the wave's 256); the FRAMES are the B operand,
+//     operand and live in REGISTERS for the life of the workgroup (88 / 96 of the wave's 256, the gate fragments and 5 / 8 value
+//     fragments in the AGPR half); the FRAMES are the B operand,
 //     one ds_read_b128 per MFMA pair, out of a pixel-major LDS tile ([pixel][24 cin], 48-byte rows: run q of 8 consecutive
 //     k starts 16 q bytes after the pixel's row start because consecutive taps are consecutive rows; writes and fragment
 //     reads conflict-free).  Operand reuse is the round-4 kernel's: every frame fragment and every filter fragment is read
@@ -30,9 +31,14 @@
 //   * software pipeline over the workgroup's tiles (one barrier per tile): while tile i is multiplied, the frames of
 //     tile i+2 are in flight (inline-asm buffer loads retired by a COUNTED s_waitcnt: gfx950 has one in-order counter for
 //     loads and stores, and the compiler would wait vmcnt(0), i.e. for the previous tile's output stores to complete),
-//     the frames of tile i+1 are converted and written to the other LDS slot, and -- bf16 -- the GLU + stores of the wave's
-//     half of tile i-1 ride between the MFMAs.  Every trip issues the same number of loads and stores (out-of-tensor
+//     the frames of tile i+1 are converted and written to the other LDS slot, and -- bf16 -- the hand-over, GLU and stores of
+//     the wave's half of tile i-1 ride between the MFMAs.  Every trip issues the same number of loads and stores (out-of-tensor
 //     lanes carry an out-of-range buffer offset), which is what makes the wait countable.
+//   * the compiler knows nothing about registers whose inline-asm loads are in flight, so it must never get the chance to copy
+//     them: inside the loop the in-flight set only crosses trip boundaries (tests/test_glu_isa_cpu.py reads every instruction
+//     there), and the PROLOGUE retires the first two tiles' loads with one wait before control reaches the loop's entry -- where
+//     the compiler does place register copies.  (Round 5 shipped a build without that for a few hours: 0.1 - 0.4 % of the launches
+//     of the un-packed bf16 kernel at B >= 512 computed their second tile from copies of registers that had not landed.)
 #include "vc_internal.h"
 #include "vc_device_util.h"
 #include <type_traits>
