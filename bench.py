@@ -211,7 +211,7 @@ def named_kernel_report(lib, dev):
                  'copy_roof': {'us': rf['us'], 'us_back_to_back': rf['us_back_to_back'], 'GBs_back_to_back': rf['algorithmic_bytes'] / rf['us_back_to_back'] / 1e3,
                                'kernel_frac_of_copy_roof': rf['us'] / r['us'], 'kernel_frac_of_copy_roof_back_to_back': rf['us_back_to_back'] / r['us_back_to_back'],
                                'what': 'vc_prof_glu_copy_roof: same grid (256 workgroups x 512 threads), every workgroup reads its slab\'s 46 KB fragment image and its '
-                                       'tiles\' frames (16-byte loads, next tile in flight) and writes its 32 x 128 output block per tile with the kernel\'s own dword '
+                                       'tiles\' frames (16-byte loads, eight tiles in flight) and writes its 32 x 128 output block per tile with the kernel\'s own dword '
                                        'stores (two full 128-byte lines per instruction); no arithmetic, no LDS'},
                  'zero_operands_us_back_to_back': z['us_back_to_back']}
     nk['bf16_mode'] = dict(bf[256]); nk['bf16_mode']['B4096'] = bf[4096]

@@ -48,11 +48,12 @@ int  vc_prof_records(int kind, double* ms, double* flops, int max_n);
  * (a key built after the capture's own masking never matched, every step re-captured). */
 int  vc_plan_num_step_graphs(const struct vc_plan* p);
 /* Tuning switches of the gated conv1d + GLU kernel for the calling thread's following launches (0 = production).  bit 0: do NOT raise
- * the issue priority of the younger K set's waves (s_setprio 1 is the production setting). */
+ * the issue priority of the younger K set's waves (s_setprio 1 is the production setting).  bit 2: vc_prof_glu_copy_roof writes its
+ * blocks with 16-byte stores instead of the kernel's dword stores (the kernel itself ignores the bit). */
 int  vc_tune_glu(int flags);
 /* Measurement control for the north-star kernel (bench.py named_kernel.copy_roof): ONE launch on vc_gated_conv1d_glu_fwd_packed's grid
  * (G = 1) that performs that kernel's memory operations only -- every workgroup reads its slab's bf16 fragment image and its tiles'
- * frames and writes its output rows with the same dword stores -- and no arithmetic.  Recorded under profiling kind 2. */
+ * frames (eight tiles in flight) and writes its output rows with the same dword stores -- and no arithmetic.  Recorded under profiling kind 2. */
 int  vc_prof_glu_copy_roof(const float* x, const void* image_bf16, float* out, int B, int T, int Cout2, void* stream);
 
 #ifdef __cplusplus

@@ -506,8 +506,8 @@ __global__ __launch_bounds__(512, 1) void gated_conv1d_glu_kernel(const WsConvAr
 
 // same grid, same frame and fragment-image reads, same output stores, no arithmetic: what the memory system alone allows a launch of
 // this shape (bench.py named_kernel.copy_roof; include/vc_cyclegan_testing.h: vc_prof_glu_copy_roof).  A streaming kernel: the loads of
-// tile i + 1 are in flight while tile i's stores are issued, nothing waits on a store, the stored value does not depend on the tile's
-// loads (they are summed into a value that leaves once, at the end).
+// eight tiles are in flight while a tile's stores are issued, the stored value does not depend on the tile's loads (they are summed into
+// a value that leaves once, at the end).
 __global__ __launch_bounds__(512, 1) void glu_copy_roof_kernel(const WsConvArgs a) {
     constexpr int CIN = 24, TP = 128;
     const int tid = threadIdx.x, lane = tid & 63, w8 = tid >> 6, pb = w8 & 3, kset = w8 >> 2, l31 = lane & 31, h = lane >> 5;
@@ -533,21 +533,40 @@ __global__ __launch_bounds__(512, 1) void glu_copy_roof_kernel(const WsConvArgs 
             v[j] = ok ? *reinterpret_cast<const f32x4*>(x + ((long)b * CIN + c) * a.T + t) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
-    f32x4 cur[2], nxt[2];
-    load_tile(blockIdx.x, cur);
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        load_tile(tile + gridDim.x, nxt);
+    // DEPTH tiles of frames in flight: a tile's loads are consumed DEPTH trips after they were issued (the first version of this control consumed
+    // them one trip later and measured memory LATENCY per trip -- 1.6 us x 64 trips at B = 4096, by coincidence the kernel's own time)
+    constexpr int DEPTH = 8;
+    f32x4 buf[DEPTH][2];
+#pragma unroll
+    for (int k = 0; k < DEPTH; ++k) load_tile(blockIdx.x + k * (int)gridDim.x, buf[k]);
+    auto store_tile = [&](int tile) {
         const int b = tile / tps, tt = tile - b * tps;
         const int t = tt * TP + pb * 32 + l31;
-        if (t < a.T) {
+        if (a.flags & 4) {                                  // vc_tune_glu bit 2: the same 16 KB block as 16-byte stores (what an LDS-transposed epilogue would issue)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int idx = tid + 512 * k, row = slab * 32 + (idx >> 5), tq = tt * TP + 4 * (idx & 31);
+                if (tq < a.T) *reinterpret_cast<f32x4*>(y + ((long)b * C + row) * a.T + tq) = f32x4{1.f, 1.f, 1.f, 1.f};
+            }
+        } else if (t < a.T) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int row = slab * 32 + 8 * (2 * kset + (i >> 2)) + 4 * h + (i & 3);
                 y[((long)b * C + row) * a.T + t] = 1.f;
             }
         }
+    };
+    for (int tile = blockIdx.x; tile < ntiles; ) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) { acc += cur[j][0] + cur[j][1] + cur[j][2] + cur[j][3]; cur[j] = nxt[j]; }
+        for (int k = 0; k < DEPTH; ++k) {
+            if (tile < ntiles) {
+                store_tile(tile);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc += buf[k][j][0] + buf[k][j][1] + buf[k][j][2] + buf[k][j][3];
+                load_tile(tile + DEPTH * (int)gridDim.x, buf[k]);
+                tile += gridDim.x;
+            }
+        }
     }
 #pragma unroll
     for (int i = 0; i < 6; ++i) acc += iv[i][0] + iv[i][1] + iv[i][2] + iv[i][3];
@@ -605,8 +624,9 @@ int launch_gated_conv1d_glu(const WsConvArgs& a_, int cin, int kw, int math, hip
 int launch_glu_copy_roof(const WsConvArgs& a, int cin, int kw, hipStream_t s) {
     dim3 grid;
     if (!glu_grid(a, cin, kw, &grid) || !a.wimg) return -2;
+    WsConvArgs b = a; b.flags = glu_tune_flags();
     ProfScope ps(2, 0.0, s);
-    glu_copy_roof_kernel<<<grid, dim3(512), 0, s>>>(a);
+    glu_copy_roof_kernel<<<grid, dim3(512), 0, s>>>(b);
     VC_HIP(hipGetLastError());
     return 0;
 }
