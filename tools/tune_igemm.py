@@ -110,7 +110,7 @@ def main():
         shapes.append((nm, g, B, ('dgrad',)))                     # generator-loss backward through D's inputs
         shapes.append((nm + '_2B', g, 2 * B, ('fwd', 'dgrad', 'wgrad')))
     for nm, (Cin, H, W, Cout, kh, kw, sh, sw), Bs, oplist in shapes:
-        if args.only and args.only not in nm:
+        if args.only and not any(o in nm for o in args.only.split(',')):
             continue
         G = 2
         x = U.dev(rng.standard_normal((G, Bs, Cin, H, W)).astype(np.float32))

@@ -261,15 +261,24 @@ int launch_pack_filter_bf16(const float* w, long w_gs, void* ap, long ap_gs_byte
 // round trip weigh half as much -- on a 3-stage ring (48 KB per stage), one workgroup per CU.
 // ROLE changes no code: 0 = convolution / input gradient, 1 = the filter-gradient GEMM -- two kernel names, so that rocprofv3
 // statistics and PMC counters of a step separate the two uses
-template <int BM, int NST, int ROLE> __global__ __launch_bounds__(256, NST <= 2 ? 2 : 1) void conv_bf16_kernel(const ConvBf16Args p) {
+// SPEC (round 5): 512 threads = 4 multiplying waves + 4 copying waves, one of each per SIMD.  An LDS-direct copy holds the issuing
+// wave for 60 - 180 cycles (the CU's address path moves 64 B / clock and four waves queue on it); with one wave per SIMD doing both,
+// the matrix pipe idled behind every copy: measured 0.62 of the K loop busy at BM = 256 (12 copies against 32 MFMAs per chunk), 0.28 - 0.48
+// on the smaller tiles.  The copying waves take all of them (the same pieces, the same order, the same counted wait before the
+// chunk's barrier); the multiplying waves issue only ds_read_b128 and MFMA between two barriers.
+template <int BM, int NST, int ROLE, bool SPEC = false> __global__ __launch_bounds__(SPEC ? 512 : 256, (!SPEC && NST <= 2) ? 2 : 1)
+void conv_bf16_kernel(const ConvBf16Args p) {
     touch_kernarg(p);
+    constexpr int NT = SPEC ? 512 : 256;
     constexpr int BN = 128, MI = BM / 64;                 // a wave owns MI x 2 MFMA tiles: rows [wm * BM/2, +BM/2), pixels [wn * 64, +64)
     constexpr int ASZ = 8 * BM * 16, XSZ = 8 * BN * 16, STAGE = ASZ + XSZ;      // one K chunk: [octet][row][16 B] for both operands
     constexpr int LDY = BN + 4;
     static_assert(BM * LDY * 4 <= 3 * STAGE, "the epilogue stages the tile inside the operand buffers");
     __shared__ __attribute__((aligned(16))) char smem[BM * LDY * 4 > NST * STAGE ? BM * LDY * 4 : NST * STAGE];
 
-    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tid = threadIdx.x, lane = tid & 63, wv8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wv = wv8 & 3;                               // multiplying wave wv and copying wave wv (SPEC: waves 4 - 7) share this index
+    const bool copier = SPEC && wv8 >= 4;
     const int l31 = lane & 31, h = lane >> 5;
     const int wm = wv >> 1, wn = wv & 1;
 
@@ -381,16 +390,8 @@ template <int BM, int NST, int ROLE> __global__ __launch_bounds__(256, NST <= 2 
         else if constexpr ((NST - 2) * GL == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else static_assert(NST == 2, "add the counted wait for this ring depth");
     };
-#pragma unroll
-    for (int k = 0; k < NST - 1; ++k) { fetch_tab(c0 + min(k, cn - 1)); issue(c0 + min(k, cn - 1), k); }
-    fetch_tab(c0 + min(NST - 1, cn - 1));
-    int st = 0;                                             // stage of chunk c
-    for (int c = 0; c < cn; ++c) {
-        wait_landed();
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        const int stn = st == 0 ? NST - 1 : st - 1;         // (c + NST - 1) % NST: the stage chunk c - 1 has just left
-        const int cnx = c0 + min(c + NST - 1, cn - 1);
+    // one K chunk of MFMAs out of stage st; REFILL: a quarter of the refill of stage stn rides behind each step (the 256-thread form)
+    auto multiply_chunk = [&](int st, int stn, int cnx, int c, auto REFILL) {
         const char* As = smem + st * STAGE + ((wm * (BM / 2) + l31) + h * BM) * 16;
         const char* Xs = smem + st * STAGE + ASZ + ((wn * 64 + l31) + h * BN) * 16;
         // MFMA step s multiplies octets 2 s (lanes 0-31) and 2 s + 1 (lanes 32-63); the fragments of step s + 1 are
@@ -411,27 +412,69 @@ template <int BM, int NST, int ROLE> __global__ __launch_bounds__(256, NST <= 2 
                 acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s & 1][i], fb[s & 1][0], acc[i][0], 0, 0, 0);
                 acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s & 1][i], fb[s & 1][1], acc[i][1], 0, 0, 0);
             }
-            // a quarter of the refill of stage stn behind this step's MFMAs (the table entries were fetched an iteration ago)
-            if (s == 0) issue_part(cnx, stn, std::integral_constant<int, 0>{});
-            else if (s == 1) issue_part(cnx, stn, std::integral_constant<int, 1>{});
-            else if (s == 2) issue_part(cnx, stn, std::integral_constant<int, 2>{});
-            else { issue_part(cnx, stn, std::integral_constant<int, 3>{}); fetch_tab(c0 + min(c + NST, cn - 1)); }   // next used a barrier + a step of MFMAs from here
+            if constexpr (decltype(REFILL)::value) {
+                // a quarter of the refill of stage stn behind this step's MFMAs (the table entries were fetched an iteration ago)
+                if (s == 0) issue_part(cnx, stn, std::integral_constant<int, 0>{});
+                else if (s == 1) issue_part(cnx, stn, std::integral_constant<int, 1>{});
+                else if (s == 2) issue_part(cnx, stn, std::integral_constant<int, 2>{});
+                else { issue_part(cnx, stn, std::integral_constant<int, 3>{}); fetch_tab(c0 + min(c + NST, cn - 1)); }   // next used a barrier + a step of MFMAs from here
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
-        st = st + 1 == NST ? 0 : st + 1;
+    };
+    if (!SPEC || copier) {
+#pragma unroll
+        for (int k = 0; k < NST - 1; ++k) { fetch_tab(c0 + min(k, cn - 1)); issue(c0 + min(k, cn - 1), k); }
+        fetch_tab(c0 + min(NST - 1, cn - 1));
+    }
+    if constexpr (!SPEC) {
+        int st = 0;                                             // stage of chunk c
+        for (int c = 0; c < cn; ++c) {
+            wait_landed();
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            const int stn = st == 0 ? NST - 1 : st - 1;         // (c + NST - 1) % NST: the stage chunk c - 1 has just left
+            multiply_chunk(st, stn, c0 + min(c + NST - 1, cn - 1), c, std::true_type{});
+            st = st + 1 == NST ? 0 : st + 1;
+        }
+    } else if (copier) {
+        // every wave of the workgroup passes the same cn barriers: copying waves retire chunk c's pieces, meet the multiplying waves
+        // (which have finished chunk c - 1), then refill the stage chunk c - 1 has left
+        int st = 0;
+        for (int c = 0; c < cn; ++c) {
+            wait_landed();
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            const int stn = st == 0 ? NST - 1 : st - 1;
+            issue(c0 + min(c + NST - 1, cn - 1), stn);
+            fetch_tab(c0 + min(c + NST, cn - 1));
+            st = st + 1 == NST ? 0 : st + 1;
+        }
+    } else {
+        __builtin_amdgcn_s_setprio(1);                          // the SIMD's other wave only issues copies: MFMAs first
+        int st = 0;
+        for (int c = 0; c < cn; ++c) {
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            multiply_chunk(st, 0, 0, c, std::false_type{});
+            st = st + 1 == NST ? 0 : st + 1;
+        }
+        __builtin_amdgcn_s_setprio(0);
     }
     __syncthreads();                                        // (drains the ring's trailing copies: vmcnt(0))
 
     // ---- epilogue: tile through LDS, then bias (+ addend) and 16-byte stores, or one pixel per lane for atomics /
     //      strided parity classes (the two paths of vc_conv_igemm.hip)
     float* Ys = reinterpret_cast<float*>(smem);
+    if (!copier) {
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                Ys[(wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * LDY + wn * 64 + j * 32 + l31] = acc[i][j][r];
+                for (int r = 0; r < 16; ++r)
+                    Ys[(wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * LDY + wn * 64 + j * 32 + l31] = acc[i][j][r];
+    }
     __syncthreads();
     const bool atomic = p.splitk > 1 || p.accumulate;
     const bool first = sp == 0;
@@ -440,8 +483,8 @@ template <int BM, int NST, int ROLE> __global__ __launch_bounds__(256, NST <= 2 
     const float* Dg = (p.addend && first) ? p.addend + (long)g * p.add_gs : nullptr;
     if (p.vec4 && !atomic) {
 #pragma unroll 4
-        for (int i = 0; i < BM * BN / 4 / 256; ++i) {
-            const int idx = tid + i * 256, ml = idx >> 5, n4 = (idx & 31) * 4;
+        for (int i = 0; i < BM * BN / 4 / NT; ++i) {
+            const int idx = tid + i * NT, ml = idx >> 5, n4 = (idx & 31) * 4;
             const int m = mt * BM + ml, P0 = nt * BN + n4;
             if (m >= p.M || P0 >= p.Ptot) continue;
             f32x4 v = *reinterpret_cast<const f32x4*>(Ys + ml * LDY + n4);
@@ -459,8 +502,8 @@ template <int BM, int NST, int ROLE> __global__ __launch_bounds__(256, NST <= 2 
             obase = (long)b * p.y_bs + (long)(ii * p.so_h + p.o_h0) * p.yW + (j * p.so_w + p.o_w0);
         }
 #pragma unroll 4
-        for (int i = 0; i < BM * BN / 256; ++i) {
-            const int ml = (tid >> 7) + i * 2, m = mt * BM + ml;
+        for (int i = 0; i < BM * BN / NT; ++i) {
+            const int ml = (tid >> 7) + i * (NT / 128), m = mt * BM + ml;
             if (m >= p.M || Pn >= p.Ptot) continue;
             float v = Ys[ml * LDY + n];
             if (Bg) v += Bg[m];
@@ -536,7 +579,15 @@ int launch_conv_bf16(const ConvBf16Args& a, hipStream_t s, double flops, int pro
     ProfScope ps(prof_kind, flops, s);
 #define VC_BF16_LAUNCH(BM, NST) do { if (prof_kind == 1) conv_bf16_kernel<BM, NST, 1><<<grid, 256, 0, s>>>(a); \
                                      else conv_bf16_kernel<BM, NST, 0><<<grid, 256, 0, s>>>(a); } while (0)
-    if (a.bm == 256) VC_BF16_LAUNCH(256, 3);
+    // 256-row tiles run wave-specialised (4 multiplying + 4 copying waves; K loop 0.62 -> 0.80 busy, whole bf16 step at batch 64 -0.9 ms
+    // serialised, -0.25 ms with the chains overlapped).  On 64-row tiles the same split doubles a workgroup's rate but costs the second
+    // resident workgroup: measured slower, not built.  VC_BF16_SPEC=0 switches it off (A/B measurements).
+    static const bool spec = !(getenv("VC_BF16_SPEC") && atoi(getenv("VC_BF16_SPEC")) == 0);
+    if (a.bm == 256 && spec) {
+        if (prof_kind == 1) conv_bf16_kernel<256, 3, 1, true><<<grid, 512, 0, s>>>(a);
+        else conv_bf16_kernel<256, 3, 0, true><<<grid, 512, 0, s>>>(a);
+    }
+    else if (a.bm == 256) VC_BF16_LAUNCH(256, 3);
     else if (a.bm == 64) { if (a.nst == 4) VC_BF16_LAUNCH(64, 4); else VC_BF16_LAUNCH(64, 2); }
     else { if (a.nst == 4) VC_BF16_LAUNCH(128, 4); else VC_BF16_LAUNCH(128, 2); }
 #undef VC_BF16_LAUNCH

@@ -69,10 +69,12 @@ static int zero_step_grads(const vc_plan* p, float* grads, int B, int Bbwd, hipS
 // hp != nullptr: lambda_cycle / lambda_identity are read from hp[0..1] on the device (a captured step is replayed with new
 // values); the host copies still decide the schedule (lambda_identity == 0 skips the identity half).
 // bf16 data path: build every layer's filter images from the step's fp32 weights (both generators / both discriminators
-// as the two groups of one launch).  Runs on the step's main stream before anything forks from it.
-static int refresh_filter_images(const vc_plan* p, const float* params, hipStream_t s) {
+// as the two groups of one launch).  Two launches: the generators' forward images on the step's main stream (the first-hop forward
+// needs them at once), everything else -- the generators' input-gradient images and all of the discriminators' -- is handed back in
+// `later` and goes out on the side stream under the first-hop forward (round 4: one launch of 0.52 ms at batch 64 with nothing beside it).
+static int refresh_filter_images(const vc_plan* p, const float* params, hipStream_t s, std::vector<PackFilterJob>* later) {
     const long PG = p->G.total, PD = p->D.total;
-    struct Job { const float* w; long w_gs; const int* wsrc; int a_ms, M, kp; size_t off, gs; };
+    struct Job { const float* w; long w_gs; const int* wsrc; int a_ms, M, kp; size_t off, gs; bool now; };
     std::vector<Job> jobs; size_t tot = 256;        // offsets are never 0, so 0 / nullptr can mean 'no image'
     const bool first = p->img_g.empty();
     std::vector<vc_plan::LayerImages> ig(p->G.layers.size()), id(p->D.layers.size());
@@ -85,7 +87,7 @@ static int refresh_filter_images(const vc_plan* p, const float* params, hipStrea
             Table t; VC_CHECK(get_fwd_table(g, &t));
             if (t.koct > 0 && g.Cout >= 64) {
                 const size_t a = align256((size_t)g.Cout * t.koct * 16);
-                jobs.push_back(Job{base + n.layers[i].w, gs, t.wsrc, 1, g.Cout, t.koct * 8, tot, a});
+                jobs.push_back(Job{base + n.layers[i].w, gs, t.wsrc, 1, g.Cout, t.koct * 8, tot, a, net == 0});
                 img[i].fwd = (const char*)tot; tot += 2 * a;
             }
             bool all = g.Cin >= 64; size_t off[4]; Job cj[4]; int nc = 0;
@@ -93,7 +95,7 @@ static int refresh_filter_images(const vc_plan* p, const float* params, hipStrea
                 Table td; VC_CHECK(get_dgrad_table(g, ph, pw, &td));
                 if (td.koct <= 0) { all = false; break; }
                 const size_t a = align256((size_t)g.Cin * td.koct * 16);
-                cj[nc] = Job{base + n.layers[i].w, gs, td.wsrc, g.Cout, g.Cin, td.koct * 8, tot, a}; off[nc++] = tot; tot += 2 * a;
+                cj[nc] = Job{base + n.layers[i].w, gs, td.wsrc, g.Cout, g.Cin, td.koct * 8, tot, a, false}; off[nc++] = tot; tot += 2 * a;
             }
             if (all && nc) { for (int k = 0; k < nc; ++k) { jobs.push_back(cj[k]); img[i].dg[k] = (const char*)off[k]; } img[i].has_dg = true; }
             else if (nc) tot = off[0];            // give the partial reservation back
@@ -115,8 +117,8 @@ static int refresh_filter_images(const vc_plan* p, const float* params, hipStrea
     }
     std::vector<PackFilterJob> pj;
     for (const Job& j : jobs)
-        pj.push_back(PackFilterJob{j.w, (unsigned short*)(p->img_block + j.off), j.wsrc, j.w_gs, (long)j.gs / 2, j.a_ms, j.M, j.kp, 0, 0});
-    return launch_pack_filter_multi(pj, 2, s);
+        (j.now ? pj : *later).push_back(PackFilterJob{j.w, (unsigned short*)(p->img_block + j.off), j.wsrc, j.w_gs, (long)j.gs / 2, j.a_ms, j.M, j.kp, 0, 0});
+    return pj.empty() ? 0 : launch_pack_filter_multi(pj, 2, s);
 }
 
 static int step_grads_impl(const vc_plan* p, const float* params, float* grads,
@@ -148,7 +150,8 @@ static int step_grads_impl(const vc_plan* p, const float* params, float* grads,
     const int Bbwd = (lambda_identity == 0.0f) ? B : 2 * B;
 
     hipStream_t s2 = (p->use_side & 1) ? p->side : s;
-    if (p->math == VC_MATH_BF16) VC_CHECK(refresh_filter_images(p, params, s));
+    std::vector<PackFilterJob> later_images;
+    if (p->math == VC_MATH_BF16) VC_CHECK(refresh_filter_images(p, params, s, &later_images));
     StepImages scope(p->math == VC_MATH_BF16 ? p : nullptr);
     // 1. first-hop inputs: g0 = A2B on [A;B], g1 = B2A on [B;A]   (model.py:44,51 / 47,50)
     VC_CHECK(launch_copy_list({{X1, A, ft1}, {X1 + ft1, Bm, ft1}, {X1 + X1g, Bm, ft1}, {X1 + X1g + ft1, A, ft1}}, s));
@@ -157,6 +160,9 @@ static int step_grads_impl(const vc_plan* p, const float* params, float* grads,
     //    work on `stream`: under hipGraph capture, an event recorded on a stream that has captured nothing yet does not
     //    pull the waiting stream into the capture (ROCm 7.2; the replayed graph then crashes at hipStreamEndCapture).
     if (s2 != s) { VC_HIP(hipEventRecord(p->ev_fork, s)); VC_HIP(hipStreamWaitEvent(s2, p->ev_fork, 0)); }
+    // the filter images nothing reads before the discriminator forward (side stream, in order behind this launch) and the backward
+    // passes (behind the join after the discriminator forward)
+    if (!later_images.empty()) VC_CHECK(launch_pack_filter_multi(later_images, 2, s2));
     VC_CHECK(zero_step_grads(p, grads, B, Bbwd, s2));
     // 2. O1[g0] = [gen_B; id_B], O1[g1] = [gen_A; id_A]
     VC_CHECK(gen_forward(p, params, PG, X1, X1g, O1, O1g, S1, 2, 2 * B, s));
