@@ -5,7 +5,9 @@ iteration, GL = 4 + 2 (BM / 64) copies per chunk and wave.  gfx950 has ONE in-or
 count is only right if an iteration of the K loop issues exactly GL LDS-direct copies and NOTHING else that counts (a spill, a
 hoisted table load, a merged or split copy would declare a chunk landed too early -- garbage operands, silently).  This test reads
 the assembly hipcc produces for gfx950 and checks, for every built (BM, NST, ROLE): one K loop with one barrier, GL copies, the
-counted wait in front of the barrier, 4 * 2 * (BM / 64) MFMAs, no other vector-memory instruction, no scratch."""
+counted wait in front of the barrier, 4 * 2 * (BM / 64) MFMAs, no other vector-memory instruction, no scratch.  The wave-specialised
+form (SPEC, 256-row tiles) has TWO loops that meet at the same barrier: the copying waves' (GL copies, the counted wait, nothing else
+that counts) and the multiplying waves' (the MFMAs, no vector-memory instruction at all)."""
 import os
 import re
 import shutil
@@ -32,9 +34,9 @@ def asm(tmp_path_factory):
     return open(out).read()
 
 
-def _kernel(text, bm, nst, role):
+def _kernel(text, bm, nst, role, spec=False):
     lines = text.split('\n')
-    tag = '_Z16conv_bf16_kernelILi%dELi%dELi%dEEv' % (bm, nst, role)
+    tag = '_Z16conv_bf16_kernelILi%dELi%dELi%dELb%dEEv' % (bm, nst, role, int(spec))
     starts = [i for i, l in enumerate(lines) if l.startswith(tag) and ':' in l.split(';')[0]]
     assert len(starts) == 1, (tag, len(starts))
     body = []
@@ -49,10 +51,7 @@ def _instrs(block):
     return [l.strip() for l in block if l.startswith('\t') and not l.strip().startswith(('.', ';'))]
 
 
-@pytest.mark.parametrize('bm,nst,role', CONFIGS)
-def test_k_loop_issues_the_counted_copies(asm, bm, nst, role):
-    body = _kernel(asm, bm, nst, role)
-    gl = 4 + 2 * (bm // 64)
+def _loops(body):
     loops, cur = {}, None
     for l in body:
         if re.match(r'^(\.LBB\d+_\d+:|; %bb\.\d+:)', l):
@@ -60,6 +59,14 @@ def test_k_loop_issues_the_counted_copies(asm, bm, nst, role):
             cur = h.group(1) if h else (l.split(':')[0].lstrip('.L') if 'Loop Header' in l else None)
         if cur is not None:
             loops.setdefault(cur, []).append(l)
+    return loops
+
+
+@pytest.mark.parametrize('bm,nst,role', CONFIGS)
+def test_k_loop_issues_the_counted_copies(asm, bm, nst, role):
+    body = _kernel(asm, bm, nst, role)
+    gl = 4 + 2 * (bm // 64)
+    loops = _loops(body)
     kloop = [v for v in loops.values() if any(x.startswith('v_mfma') for x in _instrs(v))]
     assert len(kloop) == 1, (bm, nst, role, list(loops))
     ins = _instrs(kloop[0])
@@ -84,11 +91,37 @@ def test_k_loop_issues_the_counted_copies(asm, bm, nst, role):
     assert max(runs) <= gl // 4 + 1, (seq, runs)
     assert seq[0] == 'M' and len(runs) >= 4, seq
 
+@pytest.mark.parametrize('role', (0, 1))
+def test_wave_specialised_loops(asm, role):
+    bm, nst = 256, 3
+    gl = 4 + 2 * (bm // 64)
+    loops = [_instrs(v) for v in _loops(_kernel(asm, bm, nst, role, spec=True)).values()]
+    loops = [v for v in loops if 's_barrier' in v]
+    assert len(loops) == 2, len(loops)
+    mult = [v for v in loops if any(x.startswith('v_mfma') for x in v)]
+    copy = [v for v in loops if not any(x.startswith('v_mfma') for x in v)]
+    assert len(mult) == 1 and len(copy) == 1
+    mult, copy = mult[0], copy[0]
+    vm = lambda ins: [x for x in ins if re.match(r'(buffer_|global_|flat_|scratch_)', x)]
+    # multiplying waves: the chunk's MFMAs between two barriers, fragments by ds_read_b128, nothing the vector-memory counter sees
+    assert len([x for x in mult if x.startswith('v_mfma_f32_32x32x16_bf16')]) == 4 * 2 * (bm // 64)
+    assert not vm(mult) and not [x for x in mult if 'vmcnt' in x], (vm(mult)[:3], [x for x in mult if 'vmcnt' in x])
+    assert mult.count('s_barrier') == 1
+    assert len([x for x in mult if x.startswith('ds_read_b128')]) == 4 * (2 + bm // 64)
+    # copying waves: exactly the chunk's GL pieces per trip, retired by the counted wait in front of the barrier
+    copies = [x for x in copy if re.match(r'buffer_load_dwordx4 .*\blds\b', x)]
+    assert len(copies) == gl and vm(copy) == copies, (len(copies), [x for x in vm(copy) if x not in copies][:3])
+    assert [x for x in copy if 'vmcnt' in x] == ['s_waitcnt vmcnt(%d)' % ((nst - 2) * gl)]
+    assert copy.count('s_barrier') == 1
+    w, b, c0 = copy.index('s_waitcnt vmcnt(%d)' % ((nst - 2) * gl)), copy.index('s_barrier'), copy.index(copies[0])
+    assert w < b < c0, (w, b, c0)
+
+
 def test_no_scratch(asm):
     seen = {}
     for blk in re.split(r'\n  - \.agpr_count', asm)[1:]:
         n = re.search(r'\.name:\s+(\S+)', blk); s = re.search(r'\.private_segment_fixed_size:\s+(\d+)', blk)
         if n and s and 'conv_bf16_kernel' in n.group(1):
             seen[n.group(1)] = int(s.group(1))
-    assert len(seen) == len(CONFIGS), seen
+    assert len(seen) == len(CONFIGS) + 2, seen          # + the wave-specialised pair
     assert all(v == 0 for v in seen.values()), seen
