@@ -6,7 +6,7 @@ count is only right if an iteration of the K loop issues exactly GL LDS-direct c
 hoisted table load, a merged or split copy would declare a chunk landed too early -- garbage operands, silently).  This test reads
 the assembly hipcc produces for gfx950 and checks, for every built (BM, NST, ROLE): one K loop with one barrier, GL copies, the
 counted wait in front of the barrier, 4 * 2 * (BM / 64) MFMAs, no other vector-memory instruction, no scratch.  The wave-specialised
-form (SPEC, 256-row tiles) has TWO loops that meet at the same barrier: the copying waves' (GL copies, the counted wait, nothing else
+form (SPEC: the configurations with one workgroup per CU) has TWO loops that meet at the same barrier: the copying waves' (GL copies, the counted wait, nothing else
 that counts) and the multiplying waves' (the MFMAs, no vector-memory instruction at all)."""
 import os
 import re
@@ -91,9 +91,12 @@ def test_k_loop_issues_the_counted_copies(asm, bm, nst, role):
     assert max(runs) <= gl // 4 + 1, (seq, runs)
     assert seq[0] == 'M' and len(runs) >= 4, seq
 
+SPEC_CONFIGS = [(256, 3), (128, 4), (64, 4)]           # the one-workgroup-per-CU configurations
+
+
+@pytest.mark.parametrize('bm,nst', SPEC_CONFIGS)
 @pytest.mark.parametrize('role', (0, 1))
-def test_wave_specialised_loops(asm, role):
-    bm, nst = 256, 3
+def test_wave_specialised_loops(asm, role, bm, nst):
     gl = 4 + 2 * (bm // 64)
     loops = [_instrs(v) for v in _loops(_kernel(asm, bm, nst, role, spec=True)).values()]
     loops = [v for v in loops if 's_barrier' in v]
@@ -123,5 +126,5 @@ def test_no_scratch(asm):
         n = re.search(r'\.name:\s+(\S+)', blk); s = re.search(r'\.private_segment_fixed_size:\s+(\d+)', blk)
         if n and s and 'conv_bf16_kernel' in n.group(1):
             seen[n.group(1)] = int(s.group(1))
-    assert len(seen) == len(CONFIGS) + 2, seen          # + the wave-specialised pair
+    assert len(seen) == len(CONFIGS) + 2 * len(SPEC_CONFIGS), seen          # + the wave-specialised forms
     assert all(v == 0 for v in seen.values()), seen

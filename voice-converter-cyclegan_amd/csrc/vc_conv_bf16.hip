@@ -579,17 +579,20 @@ int launch_conv_bf16(const ConvBf16Args& a, hipStream_t s, double flops, int pro
     ProfScope ps(prof_kind, flops, s);
 #define VC_BF16_LAUNCH(BM, NST) do { if (prof_kind == 1) conv_bf16_kernel<BM, NST, 1><<<grid, 256, 0, s>>>(a); \
                                      else conv_bf16_kernel<BM, NST, 0><<<grid, 256, 0, s>>>(a); } while (0)
-    // 256-row tiles run wave-specialised (4 multiplying + 4 copying waves; K loop 0.62 -> 0.80 busy, whole bf16 step at batch 64 -0.9 ms
-    // serialised, -0.25 ms with the chains overlapped).  On 64-row tiles the same split doubles a workgroup's rate but costs the second
-    // resident workgroup: measured slower, not built.  VC_BF16_SPEC=0 switches it off (A/B measurements).
+    // One workgroup per CU (256-row tiles; the 4-stage ring of the smaller tiles) runs wave-specialised: 4 multiplying + 4 copying waves
+    // (K loop 0.62 -> 0.80 busy at 256 rows).  Two workgroups per CU (NST = 2) already have a second wave per SIMD to cover a copy's issue
+    // time, and the split would cost them the second resident workgroup: measured slower, not built.  VC_BF16_SPEC=0: the 256-thread
+    // form everywhere (A/B measurements).
+#define VC_BF16_LAUNCH_SPEC(BM, NST) do { if (prof_kind == 1) conv_bf16_kernel<BM, NST, 1, true><<<grid, 512, 0, s>>>(a); \
+                                          else conv_bf16_kernel<BM, NST, 0, true><<<grid, 512, 0, s>>>(a); } while (0)
     static const bool spec = !(getenv("VC_BF16_SPEC") && atoi(getenv("VC_BF16_SPEC")) == 0);
-    if (a.bm == 256 && spec) {
-        if (prof_kind == 1) conv_bf16_kernel<256, 3, 1, true><<<grid, 512, 0, s>>>(a);
-        else conv_bf16_kernel<256, 3, 0, true><<<grid, 512, 0, s>>>(a);
-    }
+    if (spec && a.bm == 256) VC_BF16_LAUNCH_SPEC(256, 3);
+    else if (spec && a.bm == 128 && a.nst == 4) VC_BF16_LAUNCH_SPEC(128, 4);
+    else if (spec && a.bm == 64 && a.nst == 4) VC_BF16_LAUNCH_SPEC(64, 4);
     else if (a.bm == 256) VC_BF16_LAUNCH(256, 3);
     else if (a.bm == 64) { if (a.nst == 4) VC_BF16_LAUNCH(64, 4); else VC_BF16_LAUNCH(64, 2); }
     else { if (a.nst == 4) VC_BF16_LAUNCH(128, 4); else VC_BF16_LAUNCH(128, 2); }
+#undef VC_BF16_LAUNCH_SPEC
 #undef VC_BF16_LAUNCH
     VC_HIP(hipGetLastError());
     return 0;
