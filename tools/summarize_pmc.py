@@ -28,7 +28,8 @@ print('TOTAL MB/step, %.1f' % tot)
 # conv_bf16_kernel<.., 1> as a GEMM, + wgrad_kernel for o1)
 def role(k):
     if k.startswith('conv_bf16_kernel'):
-        return 'wgrad' if k.rstrip('>').replace(' ', '').endswith(',1') else 'igemm'
+        args = k[k.index('<') + 1:].rstrip('>').replace(' ', '').split(',')      # <tile rows, ring stages, ROLE[, SPEC]>
+        return 'wgrad' if len(args) > 2 and args[2] == '1' else 'igemm'
     return 'igemm' if k.startswith('igemm_kernel') else 'wgrad' if k.startswith('wgrad_kernel') else None
 
 
