@@ -114,7 +114,10 @@ def test_conv_bf16_modes(built_lib, case, mode):
     assert lib.vc_set_math_mode(3) != 0 and lib.vc_get_math_mode() == 0      # unknown mode is refused
 
 
-@pytest.mark.parametrize('cfg', [(128, 2, 1), (128, 4, 1), (64, 2, 1), (64, 4, 1), (128, 4, 2), (64, 2, 4), (256, 3, 1), (256, 3, 2)])
+@pytest.mark.parametrize('cfg', [(128, 2, 1), (128, 4, 1), (64, 2, 1), (64, 4, 1), (128, 4, 2), (64, 2, 4), (256, 3, 1), (256, 3, 2),
+                                 # the one-workgroup-per-CU configurations once more in their 256-thread form (production runs them
+                                 # wave-specialised: 4 multiplying + 4 copying waves; vc_tune_conv_bf16_spec(0) is the A/B switch)
+                                 (128, 4, 1, 'plain'), (64, 4, 2, 'plain'), (256, 3, 1, 'plain')])
 @pytest.mark.parametrize('case', [(128, 1, 128, 512, 1, 5, 1, 2, 4),      # G.d1: stride 2 -> two input-gradient parity classes
                                   (512, 1, 32, 2048, 1, 3, 1, 1, 8),      # residual h1
                                   (256, 12, 32, 1024, 3, 3, 2, 2, 2),     # D.d2: 2-D, four parity classes
@@ -127,13 +130,15 @@ def test_conv_bf16_data_path_every_configuration(built_lib, case, cfg):
     from voice_converter_cyclegan_amd._lib import lib, check
     O = _oracle()
     check(lib.vc_set_math_mode(1))
-    check(lib.vc_tune_conv_bf16_override(*cfg))
+    check(lib.vc_tune_conv_bf16_override(*cfg[:3]))
+    check(lib.vc_tune_conv_bf16_spec(0 if len(cfg) > 3 else 1))
     O.set_operand_rounding('bf16')
     try:
         _conv_check(case)
     finally:
         O.set_operand_rounding(None)
         check(lib.vc_tune_conv_bf16_override(0, 0, 0))
+        check(lib.vc_tune_conv_bf16_spec(-1))
         check(lib.vc_set_math_mode(0))
     assert lib.vc_tune_conv_bf16_override(96, 2, 1) != 0          # not a built configuration
 

@@ -519,6 +519,8 @@ void conv_bf16_kernel(const ConvBf16Args p) {
 // launches that would leave most of the chip idle split.
 // tests / tuning: force one configuration of conv_bf16_kernel for every following launch of the process (0 = automatic)
 static thread_local int g_bf16_bm = 0, g_bf16_nst = 0, g_bf16_sk = 0;      // per calling thread
+static thread_local int g_bf16_spec = -1;                                  // -1: the process default (on unless VC_BF16_SPEC=0)
+extern "C" int vc_tune_conv_bf16_spec(int on) { g_bf16_spec = on < 0 ? -1 : (on ? 1 : 0); return 0; }
 extern "C" int vc_tune_conv_bf16_override(int tile_rows, int stages, int splitk) {
     const bool ok = (tile_rows == 0 && stages == 0 && splitk == 0) ||
                     ((((tile_rows == 64 || tile_rows == 128) && (stages == 2 || stages == 4)) || (tile_rows == 256 && stages == 3)) && splitk >= 1 && splitk <= 16);
@@ -581,11 +583,12 @@ int launch_conv_bf16(const ConvBf16Args& a, hipStream_t s, double flops, int pro
                                      else conv_bf16_kernel<BM, NST, 0><<<grid, 256, 0, s>>>(a); } while (0)
     // One workgroup per CU (256-row tiles; the 4-stage ring of the smaller tiles) runs wave-specialised: 4 multiplying + 4 copying waves
     // (K loop 0.62 -> 0.80 busy at 256 rows).  Two workgroups per CU (NST = 2) already have a second wave per SIMD to cover a copy's issue
-    // time, and the split would cost them the second resident workgroup: measured slower, not built.  VC_BF16_SPEC=0: the 256-thread
-    // form everywhere (A/B measurements).
+    // time, and the split would cost them the second resident workgroup: measured slower, not built.  VC_BF16_SPEC=0 (process) /
+    // vc_tune_conv_bf16_spec(0) (calling thread): the 256-thread form everywhere (A/B measurements, tests).
 #define VC_BF16_LAUNCH_SPEC(BM, NST) do { if (prof_kind == 1) conv_bf16_kernel<BM, NST, 1, true><<<grid, 512, 0, s>>>(a); \
                                           else conv_bf16_kernel<BM, NST, 0, true><<<grid, 512, 0, s>>>(a); } while (0)
-    static const bool spec = !(getenv("VC_BF16_SPEC") && atoi(getenv("VC_BF16_SPEC")) == 0);
+    static const bool spec_default = !(getenv("VC_BF16_SPEC") && atoi(getenv("VC_BF16_SPEC")) == 0);
+    const bool spec = g_bf16_spec < 0 ? spec_default : g_bf16_spec != 0;
     if (spec && a.bm == 256) VC_BF16_LAUNCH_SPEC(256, 3);
     else if (spec && a.bm == 128 && a.nst == 4) VC_BF16_LAUNCH_SPEC(128, 4);
     else if (spec && a.bm == 64 && a.nst == 4) VC_BF16_LAUNCH_SPEC(64, 4);
