@@ -309,6 +309,43 @@ __device__ __forceinline__ void emit_channel_octets(const f32x4 (&o)[NV], const 
     }
 }
 
+// The filter-gradient GEMM of the bf16 mode reduces over pixels and reads dY as PIXEL octets, dYq[pixel octet][conv channel][8] bf16 (16-byte
+// units: 8 consecutive pixels of one channel; csrc/vc_ops.hip: conv_wgrad).  Round 4 / early round 5 re-read the fp32 dY in a pack launch per
+// filter gradient (37 launches, 0.47 ms of the batch-64 step, 6 bytes of traffic per element); the kernel that produces dY writes this form
+// too: a block's rows are consecutive channels of one sample, a lane's values are 4 (shuffled: 2) consecutive pixels of its row -- half (a
+// quarter) of a unit -- dropped as bf16 (RNE, the pack kernel's conversion) into an LDS tile [octet][row][8]; the block then writes, per
+// pixel octet, its rows' units side by side: 256 / LPR x 16 contiguous bytes.  Same plane / `which` conventions as emit_channel_octets.
+template <int LPR, int NV, bool SHUF>
+__device__ __forceinline__ void emit_pixel_octets(const f32x4 (&o)[NV], const bool (&ok)[NV], bool rowv, int which, int Lc,
+                                                  u32x4* dst /* unit of (the sample's pixel octet 0, first channel of the block's plane) */,
+                                                  long po_stride /* units between consecutive pixel octets = the convolution's channel count */, int rows_valid) {
+    constexpr int R = 256 / LPR, LMAX = LPR * 4 * NV;
+    __shared__ __attribute__((aligned(16))) unsigned short tile[(LMAX / 8) * R * 8];
+    const int r = threadIdx.x / LPR, sub = threadIdx.x % LPR;
+    __syncthreads();                                        // an earlier plane of this block has left the tile
+    if (rowv) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) if (ok[j]) {
+            if constexpr (SHUF) {
+                const int pos = (sub + j * LPR) * 2;
+                unsigned short* q = tile + ((pos >> 3) * R + r) * 8 + (pos & 7);
+                q[0] = __builtin_bit_cast(unsigned short, (__bf16)o[j][which]); q[1] = __builtin_bit_cast(unsigned short, (__bf16)o[j][which + 2]);
+            } else {
+                const int pos = (sub + j * LPR) * 4;
+                unsigned short* q = tile + ((pos >> 3) * R + r) * 8 + (pos & 7);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) q[e] = __builtin_bit_cast(unsigned short, (__bf16)o[j][e]);
+            }
+        }
+    }
+    __syncthreads();
+    const int npo = Lc >> 3;
+    for (int u = threadIdx.x; u < npo * rows_valid; u += 256) {
+        const int po = u / rows_valid, rr = u - po * rows_valid;
+        dst[(long)po * po_stride + rr] = *reinterpret_cast<const u32x4*>(tile + (po * R + rr) * 8);
+    }
+}
+
 template <int MODE, int LPR, int NV, bool PS>
 __global__ __launch_bounds__(256) void norm_fwd_v4_kernel(const NormArgs p) {
     touch_kernarg(p);
@@ -396,12 +433,13 @@ __global__ __launch_bounds__(256) void norm_bwd_v4_kernel(const NormArgs p) {
     const int unit = unit0 + threadIdx.x / LPR, sub = threadIdx.x % LPR;
     const int total = p.G * p.B * p.C;
     const bool rowv = unit < total;
-    if (!rowv && !p.outp) return;                           // (with a packed output every thread meets the block's barriers)
+    if (!rowv && !p.outp && !p.outq) return;                // (with a packed output every thread meets the block's barriers)
     const int uu = rowv ? unit : 0;
     const int g = uu / (p.B * p.C); const int rem = uu - g * (p.B * p.C);
     const int b = rem / p.C, c = rem - b * p.C;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     const float* y = p.y + (long)g * p.y_gs;
+    const bool dy_on = p.dy != nullptr;                      // bf16 data path inside a train step: both readers of dy take the octet forms, the fp32 copy is not written
     float* dy = p.dy + (long)g * p.dy_gs;
     const float* dout = p.dout + (long)g * p.do_gs + ((long)b * p.C + c) * p.L;
     // dy once more as bf16 channel octets in the convolution's layout [b][Cout / 8][OH OW][8] (what its input gradient gathers): branch br
@@ -412,11 +450,18 @@ __global__ __launch_bounds__(256) void norm_bwd_v4_kernel(const NormArgs p) {
         const int g0 = u0 / (p.B * p.C); const int rem0 = u0 - g0 * (p.B * p.C);
         const int b0 = rem0 / p.C, c0 = rem0 - b0 * p.C;
         const int left = (total - unit0) / 8, nv = left < (256 / LPR) / 8 ? (left > 0 ? left : 0) : (256 / LPR) / 8;
-        u32x4* base = reinterpret_cast<u32x4*>(reinterpret_cast<char*>(p.outp) + (long)g0 * p.outp_gs);
 #pragma unroll
         for (int which = 0; which < (PS ? 2 : 1); ++which) {
             const int chb = br * Cc + which * p.C + c0;
-            emit_channel_octets<LPR, NV, PS>(val, okv, rowv, which, Lc, base + ((long)b0 * Cout8 + chb / 8) * Lc, nv);
+            if (p.outp) {
+                u32x4* base = reinterpret_cast<u32x4*>(reinterpret_cast<char*>(p.outp) + (long)g0 * p.outp_gs);
+                emit_channel_octets<LPR, NV, PS>(val, okv, rowv, which, Lc, base + ((long)b0 * Cout8 + chb / 8) * Lc, nv);
+            }
+            if (p.outq) {       // [outq_po0 + the sample's first pixel octet + po][conv channel][8]
+                u32x4* base = reinterpret_cast<u32x4*>(reinterpret_cast<char*>(p.outq) + (long)g0 * p.outq_gs);
+                const int rows = total - unit0 < 256 / LPR ? (total > unit0 ? total - unit0 : 0) : 256 / LPR;
+                emit_pixel_octets<LPR, NV, PS>(val, okv, rowv, which, Lc, base + ((long)p.outq_po0 + (long)b0 * (Lc >> 3)) * (NB * Cc) + chb, (long)NB * Cc, rows);
+            }
         }
     };
     const float invL = 1.f / (float)p.L;
@@ -446,10 +491,10 @@ __global__ __launch_bounds__(256) void norm_bwd_v4_kernel(const NormArgs p) {
         for (int j = 0; j < NV; ++j) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) { const float sg = sigmoidf_(gt[j][e]); dv[j][e] = dO[j][e] * sg; dg[j][e] = dO[j][e] * v[j][e] * sg * (1.f - sg); }
-            if (ok[j]) { r0.store(dy, (sub + j * LPR) * 4, dv[j]); r1.store(dy, (sub + j * LPR) * 4, dg[j]); }
+            if (ok[j] && dy_on) { r0.store(dy, (sub + j * LPR) * 4, dv[j]); r1.store(dy, (sub + j * LPR) * 4, dg[j]); }
         }
         if (dbias) { bias_sums(dv, 0); bias_sums(dg, 1); }
-        if (p.outp) { emit_dy(dv, ok, 0); emit_dy(dg, ok, 1); }
+        if (p.outp || p.outq) { emit_dy(dv, ok, 0); emit_dy(dg, ok, 1); }
         return;
     }
     const float* gam = p.gamma + (long)g * p.par_gs;
@@ -470,11 +515,11 @@ __global__ __launch_bounds__(256) void norm_bwd_v4_kernel(const NormArgs p) {
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
             d[j] = ok[j] ? (dO[j] - s1 * invL - xv[j] * (s2 * invL)) * (ga * rs) : zero;
-            if (ok[j]) r0.store(dy, (sub + j * LPR) * 4, d[j]);
+            if (ok[j] && dy_on) r0.store(dy, (sub + j * LPR) * 4, d[j]);
         }
         if (dbias) bias_sums(d, 0);
         if (sub == 0 && dgam && rowv) { atomicAdd(dgam + c, s2); atomicAdd(dbet + c, s1); }
-        if (p.outp) emit_dy(d, ok, 0);
+        if (p.outp || p.outq) emit_dy(d, ok, 0);
         return;
     }
     const float mu2 = st[2 * (p.C + c)], rs2 = st[2 * (p.C + c) + 1], ga2 = gam[p.C + c], be2 = bet[p.C + c];
@@ -497,14 +542,14 @@ __global__ __launch_bounds__(256) void norm_bwd_v4_kernel(const NormArgs p) {
     for (int j = 0; j < NV; ++j) {
         dv[j] = ok[j] ? (dnv[j] - s1v * invL - xv[j] * (s2v * invL)) * (ga * rs) : zero;
         dg[j] = ok[j] ? (dng[j] - s1g * invL - xg[j] * (s2g * invL)) * (ga2 * rs2) : zero;
-        if (ok[j]) { r0.store(dy, (sub + j * LPR) * 4, dv[j]); r1.store(dy, (sub + j * LPR) * 4, dg[j]); }
+        if (ok[j] && dy_on) { r0.store(dy, (sub + j * LPR) * 4, dv[j]); r1.store(dy, (sub + j * LPR) * 4, dg[j]); }
     }
     if (dbias) { bias_sums(dv, 0); bias_sums(dg, 1); }
     if (sub == 0 && dgam && rowv) {
         atomicAdd(dgam + c, s2v); atomicAdd(dbet + c, s1v);
         atomicAdd(dgam + p.C + c, s2g); atomicAdd(dbet + p.C + c, s1g);
     }
-    if (p.outp) { emit_dy(dv, ok, 0); emit_dy(dg, ok, 1); }
+    if (p.outp || p.outq) { emit_dy(dv, ok, 0); emit_dy(dg, ok, 1); }
 }
 
 // GLU backward without norm (module.py:201-203 / 161-163: the two h1 blocks) for rows of ANY length that is a multiple of 4
@@ -1035,6 +1080,11 @@ static int norm_dispatch(const NormArgs& a, hipStream_t s) {
         bool ok = !det && (a.L & 3) == 0 && al(a.y, a.y_gs);
         if (FWD) ok = ok && al(a.out, a.out_gs) && (MODE != 2 || al(a.res, a.res_gs));
         else ok = ok && al(a.dy, a.dy_gs) && al(a.dout, a.do_gs);
+        if (!FWD && !a.dy && !(a.outp || a.outq)) { vc_set_error("norm backward: dy may only be left out when an octet form of it is written"); return -1; }
+        if (!FWD && a.outq && !(ok && a.L <= 512 && a.C % 32 == 0 && ((a.ps ? a.L >> 1 : a.L) & 7) == 0 && al(a.outq, a.outq_gs / 4))) {
+            vc_set_error("norm backward: pixel octets were requested for a launch that does not produce them (ask norm_bwd_emits_pixel_octets first)");
+            return -1;
+        }
         if (a.outp && !(ok && a.L <= 512 && a.C % 32 == 0 && al(a.outp, a.outp_gs / 4))) {
             vc_set_error("norm forward / backward: a packed bf16 output was requested for a launch the 16-byte kernels do not serve (ask norm_fwd_emits_packed / norm_bwd_emits_packed first)");
             return -1;
@@ -1086,6 +1136,9 @@ bool norm_fwd_emits_packed(const NormArgs& a) {
 bool norm_bwd_emits_packed(const NormArgs& a) {             // same question for the backward's dy (not in deterministic mode: its kernels walk the batch)
     auto al = [](const void* q, long gs) { return ((uintptr_t)q & 15) == 0 && (gs & 3) == 0; };
     return !a.det && (a.L & 3) == 0 && a.L <= 512 && a.C % 32 == 0 && al(a.y, a.y_gs) && al(a.dy, a.dy_gs) && al(a.dout, a.do_gs);
+}
+bool norm_bwd_emits_pixel_octets(const NormArgs& a) {      // ... and as pixel octets: the convolution's pixels per sample come in whole octets
+    return norm_bwd_emits_packed(a) && ((a.ps ? a.L >> 1 : a.L) & 7) == 0 && !(a.L > 512);
 }
 int launch_norm_fwd(int mode, const NormArgs& a, hipStream_t s) {
     if (a.ps && (a.L & 1)) { vc_set_error("pixel shuffle needs even L"); return -1; }

@@ -63,8 +63,13 @@ int conv_dgrad(const float* dy, long dy_gs, const float* w, long w_gs, float* dx
                bool prezeroed = false, bool* query = nullptr, const char* const* packed_w = nullptr,
                const char* dy_packed = nullptr, long dy_packed_gs = 0);   // dy_packed: dy already as bf16 channel octets (its producer wrote them; group stride in bytes)
 bool conv_dgrad_packs_input(const Geom& g, int B, int math);          // the input gradient of this geometry at batch B runs on the 16-bit data path
+// bf16 data path: the layer's stacked pixel-octet dY [all applications' pixel octets][Cout][8] bf16 (group stride in bytes; room for every
+// application of the launch) and which applications' parts their norm backward has already written (bit k = application k): the
+// launch reads it in place and packs only the others
+struct WgradPacked { char* dyq; long dyq_gs; size_t cap; unsigned ready; };   // cap: bytes of one group's buffer
 int conv_wgrad(const WgradApp* apps, int napps, float* dw, long dw_gs, int G, const Geom& g, int math, hipStream_t s,
-               bool store, bool* query = nullptr);
+               bool store, bool* query = nullptr, const WgradPacked* pq = nullptr);
+bool conv_wgrad_reads_pixel_octets(const Geom& g, long pixels, int math);   // the filter gradient of this geometry runs as the bf16 GEMM over `pixels` (>= one application's)
 void drop_pack_spaces(std::initializer_list<hipStream_t> streams);
 long ws_generation(std::initializer_list<hipStream_t> streams);
 
@@ -123,9 +128,13 @@ long scratch_floats_net(const std::vector<LayerGeo>& geo, int B);
 // An earlier application of the same network whose filter gradients were deferred (the cycle hop): the first-hop
 // backward reduces both applications into dW with ONE launch per layer (WgradArgs segments).
 struct DeferredApp { const float* x; long x_gs; const float* save; long save_gs; const SaveMap* sm;
-                     const float* scratch; long scr_gs; const float* dtop; long dtop_gs; int B; };
+                     const float* scratch; long scr_gs; const float* dtop; long dtop_gs; int B;
+                     unsigned q_ready = 0, dy_dropped = 0; };   // bit i: layer i's dY of that application already lies as pixel octets in ITS scratch's stacked
+                                                                // buffer / its fp32 copy was never written (BwdOpts::drop_fp32_dy)
 enum { W_NONE = 0, W_SELF = 1 };
-struct BwdOpts { bool record_buckets = false, wgrad_store = false; int wmode = W_SELF; const DeferredApp* deferred = nullptr; };
+struct BwdOpts { bool record_buckets = false, wgrad_store = false; int wmode = W_SELF; const DeferredApp* deferred = nullptr;
+                 unsigned* q_ready_out = nullptr; unsigned* dy_dropped_out = nullptr;
+                 bool drop_fp32_dy = false; };        // the caller guarantees every reader of a layer's dy takes the octet forms whenever the norm backward wrote them (train step: yes)   // W_NONE passes: which layers' dY went out as pixel octets (for the DeferredApp of the pass that reduces them)
 int gen_forward(const vc_plan* p, const float* params, long par_gs, const float* x, long x_gs,
                 float* y, long y_gs, float* save, int G, int B, hipStream_t s);
 int gen_backward(const vc_plan* p, const float* params, long par_gs, const float* x, long x_gs,
@@ -137,6 +146,6 @@ int disc_forward(const vc_plan* p, const float* params, long par_gs, const float
 int disc_backward(const vc_plan* p, const float* params, long par_gs, const float* x, long x_gs,
                   const float* o, long o_gs, const float* dout, long do_gs, float* save, int Bl,
                   float* dparams, long dpar_gs, float* dx, long dx_gs, int dx_acc,
-                  float* scratch, long scr_gs, int G, int B, hipStream_t s, bool wgrad_store = false);
+                  float* scratch, long scr_gs, int G, int B, hipStream_t s, bool wgrad_store = false, bool drop_fp32_dy = false);
 // The step's prebuilt filter images describe `params` of the running step: only the step hands them to its network passes
 struct StepImages { explicit StepImages(const vc_plan* p); ~StepImages(); };

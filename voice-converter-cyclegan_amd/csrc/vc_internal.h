@@ -182,6 +182,8 @@ struct NormArgs {
     const float* dout; const float* stats_in;
     float* out; float* stats; float* dy; float* dgamma; float* dbeta; float* dbias;
     void* outp; long outp_gs;             // optional: the output (forward) / dy (backward) once more as bf16 channel octets [b][channels / 8][positions][8] (group stride in BYTES)
+    void* outq; long outq_gs; int outq_po0;   // optional (backward): dy once more as bf16 PIXEL octets [outq_po0 + pixel octet][conv channel][8] -- the filter-gradient
+                                          // GEMM's operand, this application's part of the layer's stacked buffer (group stride in BYTES)
     long y_gs, res_gs, par_gs, out_gs, st_gs, do_gs, dy_gs, dpar_gs, dbias_gs;
     int G, B, C, L, ps;
     int det;                              // backward: reduce dgamma / dbeta / dbias over the batch inside one lane group (fixed order, no atomics)
@@ -200,6 +202,7 @@ int launch_add(float* dst, const float* src, long n, hipStream_t s);   // dst +=
 int launch_norm_fwd(int mode, const NormArgs& a, hipStream_t s);
 bool norm_fwd_emits_packed(const NormArgs& a);     // NormArgs::outp is honoured for this launch (else: leave it null)
 bool norm_bwd_emits_packed(const NormArgs& a);     // ... by launch_norm_bwd: dy as channel octets in the convolution's layout
+bool norm_bwd_emits_pixel_octets(const NormArgs& a);   // NormArgs::outq is honoured by launch_norm_bwd (the convolution's pixel count per sample is a multiple of 8, ...)
 int launch_norm_bwd(int mode, const NormArgs& a, hipStream_t s);
 int launch_bias_grad(const float* dy, long dy_gs, float* db, long db_gs, int G, int B, int C, int L, hipStream_t s);
 int launch_head_fwd(const float* x, long x_gs, const float* w, const float* b, long par_gs,

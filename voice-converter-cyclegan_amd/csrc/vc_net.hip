@@ -246,9 +246,12 @@ static long scratch_dyp_floats(const std::vector<LayerGeo>& geo, int B) {
     for (const LayerGeo& l : geo) m = std::max(m, align64((l.raw_ps * B + 1) / 2));
     return m;
 }
+// + per layer the filter-gradient GEMM's dY operand (bf16 pixel octets, both applications of the layer stacked: the cycle-hop pass writes
+// its B samples' part here, the first-hop pass adds up to 2 B more and reduces: room for 3 B), written by the norm backward of each pass
+static long scratch_dyq_floats(const LayerGeo& l, int B) { return align64((3 * l.raw_ps * B + 1) / 2); }
 long scratch_floats_net(const std::vector<LayerGeo>& geo, int B) {
     long o = 0;
-    for (const LayerGeo& l : geo) o += align64(l.raw_ps * B) + align64(l.act_ps * B);
+    for (const LayerGeo& l : geo) o += align64(l.raw_ps * B) + align64(l.act_ps * B) + scratch_dyq_floats(l, B);
     return o + scratch_dyp_floats(geo, B);
 }
 extern "C" int64_t vc_scratch_floats(const vc_plan* p, int B) {
@@ -271,6 +274,8 @@ struct NetCtx {
     const std::vector<vc_plan::LayerImages>* images = nullptr;   // bf16 data path: this step's prebuilt filter images
     bool keep_packed = false;              // bf16 data path, inside a train step: forward leaves the packed inputs in the save area (SaveMap::actp)
     bool fuse_glu = false;                 // forward only: gated blocks without instance norm go out as one conv + GLU kernel
+    unsigned* q_ready_out = nullptr;       // W_NONE passes report which layers' dY they left as pixel octets (BwdOpts::q_ready_out)
+    unsigned* dy_dropped_out = nullptr; bool drop_dy = false;   // BwdOpts::drop_fp32_dy
     int wmode = W_SELF;                    // W_NONE: leave the conv filter gradients to a later application (DeferredApp)
     bool wgrad_store = false;              // this backward's filter gradients are the step's only contribution to dparams' conv kernels
     const DeferredApp* deferred = nullptr; // reduce this earlier application in the same launches
@@ -278,9 +283,11 @@ struct NetCtx {
     const hipEvent_t* ev_free = nullptr;                                            // ... and ev_free[k] after its input gradient is issued
 };
 // scratch map of one group: dY[i], dA[i] per layer (dA[i] = gradient w.r.t. the activation (output) of layer i)
-static long scratch_map(const std::vector<LayerGeo>& geo, int B, long* dY, long* dA) {      // returns the offset of the packed-dY region
+static long scratch_map(const std::vector<LayerGeo>& geo, int B, long* dY, long* dA, long* dYq = nullptr) {      // returns the offset of the packed-dY region
     long o = 0;
     for (size_t i = 0; i < geo.size(); ++i) { dY[i] = o; o += align64(geo[i].raw_ps * B); dA[i] = o; o += align64(geo[i].act_ps * B); }
+    long q = o + scratch_dyp_floats(geo, B);             // behind the channel-octet region: the layers' stacked pixel-octet buffers
+    for (size_t i = 0; i < geo.size(); ++i) { if (dYq) dYq[i] = q; q += scratch_dyq_floats(geo[i], B); }
     return o;
 }
 
@@ -370,10 +377,11 @@ static int net_backward(NetCtx& c, const float* x, long x_gs, const float* dtop,
                         float* dx, long dx_gs, int dx_acc, float* scratch, long scr_gs) {
     const int nl = (int)c.n->layers.size();
     VC_ARG(nl <= 24, "net_backward: more than 24 layers");
-    long dYo[24], dAo[24];
-    const long dYp_off = scratch_map(*c.geo, c.B, dYo, dAo);
-    long dYd[24], dAd[24];
-    if (c.deferred) scratch_map(*c.geo, c.deferred->B, dYd, dAd);
+    long dYo[24], dAo[24], dYqo[24];
+    const long dYp_off = scratch_map(*c.geo, c.B, dYo, dAo, dYqo);
+    long dYd[24], dAd[24], dYqd[24];
+    if (c.deferred) scratch_map(*c.geo, c.deferred->B, dYd, dAd, dYqd);
+    unsigned q_ready = 0, dy_dropped = 0;
     hipStream_t ws = c.ws ? c.ws : c.s;       // the plan sizes its event pools for its own networks (18 / 4 layers)
     // one launch zeroes every dA that a split-K input-gradient will accumulate into
     {
@@ -417,8 +425,18 @@ static int net_backward(NetCtx& c, const float* x, long x_gs, const float* dtop,
                 a.outp = (char*)(scratch + dYp_off); a.outp_gs = scr_gs * 4;
                 dy_packed = (const char*)a.outp;
             }
+            // ... and its filter gradient (the bf16 GEMM over pixels) reads dy as pixel octets out of the layer's stacked buffer: this
+            // pass's own scratch, or the deferred application's when that pass opened the buffer (its part sits in front)
+            if (c.dparams && norm_bwd_emits_pixel_octets(a) && conv_wgrad_reads_pixel_octets(lg.g, (long)c.B * lg.g.OH * lg.g.OW, c.math) &&
+                (!c.deferred || c.B <= 2 * c.deferred->B)) {
+                if (c.deferred) { a.outq = (char*)const_cast<float*>(c.deferred->scratch + dYqd[i]); a.outq_gs = c.deferred->scr_gs * 4; a.outq_po0 = c.deferred->B * lg.g.OH * lg.g.OW / 8; }
+                else { a.outq = (char*)(scratch + dYqo[i]); a.outq_gs = scr_gs * 4; a.outq_po0 = 0; }
+                q_ready |= 1u << i;
+            }
+            // both readers of this dy take the octet forms (or do not exist): its fp32 copy -- the largest stream of the kernel -- stays unwritten
+            if (c.drop_dy && ((i == 0 && !dx) || dy_packed) && (!c.dparams || (q_ready >> i & 1u)) && (dy_packed || a.outq)) { a.dy = nullptr; dy_dropped |= 1u << i; }
             VC_CHECK(launch_norm_bwd(L.mode, a, c.s));
-            dyp = scratch + dYo[i]; dy_gs = scr_gs;
+            dyp = a.dy ? scratch + dYo[i] : nullptr; dy_gs = scr_gs;
             if (c.dparams && c.wmode != W_NONE && ws != c.s) { VC_HIP(hipEventRecord(c.ev_layer[i], c.s)); VC_HIP(hipStreamWaitEvent(ws, c.ev_layer[i], 0)); }
         }
         if (c.dparams && c.wmode != W_NONE) {
@@ -426,7 +444,7 @@ static int net_backward(NetCtx& c, const float* x, long x_gs, const float* dtop,
             if (c.deferred) {
                 const DeferredApp& d = *c.deferred;
                 apps[na++] = WgradApp{i == 0 ? d.x : d.save + d.sm->act[i - 1], i == 0 ? d.x_gs : d.save_gs,
-                                      L.mode == M_PLAIN ? d.dtop : d.scratch + dYd[i], L.mode == M_PLAIN ? d.dtop_gs : d.scr_gs, d.B};
+                                      L.mode == M_PLAIN ? d.dtop : (d.dy_dropped >> i & 1u) ? nullptr : d.scratch + dYd[i], L.mode == M_PLAIN ? d.dtop_gs : d.scr_gs, d.B};
                 if (c.keep_packed && i > 0 && conv_fwd_packs_input(lg.g, d.B, c.math)) {   // d.B: the batch of that forward
                     apps[na - 1].xp = (const char*)(d.save + d.sm->actp[i - 1]); apps[na - 1].xp_gs = d.save_gs * 4;
                 }
@@ -435,7 +453,13 @@ static int net_backward(NetCtx& c, const float* x, long x_gs, const float* dtop,
             if (c.keep_packed && i > 0 && conv_fwd_packs_input(lg.g, c.Bl, c.math)) {       // c.Bl: the batch the forward ran (and laid out) with
                 apps[na - 1].xp = (const char*)(c.save + c.sm.actp[i - 1]); apps[na - 1].xp_gs = c.save_gs * 4;
             }
-            VC_CHECK(conv_wgrad(apps, na, c.dparams + L.w, c.dpar_gs, c.G, lg.g, c.math, ws, c.wgrad_store));
+            WgradPacked pq{nullptr, 0, 0, 0};
+            if (c.deferred) {
+                pq.dyq = (char*)const_cast<float*>(c.deferred->scratch + dYqd[i]); pq.dyq_gs = c.deferred->scr_gs * 4;
+                pq.cap = (size_t)scratch_dyq_floats(lg, c.deferred->B) * 4;
+                pq.ready = (c.deferred->q_ready >> i & 1u) | ((q_ready >> i & 1u) << 1);
+            } else { pq.dyq = (char*)(scratch + dYqo[i]); pq.dyq_gs = scr_gs * 4; pq.cap = (size_t)scratch_dyq_floats(lg, c.B) * 4; pq.ready = q_ready >> i & 1u; }
+            VC_CHECK(conv_wgrad(apps, na, c.dparams + L.w, c.dpar_gs, c.G, lg.g, c.math, ws, c.wgrad_store, nullptr, &pq));
         }
         for (int k = 0; k < c.n_ev; ++k) if (c.ev_first[k] == i) VC_HIP(hipEventRecord(c.ev[k], ws));
         if (i == 0) {
@@ -454,6 +478,8 @@ static int net_backward(NetCtx& c, const float* x, long x_gs, const float* dtop,
         dcur = scratch + dAo[i - 1]; dcur_gs = scr_gs;
     }
     if (ws != c.s) { VC_HIP(hipEventRecord(c.ev_wjoin, ws)); VC_HIP(hipStreamWaitEvent(c.s, c.ev_wjoin, 0)); }   // join
+    if (c.q_ready_out) *c.q_ready_out = q_ready;
+    if (c.dy_dropped_out) *c.dy_dropped_out = dy_dropped;
     return 0;
 }
 
@@ -495,7 +521,7 @@ int gen_backward(const vc_plan* p, const float* params, long par_gs, const float
                         const BwdOpts& o) {
     VC_ARG(!p->inference, "this plan was created for inference only (vc_plan_create_inference)");
     NetCtx c = gen_ctx(p, params, par_gs, dparams, dpar_gs, save, G, B, Bl, s);
-    c.wgrad_store = o.wgrad_store; c.wmode = o.wmode; c.deferred = o.deferred;
+    c.wgrad_store = o.wgrad_store; c.wmode = o.wmode; c.deferred = o.deferred; c.q_ready_out = o.q_ready_out; c.dy_dropped_out = o.dy_dropped_out; c.drop_dy = o.drop_fp32_dy;
     c.images = step_images(p, true, G); c.keep_packed = c.images != nullptr;
     if ((p->use_side & 2) && dparams && o.wmode != W_NONE) { c.ws = p->wstream; c.ev_layer = p->ev_layer; c.ev_wjoin = p->ev_wjoin; }
     if (o.record_buckets) { c.ev_first = p->bucket_first; c.ev = p->g_ready; c.ev_free = p->g_free; c.n_ev = vc_plan::kBuckets; }
@@ -515,10 +541,10 @@ int disc_forward(const vc_plan* p, const float* params, long par_gs, const float
 int disc_backward(const vc_plan* p, const float* params, long par_gs, const float* x, long x_gs,
                          const float* o, long o_gs, const float* dout, long do_gs, float* save, int Bl,
                          float* dparams, long dpar_gs, float* dx, long dx_gs, int dx_acc,
-                         float* scratch, long scr_gs, int G, int B, hipStream_t s, bool wgrad_store) {
+                         float* scratch, long scr_gs, int G, int B, hipStream_t s, bool wgrad_store, bool drop_fp32_dy) {
     VC_ARG(!p->inference, "this plan was created for inference only (vc_plan_create_inference)");
     NetCtx c = disc_ctx(p, params, par_gs, dparams, dpar_gs, save, G, B, Bl, s);
-    c.wgrad_store = wgrad_store;
+    c.wgrad_store = wgrad_store; c.drop_dy = drop_fp32_dy;
     c.images = step_images(p, false, G); c.keep_packed = c.images != nullptr;
     if ((p->use_side & 4) && dparams) { c.ws = p->wstream_d; c.ev_layer = p->ev_layer_d; c.ev_wjoin = p->ev_wjoin_d; }
     const int last = (int)p->D.layers.size() - 1;

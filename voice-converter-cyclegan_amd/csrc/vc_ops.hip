@@ -362,8 +362,13 @@ static int get_gemm_table(int N, int noct, GemmTab* out) {
 
 // dW (+)= sum over the applications; store: dW holds nothing yet (plain stores when the launch does not split K)
 // query != nullptr: only report whether the launch would accumulate with atomics (needs a zeroed dW)
+bool conv_wgrad_reads_pixel_octets(const Geom& g, long pixels, int math) {
+    if (math != VC_MATH_BF16 || c1_path(g)) return false;
+    Table t; if (get_fwd_table(g, &t, nullptr)) return false;
+    return bf16_path(t, math, g.Cout, pixels) && (g.OH * g.OW) % 8 == 0 && g.OW % 8 == 0;
+}
 int conv_wgrad(const WgradApp* apps, int napps, float* dw, long dw_gs, int G, const Geom& g, int math, hipStream_t s,
-                      bool store, bool* query) {
+                      bool store, bool* query, const WgradPacked* pq) {
     if (c1_path(g)) {
         if (query) { *query = true; return 0; }
         for (int k = 0; k < napps; ++k) {
@@ -405,8 +410,12 @@ int conv_wgrad(const WgradApp* apps, int napps, float* dw, long dw_gs, int G, co
             if (a.splitk > 1) a.accumulate = 1;
             size_t xp_g[2] = {0, 0}, xp_tot = 0;
             for (int k = 0; k < napps; ++k) if (!apps[k].xp) { xp_g[k] = align256((size_t)apps[k].B * g.Cin * g.H * g.W * 2); xp_tot += xp_g[k] * G; }
-            char* wsp; VC_CHECK(pack_space(s, (xcol_g + dyq_g) * G + xp_tot, &wsp));
-            char* xcol = wsp; char* dyq = wsp + xcol_g * G; char* xtmp = dyq + dyq_g * G;
+            // the stacked dY: the layer's own buffer when its norm backward wrote (part of) it, else this launch's pack space
+            const bool stacked = pq && pq->dyq && pq->cap >= (size_t)npo * g.Cout * 16 && ((uintptr_t)pq->dyq & 15) == 0 && pq->dyq_gs % 16 == 0;
+            char* wsp; VC_CHECK(pack_space(s, (xcol_g + (stacked ? 0 : dyq_g)) * G + xp_tot, &wsp));
+            char* xcol = wsp; char* dyq = stacked ? pq->dyq : wsp + xcol_g * G; char* xtmp = wsp + (xcol_g + (stacked ? 0 : dyq_g)) * G;
+            const long dyq_gs = stacked ? pq->dyq_gs : (long)dyq_g;
+            a.x_gs = dyq_gs;
             double flops = 0;
             for (int k = 0; k < napps; ++k) {
                 const char* xp = apps[k].xp; long xp_gs = apps[k].xp_gs;
@@ -415,7 +424,10 @@ int conv_wgrad(const WgradApp* apps, int napps, float* dw, long dw_gs, int G, co
                     xp = xtmp; xp_gs = (long)xp_g[k]; xtmp += xp_g[k] * G;
                 }
                 VC_CHECK(launch_im2col_bf16(xp, xp_gs, xcol, (long)xcol_g, t.taps, t.ntaps, G, apps[k].B, g.Cin, g.H, g.W, g.OH, g.OW, g.sh, g.sw, po0[k], s));
-                VC_CHECK(launch_pack_pixel_octets_bf16(apps[k].dy, apps[k].dy_gs, dyq, (long)dyq_g, G, apps[k].B, g.Cout, NPB, po0[k], s));
+                if (!(stacked && (pq->ready >> k & 1))) {
+                    VC_ARG(apps[k].dy, "conv filter gradient: an application's fp32 dy was left unwritten but its pixel octets are not in the stacked buffer");
+                    VC_CHECK(launch_pack_pixel_octets_bf16(apps[k].dy, apps[k].dy_gs, dyq, dyq_gs, G, apps[k].B, g.Cout, NPB, po0[k], s));
+                }
                 flops += 2.0 * G * apps[k].B * NPB * (double)g.Cout * t.valid;
             }
             a.A = xcol; a.X = dyq;

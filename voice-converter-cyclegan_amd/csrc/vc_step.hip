@@ -196,22 +196,24 @@ static int step_grads_impl(const vc_plan* p, const float* params, float* grads,
     VC_CHECK(fork());
     // 7. discriminator_loss backward over [fake; real] -> D gradients (model.py:94,107)   [side stream, own scratch]
     VC_CHECK(disc_backward(p, params + 2 * PG, PD, DX, DXg, DO, DOg, dDO_D, dDDg, SD, 2 * B,
-                           grads + 2 * PG, PD, nullptr, 0, 0, ws + m.SCR2, scr_gs, 2, 2 * B, s2, /*wgrad_store=*/true));
+                           grads + 2 * PG, PD, nullptr, 0, 0, ws + m.SCR2, scr_gs, 2, 2 * B, s2, /*wgrad_store=*/true, /*drop_fp32_dy=*/true));
     VC_HIP(hipEventRecord(p->d_ready, s2));
     // 8. adversarial generator terms: gradient through D's inputs only (var_list = generator_vars, model.py:95,108)
     //    g0 = D_A -> d gen_A = dO1[g1][0:B]; g1 = D_B -> d gen_B = dO1[g0][0:B]
     VC_CHECK(disc_backward(p, params + 2 * PG, PD, DX, DXg, DO, DOg, dDO_G, dDGg, SD, 2 * B,
-                           nullptr, 0, dO1 + dO1g, -dO1g, 0, SCR, scr_gs, 2, B, s));
+                           nullptr, 0, dO1 + dO1g, -dO1g, 0, SCR, scr_gs, 2, B, s, /*wgrad_store=*/false, /*drop_fp32_dy=*/true));
     VC_HIP(hipEventRecord(p->d_free, s));     // last read of the discriminator weights in this step
     // 9. cycle hop backward: g0 = A2B on gen_A -> adds into d gen_A; g1 = B2A on gen_B -> d gen_B.  Its filter
     //    gradients are NOT launched here: step 10 reduces both applications of every layer in one launch.
-    BwdOpts oc; oc.wmode = W_NONE;
+    unsigned cyc_q_ready = 0, cyc_dy_dropped = 0;   // layers whose cycle-hop dY already lies in SCRC's stacked pixel-octet buffers (bf16 data path)
+    BwdOpts oc; oc.wmode = W_NONE; oc.q_ready_out = &cyc_q_ready; oc.dy_dropped_out = &cyc_dy_dropped;
+    oc.drop_fp32_dy = true;                 // this step's first-hop pass reduces at most 2 B more samples: it always takes the stacked buffers
     VC_CHECK(gen_backward(p, params, PG, O1 + O1g, -O1g, dCY, dCYg, S2, B, grads, PG,
                           dO1 + dO1g, -dO1g, 1, SCRC, scrc_gs, 2, B, s, oc));
     // 10. first-hop backward over [generation; identity] (+ the deferred cycle-hop filter gradients)
     const SaveMap sm2 = save_map(p->G, p->gg, B);
-    const DeferredApp cyc{O1 + O1g, -O1g, S2, sm2.total, &sm2, SCRC, scrc_gs, dCY, dCYg, B};
-    BwdOpts o1; o1.record_buckets = true; o1.wgrad_store = true; o1.deferred = &cyc;
+    const DeferredApp cyc{O1 + O1g, -O1g, S2, sm2.total, &sm2, SCRC, scrc_gs, dCY, dCYg, B, cyc_q_ready, cyc_dy_dropped};
+    BwdOpts o1; o1.record_buckets = true; o1.wgrad_store = true; o1.deferred = &cyc; o1.drop_fp32_dy = true;
     VC_CHECK(gen_backward(p, params, PG, X1, X1g, dO1, dO1g, S1, 2 * B, grads, PG,
                           nullptr, 0, 0, SCR, scr_gs, 2, Bbwd, s, o1));
     VC_CHECK(join());      // the caller's next work on `stream` (Adam) sees the discriminator gradients
