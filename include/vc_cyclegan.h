@@ -215,7 +215,8 @@ int  vc_plan_get_deterministic(const vc_plan* p);
 /* Workspace sizes in floats for batch B per group. */
 int64_t vc_generator_save_floats(const vc_plan* p, int B);       /* activations kept for backward */
 int64_t vc_discriminator_save_floats(const vc_plan* p, int B);
-int64_t vc_scratch_floats(const vc_plan* p, int B);              /* backward scratch (max over G and D) */
+int64_t vc_scratch_floats(const vc_plan* p, int B);              /* backward scratch (max over G and D); larger in bf16 mode (the filter-gradient GEMMs'
+                                                                 * pixel-octet operands live in it): query again after vc_plan_set_math_mode */
 
 /* module.generator_gatedcnn (module.py:148-185) for G networks in lock-step.
  * params: base of group 0's parameter block, par_gs = signed stride to group 1's.
@@ -247,7 +248,8 @@ int vc_discriminator_backward(const vc_plan* p, const float* params, int64_t par
  * [generator_A2B | generator_B2A | discriminator_A | discriminator_B]. */
 int64_t vc_flat_param_floats(const vc_plan* p);
 int64_t vc_flat_offset(const vc_plan* p, int net /*0..3*/);
-int64_t vc_step_workspace_floats(const vc_plan* p, int B);
+int64_t vc_step_workspace_floats(const vc_plan* p, int B);       /* depends on the plan's math mode (bf16 is larger): query after vc_plan_set_math_mode;
+                                                                 * the step entry points refuse a workspace that is too small */
 /* One fused forward+backward of the whole CycleGAN graph (model.py:44-90):
  * inputs A,B [B][F][T]; params/grads flat buffers (16-byte aligned); every element of grads is (over)written: filter
  * gradients by plain stores of their single launch, everything that is accumulated (biases, gamma/beta, padding) is

@@ -124,7 +124,7 @@ struct vc_plan {
 };
 struct SaveMap { std::vector<long> raw, act, st, actp; long total; };
 SaveMap save_map(const NetDesc& n, const std::vector<LayerGeo>& geo, int B);
-long scratch_floats_net(const std::vector<LayerGeo>& geo, int B);
+long scratch_floats_net(const std::vector<LayerGeo>& geo, int B, int math);
 // An earlier application of the same network whose filter gradients were deferred (the cycle hop): the first-hop
 // backward reduces both applications into dW with ONE launch per layer (WgradArgs segments).
 struct DeferredApp { const float* x; long x_gs; const float* save; long save_gs; const SaveMap* sm;

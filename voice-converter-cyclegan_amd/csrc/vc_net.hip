@@ -248,15 +248,16 @@ static long scratch_dyp_floats(const std::vector<LayerGeo>& geo, int B) {
 }
 // + per layer the filter-gradient GEMM's dY operand (bf16 pixel octets, both applications of the layer stacked: the cycle-hop pass writes
 // its B samples' part here, the first-hop pass adds up to 2 B more and reduces: room for 3 B), written by the norm backward of each pass
+// (bf16 mode only: the fp32 workspace does not carry them)
 static long scratch_dyq_floats(const LayerGeo& l, int B) { return align64((3 * l.raw_ps * B + 1) / 2); }
-long scratch_floats_net(const std::vector<LayerGeo>& geo, int B) {
+long scratch_floats_net(const std::vector<LayerGeo>& geo, int B, int math) {
     long o = 0;
-    for (const LayerGeo& l : geo) o += align64(l.raw_ps * B) + align64(l.act_ps * B) + scratch_dyq_floats(l, B);
+    for (const LayerGeo& l : geo) o += align64(l.raw_ps * B) + align64(l.act_ps * B) + (math == VC_MATH_BF16 ? scratch_dyq_floats(l, B) : 0);
     return o + scratch_dyp_floats(geo, B);
 }
 extern "C" int64_t vc_scratch_floats(const vc_plan* p, int B) {
     if (!p) return 0;
-    return std::max(scratch_floats_net(p->gg, B), scratch_floats_net(p->dg, B));
+    return std::max(scratch_floats_net(p->gg, B, p->math), scratch_floats_net(p->dg, B, p->math));
 }
 extern "C" int vc_discriminator_out_elems(const vc_plan* p) { return p ? p->d_hw : 0; }
 
@@ -286,8 +287,10 @@ struct NetCtx {
 static long scratch_map(const std::vector<LayerGeo>& geo, int B, long* dY, long* dA, long* dYq = nullptr) {      // returns the offset of the packed-dY region
     long o = 0;
     for (size_t i = 0; i < geo.size(); ++i) { dY[i] = o; o += align64(geo[i].raw_ps * B); dA[i] = o; o += align64(geo[i].act_ps * B); }
-    long q = o + scratch_dyp_floats(geo, B);             // behind the channel-octet region: the layers' stacked pixel-octet buffers
-    for (size_t i = 0; i < geo.size(); ++i) { if (dYq) dYq[i] = q; q += scratch_dyq_floats(geo[i], B); }
+    if (dYq) {                                           // bf16 mode; behind the channel-octet region: the layers' stacked pixel-octet buffers
+        long q = o + scratch_dyp_floats(geo, B);
+        for (size_t i = 0; i < geo.size(); ++i) { dYq[i] = q; q += scratch_dyq_floats(geo[i], B); }
+    }
     return o;
 }
 
@@ -378,9 +381,10 @@ static int net_backward(NetCtx& c, const float* x, long x_gs, const float* dtop,
     const int nl = (int)c.n->layers.size();
     VC_ARG(nl <= 24, "net_backward: more than 24 layers");
     long dYo[24], dAo[24], dYqo[24];
-    const long dYp_off = scratch_map(*c.geo, c.B, dYo, dAo, dYqo);
+    const bool qmap = c.math == VC_MATH_BF16;            // the scratch was sized for the plan's mode (vc_scratch_floats / vc_step_workspace_floats)
+    const long dYp_off = scratch_map(*c.geo, c.B, dYo, dAo, qmap ? dYqo : nullptr);
     long dYd[24], dAd[24], dYqd[24];
-    if (c.deferred) scratch_map(*c.geo, c.deferred->B, dYd, dAd, dYqd);
+    if (c.deferred) scratch_map(*c.geo, c.deferred->B, dYd, dAd, qmap ? dYqd : nullptr);
     unsigned q_ready = 0, dy_dropped = 0;
     hipStream_t ws = c.ws ? c.ws : c.s;       // the plan sizes its event pools for its own networks (18 / 4 layers)
     // one launch zeroes every dA that a split-K input-gradient will accumulate into
@@ -454,12 +458,13 @@ static int net_backward(NetCtx& c, const float* x, long x_gs, const float* dtop,
                 apps[na - 1].xp = (const char*)(c.save + c.sm.actp[i - 1]); apps[na - 1].xp_gs = c.save_gs * 4;
             }
             WgradPacked pq{nullptr, 0, 0, 0};
-            if (c.deferred) {
+            if (!qmap) {}
+            else if (c.deferred) {
                 pq.dyq = (char*)const_cast<float*>(c.deferred->scratch + dYqd[i]); pq.dyq_gs = c.deferred->scr_gs * 4;
                 pq.cap = (size_t)scratch_dyq_floats(lg, c.deferred->B) * 4;
                 pq.ready = (c.deferred->q_ready >> i & 1u) | ((q_ready >> i & 1u) << 1);
             } else { pq.dyq = (char*)(scratch + dYqo[i]); pq.dyq_gs = scr_gs * 4; pq.cap = (size_t)scratch_dyq_floats(lg, c.B) * 4; pq.ready = q_ready >> i & 1u; }
-            VC_CHECK(conv_wgrad(apps, na, c.dparams + L.w, c.dpar_gs, c.G, lg.g, c.math, ws, c.wgrad_store, nullptr, &pq));
+            VC_CHECK(conv_wgrad(apps, na, c.dparams + L.w, c.dpar_gs, c.G, lg.g, c.math, ws, c.wgrad_store, nullptr, qmap ? &pq : nullptr));
         }
         for (int k = 0; k < c.n_ev; ++k) if (c.ev_first[k] == i) VC_HIP(hipEventRecord(c.ev[k], ws));
         if (i == 0) {

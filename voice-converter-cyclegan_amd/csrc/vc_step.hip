@@ -29,7 +29,7 @@ static StepMap step_map(const vc_plan* p, int B) {
     m.s2_gs = vc_generator_save_floats(p, B);     m.S2 = take(m.s2_gs);
     m.sd_gs = vc_discriminator_save_floats(p, 2 * B); m.SD = take(m.sd_gs);
     m.scr_gs = vc_scratch_floats(p, 2 * B); m.SCR = take(m.scr_gs);   // backward calls with batch B use a smaller group stride inside it
-    m.scrc_gs = scratch_floats_net(p->gg, B); m.SCRC = take(m.scrc_gs);   // cycle-hop backward: its dY buffers stay live until the
+    m.scrc_gs = scratch_floats_net(p->gg, B, p->math); m.SCRC = take(m.scrc_gs);   // cycle-hop backward: its dY buffers stay live until the
                                                                           // first-hop backward has reduced them into the filter gradients
     m.SCR2 = take(m.scr_gs);                      // scratch of the discriminator_loss backward (runs on the side stream)
     m.ACC = o; o += align64(VC_LOSS_BLOCKS * 10);     // per-block partial sums of the loss kernel
