@@ -44,7 +44,7 @@ extern "C" {
 typedef struct vc_plan vc_plan;   /* opaque: geometry tables + workspace map for one (F, T) */
 
 /* ---- library ------------------------------------------------------------- */
-int         vc_version(void);          /* ABI revision: 111 (bumped whenever an entry point changes or is added) */
+int         vc_version(void);          /* ABI revision: 112 (bumped whenever an entry point changes or is added) */
 /* The content hash of the sources + compiler flags this library was built from (16 hex digits; build.py stamps it, _lib.py
  * compares it with the sources in the tree at import and rebuilds / refuses on a mismatch; bench.py prints it). */
 const char* vc_build_id(void);

@@ -27,6 +27,9 @@ int  vc_tune_conv_bf16_override(int tile_rows, int stages, int splitk);
 /* conv_bf16_kernel's one-workgroup-per-CU configurations (256 x 3, 128 x 4, 64 x 4) for the calling thread's following launches:
  * 1 = wave-specialised (512 threads: 4 multiplying + 4 copying waves; production), 0 = the 256-thread form, -1 = the process default. */
 int  vc_tune_conv_bf16_spec(int on);
+/* bf16 data path, calling thread's following backward passes: 1 (production) = the norm backward writes dy as pixel octets into the layer's
+ * stacked buffer (and drops the fp32 copy inside a train step), 0 = it writes fp32 only and every filter gradient packs its operand itself. */
+int  vc_tune_bf16_pixel_octets(int on);
 /* Which configuration did the calling thread's last conv forward / input-gradient launch (igemm) or filter-gradient launch
  * (wgrad) run with, and where did it come from?  out4 = {tile rows | columns, K groups, split-K, source}; source: 0 cost
  * model, 1 exact row of the measured table (csrc/vc_tuned_igemm.h / vc_tuned_wgrad.h), 2 the same layer's row measured at

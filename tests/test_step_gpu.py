@@ -907,6 +907,47 @@ def test_bf16_data_path_at_the_benchmarked_size(built_lib):
         eng.set_math('fp32')
 
 
+def test_bf16_dy_in_octet_forms_equals_the_pack_launches(built_lib):
+    """bf16 data path: inside a train step the norm backward writes dy as channel octets (input gradient) and pixel octets (filter-gradient
+    GEMM, both applications of a layer stacked in one buffer) and no fp32 copy at all.  Control (vc_tune_bf16_pixel_octets(0)): fp32 dy, every
+    filter gradient packs its operand in its own launch -- the same bf16 values (RNE of the same fp32 numbers) in the same places.  With
+    every convolution forced to a configuration without split-K (no atomics in forward, input gradients and filter gradients: one summation
+    order) the two steps are the same arithmetic: losses and generations bitwise, every convolution kernel's gradient bitwise (but D.h1's:
+    its Cin = 1 kernel sums with atomics), the atomically summed leaves (bias, gamma, beta, dense head) to 1e-4 (measured 6e-6).
+    lambda_identity > 0 only.  OPEN (round 5; the GPU minutes ran out before the cause was found): in the
+    lambda_identity == 0 schedule (first-hop pass over the first B of 2 B laid-out samples) this comparison -- steps issued back to back
+    with only the caller's stream synchronised in between, generation outputs requested -- shows generator_B2A's gradients 2e-3 rel-L2
+    apart between the two modes (A2B and both discriminators agree; same numbers with the generator passes' own emission switched off, in
+    either order of the two modes), while the same steps separated by a device-wide synchronisation and without the generation outputs
+    agree to 3e-6 in every order tried (tools: profiles/r05_octet_control.txt).  The goldens' 2e-2 bf16 tolerance does not see 2e-3."""
+    from tests import gpu_util as U
+    from voice_converter_cyclegan_amd._lib import lib, check
+    B = 8
+    O, P, A, Bm, eng = _setup(B, gap=False)
+    eng.set_math('bf16')
+    check(lib.vc_tune_conv_bf16_override(128, 4, 1)); check(lib.vc_tune_igemm_override(64, 1, 1)); check(lib.vc_tune_wgrad_override(64, 1, 1))
+
+    def errs(got, ref):
+        return {n: float(np.linalg.norm(got[n].astype(np.float64) - r.astype(np.float64)) / (np.linalg.norm(r.astype(np.float64)) + 1e-30))
+                for n, r in ref.items() if not _is_noise_bias(n)}
+
+    try:
+        gA = torch.empty((B, 24, 128), device=U.DEV); hA = torch.empty_like(gA)
+        check(lib.vc_tune_bf16_pixel_octets(1)); eng.step_grads(A, Bm, 10.0, 5.0, gen_A=gA); g1 = eng.tf_gradients(); l1 = eng.losses.clone()
+        check(lib.vc_tune_bf16_pixel_octets(0)); eng.step_grads(A, Bm, 10.0, 5.0, gen_A=hA); g0 = eng.tf_gradients(); l0 = eng.losses.clone()
+        assert torch.equal(gA, hA) and torch.equal(l1, l0), (l1, l0)
+        bad = []
+        for n, e in errs(g1, g0).items():
+            exact = n.endswith('/kernel') and 'dense' not in n and not ('discriminator' in n and '/h1_conv' in n)
+            if e > (0.0 if exact else 1e-4):          # (measured on the leaves: up to 6e-6)
+                bad.append((n, e))
+        assert not bad, sorted(bad, key=lambda t: -t[1])[:6]
+    finally:
+        check(lib.vc_tune_bf16_pixel_octets(1))
+        check(lib.vc_tune_conv_bf16_override(0, 0, 0)); check(lib.vc_tune_igemm_override(0, 0, 0)); check(lib.vc_tune_wgrad_override(0, 0, 0))
+        eng.set_math('fp32')
+
+
 def test_error_behaviour_of_the_c_abi(built_lib):
     """bad arguments come back as an error code + vc_last_error text, never as a launch (include/vc_cyclegan.h conventions)"""
     from voice_converter_cyclegan_amd import _lib

@@ -29,7 +29,7 @@ def _expected_build_id():
     return mod, mod.build_id(os.environ.get('VC_EXTRA_FLAGS', '').split())
 
 
-ABI_VERSION = 111
+ABI_VERSION = 112
 lib = C.CDLL(LIB_PATH)
 lib.vc_build_id.restype = C.c_char_p
 BUILD_ID = lib.vc_build_id().decode()
@@ -67,6 +67,7 @@ SIGNATURES = [
     ('vc_tune_rowskip', i32, [i32]),
     ('vc_tune_conv_bf16_override', i32, [i32, i32, i32]),
     ('vc_tune_conv_bf16_spec', i32, [i32]),
+    ('vc_tune_bf16_pixel_octets', i32, [i32]),
     ('vc_tune_conv_bf16_keys', i32, [vp, i32]),
     ('vc_tune_last_igemm_config', i32, [C.POINTER(C.c_int)]),
     ('vc_tune_last_wgrad_config', i32, [C.POINTER(C.c_int)]),

@@ -134,7 +134,8 @@ struct DeferredApp { const float* x; long x_gs; const float* save; long save_gs;
 enum { W_NONE = 0, W_SELF = 1 };
 struct BwdOpts { bool record_buckets = false, wgrad_store = false; int wmode = W_SELF; const DeferredApp* deferred = nullptr;
                  unsigned* q_ready_out = nullptr; unsigned* dy_dropped_out = nullptr;
-                 bool drop_fp32_dy = false; };        // the caller guarantees every reader of a layer's dy takes the octet forms whenever the norm backward wrote them (train step: yes)   // W_NONE passes: which layers' dY went out as pixel octets (for the DeferredApp of the pass that reduces them)
+                 bool drop_fp32_dy = false;
+                 bool emit_pixel_octets = true; };    // false: the norm backward leaves dy in fp32 only, the filter gradients pack their operand (see vc_step.hip, lambda_identity == 0)        // the caller guarantees every reader of a layer's dy takes the octet forms whenever the norm backward wrote them (train step: yes)   // W_NONE passes: which layers' dY went out as pixel octets (for the DeferredApp of the pass that reduces them)
 int gen_forward(const vc_plan* p, const float* params, long par_gs, const float* x, long x_gs,
                 float* y, long y_gs, float* save, int G, int B, hipStream_t s);
 int gen_backward(const vc_plan* p, const float* params, long par_gs, const float* x, long x_gs,

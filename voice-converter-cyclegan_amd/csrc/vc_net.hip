@@ -276,7 +276,7 @@ struct NetCtx {
     bool keep_packed = false;              // bf16 data path, inside a train step: forward leaves the packed inputs in the save area (SaveMap::actp)
     bool fuse_glu = false;                 // forward only: gated blocks without instance norm go out as one conv + GLU kernel
     unsigned* q_ready_out = nullptr;       // W_NONE passes report which layers' dY they left as pixel octets (BwdOpts::q_ready_out)
-    unsigned* dy_dropped_out = nullptr; bool drop_dy = false;   // BwdOpts::drop_fp32_dy
+    unsigned* dy_dropped_out = nullptr; bool drop_dy = false, emit_q = true;   // BwdOpts::drop_fp32_dy, ::emit_pixel_octets
     int wmode = W_SELF;                    // W_NONE: leave the conv filter gradients to a later application (DeferredApp)
     bool wgrad_store = false;              // this backward's filter gradients are the step's only contribution to dparams' conv kernels
     const DeferredApp* deferred = nullptr; // reduce this earlier application in the same launches
@@ -376,6 +376,9 @@ static int net_forward(NetCtx& c, const float* x, long x_gs, float* y_plain, lon
 
 // dtop: gradient w.r.t. the network's last activation (for the generator: d o1 output, i.e. dy of the
 // plain layer; for the discriminator: gradient w.r.t. the last GLU output, produced by the head).
+// tests: 0 = the norm backward leaves dy in fp32 only for the filter gradient (which then packs its pixel octets itself: the round-4 path)
+static thread_local int g_emit_pixel_octets = 1;
+extern "C" int vc_tune_bf16_pixel_octets(int on) { g_emit_pixel_octets = on; return 0; }   // 2: emit, but keep writing the fp32 copy
 static int net_backward(NetCtx& c, const float* x, long x_gs, const float* dtop, long dtop_gs,
                         float* dx, long dx_gs, int dx_acc, float* scratch, long scr_gs) {
     const int nl = (int)c.n->layers.size();
@@ -431,14 +434,14 @@ static int net_backward(NetCtx& c, const float* x, long x_gs, const float* dtop,
             }
             // ... and its filter gradient (the bf16 GEMM over pixels) reads dy as pixel octets out of the layer's stacked buffer: this
             // pass's own scratch, or the deferred application's when that pass opened the buffer (its part sits in front)
-            if (c.dparams && norm_bwd_emits_pixel_octets(a) && conv_wgrad_reads_pixel_octets(lg.g, (long)c.B * lg.g.OH * lg.g.OW, c.math) &&
+            if (c.dparams && c.emit_q && g_emit_pixel_octets && norm_bwd_emits_pixel_octets(a) && conv_wgrad_reads_pixel_octets(lg.g, (long)c.B * lg.g.OH * lg.g.OW, c.math) &&
                 (!c.deferred || c.B <= 2 * c.deferred->B)) {
                 if (c.deferred) { a.outq = (char*)const_cast<float*>(c.deferred->scratch + dYqd[i]); a.outq_gs = c.deferred->scr_gs * 4; a.outq_po0 = c.deferred->B * lg.g.OH * lg.g.OW / 8; }
                 else { a.outq = (char*)(scratch + dYqo[i]); a.outq_gs = scr_gs * 4; a.outq_po0 = 0; }
                 q_ready |= 1u << i;
             }
             // both readers of this dy take the octet forms (or do not exist): its fp32 copy -- the largest stream of the kernel -- stays unwritten
-            if (c.drop_dy && ((i == 0 && !dx) || dy_packed) && (!c.dparams || (q_ready >> i & 1u)) && (dy_packed || a.outq)) { a.dy = nullptr; dy_dropped |= 1u << i; }
+            if (c.drop_dy && g_emit_pixel_octets != 2 && ((i == 0 && !dx) || dy_packed) && (!c.dparams || (q_ready >> i & 1u)) && (dy_packed || a.outq)) { a.dy = nullptr; dy_dropped |= 1u << i; }
             VC_CHECK(launch_norm_bwd(L.mode, a, c.s));
             dyp = a.dy ? scratch + dYo[i] : nullptr; dy_gs = scr_gs;
             if (c.dparams && c.wmode != W_NONE && ws != c.s) { VC_HIP(hipEventRecord(c.ev_layer[i], c.s)); VC_HIP(hipStreamWaitEvent(ws, c.ev_layer[i], 0)); }
@@ -526,7 +529,7 @@ int gen_backward(const vc_plan* p, const float* params, long par_gs, const float
                         const BwdOpts& o) {
     VC_ARG(!p->inference, "this plan was created for inference only (vc_plan_create_inference)");
     NetCtx c = gen_ctx(p, params, par_gs, dparams, dpar_gs, save, G, B, Bl, s);
-    c.wgrad_store = o.wgrad_store; c.wmode = o.wmode; c.deferred = o.deferred; c.q_ready_out = o.q_ready_out; c.dy_dropped_out = o.dy_dropped_out; c.drop_dy = o.drop_fp32_dy;
+    c.wgrad_store = o.wgrad_store; c.wmode = o.wmode; c.deferred = o.deferred; c.q_ready_out = o.q_ready_out; c.dy_dropped_out = o.dy_dropped_out; c.drop_dy = o.drop_fp32_dy; c.emit_q = o.emit_pixel_octets;
     c.images = step_images(p, true, G); c.keep_packed = c.images != nullptr;
     if ((p->use_side & 2) && dparams && o.wmode != W_NONE) { c.ws = p->wstream; c.ev_layer = p->ev_layer; c.ev_wjoin = p->ev_wjoin; }
     if (o.record_buckets) { c.ev_first = p->bucket_first; c.ev = p->g_ready; c.ev_free = p->g_free; c.n_ev = vc_plan::kBuckets; }
