@@ -28,7 +28,8 @@ int  vc_tune_conv_bf16_override(int tile_rows, int stages, int splitk);
  * 1 = wave-specialised (512 threads: 4 multiplying + 4 copying waves; production), 0 = the 256-thread form, -1 = the process default. */
 int  vc_tune_conv_bf16_spec(int on);
 /* bf16 data path, calling thread's following backward passes: 1 (production) = the norm backward writes dy as pixel octets into the layer's
- * stacked buffer (and drops the fp32 copy inside a train step), 0 = it writes fp32 only and every filter gradient packs its operand itself. */
+ * stacked buffer (and drops the fp32 copy inside a train step), 0 = it writes fp32 only and every filter gradient packs its operand itself,
+ * 2 = octets written and the fp32 copy kept (separates the two halves of the change in control experiments). */
 int  vc_tune_bf16_pixel_octets(int on);
 /* Which configuration did the calling thread's last conv forward / input-gradient launch (igemm) or filter-gradient launch
  * (wgrad) run with, and where did it come from?  out4 = {tile rows | columns, K groups, split-K, source}; source: 0 cost
