@@ -181,6 +181,16 @@ def named_kernel_h1(lib, dev, B=256, reps=20, peak=FP32_MFMA_PEAK_TFLOPS, math='
     finally:
         check(lib.vc_set_math_mode(0))
     t = ms.value * 1e-3 / max(n.value, 1)
+    err = None
+    if math == 'bf16' and variant == 'packed' and data == 'rand':
+        # what the bf16 operands cost against the exact-fp32 kernel on the same inputs (that kernel is held to 1e-4 of the oracle by
+        # tests/test_ops_gpu.py::test_gated_conv1d_glu_fused): max |diff| / max |ref| and relative L2.  The north star couples its roofline
+        # target to "fp32 parity within 1e-3": a figure above that means only the exact-fp32 entry answers it.
+        y_bf = y.clone()
+        check(lib.vc_set_math_mode(0))
+        check(lib.vc_gated_conv1d_glu_fwd(ptr(x), 0, ptr(w), 0, ptr(b), 0, ptr(y), 0, 1, B, 24, 128, 256, 15, s))
+        torch.cuda.synchronize()
+        err = {'max_rel': float((y_bf - y).abs().max() / y.abs().max()), 'rel_l2': float((y_bf - y).norm() / y.norm())}
     algo = B * (24 * 128 + 128 * 128) * 4 + (15 * 24 * 256 + 256) * 4         # 20.29 MB at B=256; also what the kernel moves
     flops = 2.0 * B * 128 * 256 * 15 * 24
     return {'kernel': 'gated_conv1d_glu_kernel: G.h1 value + gate conv1d + GLU forward in one kernel, B=%d, %s, %s' % (B, math, variant),
@@ -189,6 +199,7 @@ def named_kernel_h1(lib, dev, B=256, reps=20, peak=FP32_MFMA_PEAK_TFLOPS, math='
                     'frac_back_to_back': algo / t_b2b / 1e9 / HBM_PEAK_GBS},
             'mfma': {'achieved_TFLOPs': flops / t / 1e12, 'peak_TFLOPs': peak, 'frac': flops / t / 1e12 / peak,
                      'frac_back_to_back': flops / t_b2b / 1e12 / peak},
+            'err_vs_fp32': err,
             'note': ('exact-fp32 MFMA makes this kernel FLOP-bound: 38.4 us at the fp32 peak vs 2.5 us of HBM time' if math == 'fp32'
                      else 'bf16 MFMA operands (rounded once on their way into LDS), fp32 tensors in HBM, fp32 accumulate')}
 
@@ -206,7 +217,7 @@ def named_kernel_report(lib, dev):
         rf = named_kernel_h1(lib, dev, B=B, reps=reps, peak=BF16_MFMA_PEAK_TFLOPS, math='bf16', variant='roof')
         z = named_kernel_h1(lib, dev, B=B, reps=reps, peak=BF16_MFMA_PEAK_TFLOPS, math='bf16', variant='packed', data='zero')
         bf[B] = {'us': r['us'], 'us_back_to_back': r['us_back_to_back'], 'hbm_frac': r['hbm']['frac'], 'hbm_frac_back_to_back': r['hbm']['frac_back_to_back'],
-                 'achieved_TFLOPs': r['mfma']['achieved_TFLOPs'], 'algorithmic_bytes': r['algorithmic_bytes'],
+                 'achieved_TFLOPs': r['mfma']['achieved_TFLOPs'], 'algorithmic_bytes': r['algorithmic_bytes'], 'err_vs_fp32': r['err_vs_fp32'],
                  'plain_us': pl['us'], 'plain_us_back_to_back': pl['us_back_to_back'],
                  'copy_roof': {'us': rf['us'], 'us_back_to_back': rf['us_back_to_back'], 'GBs_back_to_back': rf['algorithmic_bytes'] / rf['us_back_to_back'] / 1e3,
                                'kernel_frac_of_copy_roof': rf['us'] / r['us'], 'kernel_frac_of_copy_roof_back_to_back': rf['us_back_to_back'] / r['us_back_to_back'],
@@ -487,6 +498,7 @@ def main():
     from voice_converter_cyclegan_amd.engine import CycleGANEngine
     from voice_converter_cyclegan_amd._lib import lib
 
+    assert lib.vc_thread_is_product_run() == 1, 'a test / tuning switch is active: the bench runs production kernel configurations only'
     dev = 'cuda:%d' % local_rank
     eng = CycleGANEngine(num_features=args.features, device=dev, seed=42)
     if args.serial:

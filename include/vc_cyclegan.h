@@ -44,9 +44,12 @@ extern "C" {
 typedef struct vc_plan vc_plan;   /* opaque: geometry tables + workspace map for one (F, T) */
 
 /* ---- library ------------------------------------------------------------- */
-int         vc_version(void);          /* ABI revision: 112 (bumped whenever an entry point changes or is added) */
+int         vc_version(void);          /* ABI revision: 113 (bumped whenever an entry point changes or is added) */
+int         vc_thread_is_product_run(void);   /* 1 when every test / tuning switch of vc_cyclegan_testing.h is at its production value in the
+                                               * calling thread (model.CycleGAN.train and bench.py refuse to run otherwise: a forced tile
+                                               * configuration left behind by a test must never be trained or benched with) */
 /* The content hash of the sources + compiler flags this library was built from (16 hex digits; build.py stamps it, _lib.py
- * compares it with the sources in the tree at import and rebuilds / refuses on a mismatch; bench.py prints it). */
+ * compares it with the sources in the tree at import and refuses to load on a mismatch; bench.py prints it). */
 const char* vc_build_id(void);
 const char* vc_last_error(void);
 /* CRC-32C (Castagnoli) of `n` host bytes, continuing from `crc` (0 to start): the checksum inside TensorFlow's
@@ -226,12 +229,14 @@ int vc_generator_forward(const vc_plan* p, const float* params, int64_t par_gs,
                          float* save, int G, int B, void* stream);
 /* Backward of the same application.  dy [G][B][F][T]; gradients ACCUMULATE into
  * dparams (layout == params; NULL skips all weight gradients); dx (NULL to skip)
- * receives d/dx, added to its contents if dx_accumulate.  scratch: vc_scratch_floats(p,B)*G. */
+ * receives d/dx, added to its contents if dx_accumulate.  scratch: scratch_floats >= vc_scratch_floats(p,B)*G floats, queried
+ * AFTER the plan's math mode was set (bf16 lays more into it); a smaller scratch is refused with VC_E_NOMEM (ABI 113: the size
+ * used to be implied, and a scratch sized before vc_plan_set_math_mode(bf16) was overrun silently). */
 int vc_generator_backward(const vc_plan* p, const float* params, int64_t par_gs,
                           const float* x, int64_t x_gs, const float* dy, int64_t dy_gs,
                           const float* save, float* dparams, int64_t dpar_gs,
                           float* dx, int64_t dx_gs, int dx_accumulate,
-                          float* scratch, int G, int B, void* stream);
+                          float* scratch, int64_t scratch_floats, int G, int B, void* stream);
 /* module.discriminator (module.py:188-213).  x [G][B][F][T] -> o [G][B][H'*W']. */
 int vc_discriminator_out_elems(const vc_plan* p);   /* H'*W' per sample (48 for 24x128) */
 int vc_discriminator_forward(const vc_plan* p, const float* params, int64_t par_gs,
@@ -241,7 +246,7 @@ int vc_discriminator_backward(const vc_plan* p, const float* params, int64_t par
                               const float* x, int64_t x_gs, const float* dout, int64_t do_gs,
                               const float* save, float* dparams, int64_t dpar_gs,
                               float* dx, int64_t dx_gs, int dx_accumulate,
-                              float* scratch, int G, int B, void* stream);
+                              float* scratch, int64_t scratch_floats, int G, int B, void* stream);
 
 /* ---- step level: model.CycleGAN.train (model.py:110-125) minus the update ---- */
 /* Offsets (floats) of the networks inside the flat parameter / gradient / Adam buffers:

@@ -31,6 +31,14 @@ int  vc_tune_conv_bf16_spec(int on);
  * stacked buffer (and drops the fp32 copy inside a train step), 0 = it writes fp32 only and every filter gradient packs its operand itself,
  * 2 = octets written and the fp32 copy kept (separates the two halves of the change in control experiments). */
 int  vc_tune_bf16_pixel_octets(int on);
+/* D.h1's input gradient (Cin = 1, csrc/vc_conv_small.hip) for the calling thread's following launches: 1 = the gather kernel of deterministic
+ * mode (fixed summation order) without the rest of that mode, 0 = the atomic scatter (production).  The scatter's summation order is the one
+ * run-to-run noise source of a split-K-free step that PROPAGATES: it feeds the generators' output gradients. */
+int  vc_tune_c1_dgrad_gather(int on);
+/* Bit mask of the switches of this header that are NOT at their production value in the calling thread (0 = a product run; the product
+ * header's vc_thread_is_product_run() is `== 0` of this).  bits: 1 igemm, 2 wgrad, 4 conv_bf16 override, 8 conv_bf16_spec, 16 pixel octets,
+ * 32 rowskip, 64 wgrad_store, 128 glu, 256 c1 gather. */
+int  vc_testing_hooks_active(void);
 /* Which configuration did the calling thread's last conv forward / input-gradient launch (igemm) or filter-gradient launch
  * (wgrad) run with, and where did it come from?  out4 = {tile rows | columns, K groups, split-K, source}; source: 0 cost
  * model, 1 exact row of the measured table (csrc/vc_tuned_igemm.h / vc_tuned_wgrad.h), 2 the same layer's row measured at
@@ -62,6 +70,14 @@ int  vc_tune_glu(int flags);
  * (G = 1) that performs that kernel's memory operations only -- every workgroup reads its slab's bf16 fragment image and its tiles'
  * frames (eight tiles in flight) and writes its output rows with the same dword stores -- and no arithmetic.  Recorded under profiling kind 2. */
 int  vc_prof_glu_copy_roof(const float* x, const void* image_bf16, float* out, int B, int T, int Cout2, void* stream);
+
+/* Stale-read probes (tools/stale_read_probe.py, tests): vc_testing_describe_step writes "name offset floats" lines for every buffer of the
+ * train step inside the caller's workspace (the backward scratch areas as each of the four backward passes lays them out) into buf and
+ * returns the bytes needed; vc_testing_poison_internal fills the plan-internal buffers (packed-operand workspaces of the plan's streams
+ * and of `stream`, the bf16 filter images) with `byte` (0xff = NaN in fp32 and bf16) after a device-wide synchronisation. */
+struct vc_plan;
+long long vc_testing_describe_step(const struct vc_plan* p, int B, int Bbwd, char* buf, long long cap);
+int  vc_testing_poison_internal(const struct vc_plan* p, void* stream, int byte);
 
 #ifdef __cplusplus
 }

@@ -22,10 +22,11 @@ def _header_functions(names=('vc_cyclegan.h', 'vc_cyclegan_testing.h')):
 def test_product_header_carries_no_test_hooks():
     """vc_tune_* / vc_prof_* live in include/vc_cyclegan_testing.h; the product path (engine / model / module) calls none."""
     prod = _header_functions(('vc_cyclegan.h',))
-    assert not [n for n in prod if n.startswith(('vc_tune_', 'vc_prof_'))]
+    assert not [n for n in prod if n.startswith(('vc_tune_', 'vc_prof_', 'vc_testing_'))]
     pkg = os.path.join(ROOT, 'voice-converter-cyclegan_amd')
     for f in ('model.py', 'module.py', 'data.py', 'tfio.py', 'layout.py'):
-        assert 'vc_tune_' not in open(os.path.join(pkg, f)).read(), f
+        src = open(os.path.join(pkg, f)).read()
+        assert 'vc_tune_' not in src and 'vc_testing_' not in src and 'vc_prof_' not in src, f
 
 
 def test_header_symbols_exported_and_bound(built_lib):
@@ -36,7 +37,7 @@ def test_header_symbols_exported_and_bound(built_lib):
         assert hasattr(built_lib.lib, n), 'symbol %s declared in include/*.h is not exported' % n
         assert n in bound, 'symbol %s has no ctypes signature in _lib.SIGNATURES' % n
     assert bound <= set(names), 'python binds symbols the header does not declare: %s' % (bound - set(names))
-    assert built_lib.lib.vc_version() == built_lib.ABI_VERSION == 112
+    assert built_lib.lib.vc_version() == built_lib.ABI_VERSION == 113
 
 
 def test_library_is_stamped_with_the_hash_of_its_sources(built_lib, tmp_path, monkeypatch):

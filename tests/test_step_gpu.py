@@ -157,7 +157,7 @@ def _gen_fwd_bwd_gpu(eng, A, dy, T, B):
     eng.grads.zero_()
     check(lib.vc_generator_forward(p, ptr(eng.params[off:]), 0, ptr(x_d), 0, ptr(y_d), 0, ptr(save), 1, B, U.stream()))
     check(lib.vc_generator_backward(p, ptr(eng.params[off:]), 0, ptr(x_d), 0, ptr(dy_d), 0, ptr(save),
-                                    ptr(eng.grads[off:]), 0, ptr(dx_d), 0, 0, ptr(scr), 1, B, U.stream()))
+                                    ptr(eng.grads[off:]), 0, ptr(dx_d), 0, 0, ptr(scr), scr.numel(), 1, B, U.stream()))
     torch.cuda.synchronize()
     return y_d, dx_d
 
@@ -185,7 +185,7 @@ def test_discriminator_forward_backward(built_lib, mode):
         eng.grads.zero_()
         check(lib.vc_discriminator_forward(p, ptr(eng.params[off:]), 0, ptr(x_d), 0, ptr(o_d), 0, ptr(save), 1, B, U.stream()))
         check(lib.vc_discriminator_backward(p, ptr(eng.params[off:]), 0, ptr(x_d), 0, ptr(do_d), 0, ptr(save),
-                                            ptr(eng.grads[off:]), 0, ptr(dx_d), 0, 0, ptr(scr), 1, B, U.stream()))
+                                            ptr(eng.grads[off:]), 0, ptr(dx_d), 0, 0, ptr(scr), scr.numel(), 1, B, U.stream()))
         torch.cuda.synchronize()
     assert U.rel_err(o_d.cpu().numpy(), o.reshape(B, hw)) < tol
     e = U.rel_err(dx_d.cpu().numpy(), dx)
@@ -422,6 +422,75 @@ def test_zero_lambda_identity_schedule(built_lib, mode):
             assert e2 < 5e-2 + 2.0 * np.sqrt(f), (n, float(e2), f)
 
 
+@pytest.mark.parametrize('mode', ['fp32', 'bf16'])
+def test_schedule_switch_5_to_0(built_lib, mode):
+    """train.py:98-99 sets lambda_identity = 0 once num_iterations exceeds 10 000: the step switches from the schedule that
+    back-propagates [generation; identity] (2 B samples) to the one that propagates the generation half only, on an engine whose
+    workspace, packed-operand buffers and filter images were last written by the OTHER schedule.
+    (a) one step at lambda_identity = 5, then two at 0, each against the oracle (model.py:110-125) from the same state at the mode's
+        tolerance: 8 losses, generation_A / _B, every gradient;
+    (b) deterministic mode: the two lambda_identity = 0 steps of the switched engine equal, BITWISE (losses, all 119.8 M gradients,
+        parameters after the update), the same two steps on a FRESH engine loaded with the state the first one had after its
+        lambda_identity = 5 step -- an engine that never ran the other schedule."""
+    from tests import gpu_util as U
+    from voice_converter_cyclegan_amd.engine import CycleGANEngine
+    B = 2 if mode == 'fp32' else 1
+    rounding = 'bf16' if mode == 'bf16' else None
+    O, P, A, Bm, eng = _setup(B, seed=27 if mode == 'bf16' else 11, lambda_identity=5.0, rounding=rounding)
+    gen_A = torch.empty((B, 24, 128), device=U.DEV); gen_B = torch.empty_like(gen_A)
+    tol_l, tol_g = (TOL, TOL) if mode == 'fp32' else (2e-3, BF16_TOL)
+    with _math(mode, O, eng):
+        orc = O.CycleGANOracle({k: v.copy() for k, v in P.items()})
+        for step, lam in enumerate((5.0, 0.0, 0.0)):
+            orc.train(A, Bm, 10.0, lam, 2e-4, 1e-4)
+            eng.train_step(A, Bm, 10.0, lam, 2e-4, 1e-4, gen_A=gen_A, gen_B=gen_B)
+            torch.cuda.synchronize()
+            for k, v in orc.last.items():
+                assert abs(eng.last_losses[k] - v) <= tol_l * max(1.0, abs(v)), (step, lam, k, eng.last_losses[k], float(v))
+            gA, gB = gen_A.cpu().numpy(), gen_B.cpu().numpy()
+            assert U.rel_err(gA, orc.last_fakes[0]) < tol_g and U.rel_err(gB, orc.last_fakes[1]) < tol_g, (step, lam)
+            ref = dict(orc.last_grads[0]); ref.update(orc.last_grads[1])
+            got = eng.tf_gradients()
+            # how many L1 elements of the ORACLE's forward lie within reach of a sign flip by the other side's forward error?
+            dfw = np.concatenate([(gA - orc.last_fakes[0]).ravel(), (gB - orc.last_fakes[1]).ravel()]).astype(np.float64)
+            f = float((orc.last_l1_dist < 3.0 * float(np.sqrt((dfw ** 2).mean()))).mean())
+            if mode == 'fp32' and orc.last_l1_gap >= L1_GAP_MIN:
+                bad = _cmp_grads(got, ref)
+                assert not bad, (step, lam, bad[:8])
+            else:
+                assert f < 1e-2, (step, lam, f)
+                base = 1e-3 if mode == 'fp32' else 5e-2
+                for n, r in ref.items():
+                    if _is_noise_bias(n):
+                        continue
+                    e2 = np.linalg.norm(got[n].reshape(r.shape).astype(np.float64) - r) / (np.linalg.norm(r) + 1e-30)
+                    assert e2 < base + 2.0 * np.sqrt(f), (step, lam, n, float(e2), f)
+            _load_oracle_state(eng, orc)          # both sides continue from the SAME state: each step is judged on its own
+        # (b) deterministic mode, bitwise against an engine that never ran the lambda_identity > 0 schedule
+        eng.set_deterministic(True)
+        eng.load_tf_variables(P); eng.m.zero_(); eng.v.zero_()
+        eng.b1p = [np.float32(0.5), np.float32(0.5)]; eng.b2p = [np.float32(0.999), np.float32(0.999)]
+        eng.train_step(A, Bm, 10.0, 5.0, 2e-4, 1e-4)
+        torch.cuda.synchronize()
+        state = eng.state_dict()
+        fresh = CycleGANEngine(num_features=24, device=U.DEV)
+        fresh.set_math(mode); fresh.set_deterministic(True)
+        fresh.load_state_dict(state)
+        try:
+            for step in range(2):
+                for e in (eng, fresh):
+                    e.grads.fill_(float('nan'))
+                    e.train_step(A, Bm, 10.0, 0.0, 2e-4, 1e-4)
+                torch.cuda.synchronize()
+                assert bool(torch.isfinite(eng.grads).all())
+                assert torch.equal(eng.losses, fresh.losses), (step, eng.losses, fresh.losses)
+                assert torch.equal(eng.grads, fresh.grads), (step, float((eng.grads - fresh.grads).abs().max()))
+                assert torch.equal(eng.params, fresh.params) and torch.equal(eng.m, fresh.m) and torch.equal(eng.v, fresh.v), step
+        finally:
+            fresh.close()
+            eng.set_deterministic(False)
+
+
 def test_config5_geometry_36x256(built_lib):
     """BASELINE configs[4] geometry (36 MCEPs x 256 frames, o1.filters = num_features; module.py:148-213 with F = 36, T = 256)
     at network AND step level, B = 1: generator forward (h1's 36-row taps padded to 64 K rows; wsconv / fused h1 paths not
@@ -452,7 +521,7 @@ def test_config5_geometry_36x256(built_lib):
     eng.grads.zero_()
     check(lib.vc_discriminator_forward(p, ptr(eng.params[off:]), 0, ptr(x_d), 0, ptr(o_d), 0, ptr(save), 1, B, U.stream()))
     check(lib.vc_discriminator_backward(p, ptr(eng.params[off:]), 0, ptr(x_d), 0, ptr(do_d), 0, ptr(save),
-                                        ptr(eng.grads[off:]), 0, ptr(dx_d), 0, 0, ptr(scr), 1, B, U.stream()))
+                                        ptr(eng.grads[off:]), 0, ptr(dx_d), 0, 0, ptr(scr), scr.numel(), 1, B, U.stream()))
     torch.cuda.synchronize()
     assert U.rel_err(o_d.cpu().numpy(), o.reshape(B, hw)) < TOL
     assert U.rel_err(dx_d.cpu().numpy(), dx) < TOL
@@ -907,45 +976,138 @@ def test_bf16_data_path_at_the_benchmarked_size(built_lib):
         eng.set_math('fp32')
 
 
-def test_bf16_dy_in_octet_forms_equals_the_pack_launches(built_lib):
+def _conv_kernel_names(names):
+    """gradient tensors written by ONE launch with a fixed summation order once split-K is forced off: every convolution kernel but D.h1's
+    (its Cin = 1 filter gradient sums with atomics); biases / gamma / beta / the dense head are atomically summed leaves"""
+    return [n for n in names if n.endswith('/kernel') and 'dense' not in n and not ('discriminator' in n and '/h1_conv' in n)]
+
+
+@contextlib.contextmanager
+def _no_summation_order_noise(lib, check, eng, mode):
+    """Every launch of the step in a configuration with ONE summation order: no split-K anywhere (forward, input gradients, filter
+    gradients) and D.h1's input gradient as a gather instead of the atomic scatter.  What is left to vary from run to run are the
+    atomically summed LEAVES (bias / gamma / beta / dense head / D.h1's kernel), which feed nothing."""
+    eng.set_math(mode)
+    check(lib.vc_tune_conv_bf16_override(128, 4, 1)); check(lib.vc_tune_igemm_override(64, 1, 1)); check(lib.vc_tune_wgrad_override(64, 1, 1))
+    check(lib.vc_tune_c1_dgrad_gather(1))
+    try:
+        yield
+    finally:
+        check(lib.vc_tune_c1_dgrad_gather(0)); check(lib.vc_tune_bf16_pixel_octets(1))
+        check(lib.vc_tune_conv_bf16_override(0, 0, 0)); check(lib.vc_tune_igemm_override(0, 0, 0)); check(lib.vc_tune_wgrad_override(0, 0, 0))
+        eng.set_math('fp32')
+        assert lib.vc_thread_is_product_run() == 1
+
+
+def _rel_l2(got, ref, names):
+    return {n: float(np.linalg.norm(got[n].astype(np.float64) - ref[n].astype(np.float64)) / (np.linalg.norm(ref[n].astype(np.float64)) + 1e-30)) for n in names}
+
+
+@pytest.mark.parametrize('lam', [5.0, 0.0])
+def test_bf16_dy_in_octet_forms_equals_the_pack_launches(built_lib, lam):
     """bf16 data path: inside a train step the norm backward writes dy as channel octets (input gradient) and pixel octets (filter-gradient
     GEMM, both applications of a layer stacked in one buffer) and no fp32 copy at all.  Control (vc_tune_bf16_pixel_octets(0)): fp32 dy, every
     filter gradient packs its operand in its own launch -- the same bf16 values (RNE of the same fp32 numbers) in the same places.  With
-    every convolution forced to a configuration without split-K (no atomics in forward, input gradients and filter gradients: one summation
-    order) the two steps are the same arithmetic: losses and generations bitwise, every convolution kernel's gradient bitwise (but D.h1's:
-    its Cin = 1 kernel sums with atomics), the atomically summed leaves (bias, gamma, beta, dense head) to 1e-4 (measured 6e-6).
-    lambda_identity > 0 only.  OPEN (round 5; the GPU minutes ran out before the cause was found): in the
-    lambda_identity == 0 schedule (first-hop pass over the first B of 2 B laid-out samples) this comparison -- steps issued back to back
-    with only the caller's stream synchronised in between, generation outputs requested -- shows generator_B2A's gradients 2e-3 rel-L2
-    apart between the two modes (A2B and both discriminators agree; same numbers with the generator passes' own emission switched off, in
-    either order of the two modes), while the same steps separated by a device-wide synchronisation and without the generation outputs
-    agree to 3e-6 in every order tried (tools: profiles/r05_octet_control.txt).  The goldens' 2e-2 bf16 tolerance does not see 2e-3."""
+    every launch forced to ONE summation order (_no_summation_order_noise) the two steps are the same arithmetic: losses and generations
+    bitwise, every convolution kernel's gradient bitwise, the atomically summed leaves to 1e-4 (measured 6e-6).
+    Both schedules (lambda_identity > 0: first-hop pass over 2 B samples; == 0, train.py:98-99 after 10 000 iterations: over the first B
+    of 2 B laid-out samples), each PRECEDED BY A STEP OF THE OTHER schedule and issued back to back with generation outputs requested.
+    Round 5 recorded an 'open finding' here (generator_B2A 2e-3 apart at lambda_identity == 0); round 6 found it is neither schedule- nor
+    octet-related: D.h1's input gradient scatters with atomics, its 1-ulp summation-order noise in d generation_A/B flips the bf16 rounding
+    of an element now and then (about one step in ten at B = 8), and every layer below re-rounds to bf16, so the flip grows layer by layer
+    to the bf16 noise floor (1.7e-3 at h1, 7e-9 at o1; tools/stale_read_probe3.py, profiles/r06_stale_read_probe.txt).  Round 5's version of
+    this test left the scatter in and passed or failed by chance."""
     from tests import gpu_util as U
     from voice_converter_cyclegan_amd._lib import lib, check
     B = 8
     O, P, A, Bm, eng = _setup(B, gap=False)
-    eng.set_math('bf16')
-    check(lib.vc_tune_conv_bf16_override(128, 4, 1)); check(lib.vc_tune_igemm_override(64, 1, 1)); check(lib.vc_tune_wgrad_override(64, 1, 1))
-
-    def errs(got, ref):
-        return {n: float(np.linalg.norm(got[n].astype(np.float64) - r.astype(np.float64)) / (np.linalg.norm(r.astype(np.float64)) + 1e-30))
-                for n, r in ref.items() if not _is_noise_bias(n)}
-
-    try:
+    with _no_summation_order_noise(lib, check, eng, 'bf16'):
         gA = torch.empty((B, 24, 128), device=U.DEV); hA = torch.empty_like(gA)
-        check(lib.vc_tune_bf16_pixel_octets(1)); eng.step_grads(A, Bm, 10.0, 5.0, gen_A=gA); g1 = eng.tf_gradients(); l1 = eng.losses.clone()
-        check(lib.vc_tune_bf16_pixel_octets(0)); eng.step_grads(A, Bm, 10.0, 5.0, gen_A=hA); g0 = eng.tf_gradients(); l0 = eng.losses.clone()
+        other = 0.0 if lam > 0 else 5.0
+        eng.step_grads(A, Bm, 10.0, other, gen_A=gA)                            # the step before: the OTHER schedule
+        check(lib.vc_tune_bf16_pixel_octets(1)); eng.step_grads(A, Bm, 10.0, lam, gen_A=gA); g1 = eng.tf_gradients(); l1 = eng.losses.clone()
+        eng.step_grads(A, Bm, 10.0, other, gen_A=hA)
+        check(lib.vc_tune_bf16_pixel_octets(0)); eng.step_grads(A, Bm, 10.0, lam, gen_A=hA); g0 = eng.tf_gradients(); l0 = eng.losses.clone()
         assert torch.equal(gA, hA) and torch.equal(l1, l0), (l1, l0)
-        bad = []
-        for n, e in errs(g1, g0).items():
-            exact = n.endswith('/kernel') and 'dense' not in n and not ('discriminator' in n and '/h1_conv' in n)
-            if e > (0.0 if exact else 1e-4):          # (measured on the leaves: up to 6e-6)
-                bad.append((n, e))
+        names = [n for n in g0 if not _is_noise_bias(n)]
+        exact = set(_conv_kernel_names(names))
+        bad = [(n, e) for n, e in _rel_l2(g1, g0, names).items() if e > (0.0 if n in exact else 1e-4)]
         assert not bad, sorted(bad, key=lambda t: -t[1])[:6]
-    finally:
-        check(lib.vc_tune_bf16_pixel_octets(1))
-        check(lib.vc_tune_conv_bf16_override(0, 0, 0)); check(lib.vc_tune_igemm_override(0, 0, 0)); check(lib.vc_tune_wgrad_override(0, 0, 0))
-        eng.set_math('fp32')
+
+
+@pytest.mark.parametrize('mode', ['fp32', 'bf16'])
+def test_steps_repeat_bitwise_across_schedule_switches_from_poisoned_buffers(built_lib, mode):
+    """No buffer of the step is read before THIS step has written it, in either schedule and across switches between them (VERDICT r5
+    item 1, the question behind round 5's 'open finding').  Before every step the caller's workspace AND the plan-internal buffers
+    (packed-operand workspaces of every stream, the bf16 filter images) are filled with 0xff bytes -- NaN as fp32 and as bf16 -- so a read
+    of anything a step did not produce itself poisons a gradient; with every launch forced to one summation order
+    (_no_summation_order_noise) each step of the sequence 5 0 0 5 0 5 5 0 must then equal the first step of its schedule BITWISE in every
+    convolution kernel's gradient, the 8 losses and generation_A, and to 1e-4 in the atomically summed leaves.  train.py:98-99."""
+    from tests import gpu_util as U
+    from voice_converter_cyclegan_amd._lib import lib, check
+    B = 8
+    O, P, A, Bm, eng = _setup(B, gap=False)
+    with _no_summation_order_noise(lib, check, eng, mode):
+        gA = torch.empty((B, 24, 128), device=U.DEV)
+        first = {}
+        for k, lam in enumerate((5.0, 0.0, 0.0, 5.0, 0.0, 5.0, 5.0, 0.0)):
+            if eng._ws is not None:
+                torch.cuda.synchronize()
+                eng._ws.view(torch.int32).fill_(-1); eng.grads.view(torch.int32).fill_(-1)     # (the step overwrites EVERY gradient element)
+                check(lib.vc_testing_poison_internal(eng.plan(128), eng._stream(), 0xff))
+            gA.fill_(float('nan'))
+            eng.step_grads(A, Bm, 10.0, lam, gen_A=gA)
+            g, l, ga = eng.tf_gradients(), eng.losses.clone(), gA.clone()
+            assert bool(torch.isfinite(l).all()) and bool(torch.isfinite(ga).all()), (k, lam, l)
+            nan = [n for n, v in g.items() if not np.isfinite(v).all()]
+            assert not nan, ('step %d (lambda_identity %g) read something it had not written' % (k, lam), nan[:6])
+            if lam not in first:
+                first[lam] = (g, l, ga)
+                continue
+            g0, l0, ga0 = first[lam]
+            assert torch.equal(l, l0) and torch.equal(ga, ga0), (k, lam, l, l0)
+            names = [n for n in g0 if not _is_noise_bias(n)]
+            exact = set(_conv_kernel_names(names))
+            bad = [(n, e) for n, e in _rel_l2(g, g0, names).items() if e > (0.0 if n in exact else 1e-4)]
+            assert not bad, (k, lam, sorted(bad, key=lambda t: -t[1])[:6])
+        # the two schedules really are different computations (identity half propagated or not)
+        d = _rel_l2(first[0.0][0], first[5.0][0], ['generator_A2B/o1_conv/kernel'])
+        assert d['generator_A2B/o1_conv/kernel'] > 1e-2, d
+
+
+def test_bf16_run_to_run_variation_is_rounding_flips_not_a_defect(built_lib):
+    """What round 5 saw, reproduced on purpose and bounded.  Split-K forced off, but D.h1's input gradient left as the production atomic
+    scatter: 60 identical bf16 steps then fall into a FEW distinct outcomes (one per near-tie element of d generation_A/B whose bf16
+    rounding the scatter's 1-ulp noise can flip), every one of them within the bf16 noise floor of the majority outcome (5e-3 rel-L2 per
+    convolution kernel; measured 1.7e-3 at h1 falling to 7e-9 at o1) -- and with the gather form (no noise source left) there is exactly one."""
+    from tests import gpu_util as U
+    from voice_converter_cyclegan_amd._lib import lib, check
+    B = 8
+    O, P, A, Bm, eng = _setup(B, gap=False)
+    A_d, B_d = eng._to_dev(A), eng._to_dev(Bm)
+    with _no_summation_order_noise(lib, check, eng, 'bf16'):
+        lo, hi = eng.offsets[0], eng.offsets[2]                   # both generators' flat gradients
+        def outcomes(n):
+            seen = []                                            # (flat generator gradient, count)
+            for _ in range(n):
+                eng.step_grads(A_d, B_d, 10.0, 5.0)
+                g = eng.grads[lo:hi]
+                for rec in seen:
+                    if float((g - rec[0]).norm() / rec[0].norm()) < 1e-5:
+                        rec[1] += 1
+                        break
+                else:
+                    seen.append([g.clone(), 1])
+            return seen
+        one = outcomes(30)
+        assert len(one) == 1, [c for _, c in one]
+        check(lib.vc_tune_c1_dgrad_gather(0))
+        many = outcomes(60)
+        major = max(many, key=lambda r: r[1])[0]
+        worst = max(float((g - major).norm() / major.norm()) for g, _ in many)
+        print('bf16, atomic scatter in D.h1 input gradient: %d outcomes in 60 identical steps %s, worst rel-L2 to the majority %.2e'
+              % (len(many), sorted((c for _, c in many), reverse=True), worst))
+        assert len(many) <= 8 and worst < 5e-3, (len(many), worst)
 
 
 def test_error_behaviour_of_the_c_abi(built_lib):

@@ -29,14 +29,14 @@ def _expected_build_id():
     return mod, mod.build_id(os.environ.get('VC_EXTRA_FLAGS', '').split())
 
 
-ABI_VERSION = 112
+ABI_VERSION = 113
 lib = C.CDLL(LIB_PATH)
 lib.vc_build_id.restype = C.c_char_p
 BUILD_ID = lib.vc_build_id().decode()
 _bmod, _want = _expected_build_id()
 if BUILD_ID != _want and not os.environ.get('VC_ALLOW_STALE_LIB'):
-    # a library built from other sources than the ones next to it must never be tested or benched: rebuild if a compiler is
-    # here, refuse otherwise.  (VC_ALLOW_STALE_LIB=1: instrumented builds of tools/, which patch a source temporarily.)
+    # a library built from other sources than the ones next to it must never be tested or benched: the import is REFUSED (never an
+    # implicit rebuild -- the caller runs __graft_entry__.build()).  (VC_ALLOW_STALE_LIB=1: instrumented builds of tools/.)
     if os.path.exists(os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')):
         raise ImportError('libvcgan_hip.so was built from other sources (build id %s, tree %s): run '
                           '`python -c "import __graft_entry__ as g; g.build()"` before importing the package' % (BUILD_ID, _want))
@@ -53,6 +53,7 @@ class ParamRec(C.Structure):
 # (name, restype, argtypes) -- every symbol declared in include/vc_cyclegan.h
 SIGNATURES = [
     ('vc_version', i32, []),
+    ('vc_thread_is_product_run', i32, []),
     ('vc_build_id', C.c_char_p, []),
     ('vc_last_error', C.c_char_p, []),
     ('vc_crc32c', C.c_uint32, [vp, C.c_uint64, C.c_uint32]),
@@ -86,6 +87,10 @@ SIGNATURES = [
     ('vc_gated_conv1d_glu_fwd_packed', i32, [vp, i64, vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, i32, i32, vp]),
     ('vc_plan_num_step_graphs', i32, [vp]),
     ('vc_tune_glu', i32, [i32]),
+    ('vc_tune_c1_dgrad_gather', i32, [i32]),
+    ('vc_testing_hooks_active', i32, []),
+    ('vc_testing_describe_step', i64, [vp, i32, i32, C.c_char_p, i64]),
+    ('vc_testing_poison_internal', i32, [vp, vp, i32]),
     ('vc_prof_glu_copy_roof', i32, [vp, vp, vp, i32, i32, i32, vp]),
     ('vc_bias_grad', i32, [vp, i64, vp, i64, i32, i32, i32, i32, vp]),
     ('vc_instnorm_glu_fwd', i32, [i32, i32, vp, i64, vp, i64, vp, vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, vp]),
@@ -108,10 +113,10 @@ SIGNATURES = [
     ('vc_discriminator_save_floats', i64, [vp, i32]),
     ('vc_scratch_floats', i64, [vp, i32]),
     ('vc_generator_forward', i32, [vp, vp, i64, vp, i64, vp, i64, vp, i32, i32, vp]),
-    ('vc_generator_backward', i32, [vp, vp, i64, vp, i64, vp, i64, vp, vp, i64, vp, i64, i32, vp, i32, i32, vp]),
+    ('vc_generator_backward', i32, [vp, vp, i64, vp, i64, vp, i64, vp, vp, i64, vp, i64, i32, vp, i64, i32, i32, vp]),
     ('vc_discriminator_out_elems', i32, [vp]),
     ('vc_discriminator_forward', i32, [vp, vp, i64, vp, i64, vp, i64, vp, i32, i32, vp]),
-    ('vc_discriminator_backward', i32, [vp, vp, i64, vp, i64, vp, i64, vp, vp, i64, vp, i64, i32, vp, i32, i32, vp]),
+    ('vc_discriminator_backward', i32, [vp, vp, i64, vp, i64, vp, i64, vp, vp, i64, vp, i64, i32, vp, i64, i32, i32, vp]),
     ('vc_flat_param_floats', i64, [vp]),
     ('vc_flat_offset', i64, [vp, i32]),
     ('vc_step_workspace_floats', i64, [vp, i32]),

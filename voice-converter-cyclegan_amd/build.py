@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(CSRC, 'build')
 LIB = os.path.join(CSRC, 'libvcgan_hip.so')
-SOURCES = ['vc_conv_igemm.hip', 'vc_conv_bf16.hip', 'vc_conv_wgrad.hip', 'vc_conv_small.hip', 'vc_conv_glu.hip', 'vc_elementwise.hip', 'vc_tables.hip', 'vc_ops.hip', 'vc_net.hip', 'vc_step.hip', 'vc_comm.hip']
+SOURCES = ['vc_testing.hip', 'vc_conv_igemm.hip', 'vc_conv_bf16.hip', 'vc_conv_wgrad.hip', 'vc_conv_small.hip', 'vc_conv_glu.hip', 'vc_elementwise.hip', 'vc_tables.hip', 'vc_ops.hip', 'vc_net.hip', 'vc_step.hip', 'vc_comm.hip']
 HEADERS = ['vc_internal.h', 'vc_host.h', 'vc_device_util.h', 'vc_tuned_igemm.h', 'vc_tuned_wgrad.h', 'vc_tuned_bf16.h', os.path.join('..', '..', 'include', 'vc_cyclegan.h'),
            os.path.join('..', '..', 'include', 'vc_cyclegan_testing.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++20', '-munsafe-fp-atomics', '-fPIC',
@@ -20,7 +20,7 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++20', '-munsafe-fp-atomics', '-
 
 def build_id(extra=()):
     """SHA-256 (first 16 hex digits) over every source and header the library is built from and the compiler flags.  The
-    library carries the value it was built with (vc_build_id()); _lib.py recomputes it at import and rebuilds / refuses on
+    library carries the value it was built with (vc_build_id()); _lib.py recomputes it at import and refuses to load on
     a mismatch, so a library older or newer than the sources next to it can neither be tested nor benched (VERDICT r4 #8:
     freshness was judged by mtime only, and the prebuilt .so travels to the GPU box next to sources with fresh mtimes)."""
     import hashlib

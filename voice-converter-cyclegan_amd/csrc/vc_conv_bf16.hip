@@ -517,17 +517,6 @@ void conv_bf16_kernel(const ConvBf16Args p) {
 // Tile rows and LDS ring depth by how many tiles the launch has.  Split-K across workgroups costs fp32 atomics on the whole output
 // plus its zero-fill (~1 TB/s of read-modify-write: 17 MB of output is ~20 us, as long as a 48-chunk K loop): only
 // launches that would leave most of the chip idle split.
-// tests / tuning: force one configuration of conv_bf16_kernel for every following launch of the process (0 = automatic)
-static thread_local int g_bf16_bm = 0, g_bf16_nst = 0, g_bf16_sk = 0;      // per calling thread
-static thread_local int g_bf16_spec = -1;                                  // -1: the process default (on unless VC_BF16_SPEC=0)
-extern "C" int vc_tune_conv_bf16_spec(int on) { g_bf16_spec = on < 0 ? -1 : (on ? 1 : 0); return 0; }
-extern "C" int vc_tune_conv_bf16_override(int tile_rows, int stages, int splitk) {
-    const bool ok = (tile_rows == 0 && stages == 0 && splitk == 0) ||
-                    ((((tile_rows == 64 || tile_rows == 128) && (stages == 2 || stages == 4)) || (tile_rows == 256 && stages == 3)) && splitk >= 1 && splitk <= 16);
-    if (!ok) { vc_set_error("vc_tune_conv_bf16_override: tile rows %d, stages %d, split-K %d is not a built configuration", tile_rows, stages, splitk); return -1; }
-    g_bf16_bm = tile_rows; g_bf16_nst = stages; g_bf16_sk = splitk;
-    return 0;
-}
 // measured choices (tools/tune_igemm.py --math bf16 --sweep on MI355X), keyed by the launch shape; everything else by the rule below
 struct TunedBf16 { int M, Ptot, koct, groups, bm, nst, sk; };
 #include "vc_tuned_bf16.h"
@@ -536,11 +525,11 @@ void conv_bf16_config(ConvBf16Args& a) {
     // 256-row tiles (one workgroup per CU, 128 x 64 per wave) when they fill the chip in whole rounds: at least 3/4 of the
     // last round's CUs busy.  VC_BF16_WIDE=0 switches the rule off (A/B measurements).
     static const bool wide_on = !(getenv("VC_BF16_WIDE") && atoi(getenv("VC_BF16_WIDE")) == 0);
-    if (!g_bf16_bm && wide_on && a.M >= 256 && a.M % 256 == 0 && a.koct >= 64) {
+    if (!vc_hooks().bf16_bm && wide_on && a.M >= 256 && a.M % 256 == 0 && a.koct >= 64) {
         const long t256 = (long)(a.M / 256) * a.ntiles * a.groups, rounds = (t256 + 255) / 256;
         if (t256 * 4 >= rounds * 256 * 3) { a.bm = 256; a.nst = 3; a.mtiles = a.M / 256; a.splitk = 1; return; }
     }
-    if (!g_bf16_bm)
+    if (!vc_hooks().bf16_bm)
         for (const TunedBf16& t : kTunedBf16)
             if (t.M == a.M && t.Ptot == a.Ptot && t.koct == a.koct && t.groups == a.groups) {
                 a.bm = t.bm; a.nst = t.nst; a.mtiles = (a.M + a.bm - 1) / a.bm;
@@ -555,13 +544,13 @@ void conv_bf16_config(ConvBf16Args& a) {
     if (t128 > 256 && a.M > 64) { a.bm = 128; a.nst = 2; }
     else if (t128 > 128 && a.M > 64) { a.bm = 128; a.nst = 4; }
     else { a.bm = 64; a.nst = 4; }
-    if (g_bf16_bm) { a.bm = (g_bf16_bm == 256 && a.M <= 128) ? 128 : g_bf16_bm; a.nst = a.bm == g_bf16_bm ? g_bf16_nst : 4; }
+    if (vc_hooks().bf16_bm) { a.bm = (vc_hooks().bf16_bm == 256 && a.M <= 128) ? 128 : vc_hooks().bf16_bm; a.nst = a.bm == vc_hooks().bf16_bm ? vc_hooks().bf16_nst : 4; }
     a.mtiles = (a.M + a.bm - 1) / a.bm;
     const long tiles = (long)a.mtiles * a.ntiles * a.groups;
     const int nchunks = a.koct / 8;
     int sk = 1;
     while (tiles * sk < 128 && nchunks / (sk * 2) >= 8 && sk < 16) sk *= 2;
-    if (g_bf16_bm) sk = std::min(g_bf16_sk, std::max(1, nchunks / 2));
+    if (vc_hooks().bf16_bm) sk = std::min(vc_hooks().bf16_sk, std::max(1, nchunks / 2));
     if (vc_det_active()) sk = 1;               // deterministic mode: no split-K atomics
     a.splitk = sk;
 }
@@ -588,7 +577,7 @@ int launch_conv_bf16(const ConvBf16Args& a, hipStream_t s, double flops, int pro
 #define VC_BF16_LAUNCH_SPEC(BM, NST) do { if (prof_kind == 1) conv_bf16_kernel<BM, NST, 1, true><<<grid, 512, 0, s>>>(a); \
                                           else conv_bf16_kernel<BM, NST, 0, true><<<grid, 512, 0, s>>>(a); } while (0)
     static const bool spec_default = !(getenv("VC_BF16_SPEC") && atoi(getenv("VC_BF16_SPEC")) == 0);
-    const bool spec = g_bf16_spec < 0 ? spec_default : g_bf16_spec != 0;
+    const bool spec = vc_hooks().bf16_spec < 0 ? spec_default : vc_hooks().bf16_spec != 0;
     if (spec && a.bm == 256) VC_BF16_LAUNCH_SPEC(256, 3);
     else if (spec && a.bm == 128 && a.nst == 4) VC_BF16_LAUNCH_SPEC(128, 4);
     else if (spec && a.bm == 64 && a.nst == 4) VC_BF16_LAUNCH_SPEC(64, 4);

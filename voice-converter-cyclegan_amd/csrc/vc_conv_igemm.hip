@@ -431,15 +431,6 @@ static int resident_per_cu(int bm, int kg) {            // LDS: 55 KB (128 rows)
     const int by_lds = 160 / ((bm == 128 ? 55 : 37) * kg), by_waves = 32 / waves;
     return std::max(1, std::min(std::min(by_lds, by_waves), bm == 128 ? 2 : 4));
 }
-// tools/tune_igemm.py: force one configuration for every following launch of the process (0 = automatic)
-static thread_local int g_force_bm = 0, g_force_kg = 0, g_force_sk = 0;      // per calling thread
-extern "C" int vc_tune_igemm_override(int bm, int kg, int splitk) {
-    const bool ok = (bm == 0 && kg == 0 && splitk == 0) ||
-                    ((bm == 64 || bm == 128) && (kg == 1 || kg == 2 || (kg == 4 && bm == 64)) && splitk >= 1 && splitk <= 64);
-    if (!ok) { vc_set_error("vc_tune_igemm_override: tile %d, K groups %d, split-K %d is not a built configuration", bm, kg, splitk); return -1; }
-    g_force_bm = bm; g_force_kg = kg; g_force_sk = splitk;
-    return 0;
-}
 // measured choices (tools/tune_igemm.py on MI355X), keyed by the launch shape; everything else goes by the cost model
 struct TunedCfg { int at, M, Ptot, krows, groups, bm, kg, sk; };
 #include "vc_tuned_igemm.h"
@@ -467,7 +458,7 @@ static void igemm_config_impl(IgemmArgs& a, int math, int& src) {
     const int nchunks = a.krows / VC_KC;
     const bool det = vc_det_active();          // deterministic mode: K is split inside the workgroup only (fixed summation order)
     a.mtiles = 0;
-    if (math != VC_MATH_FP32 && !g_force_bm) {
+    if (math != VC_MATH_FP32 && !vc_hooks().igemm_bm) {
         // bf16 operand modes: the MFMAs are 16x shorter, the launch is bound by the loader -> the tile with the least loader
         // work per MFMA (128 rows), no K groups, split-K only to fill the chip (the round-1 rule, measured for this mode)
         a.bm = a.M >= 512 ? 128 : 64; a.kg = 1;
@@ -479,13 +470,13 @@ static void igemm_config_impl(IgemmArgs& a, int math, int& src) {
         src = CFG_BF16_RULE;
         return;
     }
-    if (g_force_bm) { src = CFG_FORCED; a.bm = g_force_bm; a.kg = g_force_kg; a.splitk = det ? 1 : std::min(g_force_sk, std::max(1, nchunks / (2 * a.kg))); }
+    if (vc_hooks().igemm_bm) { src = CFG_FORCED; a.bm = vc_hooks().igemm_bm; a.kg = vc_hooks().igemm_kg; a.splitk = det ? 1 : std::min(vc_hooks().igemm_sk, std::max(1, nchunks / (2 * a.kg))); }
     else {
         const int at = a.a_ms != 1 ? 1 : 0;
         for (const TunedCfg& t : kTunedIgemm)
             if (t.at == at && t.M == a.M && t.Ptot == a.Ptot && t.krows == a.krows && t.groups == a.groups && !(det && t.sk > 1)) { a.bm = t.bm; a.kg = t.kg; a.splitk = t.sk; a.mtiles = 1; src = CFG_EXACT; break; }
     }
-    if (!g_force_bm && !a.mtiles) {
+    if (!vc_hooks().igemm_bm && !a.mtiles) {
         // No exact entry: the same LAYER (same filter-side shape: transposed?, M, K rows, groups) measured at another pixel
         // count.  The nearest one in log(pixels) within a factor of 4 lends its tile rows and K groups; split-K halves /
         // doubles with the pixel count (more pixel tiles -> less need to split K).  Makes the measured tables serve every
@@ -510,7 +501,7 @@ static void igemm_config_impl(IgemmArgs& a, int math, int& src) {
             a.splitk = sk; a.mtiles = 1; src = CFG_NEIGHBOUR;
         }
     }
-    if (g_force_bm || a.mtiles) { a.mtiles = (a.M + a.bm - 1) / a.bm; a.ntiles = (a.Ptot + 63) / 64; return; }
+    if (vc_hooks().igemm_bm || a.mtiles) { a.mtiles = (a.M + a.bm - 1) / a.bm; a.ntiles = (a.Ptot + 63) / 64; return; }
     // Cost model in microseconds, fitted to the sweep of tools/tune_igemm.py (profiles/r02_tune_sweep_b8.txt): a workgroup
     // runs `cps` chunks at a pace set by the k waves that share its SIMDs (0.2 + 0.62 k us per chunk: a lone wave
     // exposes its LDS and barrier latency, four saturate the MFMA pipe at ~65 %), plus a fixed prologue + epilogue;

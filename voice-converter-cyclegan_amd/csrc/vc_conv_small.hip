@@ -374,7 +374,8 @@ int launch_c1_fwd(const C1Args& a, hipStream_t s) {
 }
 int launch_c1_dgrad(const C1Args& a, int accumulate, hipStream_t s) {
     const int P = a.OH * a.OW, nch = (a.Cout + 63) / 64;
-    if (a.det) {
+    if (a.det || vc_hooks().c1_gather) {     // (tests: the gather form without the rest of deterministic mode -- the scatter's atomics are the one
+                                              //  summation-order source that PROPAGATES into the generators' gradient chains)
         c1_dgrad_gather_kernel<<<dim3((a.H * a.W + 255) / 256, a.B, a.G), 256, 0, s>>>(a, accumulate);
         VC_HIP(hipGetLastError());
         return 0;

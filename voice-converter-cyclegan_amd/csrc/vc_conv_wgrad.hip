@@ -266,23 +266,14 @@ __global__ __launch_bounds__(256 * KG, KG == 4 ? 4 : 2) void wgrad_kernel(const 
 // Tile width (Cout columns), K groups and split-K: the cost model of igemm_config (vc_conv_igemm.hip) with this kernel's
 // chunk (32 pixels x (64 + BN) rows; 32 or 16 MFMAs per wave).  us per chunk of one wave among k on its SIMD.
 struct WgradCfg { int bn, kg, sk; int src = 0; };   // src: 0 cost model, 1 exact measured row, 2 neighbour row, 3 forced
-// tests / tuning: force one configuration (tile columns 64 / 128, K groups, split-K) for the calling thread's following launches
-static thread_local int g_wforce_bn = 0, g_wforce_kg = 0, g_wforce_sk = 0;
-extern "C" int vc_tune_wgrad_override(int bn, int kg, int splitk) {
-    const bool ok = (bn == 0 && kg == 0 && splitk == 0) ||
-                    ((bn == 64 || bn == 128) && (kg == 1 || kg == 2 || (kg == 4 && bn == 64)) && splitk >= 1 && splitk <= 64);
-    if (!ok) { vc_set_error("vc_tune_wgrad_override: tile columns %d, K groups %d, split-K %d is not a built configuration", bn, kg, splitk); return -1; }
-    g_wforce_bn = bn; g_wforce_kg = kg; g_wforce_sk = splitk;
-    return 0;
-}
 // measured choices (tools/tune_igemm.py --sweep on MI355X), keyed by the launch shape; everything else goes by the cost model
 struct TunedWgrad { int ktiles, N, nchunks, groups, store, bn, kg, sk; };
 #include "vc_tuned_wgrad.h"
 static WgradCfg wgrad_config(const WgradArgs& a) {
     const bool det = vc_det_active();          // deterministic mode: the pixel axis is split inside the workgroup only
-    if (g_wforce_bn) {
-        const int bn = (g_wforce_bn == 128 && a.N < 128) ? 64 : g_wforce_bn;
-        return WgradCfg{bn, g_wforce_kg, det ? 1 : std::min(g_wforce_sk, std::max(1, a.nchunks / (2 * g_wforce_kg))), 3};
+    if (vc_hooks().wgrad_bn) {
+        const int bn = (vc_hooks().wgrad_bn == 128 && a.N < 128) ? 64 : vc_hooks().wgrad_bn;
+        return WgradCfg{bn, vc_hooks().wgrad_kg, det ? 1 : std::min(vc_hooks().wgrad_sk, std::max(1, a.nchunks / (2 * vc_hooks().wgrad_kg))), 3};
     }
     for (const TunedWgrad& t : kTunedWgrad)
         if (t.ktiles == a.ktiles && t.N == a.N && t.nchunks == a.nchunks && t.groups == a.groups && t.store == a.store && !(det && t.sk > 1))

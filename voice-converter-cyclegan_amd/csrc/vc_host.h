@@ -72,6 +72,7 @@ int conv_wgrad(const WgradApp* apps, int napps, float* dw, long dw_gs, int G, co
 bool conv_wgrad_reads_pixel_octets(const Geom& g, long pixels, int math);   // the filter gradient of this geometry runs as the bf16 GEMM over `pixels` (>= one application's)
 void drop_pack_spaces(std::initializer_list<hipStream_t> streams);
 long ws_generation(std::initializer_list<hipStream_t> streams);
+int poison_pack_spaces(std::initializer_list<hipStream_t> streams, int byte);
 
 // ---- networks, plans, schedules (vc_net.hip)
 enum { M_GATED_IN = 0, M_GATED = 1, M_IN_RES = 2, M_PLAIN = 3 };
@@ -133,9 +134,12 @@ struct DeferredApp { const float* x; long x_gs; const float* save; long save_gs;
                                                                 // buffer / its fp32 copy was never written (BwdOpts::drop_fp32_dy)
 enum { W_NONE = 0, W_SELF = 1 };
 struct BwdOpts { bool record_buckets = false, wgrad_store = false; int wmode = W_SELF; const DeferredApp* deferred = nullptr;
+                 // W_NONE passes report which layers' dY went out as pixel octets / were never written as fp32 (for the DeferredApp of the
+                 // pass that reduces them)
                  unsigned* q_ready_out = nullptr; unsigned* dy_dropped_out = nullptr;
-                 bool drop_fp32_dy = false;
-                 bool emit_pixel_octets = true; };    // false: the norm backward leaves dy in fp32 only, the filter gradients pack their operand (see vc_step.hip, lambda_identity == 0)        // the caller guarantees every reader of a layer's dy takes the octet forms whenever the norm backward wrote them (train step: yes)   // W_NONE passes: which layers' dY went out as pixel octets (for the DeferredApp of the pass that reduces them)
+                 // the caller guarantees that every reader of a layer's dy takes the octet forms whenever the norm backward wrote them
+                 // (inside a train step: yes): the fp32 copy is then not written at all
+                 bool drop_fp32_dy = false; };
 int gen_forward(const vc_plan* p, const float* params, long par_gs, const float* x, long x_gs,
                 float* y, long y_gs, float* save, int G, int B, hipStream_t s);
 int gen_backward(const vc_plan* p, const float* params, long par_gs, const float* x, long x_gs,

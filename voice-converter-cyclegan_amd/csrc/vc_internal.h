@@ -254,3 +254,19 @@ void vc_set_error(const char* fmt, ...);
 #define VC_HIP(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { \
     vc_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
     return (int)_e; } } while (0)
+
+// ---- test / tuning switches (include/vc_cyclegan_testing.h).  ALL of them live in one thread-local object owned by vc_testing.hip, the only
+// translation unit that writes it; the product translation units read it through vc_hooks().  vc_testing_hooks_active() tells a caller
+// (bench.py, model.CycleGAN.train) that the calling thread runs with every switch at its production value.
+struct TestHooks {
+    int igemm_bm = 0, igemm_kg = 0, igemm_sk = 0;      // vc_tune_igemm_override
+    int wgrad_bn = 0, wgrad_kg = 0, wgrad_sk = 0;      // vc_tune_wgrad_override
+    int bf16_bm = 0, bf16_nst = 0, bf16_sk = 0;        // vc_tune_conv_bf16_override
+    int bf16_spec = -1;                                // vc_tune_conv_bf16_spec (-1: the process default)
+    int pixel_octets = 1;                              // vc_tune_bf16_pixel_octets
+    int rowskip_wgrad = 1;                             // vc_tune_rowskip
+    int wgrad_store = 0;                               // vc_tune_wgrad_store
+    int glu_flags = 0;                                 // vc_tune_glu
+    int c1_gather = 0;                                 // vc_tune_c1_dgrad_gather
+};
+const TestHooks& vc_hooks();

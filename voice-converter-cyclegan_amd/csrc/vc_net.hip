@@ -276,7 +276,7 @@ struct NetCtx {
     bool keep_packed = false;              // bf16 data path, inside a train step: forward leaves the packed inputs in the save area (SaveMap::actp)
     bool fuse_glu = false;                 // forward only: gated blocks without instance norm go out as one conv + GLU kernel
     unsigned* q_ready_out = nullptr;       // W_NONE passes report which layers' dY they left as pixel octets (BwdOpts::q_ready_out)
-    unsigned* dy_dropped_out = nullptr; bool drop_dy = false, emit_q = true;   // BwdOpts::drop_fp32_dy, ::emit_pixel_octets
+    unsigned* dy_dropped_out = nullptr; bool drop_dy = false;   // BwdOpts::drop_fp32_dy
     int wmode = W_SELF;                    // W_NONE: leave the conv filter gradients to a later application (DeferredApp)
     bool wgrad_store = false;              // this backward's filter gradients are the step's only contribution to dparams' conv kernels
     const DeferredApp* deferred = nullptr; // reduce this earlier application in the same launches
@@ -292,6 +292,36 @@ static long scratch_map(const std::vector<LayerGeo>& geo, int B, long* dY, long*
         for (size_t i = 0; i < geo.size(); ++i) { dYq[i] = q; q += scratch_dyq_floats(geo[i], B); }
     }
     return o;
+}
+
+// testing (vc_testing_describe_step): the named sub-regions of a save area / a backward scratch, as "name offset floats" lines
+void describe_save(std::string& out, const char* tag, const NetDesc& n, const std::vector<LayerGeo>& geo, int B, long base, long gs, int G) {
+    const SaveMap m = save_map(n, geo, B);
+    char line[256];
+    for (int g = 0; g < G; ++g)
+        for (size_t i = 0; i < n.layers.size(); ++i) {
+            const Layer& L = n.layers[i];
+            const long st = L.mode == M_GATED_IN ? (long)B * 2 * L.C * 2 : L.mode == M_IN_RES ? (long)B * L.C * 2 : 0;
+            const bool lp = L.mode == M_PLAIN;
+            snprintf(line, sizeof line, "%s.g%d.L%zu.raw %ld %ld\n", tag, g, i, base + g * gs + m.raw[i], lp ? 0 : geo[i].raw_ps * B); out += line;
+            snprintf(line, sizeof line, "%s.g%d.L%zu.act %ld %ld\n", tag, g, i, base + g * gs + m.act[i], lp ? 0 : geo[i].act_ps * B); out += line;
+            snprintf(line, sizeof line, "%s.g%d.L%zu.st %ld %ld\n", tag, g, i, base + g * gs + m.st[i], st); out += line;
+            snprintf(line, sizeof line, "%s.g%d.L%zu.actp %ld %ld\n", tag, g, i, base + g * gs + m.actp[i], lp ? 0 : (geo[i].act_ps * B + 1) / 2); out += line;
+        }
+}
+void describe_scratch(std::string& out, const char* tag, const std::vector<LayerGeo>& geo, int B, int math, long base, long gs, int G) {
+    long dY[24], dA[24], dYq[24];
+    const bool q = math == VC_MATH_BF16;
+    const long dyp = scratch_map(geo, B, dY, dA, q ? dYq : nullptr);
+    char line[256];
+    for (int g = 0; g < G; ++g) {
+        for (size_t i = 0; i < geo.size(); ++i) {
+            snprintf(line, sizeof line, "%s.g%d.L%zu.dY %ld %ld\n", tag, g, i, base + g * gs + dY[i], geo[i].raw_ps * B); out += line;
+            snprintf(line, sizeof line, "%s.g%d.L%zu.dA %ld %ld\n", tag, g, i, base + g * gs + dA[i], geo[i].act_ps * B); out += line;
+            if (q) { snprintf(line, sizeof line, "%s.g%d.L%zu.dYq %ld %ld\n", tag, g, i, base + g * gs + dYq[i], scratch_dyq_floats(geo[i], B)); out += line; }
+        }
+        snprintf(line, sizeof line, "%s.g%d.dYp %ld %ld\n", tag, g, base + g * gs + dyp, scratch_dyp_floats(geo, B)); out += line;
+    }
 }
 
 static int net_forward(NetCtx& c, const float* x, long x_gs, float* y_plain, long y_plain_gs) {
@@ -376,9 +406,8 @@ static int net_forward(NetCtx& c, const float* x, long x_gs, float* y_plain, lon
 
 // dtop: gradient w.r.t. the network's last activation (for the generator: d o1 output, i.e. dy of the
 // plain layer; for the discriminator: gradient w.r.t. the last GLU output, produced by the head).
-// tests: 0 = the norm backward leaves dy in fp32 only for the filter gradient (which then packs its pixel octets itself: the round-4 path)
-static thread_local int g_emit_pixel_octets = 1;
-extern "C" int vc_tune_bf16_pixel_octets(int on) { g_emit_pixel_octets = on; return 0; }   // 2: emit, but keep writing the fp32 copy
+// vc_hooks().pixel_octets (tests): 0 = the norm backward leaves dy in fp32 only for the filter gradient (which then packs its pixel octets
+// itself: the round-4 path), 2 = octets written and the fp32 copy kept
 static int net_backward(NetCtx& c, const float* x, long x_gs, const float* dtop, long dtop_gs,
                         float* dx, long dx_gs, int dx_acc, float* scratch, long scr_gs) {
     const int nl = (int)c.n->layers.size();
@@ -434,14 +463,14 @@ static int net_backward(NetCtx& c, const float* x, long x_gs, const float* dtop,
             }
             // ... and its filter gradient (the bf16 GEMM over pixels) reads dy as pixel octets out of the layer's stacked buffer: this
             // pass's own scratch, or the deferred application's when that pass opened the buffer (its part sits in front)
-            if (c.dparams && c.emit_q && g_emit_pixel_octets && norm_bwd_emits_pixel_octets(a) && conv_wgrad_reads_pixel_octets(lg.g, (long)c.B * lg.g.OH * lg.g.OW, c.math) &&
+            if (c.dparams && vc_hooks().pixel_octets && norm_bwd_emits_pixel_octets(a) && conv_wgrad_reads_pixel_octets(lg.g, (long)c.B * lg.g.OH * lg.g.OW, c.math) &&
                 (!c.deferred || c.B <= 2 * c.deferred->B)) {
                 if (c.deferred) { a.outq = (char*)const_cast<float*>(c.deferred->scratch + dYqd[i]); a.outq_gs = c.deferred->scr_gs * 4; a.outq_po0 = c.deferred->B * lg.g.OH * lg.g.OW / 8; }
                 else { a.outq = (char*)(scratch + dYqo[i]); a.outq_gs = scr_gs * 4; a.outq_po0 = 0; }
                 q_ready |= 1u << i;
             }
             // both readers of this dy take the octet forms (or do not exist): its fp32 copy -- the largest stream of the kernel -- stays unwritten
-            if (c.drop_dy && g_emit_pixel_octets != 2 && ((i == 0 && !dx) || dy_packed) && (!c.dparams || (q_ready >> i & 1u)) && (dy_packed || a.outq)) { a.dy = nullptr; dy_dropped |= 1u << i; }
+            if (c.drop_dy && vc_hooks().pixel_octets != 2 && ((i == 0 && !dx) || dy_packed) && (!c.dparams || (q_ready >> i & 1u)) && (dy_packed || a.outq)) { a.dy = nullptr; dy_dropped |= 1u << i; }
             VC_CHECK(launch_norm_bwd(L.mode, a, c.s));
             dyp = a.dy ? scratch + dYo[i] : nullptr; dy_gs = scr_gs;
             if (c.dparams && c.wmode != W_NONE && ws != c.s) { VC_HIP(hipEventRecord(c.ev_layer[i], c.s)); VC_HIP(hipStreamWaitEvent(ws, c.ev_layer[i], 0)); }
@@ -529,7 +558,7 @@ int gen_backward(const vc_plan* p, const float* params, long par_gs, const float
                         const BwdOpts& o) {
     VC_ARG(!p->inference, "this plan was created for inference only (vc_plan_create_inference)");
     NetCtx c = gen_ctx(p, params, par_gs, dparams, dpar_gs, save, G, B, Bl, s);
-    c.wgrad_store = o.wgrad_store; c.wmode = o.wmode; c.deferred = o.deferred; c.q_ready_out = o.q_ready_out; c.dy_dropped_out = o.dy_dropped_out; c.drop_dy = o.drop_fp32_dy; c.emit_q = o.emit_pixel_octets;
+    c.wgrad_store = o.wgrad_store; c.wmode = o.wmode; c.deferred = o.deferred; c.q_ready_out = o.q_ready_out; c.dy_dropped_out = o.dy_dropped_out; c.drop_dy = o.drop_fp32_dy;
     c.images = step_images(p, true, G); c.keep_packed = c.images != nullptr;
     if ((p->use_side & 2) && dparams && o.wmode != W_NONE) { c.ws = p->wstream; c.ev_layer = p->ev_layer; c.ev_wjoin = p->ev_wjoin; }
     if (o.record_buckets) { c.ev_first = p->bucket_first; c.ev = p->g_ready; c.ev_free = p->g_free; c.n_ev = vc_plan::kBuckets; }
@@ -577,8 +606,13 @@ extern "C" int vc_generator_backward(const vc_plan* p, const float* params, int6
                                      const float* x, int64_t x_gs, const float* dy, int64_t dy_gs,
                                      const float* save, float* dparams, int64_t dpar_gs,
                                      float* dx, int64_t dx_gs, int dx_accumulate,
-                                     float* scratch, int G, int B, void* stream) {
+                                     float* scratch, int64_t scratch_floats, int G, int B, void* stream) {
     VC_ARG(p && params && x && dy && save && scratch && G > 0 && B > 0, "vc_generator_backward: bad args");
+    if (scratch_floats < vc_scratch_floats(p, B) * G) {
+        vc_set_error("vc_generator_backward: scratch too small: %lld < %lld floats (vc_scratch_floats depends on the plan's math mode)",
+                     (long long)scratch_floats, (long long)(vc_scratch_floats(p, B) * G));
+        return VC_E_NOMEM;
+    }
     DetScope det_scope(p->det);
     return gen_backward(p, params, par_gs, x, x_gs, dy, dy_gs, const_cast<float*>(save), B, dparams, dpar_gs,
                         dx, dx_gs, dx_accumulate, scratch, vc_scratch_floats(p, B), G, B, (hipStream_t)stream);
@@ -594,8 +628,13 @@ extern "C" int vc_discriminator_backward(const vc_plan* p, const float* params, 
                                          const float* x, int64_t x_gs, const float* dout, int64_t do_gs,
                                          const float* save, float* dparams, int64_t dpar_gs,
                                          float* dx, int64_t dx_gs, int dx_accumulate,
-                                         float* scratch, int G, int B, void* stream) {
+                                         float* scratch, int64_t scratch_floats, int G, int B, void* stream) {
     VC_ARG(p && params && x && dout && save && scratch && G > 0 && B > 0, "vc_discriminator_backward: bad args");
+    if (scratch_floats < vc_scratch_floats(p, B) * G) {
+        vc_set_error("vc_discriminator_backward: scratch too small: %lld < %lld floats (vc_scratch_floats depends on the plan's math mode)",
+                     (long long)scratch_floats, (long long)(vc_scratch_floats(p, B) * G));
+        return VC_E_NOMEM;
+    }
     DetScope det_scope(p->det);
     // the sigmoid outputs are recomputed from the saved last activation (cheap) into the tail of scratch
     hipStream_t s = (hipStream_t)stream;

@@ -41,10 +41,8 @@ static void fill_pixel_grid(IgemmArgs& a, int B, int NPB, int OWc) {
 // 545 -> 459 us (its reduction axis is the pixel axis, the skipped rows are simply not read).  The same enumeration for the
 // forward / input gradient was built and measured in round 3 (-3 % .. +7 %: pixel tiles of one weight slab then walk different
 // parts of it and lose its sharing through the XCD's L2) and removed in round 4.  vc_tune_rowskip switches it for the tests.
-static thread_local int t_rowskip_wgrad = 1;
-extern "C" int vc_tune_rowskip(int wgrad_on) { t_rowskip_wgrad = wgrad_on ? 1 : 0; return 0; }
 static bool rowskip_pays(const Table& t, int OHc, int si, int Hl) {
-    if (!t_rowskip_wgrad || OHc < 2 || t.ntaps < 2 || t.cpt <= 0) return false;
+    if (!vc_hooks().rowskip_wgrad || OHc < 2 || t.ntaps < 2 || t.cpt <= 0) return false;
     long valid = 0;
     for (int i = 0; i < OHc; ++i)
         for (int tp = 0; tp < t.ntaps; ++tp) valid += (i * si + t.tdh[tp] >= 0 && i * si + t.tdh[tp] < Hl) ? 1 : 0;
@@ -116,6 +114,17 @@ void drop_pack_spaces(std::initializer_list<hipStream_t> streams) {
         g_ws.erase(it);
         g_ws_gen.erase(s);                        // the stream is going away with its plan: nobody else's key mentions it
     }
+}
+// testing: fill the packed-operand workspaces of these streams with a byte pattern (0xff: NaN as fp32 and as bf16), so a launch that reads a
+// unit its own producer did not write in THIS step shows up as NaN instead of as last step's (identical-looking) values
+int poison_pack_spaces(std::initializer_list<hipStream_t> streams, int byte) {
+    VC_HIP(hipDeviceSynchronize());
+    std::lock_guard<std::mutex> l(g_ws_mu);
+    for (hipStream_t s : streams) {
+        auto it = g_ws.find(s);
+        if (it != g_ws.end() && it->second.p) VC_HIP(hipMemset(it->second.p, byte, it->second.cap));
+    }
+    return 0;
 }
 // the path serves launches that fill its 128 x 128 tiles; everything else stays on the table-driven fp32-storage kernels
 static bool bf16_path(const Table& t, int math, int M, long Ptot) { return math == VC_MATH_BF16 && t.koct > 0 && M >= 64 && Ptot >= 64; }
@@ -290,6 +299,7 @@ int conv_dgrad(const float* dy, long dy_gs, const float* w, long w_gs, float* dx
             return 0;
         }
     }
+    VC_ARG(query || dy, "conv input gradient: the fp32 dy was left unwritten but this launch does not run on the 16-bit data path");
     IgemmArgs cls[4]; double fl[4]; int ncls = 0;
     bool any_split = false;
     for (int ph = 0; ph < g.sh; ++ph) for (int pw = 0; pw < g.sw; ++pw) {
@@ -373,6 +383,7 @@ int conv_wgrad(const WgradApp* apps, int napps, float* dw, long dw_gs, int G, co
         if (query) { *query = true; return 0; }
         for (int k = 0; k < napps; ++k) {
             VC_CHECK(check_conv_geom(g, apps[k].B));
+            VC_ARG(apps[k].dy, "conv filter gradient (Cin = 1): an application's fp32 dy was left unwritten");
             C1Args c = c1_args(g, G, apps[k].B, math); c.x = apps[k].x; c.x_gs = apps[k].x_gs; c.dy = apps[k].dy; c.y_gs = apps[k].dy_gs;
             c.dw = dw; c.dw_gs = dw_gs;
             VC_CHECK(launch_c1_wgrad(c, s));
@@ -443,6 +454,7 @@ int conv_wgrad(const WgradApp* apps, int napps, float* dw, long dw_gs, int G, co
     double flops = 0;
     for (int k = 0; k < napps; ++k) {
         VC_CHECK(check_conv_geom(g, apps[k].B));
+        VC_ARG(query || apps[k].dy, "conv filter gradient: an application's fp32 dy was left unwritten but the launch runs on the fp32-storage kernel");
         WgradSeg& sg = a.seg[k];
         sg.X = apps[k].x; sg.dY = apps[k].dy; sg.x_gs = apps[k].x_gs; sg.dy_gs = apps[k].dy_gs;
         sg.x_bytes = (unsigned)((long)apps[k].B * a.x_bs * 4 + t.xbias); sg.dy_bytes = (unsigned)((long)apps[k].B * a.dy_bs * 4);
@@ -474,14 +486,12 @@ extern "C" int vc_conv2d_dgrad(const float* dy, int64_t dy_gs, const float* w, i
                       make_geom(Cin, H, W, Cout, kh, kw, sh, sw), vc_thread_math(), (hipStream_t)stream);
 }
 // tuning hook (tools/tune_igemm.py): operator-level filter gradients OVERWRITE dW (the step's plain-store form) while on
-static thread_local int t_wgrad_store = 0;
-extern "C" int vc_tune_wgrad_store(int on) { t_wgrad_store = on ? 1 : 0; return 0; }
 extern "C" int vc_conv2d_wgrad(const float* x, int64_t x_gs, const float* dy, int64_t dy_gs,
                                float* dw, int64_t dw_gs, int G, int B, int Cin, int H, int W, int Cout,
                                int kh, int kw, int sh, int sw, void* stream) {
     VC_ARG(x && dy && dw && G > 0 && B > 0, "vc_conv2d_wgrad: bad args");
     const WgradApp app{x, x_gs, dy, dy_gs, B};
-    return conv_wgrad(&app, 1, dw, dw_gs, G, make_geom(Cin, H, W, Cout, kh, kw, sh, sw), vc_thread_math(), (hipStream_t)stream, /*store=*/t_wgrad_store != 0);
+    return conv_wgrad(&app, 1, dw, dw_gs, G, make_geom(Cin, H, W, Cout, kh, kw, sh, sw), vc_thread_math(), (hipStream_t)stream, /*store=*/vc_hooks().wgrad_store != 0);
 }
 extern "C" int vc_gated_conv1d_glu_fwd(const float* x, int64_t x_gs, const float* w, int64_t w_gs,
                                        const float* bias, int64_t b_gs, float* out, int64_t out_gs,
@@ -494,9 +504,7 @@ extern "C" int vc_gated_conv1d_glu_fwd(const float* x, int64_t x_gs, const float
     VC_ARG(r != -2, "vc_gated_conv1d_glu_fwd: built for Cin = 24, k = 15, Cout2 %% 64 == 0, T %% 4 == 0, tensors < 2 GiB (the generator's h1 block)");
     return r;
 }
-static thread_local int t_glu_flags = 0;
-extern "C" int vc_tune_glu(int flags) { t_glu_flags = flags; return 0; }
-int glu_tune_flags() { return t_glu_flags; }
+int glu_tune_flags() { return vc_hooks().glu_flags; }
 extern "C" int64_t vc_gated_conv1d_glu_image_bytes(int Cin, int k, int Cout2) {
     return gated_conv1d_glu_image_bytes(Cin, k, Cout2, vc_thread_math() == VC_MATH_BF16 ? VC_MATH_BF16 : VC_MATH_FP32);
 }

@@ -36,6 +36,40 @@ static StepMap step_map(const vc_plan* p, int B) {
     m.total = o;
     return m;
 }
+// testing: where every buffer of the step lies inside the caller's workspace ("name offset floats" per line; the scratch areas as
+// each pass lays them out), and a poison for the plan-internal buffers -- tools/stale_read_probe.py names a stale read with them
+void describe_save(std::string& out, const char* tag, const NetDesc& n, const std::vector<LayerGeo>& geo, int B, long base, long gs, int G);
+void describe_scratch(std::string& out, const char* tag, const std::vector<LayerGeo>& geo, int B, int math, long base, long gs, int G);
+extern "C" long long vc_testing_describe_step(const vc_plan* p, int B, int Bbwd, char* buf, long long cap) {
+    if (!p || B <= 0) return -1;
+    const StepMap m = step_map(p, B);
+    std::string out; char line[256];
+    auto two = [&](const char* name, long off, long n) {
+        for (int g = 0; g < 2; ++g) { snprintf(line, sizeof line, "%s.g%d %ld %ld\n", name, g, off + g * align64(n), n); out += line; }
+    };
+    two("X1", m.X1, m.ft2); two("O1", m.O1, m.ft2); two("CY", m.CY, m.ft1); two("DX", m.DX, m.ft2); two("DO", m.DO, m.hw2);
+    two("dO1", m.dO1, m.ft2); two("dCY", m.dCY, m.ft1); two("dDO_D", m.dDO_D, m.hw2); two("dDO_G", m.dDO_G, m.hw1);
+    describe_save(out, "S1", p->G, p->gg, 2 * B, m.S1, align64(m.s1_gs), 2);
+    describe_save(out, "S2", p->G, p->gg, B, m.S2, align64(m.s2_gs), 2);
+    describe_save(out, "SD", p->D, p->dg, 2 * B, m.SD, align64(m.sd_gs), 2);
+    describe_scratch(out, "SCR.step8", p->dg, B, p->math, m.SCR, align64(m.scr_gs), 2);
+    describe_scratch(out, "SCR.step10", p->gg, Bbwd, p->math, m.SCR, align64(m.scr_gs), 2);
+    describe_scratch(out, "SCRC.step9", p->gg, B, p->math, m.SCRC, align64(m.scrc_gs), 2);
+    describe_scratch(out, "SCR2.step7", p->dg, 2 * B, p->math, m.SCR2, align64(m.scr_gs), 2);
+    snprintf(line, sizeof line, "ACC %ld %d\ntotal %ld 0\n", m.ACC, VC_LOSS_BLOCKS * 10, m.total); out += line;
+    if (buf && cap > 0) { const size_t n = std::min<size_t>(out.size(), (size_t)cap - 1); memcpy(buf, out.data(), n); buf[n] = 0; }
+    return (long long)out.size() + 1;
+}
+extern "C" int vc_testing_poison_internal(const vc_plan* p, void* stream, int byte) {
+    VC_ARG(p, "vc_testing_poison_internal: bad plan");
+    VC_CHECK(poison_pack_spaces({(hipStream_t)stream, p->side, p->wstream, p->wstream_d, p->gstream, p->ustream}, byte));
+    // (the filter images are rebuilt from the weights at the head of every step: poisoning them checks exactly that)
+    if (p->img_block) {
+        size_t sz = 0; hipDeviceptr_t base = nullptr;
+        if (hipMemGetAddressRange(&base, &sz, (hipDeviceptr_t)p->img_block) == hipSuccess && sz) VC_HIP(hipMemset(p->img_block, byte, sz));
+    }
+    return 0;
+}
 extern "C" int64_t vc_step_workspace_floats(const vc_plan* p, int B) { return p ? step_map(p, B).total : 0; }
 
 // Gradient ranges that are accumulated with atomics during the step (conv biases, instance-norm gamma/beta, the dense

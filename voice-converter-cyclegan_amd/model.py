@@ -21,6 +21,7 @@ from .module import discriminator, generator_gatedcnn
 from .utils import l1_loss, l2_loss
 from .engine import CycleGANEngine, SCOPES, LOSS_NAMES
 from . import tfio
+from . import _lib
 
 G_SUMMARIES = ('cycle_loss', 'identity_loss', 'generator_loss_A2B', 'generator_loss_B2A', 'generator_loss')
 D_SUMMARIES = ('discriminator_loss_A', 'discriminator_loss_B', 'discriminator_loss')
@@ -130,6 +131,9 @@ class CycleGAN(object):
     # ------------------------------------------------------------------ model.py:110-125
     def train(self, input_A, input_B, lambda_cycle, lambda_identity, generator_learning_rate,
               discriminator_learning_rate):
+        if not _lib.lib.vc_thread_is_product_run():
+            raise RuntimeError('a test / tuning switch of include/vc_cyclegan_testing.h is active in this thread: '
+                               'CycleGAN.train runs with production kernel configurations only')
         if self._native:
             generator_loss, discriminator_loss = self.engine.train_step(
                 input_A, input_B, lambda_cycle, lambda_identity, generator_learning_rate, discriminator_learning_rate)

@@ -151,7 +151,7 @@ class _GeneratorFn(torch.autograd.Function):
         dp = torch.zeros_like(params) if need_dp else None
         scr = torch.empty(lib.vc_scratch_floats(ctx.plan, B), device=x.device)
         check(lib.vc_generator_backward(ctx.plan, ptr(params), 0, ptr(x), 0, ptr(dy), 0, ptr(save), ptr(dp), 0,
-                                        ptr(dx), 0, 0, ptr(scr), 1, B, _stream(x)), 'vc_generator_backward')
+                                        ptr(dx), 0, 0, ptr(scr), scr.numel(), 1, B, _stream(x)), 'vc_generator_backward')
         return dx, dp, None
 
 
@@ -179,7 +179,7 @@ class _DiscriminatorFn(torch.autograd.Function):
         dp = torch.zeros_like(params) if need_dp else None
         scr = torch.empty(lib.vc_scratch_floats(ctx.plan, B), device=x.device)
         check(lib.vc_discriminator_backward(ctx.plan, ptr(params), 0, ptr(x), 0, ptr(do), 0, ptr(save), ptr(dp), 0,
-                                            ptr(dx), 0, 0, ptr(scr), 1, B, _stream(x)), 'vc_discriminator_backward')
+                                            ptr(dx), 0, 0, ptr(scr), scr.numel(), 1, B, _stream(x)), 'vc_discriminator_backward')
         return dx, dp, None
 
 
