@@ -398,6 +398,9 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--exchange', choices=['bucketed', 'single', 'both'], default='both',
+                    help='N > 1: gradient exchange of the headline (bucketed: 5 segments under the backward, the default; single: ONE all-reduce '
+                         'after it, BASELINE.json\'s literal form); both = headline bucketed + the same steps again in single mode under config.exchange_modes')
     ap.add_argument('--batch', type=int, default=8, help='per-GPU minibatch (BASELINE configs[1])')
     ap.add_argument('--global-batch', type=int, default=0,
                     help='strong scaling: total minibatch split over the ranks (BASELINE configs[3]: 256); overrides --batch')
@@ -524,8 +527,21 @@ def main():
         torch.cuda.synchronize()
 
     eng.measure_exposed = world > 1              # N > 1: how much of exchange + update is NOT hidden under the backward
+    eng.set_exchange_mode('single' if args.exchange == 'single' else 'bucketed')
     dt = time_steps(eng, A, Bm, hp, args.steps, args.warmup, barrier)
     exposed_ms = eng.exposed_update_ms() if world > 1 else None
+    exchange_modes = None
+    if world > 1:                                # the A/B the north star asks for: the same steps with the other exchange form
+        headline_mode = 'single' if args.exchange == 'single' else 'bucketed'
+        exchange_modes = {headline_mode: {'ms_per_step': 1e3 * dt / args.steps, 'exposed_update_ms': exposed_ms, 'headline': True}}
+        if args.exchange == 'both':
+            eng.set_exchange_mode('single')
+            dt2 = time_steps(eng, A, Bm, hp, args.steps, args.warmup, barrier)
+            ex2 = eng.exposed_update_ms()
+            t2 = torch.tensor([dt2], device=dev, dtype=torch.float64)
+            dist.all_reduce(t2, op=dist.ReduceOp.MAX)
+            exchange_modes['single'] = {'ms_per_step': 1e3 * float(t2.item()) / args.steps, 'exposed_update_ms': ex2, 'headline': False}
+            eng.set_exchange_mode('bucketed')
     eng.measure_exposed = False
     if world > 1:                                # every rank says what it runs with, so a SCALE line explains itself
         p_ = eng.plan(T)
@@ -569,6 +585,8 @@ def main():
         if world > 1:
             out['config']['exposed_exchange_update_ms_rank0'] = exposed_ms
             out['config']['gradient_bytes_per_step'] = 4 * int(eng.n_flat)
+            exchange_modes[next(k for k, v in exchange_modes.items() if v['headline'])]['ms_per_step'] = out['ms_per_step']     # max over ranks
+            out['config']['exchange_modes'] = exchange_modes      # ms_per_step (max over ranks) and rank 0's exposed exchange + update per mode
 
     # ---- roofline leg: the same steps again with HIP events around every implicit-GEMM launch
     if not args.no_roofline:

@@ -275,6 +275,16 @@ int vc_cyclegan_step_grads(const vc_plan* p, const float* params, float* grads,
  * backward) on `stream` and an internal side stream, joined before it returns.  enabled = 0 serialises them on `stream`
  * (used when timing individual kernels, so launches do not share the chip).  Default: enabled. */
 int vc_plan_set_overlap(vc_plan* p, int enabled);
+/* How vc_step_exchange_and_update exchanges the gradients of a data-parallel step (N > 1 ranks; with one rank it only orders the updates):
+ *   VC_EXCHANGE_BUCKETED (default): 5 segments in the order they become final -- the discriminator half, then four generator buckets in
+ *     reverse layer order (9 ncclAllReduce calls, the generators' two ranges of a bucket in one group) -- each all-reduced and updated on
+ *     the update stream while the rest of the backward still runs;
+ *   VC_EXCHANGE_SINGLE: BASELINE.json's literal form -- ONE ncclAllReduce over the whole flat gradient (479 MB) after the backward, then
+ *     both updates.  Same arithmetic (SUM, 1/world folded into Adam); the A/B partner on multi-GPU hardware (bench.py --exchange). */
+#define VC_EXCHANGE_BUCKETED 0
+#define VC_EXCHANGE_SINGLE   1
+int vc_plan_set_exchange_mode(vc_plan* p, int mode);
+int vc_plan_get_exchange_mode(const vc_plan* p);
 
 /* Makes `other_stream` wait until the discriminator half of `grads` from the most recent
  * vc_cyclegan_step_grads on this plan is final (it is produced before the generator backward) AND the step has

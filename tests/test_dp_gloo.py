@@ -41,6 +41,11 @@ def _worker(rank, world, port, q):
     w1 = sync.all_reduce(flat[nG:], async_op=True)
     w2 = sync.all_reduce(flat[:nG], async_op=True)
     w1.wait(); w2.wait()
+    # ... and the single-collective form (engine.set_exchange_mode('single') / VC_EXCHANGE_SINGLE): ONE all-reduce over the flat buffer.
+    # A SUM over two ranks has one summation order: the two forms must agree bit for bit.
+    one = torch.from_numpy(_flatten({**Gg, **Gd}, names))
+    sync.all_reduce(one)
+    assert torch.equal(one, flat), 'single all-reduce != segmented all-reduce'
     avg = flat.numpy() * sync.scale
     # TF-Adam on the exchanged gradient (grad_scale = 1/world folded in, as vc_adam_tf_update does)
     opt = O.AdamTF(names, P)

@@ -122,6 +122,8 @@ SIGNATURES = [
     ('vc_step_workspace_floats', i64, [vp, i32]),
     ('vc_cyclegan_step_grads', i32, [vp, vp, vp, vp, vp, i32, f32, f32, vp, vp, vp, vp, i64, vp]),
     ('vc_plan_set_overlap', i32, [vp, i32]),
+    ('vc_plan_set_exchange_mode', i32, [vp, i32]),
+    ('vc_plan_get_exchange_mode', i32, [vp]),
     ('vc_step_wait_d_grads', i32, [vp, vp]),
     ('vc_step_num_g_buckets', i32, [vp]),
     ('vc_step_g_bucket', i32, [vp, i32, C.POINTER(i64), C.POINTER(i64)]),

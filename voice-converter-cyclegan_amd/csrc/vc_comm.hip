@@ -116,6 +116,15 @@ int step_update_impl(const vc_plan* p, const vc_comm* comm, float* params, float
         return launch_adam(params + lo, m + lo, v + lo, grads + lo, hi - lo, disc ? alpha_d : alpha_g, beta1, beta2, eps, gscale, us,
                            hp ? hp + (disc ? 3 : 2) : nullptr);
     };
+    if (vc_plan_get_exchange_mode(p) == VC_EXCHANGE_SINGLE) {
+        // the north star's literal form: ONE all-reduce of the whole flat gradient (479 MB) once the backward has finished, then both
+        // updates.  Nothing of the exchange is hidden under the backward: the A/B partner of the bucketed form below.
+        { int r = vc_step_wait_d_grads(p, us); if (r) return r; }
+        for (int k = 0; k < vc_step_num_g_buckets(p); ++k) { int r = vc_step_wait_g_bucket(p, k, us); if (r) return r; }
+        if (R) { VC_RCCL(R->AllReduce(grads, grads, (size_t)total, kFloat32, kSum, comm->comm, us)); ++comm->n_allreduce; }
+        { int r = seg(g0, d0, false); if (r) return r; }
+        return seg(d0, total, true);
+    }
     // discriminator half: one contiguous range
     { int r = vc_step_wait_d_grads(p, us); if (r) return r; }
     if (R) { VC_RCCL(R->AllReduce(grads + d0, grads + d0, (size_t)(total - d0), kFloat32, kSum, comm->comm, us)); ++comm->n_allreduce; }

@@ -101,6 +101,7 @@ struct vc_plan {
     // filter gradients are leaves of the backward chain: they run on their own stream behind one event per layer
     hipStream_t wstream = nullptr; hipEvent_t ev_layer[24] = {}; hipEvent_t ev_wjoin = nullptr;
     hipStream_t wstream_d = nullptr; hipEvent_t ev_layer_d[8] = {}; hipEvent_t ev_wjoin_d = nullptr;   // same for the discriminator chain
+    int exchange_mode = 0;        // vc_plan_set_exchange_mode: 0 bucketed (5 segments under the backward), 1 single (one all-reduce after it)
     int use_side = 7;             // bit 0: independent chains on the side stream; bit 1 / 2: generator / discriminator filter gradients on their own streams
     // generator gradient buckets: layers [first, last] of each generator become final (in reverse layer order) during
     // the last backward of the step; an event per bucket lets the caller overlap their all-reduce with the rest of it

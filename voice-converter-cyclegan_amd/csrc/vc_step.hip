@@ -342,6 +342,12 @@ extern "C" int vc_plan_set_overlap(vc_plan* p, int enabled) {
     p->use_side = enabled == 1 ? 7 : ((enabled >> 3) & 7);   // 0 / 1: the documented switch; 8 * bits selects single mechanisms (debugging)
     return 0;
 }
+extern "C" int vc_plan_set_exchange_mode(vc_plan* p, int mode) {
+    VC_ARG(p && (mode == VC_EXCHANGE_BUCKETED || mode == VC_EXCHANGE_SINGLE), "vc_plan_set_exchange_mode: plan, mode 0 (bucketed) or 1 (single)");
+    p->exchange_mode = mode;
+    return 0;
+}
+extern "C" int vc_plan_get_exchange_mode(const vc_plan* p) { return p ? p->exchange_mode : VC_E_STATE; }
 extern "C" int vc_step_num_g_buckets(const vc_plan* p) { return p ? vc_plan::kBuckets : 0; }
 extern "C" int vc_step_g_bucket(const vc_plan* p, int k, int64_t* lo, int64_t* hi) {
     VC_ARG(p && k >= 0 && k < vc_plan::kBuckets && lo && hi, "vc_step_g_bucket: bad args");

@@ -24,6 +24,7 @@ SCOPES = ('generator_A2B', 'generator_B2A', 'discriminator_A', 'discriminator_B'
 LOSS_NAMES = ('cycle_loss', 'identity_loss', 'generator_loss_A2B', 'generator_loss_B2A', 'generator_loss',
               'discriminator_loss_A', 'discriminator_loss_B', 'discriminator_loss')   # model.py:155-167
 MATH_MODES = {'fp32': 0, 'bf16': 1, 'bf16x3': 2}
+EXCHANGE_MODES = {'bucketed': 0, 'single': 1}       # vc_plan_set_exchange_mode
 
 
 def set_default_math(mode):
@@ -148,6 +149,7 @@ class CycleGANEngine:
         self._math = 'fp32'
         self._det = False
         self._overlap = True
+        self._exchange = 'bucketed'
         # single GPU: replay the whole step as one hipGraph (vc_train_step_graph).  Off by default: measured on ROCm 7.2 the
         # replay is SLOWER than launching the step's ~330 kernels on its five streams (B=1 3.49 vs 3.21 ms, B=8 8.06 vs 7.67)
         self.use_graph = False
@@ -217,6 +219,7 @@ class CycleGANEngine:
         check(lib.vc_plan_set_deterministic(h, int(self._det)), 'vc_plan_set_deterministic')
         if not self._overlap:
             lib.vc_plan_set_overlap(h, 0)
+        check(lib.vc_plan_set_exchange_mode(h, EXCHANGE_MODES[self._exchange]), 'vc_plan_set_exchange_mode')
         return h
 
     def plan(self, T):
@@ -227,6 +230,15 @@ class CycleGANEngine:
         self._overlap = bool(enabled)
         for h in self._plans.values():
             lib.vc_plan_set_overlap(h, int(self._overlap))
+
+    def set_exchange_mode(self, mode):
+        """'bucketed' (default): the gradient exchange as 5 segments under the backward; 'single': ONE all-reduce of the flat gradient
+        after it (BASELINE.json's literal form) -- vc_plan_set_exchange_mode; same arithmetic, the A/B partner on multi-GPU hardware"""
+        if mode not in EXCHANGE_MODES:
+            raise ValueError('exchange mode must be one of %s' % sorted(EXCHANGE_MODES))
+        self._exchange = mode
+        for h in self._plans.values():
+            check(lib.vc_plan_set_exchange_mode(h, EXCHANGE_MODES[mode]), 'vc_plan_set_exchange_mode')
 
     def set_math(self, mode):
         """Arithmetic of the conv kernels of THIS engine's plans (vc_plan_set_math_mode): 'fp32' (default, the reference's
@@ -312,6 +324,8 @@ class CycleGANEngine:
     def grad_segments(self, plan):
         """[(kind, index, [(lo, hi), ...])] in the order the segments become final inside step_grads:
         the discriminator half first, then the generator buckets (each bucket = one range per generator)."""
+        if self._exchange == 'single':
+            return [('all', 0, [(0, self.n_flat)])]
         segs = [('d', 0, [(self.nG2, self.n_flat)])]
         lo, hi = _lib.i64(0), _lib.i64(0)
         for k in range(lib.vc_step_num_g_buckets(plan)):
@@ -351,9 +365,12 @@ class CycleGANEngine:
             gs = float(self.sync.scale)
             with torch.cuda.stream(side):
                 for kind, k, ranges in self.grad_segments(plan):
-                    if kind == 'd':
+                    if kind in ('d', 'all'):
                         check(lib.vc_step_wait_d_grads(plan, cs), 'vc_step_wait_d_grads')
-                    else:
+                    if kind == 'all':
+                        for kk in range(lib.vc_step_num_g_buckets(plan)):
+                            check(lib.vc_step_wait_g_bucket(plan, kk, cs), 'vc_step_wait_g_bucket')
+                    elif kind == 'g':
                         check(lib.vc_step_wait_g_bucket(plan, k, cs), 'vc_step_wait_g_bucket')
                     if self.exchange_standin is not None:      # bench.py --dp-selftest: stand-in traffic where the collective would run
                         for lo, hi in ranges:
@@ -363,9 +380,13 @@ class CycleGANEngine:
                         ws = [self.sync.all_reduce(self.grads[lo:hi], async_op=True) for lo, hi in ranges]
                     for w in ws:
                         w.wait()                     # makes the side stream wait for the collective
-                    for lo, hi in ranges:
+                    if kind == 'all':              # one exchange, then the two optimizers' ranges
+                        ranges, kinds = [(0, self.nG2), (self.nG2, self.n_flat)], ('g', 'd')
+                    else:
+                        kinds = (kind,) * len(ranges)
+                    for (lo, hi), kd in zip(ranges, kinds):
                         check(lib.vc_adam_tf_update(ptr(self.params[lo:hi]), ptr(self.m[lo:hi]), ptr(self.v[lo:hi]),
-                                                    ptr(self.grads[lo:hi]), hi - lo, alphas[1 if kind == 'd' else 0],
+                                                    ptr(self.grads[lo:hi]), hi - lo, alphas[1 if kd == 'd' else 0],
                                                     ADAM_BETA1, ADAM_BETA2, ADAM_EPS, gs, cs), 'vc_adam_tf_update')
         main.wait_stream(side)
         if self.measure_exposed:
