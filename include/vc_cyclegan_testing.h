@@ -35,9 +35,13 @@ int  vc_tune_bf16_pixel_octets(int on);
  * mode (fixed summation order) without the rest of that mode, 0 = the atomic scatter (production).  The scatter's summation order is the one
  * run-to-run noise source of a split-K-free step that PROPAGATES: it feeds the generators' output gradients. */
 int  vc_tune_c1_dgrad_gather(int on);
+/* Single-GPU parameter update (vc_step_exchange_and_update without a communicator) for the calling thread's following steps: 1 (production) =
+ * ApplyAdam layer by layer in the order the backward finishes them, behind per-layer events the backward records; 0 = the four-bucket form of
+ * the multi-GPU exchange (no per-layer events recorded).  Control for timing and for the round-6 wrong-lane-group finding. */
+int  vc_tune_layer_updates(int on);
 /* Bit mask of the switches of this header that are NOT at their production value in the calling thread (0 = a product run; the product
  * header's vc_thread_is_product_run() is `== 0` of this).  bits: 1 igemm, 2 wgrad, 4 conv_bf16 override, 8 conv_bf16_spec, 16 pixel octets,
- * 32 rowskip, 64 wgrad_store, 128 glu, 256 c1 gather. */
+ * 32 rowskip, 64 wgrad_store, 128 glu, 256 c1 gather, 512 layer updates. */
 int  vc_testing_hooks_active(void);
 /* Which configuration did the calling thread's last conv forward / input-gradient launch (igemm) or filter-gradient launch
  * (wgrad) run with, and where did it come from?  out4 = {tile rows | columns, K groups, split-K, source}; source: 0 cost

@@ -627,9 +627,16 @@ def _check_step_golden(mode, B, F, T, fname, lam=(10.0, 5.0)):
             got = G[n_].astype(np.float32).reshape(-1)[::st]
             ref = z[k].reshape(-1)
             tol = tol_w + (flip if 'generator' in n_ else 0.0)
-            e = float(np.abs(got - ref).max() / (np.abs(ref).max() + 1e-30))
-            print('complete tensor %s (stride %d, %d elements): max err / max |ref| = %.3g' % (n_, st, ref.size, e))
-            assert e < tol, (n_, e, tol)
+            # `flip` bounds the RELATIVE L2 change of the L1 seed gradient (k flipped signs of N: 2 sqrt(k / N)), so the element-by-element
+            # comparison is held to it in L2; in the maximum norm ONE legitimately flipped sign moves 15 x 256 entries of o1's filter
+            # gradient by 2 lambda / N x |activation| each -- several times the L2 figure relative to the tensor's maximum (round 6: the
+            # fused norm epilogues changed the forward's rounding by 2e-6 rms, a different near-tie element flipped, 5.7e-3 here) -- so the
+            # maximum norm gets 5 x the bound: still far below what one WRONG element (an error of the size of the tensor's values) gives.
+            d = got.astype(np.float64) - ref.astype(np.float64)
+            e2 = float(np.linalg.norm(d) / (np.linalg.norm(ref.astype(np.float64)) + 1e-30))
+            e = float(np.abs(d).max() / (np.abs(ref).max() + 1e-30))
+            print('complete tensor %s (stride %d, %d elements): rel-L2 %.3g, max err / max |ref| = %.3g' % (n_, st, ref.size, e2, e))
+            assert e2 < tol and e < 5.0 * tol, (n_, e2, e, tol)
     eng.close()
 
 

@@ -39,3 +39,32 @@ for k, st in enumerate(steps):
     d = sorted((e - s) / 1e3 for s, e, _, _ in st)
     print('   kernel durations (us): min %.1f, p10 %.1f, median %.1f, p90 %.1f, max %.1f; kernels under 5 us: %d (%.0f us in total)'
           % (d[0], d[len(d) // 10], d[len(d) // 2], d[9 * len(d) // 10], d[-1], sum(1 for x in d if x < 5), sum(x for x in d if x < 5)))
+
+# ---- where the step is NOT multiplying: intervals in which no MFMA kernel (implicit GEMM, filter gradient, gated conv1d + GLU, bf16
+# conv) runs, and what runs instead -- the part of the step a faster convolution cannot shorten
+MFMA = ('igemm_kernel', 'wgrad_kernel', 'gated_conv1d_glu_kernel', 'conv_bf16_kernel', 'wsconv1d_kernel')
+for k, st in enumerate(steps[-1:]):
+    t0 = st[0][0]
+    mf = sorted((s, e) for s, e, n, _ in st if n.startswith(MFMA))
+    merged = []
+    for s, e in mf:
+        if merged and s <= merged[-1][1]:
+            merged[-1][1] = max(merged[-1][1], e)
+        else:
+            merged.append([s, e])
+    mu = sum(e - s for s, e in merged) / 1e3
+    wall = (st[-1][0] - t0) / 1e3
+    print('last step: wall %.1f us, some MFMA kernel running %.1f us (%.1f %%), none %.1f us' % (wall, mu, 100 * mu / wall, wall - mu))
+    holes = [(merged[i][1], merged[i + 1][0]) for i in range(len(merged) - 1) if merged[i + 1][0] > merged[i][1]]
+    holes = [(st[0][0], merged[0][0])] + holes
+    holes.sort(key=lambda h: h[0] - h[1])
+    print('   largest MFMA-free intervals (start us after the step began, length us, kernels overlapping it):')
+    for a, b in holes[:14]:
+        inside = sorted({n.split('<')[0] for s, e, n, _ in st if s < b and e > a and not n.startswith(MFMA)})
+        print('     +%7.1f  %6.1f us  %s' % ((a - t0) / 1e3, (b - a) / 1e3, ', '.join(inside)[:150]))
+    # how long does each MFMA kernel run alone vs beside another MFMA kernel?
+    pts = sorted([(s, 1) for s, e in mf] + [(e, -1) for s, e in mf])
+    lvl, last, hist = 0, pts[0][0], defaultdict(float)
+    for t, d in pts:
+        hist[lvl] += (t - last) / 1e3; last = t; lvl += d
+    print('   MFMA kernels in flight: ' + ', '.join('%d: %.0f us' % (l, v) for l, v in sorted(hist.items()) if l > 0))

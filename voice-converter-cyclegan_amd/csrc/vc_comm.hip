@@ -103,6 +103,9 @@ extern "C" int vc_allreduce_f32(const vc_comm* c, float* buf, int64_t n, void* s
 // final before the generator backward starts), then the generator buckets in reverse layer order.  Each segment is
 // all-reduced (SUM over the ranks of `comm`; comm == NULL: single GPU, no collective) and then updated in place with the
 // 1/world factor folded into Adam.  All but the last small bucket ride under the rest of the backward.
+bool layer_events_on();                                    // vc_net.hip
+int step_num_layer_segments(const vc_plan* p);             // vc_step.hip
+int step_layer_segment(const vc_plan* p, int k, int64_t* lo0, int64_t* lo1, int64_t* n, int* disc, hipStream_t us);
 int step_update_impl(const vc_plan* p, const vc_comm* comm, float* params, float* grads, float* m, float* v,
                      float alpha_g, float alpha_d, const float* hp, float beta1, float beta2, float eps, hipStream_t us) {
     VC_ARG(p && params && grads && m && v, "vc_step_exchange_and_update: bad args");
@@ -124,6 +127,18 @@ int step_update_impl(const vc_plan* p, const vc_comm* comm, float* params, float
         if (R) { VC_RCCL(R->AllReduce(grads, grads, (size_t)total, kFloat32, kSum, comm->comm, us)); ++comm->n_allreduce; }
         { int r = seg(g0, d0, false); if (r) return r; }
         return seg(d0, total, true);
+    }
+    if (!comm && layer_events_on()) {
+        // one GPU, nothing to exchange: ApplyAdam layer by layer in the order the backward finishes them (D.d3 .. D.h1, G.o1 .. G.h1),
+        // each layer of both networks of a kind as soon as its gradient is final and its weights are no longer read.  Same arithmetic
+        // as the segmented form (Adam is elementwise); what is left after the backward has ended is G.h1's 0.4 MB instead of a bucket.
+        for (int k = 0; k < step_num_layer_segments(p); ++k) {
+            int64_t lo0 = 0, lo1 = 0, n = 0; int disc = 0;
+            { int r = step_layer_segment(p, k, &lo0, &lo1, &n, &disc, us); if (r) return r; }
+            { int r = seg(lo0, lo0 + n, disc != 0); if (r) return r; }
+            { int r = seg(lo1, lo1 + n, disc != 0); if (r) return r; }
+        }
+        return 0;
     }
     // discriminator half: one contiguous range
     { int r = vc_step_wait_d_grads(p, us); if (r) return r; }

@@ -1202,6 +1202,14 @@ int launch_loss(const LossArgs& a, hipStream_t s) {
     const long n1 = (long)a.B * a.FT;
     long blocks = (n1 + 255) / 256; if (blocks > VC_LOSS_BLOCKS) blocks = VC_LOSS_BLOCKS; if (blocks < 1) blocks = 1;
     loss_kernel<<<dim3((unsigned)blocks), 256, 0, s>>>(a);
+    VC_HIP(hipGetLastError());
+    return 0;
+}
+// the 8 logged scalars from the per-block partial sums.  Nothing of the backward needs them: the step issues this launch on its side
+// stream behind the discriminator_loss backward instead of between the loss kernel and the first backward kernels of both chains
+int launch_loss_finalize(const LossArgs& a, hipStream_t s) {
+    const long n1 = (long)a.B * a.FT;
+    long blocks = (n1 + 255) / 256; if (blocks > VC_LOSS_BLOCKS) blocks = VC_LOSS_BLOCKS; if (blocks < 1) blocks = 1;
     loss_finalize_kernel<<<1, 256, 0, s>>>(a.acc, (int)blocks, a.losses, (float)n1, (float)((long)a.B * a.HW),
                                            a.lambda_cycle, a.lambda_identity, a.hp);
     VC_HIP(hipGetLastError());

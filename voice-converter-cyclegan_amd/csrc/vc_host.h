@@ -112,6 +112,11 @@ struct vc_plan {
     // the main stream, the filter gradients on the wgrad stream): after both, the caller may update them in place
     hipEvent_t g_free[kBuckets] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t d_free = nullptr;                          // last read of the discriminator weights (generator_loss path)
+    // the same two moments PER LAYER (single-GPU update: vc_step_exchange_and_update without a communicator runs ApplyAdam layer by layer
+    // in backward order, each layer as soon as its gradient is final and its weights are no longer read -- at batch 1 the four-bucket
+    // form left 0.3 ms of a 2.9 ms step waiting for the update after the backward had ended, profiles/r06_timeline_b1.txt).
+    // Discriminator weights have two readers: the discriminator_loss backward (side stream) and the generator_loss backward (main).
+    hipEvent_t gl_ready[24] = {}, gl_free[24] = {}, dl_ready[8] = {}, dl_free_d[8] = {}, dl_free_g[8] = {};
     // captured train steps (vc_train_step_graph): one executable graph per (batch, schedule, buffer set)
     struct StepGraph { std::array<const void*, 12> key; hipGraph_t graph; hipGraphExec_t exec; };
     std::vector<StepGraph> graphs;
@@ -140,7 +145,8 @@ struct BwdOpts { bool record_buckets = false, wgrad_store = false; int wmode = W
                  unsigned* q_ready_out = nullptr; unsigned* dy_dropped_out = nullptr;
                  // the caller guarantees that every reader of a layer's dy takes the octet forms whenever the norm backward wrote them
                  // (inside a train step: yes): the fp32 copy is then not written at all
-                 bool drop_fp32_dy = false; };
+                 bool drop_fp32_dy = false;
+                 bool prezeroed = false; };   // backward_prezero ran for this pass (same scratch, batch, groups) earlier in stream order
 int gen_forward(const vc_plan* p, const float* params, long par_gs, const float* x, long x_gs,
                 float* y, long y_gs, float* save, int G, int B, hipStream_t s);
 int gen_backward(const vc_plan* p, const float* params, long par_gs, const float* x, long x_gs,
@@ -152,6 +158,8 @@ int disc_forward(const vc_plan* p, const float* params, long par_gs, const float
 int disc_backward(const vc_plan* p, const float* params, long par_gs, const float* x, long x_gs,
                   const float* o, long o_gs, const float* dout, long do_gs, float* save, int Bl,
                   float* dparams, long dpar_gs, float* dx, long dx_gs, int dx_acc,
-                  float* scratch, long scr_gs, int G, int B, hipStream_t s, bool wgrad_store = false, bool drop_fp32_dy = false);
+                  float* scratch, long scr_gs, int G, int B, hipStream_t s, bool wgrad_store = false, bool drop_fp32_dy = false,
+                  bool record_layers = false, bool prezeroed = false);
+int backward_prezero(const vc_plan* p, bool gen, float* scratch, long scr_gs, int G, int B, hipStream_t s);   // record_layers (train step): the plan's per-layer events dl_ready / dl_free_d (dparams) or dl_free_g
 // The step's prebuilt filter images describe `params` of the running step: only the step hands them to its network passes
 struct StepImages { explicit StepImages(const vc_plan* p); ~StepImages(); };

@@ -230,6 +230,7 @@ struct LossArgs {
 };
 #define VC_LOSS_BLOCKS 256
 int launch_loss(const LossArgs& a, hipStream_t s);
+int launch_loss_finalize(const LossArgs& a, hipStream_t s);
 int launch_crop_batch(const float* src, const long* off, const int* len, const int* start, float* out,
                       int N, int F, int n_frames, hipStream_t s);
 int launch_mean_loss(const float* y, const float* yh, long n, int squared, float* loss, float* d_yhat, hipStream_t s);
@@ -268,5 +269,6 @@ struct TestHooks {
     int wgrad_store = 0;                               // vc_tune_wgrad_store
     int glu_flags = 0;                                 // vc_tune_glu
     int c1_gather = 0;                                 // vc_tune_c1_dgrad_gather
+    int layer_updates = 1;                             // vc_tune_layer_updates
 };
 const TestHooks& vc_hooks();

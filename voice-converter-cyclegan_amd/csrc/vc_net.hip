@@ -159,6 +159,12 @@ static int plan_create(int num_features, int n_frames, bool inference, vc_plan**
     for (int k = 0; k < vc_plan::kBuckets && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&p->g_ready[k], hipEventDisableTiming);
     for (int k = 0; k < vc_plan::kBuckets && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&p->g_free[k], hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&p->d_free, hipEventDisableTiming);
+    for (int k = 0; k < 24 && e == hipSuccess; ++k) { e = hipEventCreateWithFlags(&p->gl_ready[k], hipEventDisableTiming); if (e == hipSuccess) e = hipEventCreateWithFlags(&p->gl_free[k], hipEventDisableTiming); }
+    for (int k = 0; k < 8 && e == hipSuccess; ++k) {
+        e = hipEventCreateWithFlags(&p->dl_ready[k], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&p->dl_free_d[k], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&p->dl_free_g[k], hipEventDisableTiming);
+    }
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->gstream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->ustream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_gin, hipEventDisableTiming);
@@ -187,6 +193,8 @@ extern "C" void vc_plan_destroy(vc_plan* p) {
     for (hipEvent_t ev : p->g_ready) if (ev) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : p->g_free) if (ev) (void)hipEventDestroy(ev);
     if (p->d_free) (void)hipEventDestroy(p->d_free);
+    for (auto* arr : {p->gl_ready, p->gl_free}) for (int k = 0; k < 24; ++k) if (arr[k]) (void)hipEventDestroy(arr[k]);
+    for (auto* arr : {p->dl_ready, p->dl_free_d, p->dl_free_g}) for (int k = 0; k < 8; ++k) if (arr[k]) (void)hipEventDestroy(arr[k]);
     for (auto& g : p->graphs) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); }
     if (p->gstream) (void)hipStreamDestroy(p->gstream);
     if (p->ustream) (void)hipStreamDestroy(p->ustream);
@@ -277,11 +285,13 @@ struct NetCtx {
     bool fuse_glu = false;                 // forward only: gated blocks without instance norm go out as one conv + GLU kernel
     unsigned* q_ready_out = nullptr;       // W_NONE passes report which layers' dY they left as pixel octets (BwdOpts::q_ready_out)
     unsigned* dy_dropped_out = nullptr; bool drop_dy = false;   // BwdOpts::drop_fp32_dy
+    bool prezeroed = false;                // the split-K dA buffers of this pass were zeroed ahead of time (backward_prezero)
     int wmode = W_SELF;                    // W_NONE: leave the conv filter gradients to a later application (DeferredApp)
     bool wgrad_store = false;              // this backward's filter gradients are the step's only contribution to dparams' conv kernels
     const DeferredApp* deferred = nullptr; // reduce this earlier application in the same launches
     const int* ev_first = nullptr; const hipEvent_t* ev = nullptr; int n_ev = 0;   // record ev[k] once layer ev_first[k] is done (backward)
     const hipEvent_t* ev_free = nullptr;                                            // ... and ev_free[k] after its input gradient is issued
+    const hipEvent_t* lay_ready = nullptr; const hipEvent_t* lay_free = nullptr;    // the same per layer (backward): [i] after layer i's filter gradient / input gradient is issued
 };
 // scratch map of one group: dY[i], dA[i] per layer (dA[i] = gradient w.r.t. the activation (output) of layer i)
 static long scratch_map(const std::vector<LayerGeo>& geo, int B, long* dY, long* dA, long* dYq = nullptr) {      // returns the offset of the packed-dY region
@@ -324,6 +334,7 @@ void describe_scratch(std::string& out, const char* tag, const std::vector<Layer
     }
 }
 
+bool layer_events_on() { return vc_hooks().layer_updates != 0; }
 static int net_forward(NetCtx& c, const float* x, long x_gs, float* y_plain, long y_plain_gs) {
     // one launch zeroes every raw conv output of this pass whose convolution will reduce over split-K with atomics
     bool plain_zeroed = true;
@@ -408,6 +419,22 @@ static int net_forward(NetCtx& c, const float* x, long x_gs, float* y_plain, lon
 // plain layer; for the discriminator: gradient w.r.t. the last GLU output, produced by the head).
 // vc_hooks().pixel_octets (tests): 0 = the norm backward leaves dy in fp32 only for the filter gradient (which then packs its pixel octets
 // itself: the round-4 path), 2 = octets written and the fp32 copy kept
+// one launch zeroes every dA of a backward pass that a split-K input gradient will accumulate into.  Part of the pass itself, or -- for the
+// passes whose scratch nobody else uses earlier in the step -- issued ahead of time on the side stream (BwdOpts::prezeroed: the launch sat
+// alone on the chip between the loss and the first backward kernels of both chains, profiles/r06_timeline_b8.txt)
+static int zero_split_dA(const NetCtx& c, float* scratch, long scr_gs) {
+    const int nl = (int)c.n->layers.size();
+    VC_ARG(nl <= 24, "net_backward: more than 24 layers");
+    long dYo[24], dAo[24];
+    scratch_map(*c.geo, c.B, dYo, dAo, nullptr);
+    std::vector<std::pair<float*, long>> zl;
+    for (int i = 1; i < nl; ++i) {
+        bool split = false;
+        VC_CHECK(conv_dgrad(nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, c.G, c.B, (*c.geo)[i].g, c.math, c.s, false, &split));
+        if (split) for (int g = 0; g < c.G; ++g) zl.push_back({scratch + dAo[i - 1] + (long)g * scr_gs, (*c.geo)[i - 1].act_ps * c.B});
+    }
+    return zl.empty() ? 0 : launch_zero_list(zl, c.s);
+}
 static int net_backward(NetCtx& c, const float* x, long x_gs, const float* dtop, long dtop_gs,
                         float* dx, long dx_gs, int dx_acc, float* scratch, long scr_gs) {
     const int nl = (int)c.n->layers.size();
@@ -419,16 +446,7 @@ static int net_backward(NetCtx& c, const float* x, long x_gs, const float* dtop,
     if (c.deferred) scratch_map(*c.geo, c.deferred->B, dYd, dAd, qmap ? dYqd : nullptr);
     unsigned q_ready = 0, dy_dropped = 0;
     hipStream_t ws = c.ws ? c.ws : c.s;       // the plan sizes its event pools for its own networks (18 / 4 layers)
-    // one launch zeroes every dA that a split-K input-gradient will accumulate into
-    {
-        std::vector<std::pair<float*, long>> zl;
-        for (int i = 1; i < nl; ++i) {
-            bool split = false;
-            VC_CHECK(conv_dgrad(nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, c.G, c.B, (*c.geo)[i].g, c.math, c.s, false, &split));
-            if (split) for (int g = 0; g < c.G; ++g) zl.push_back({scratch + dAo[i - 1] + (long)g * scr_gs, (*c.geo)[i - 1].act_ps * c.B});
-        }
-        if (!zl.empty()) VC_CHECK(launch_zero_list(zl, c.s));
-    }
+    if (!c.prezeroed) VC_CHECK(zero_split_dA(c, scratch, scr_gs));
     const float* dcur = dtop; long dcur_gs = dtop_gs;   // gradient w.r.t. the output activation of layer i
     const float* skip = nullptr; long skip_gs = 0;      // gradient flowing around a residual block (module.py:81)
     for (int i = nl - 1; i >= 0; --i) {
@@ -499,10 +517,12 @@ static int net_backward(NetCtx& c, const float* x, long x_gs, const float* dtop,
             VC_CHECK(conv_wgrad(apps, na, c.dparams + L.w, c.dpar_gs, c.G, lg.g, c.math, ws, c.wgrad_store, nullptr, qmap ? &pq : nullptr));
         }
         for (int k = 0; k < c.n_ev; ++k) if (c.ev_first[k] == i) VC_HIP(hipEventRecord(c.ev[k], ws));
+        if (c.lay_ready && layer_events_on()) VC_HIP(hipEventRecord(c.lay_ready[i], ws));
         if (i == 0) {
             if (dx) VC_CHECK(conv_dgrad(dyp, dy_gs, c.params + L.w, c.par_gs, dx, dx_gs, nullptr, 0, dx_acc, c.G, c.B, lg.g, c.math, c.s,
                                         false, nullptr, (c.images && (*c.images)[i].has_dg) ? (*c.images)[i].dg : nullptr, dy_packed, scr_gs * 4));
             for (int k = 0; k < c.n_ev; ++k) if (c.ev_free && c.ev_first[k] == i) VC_HIP(hipEventRecord(c.ev_free[k], c.s));
+            if (c.lay_free && layer_events_on()) VC_HIP(hipEventRecord(c.lay_free[i], c.s));
             break;        // falls through to the join below
         }
         // gradient w.r.t. this layer's input = activation of layer i-1; the head of a residual block adds the skip
@@ -512,6 +532,7 @@ static int net_backward(NetCtx& c, const float* x, long x_gs, const float* dtop,
                             nullptr, (c.images && (*c.images)[i].has_dg) ? (*c.images)[i].dg : nullptr, dy_packed, scr_gs * 4));
         if (block_head) skip = nullptr;
         for (int k = 0; k < c.n_ev; ++k) if (c.ev_free && c.ev_first[k] == i) VC_HIP(hipEventRecord(c.ev_free[k], c.s));
+        if (c.lay_free && layer_events_on()) VC_HIP(hipEventRecord(c.lay_free[i], c.s));
         dcur = scratch + dAo[i - 1]; dcur_gs = scr_gs;
     }
     if (ws != c.s) { VC_HIP(hipEventRecord(c.ev_wjoin, ws)); VC_HIP(hipStreamWaitEvent(c.s, c.ev_wjoin, 0)); }   // join
@@ -558,11 +579,17 @@ int gen_backward(const vc_plan* p, const float* params, long par_gs, const float
                         const BwdOpts& o) {
     VC_ARG(!p->inference, "this plan was created for inference only (vc_plan_create_inference)");
     NetCtx c = gen_ctx(p, params, par_gs, dparams, dpar_gs, save, G, B, Bl, s);
+    c.prezeroed = o.prezeroed;
     c.wgrad_store = o.wgrad_store; c.wmode = o.wmode; c.deferred = o.deferred; c.q_ready_out = o.q_ready_out; c.dy_dropped_out = o.dy_dropped_out; c.drop_dy = o.drop_fp32_dy;
     c.images = step_images(p, true, G); c.keep_packed = c.images != nullptr;
     if ((p->use_side & 2) && dparams && o.wmode != W_NONE) { c.ws = p->wstream; c.ev_layer = p->ev_layer; c.ev_wjoin = p->ev_wjoin; }
-    if (o.record_buckets) { c.ev_first = p->bucket_first; c.ev = p->g_ready; c.ev_free = p->g_free; c.n_ev = vc_plan::kBuckets; }
+    if (o.record_buckets) { c.ev_first = p->bucket_first; c.ev = p->g_ready; c.ev_free = p->g_free; c.n_ev = vc_plan::kBuckets; c.lay_ready = p->gl_ready; c.lay_free = p->gl_free; }
     return net_backward(c, x, x_gs, dy, dy_gs, dx, dx_gs, dx_acc, scratch, scr_gs);
+}
+// the zero launch of a later gen_backward / disc_backward at batch B on this scratch, issued now on stream s (BwdOpts::prezeroed)
+int backward_prezero(const vc_plan* p, bool gen, float* scratch, long scr_gs, int G, int B, hipStream_t s) {
+    NetCtx c = gen ? gen_ctx(p, nullptr, 0, nullptr, 0, nullptr, G, B, B, s) : disc_ctx(p, nullptr, 0, nullptr, 0, nullptr, G, B, B, s);
+    return zero_split_dA(c, scratch, scr_gs);
 }
 int disc_forward(const vc_plan* p, const float* params, long par_gs, const float* x, long x_gs,
                         float* o, long o_gs, float* save, int G, int B, hipStream_t s) {
@@ -578,11 +605,13 @@ int disc_forward(const vc_plan* p, const float* params, long par_gs, const float
 int disc_backward(const vc_plan* p, const float* params, long par_gs, const float* x, long x_gs,
                          const float* o, long o_gs, const float* dout, long do_gs, float* save, int Bl,
                          float* dparams, long dpar_gs, float* dx, long dx_gs, int dx_acc,
-                         float* scratch, long scr_gs, int G, int B, hipStream_t s, bool wgrad_store, bool drop_fp32_dy) {
+                         float* scratch, long scr_gs, int G, int B, hipStream_t s, bool wgrad_store, bool drop_fp32_dy, bool record_layers, bool prezeroed) {
     VC_ARG(!p->inference, "this plan was created for inference only (vc_plan_create_inference)");
     NetCtx c = disc_ctx(p, params, par_gs, dparams, dpar_gs, save, G, B, Bl, s);
     c.wgrad_store = wgrad_store; c.drop_dy = drop_fp32_dy;
     c.images = step_images(p, false, G); c.keep_packed = c.images != nullptr;
+    c.prezeroed = prezeroed;
+    if (record_layers) { if (dparams) { c.lay_ready = p->dl_ready; c.lay_free = p->dl_free_d; } else c.lay_free = p->dl_free_g; }
     if ((p->use_side & 4) && dparams) { c.ws = p->wstream_d; c.ev_layer = p->ev_layer_d; c.ev_wjoin = p->ev_wjoin_d; }
     const int last = (int)p->D.layers.size() - 1;
     // the head's input gradient goes where net_backward's scratch map puts dA[last]

@@ -198,6 +198,13 @@ static int step_grads_impl(const vc_plan* p, const float* params, float* grads,
     // passes (behind the join after the discriminator forward)
     if (!later_images.empty()) VC_CHECK(launch_pack_filter_multi(later_images, 2, s2));
     VC_CHECK(zero_step_grads(p, grads, B, Bbwd, s2));
+    // ... and the split-K destinations of the three backward passes whose scratch is theirs alone until they run (step 10 shares SCR with step 8)
+    const bool pz = s2 != s;
+    if (pz) {
+        VC_CHECK(backward_prezero(p, false, ws + m.SCR2, align64(m.scr_gs), 2, 2 * B, s2));
+        VC_CHECK(backward_prezero(p, false, ws + m.SCR, align64(m.scr_gs), 2, B, s2));
+        VC_CHECK(backward_prezero(p, true, ws + m.SCRC, align64(m.scrc_gs), 2, B, s2));
+    }
     // 2. O1[g0] = [gen_B; id_B], O1[g1] = [gen_A; id_A]
     VC_CHECK(gen_forward(p, params, PG, X1, X1g, O1, O1g, S1, 2, 2 * B, s));
     // Two pairs of chains are independent and run side by side (main stream s / side stream s2, fork+join by events):
@@ -230,17 +237,19 @@ static int step_grads_impl(const vc_plan* p, const float* params, float* grads,
     VC_CHECK(fork());
     // 7. discriminator_loss backward over [fake; real] -> D gradients (model.py:94,107)   [side stream, own scratch]
     VC_CHECK(disc_backward(p, params + 2 * PG, PD, DX, DXg, DO, DOg, dDO_D, dDDg, SD, 2 * B,
-                           grads + 2 * PG, PD, nullptr, 0, 0, ws + m.SCR2, scr_gs, 2, 2 * B, s2, /*wgrad_store=*/true, /*drop_fp32_dy=*/true));
+                           grads + 2 * PG, PD, nullptr, 0, 0, ws + m.SCR2, scr_gs, 2, 2 * B, s2, /*wgrad_store=*/true, /*drop_fp32_dy=*/true, /*record_layers=*/true, /*prezeroed=*/pz));
+    VC_CHECK(launch_loss_finalize(la, s2));    // the 8 scalars: off the backward's critical path (joined with the side stream before the step returns)
     VC_HIP(hipEventRecord(p->d_ready, s2));
     // 8. adversarial generator terms: gradient through D's inputs only (var_list = generator_vars, model.py:95,108)
     //    g0 = D_A -> d gen_A = dO1[g1][0:B]; g1 = D_B -> d gen_B = dO1[g0][0:B]
     VC_CHECK(disc_backward(p, params + 2 * PG, PD, DX, DXg, DO, DOg, dDO_G, dDGg, SD, 2 * B,
-                           nullptr, 0, dO1 + dO1g, -dO1g, 0, SCR, scr_gs, 2, B, s, /*wgrad_store=*/false, /*drop_fp32_dy=*/true));
+                           nullptr, 0, dO1 + dO1g, -dO1g, 0, SCR, scr_gs, 2, B, s, /*wgrad_store=*/false, /*drop_fp32_dy=*/true, /*record_layers=*/true, /*prezeroed=*/pz));
     VC_HIP(hipEventRecord(p->d_free, s));     // last read of the discriminator weights in this step
     // 9. cycle hop backward: g0 = A2B on gen_A -> adds into d gen_A; g1 = B2A on gen_B -> d gen_B.  Its filter
     //    gradients are NOT launched here: step 10 reduces both applications of every layer in one launch.
     unsigned cyc_q_ready = 0, cyc_dy_dropped = 0;   // layers whose cycle-hop dY already lies in SCRC's stacked pixel-octet buffers (bf16 data path)
     BwdOpts oc; oc.wmode = W_NONE; oc.q_ready_out = &cyc_q_ready; oc.dy_dropped_out = &cyc_dy_dropped;
+    oc.prezeroed = pz;
     oc.drop_fp32_dy = true;                 // this step's first-hop pass reduces at most 2 B more samples: it always takes the stacked buffers
     VC_CHECK(gen_backward(p, params, PG, O1 + O1g, -O1g, dCY, dCYg, S2, B, grads, PG,
                           dO1 + dO1g, -dO1g, 1, SCRC, scrc_gs, 2, B, s, oc));
@@ -361,6 +370,22 @@ extern "C" int vc_step_wait_g_bucket(const vc_plan* p, int k, void* other_stream
     VC_ARG(p && k >= 0 && k < vc_plan::kBuckets, "vc_step_wait_g_bucket: bad args");
     VC_HIP(hipStreamWaitEvent((hipStream_t)other_stream, p->g_ready[k], 0));
     VC_HIP(hipStreamWaitEvent((hipStream_t)other_stream, p->g_free[k], 0));
+    return 0;
+}
+// single-GPU update: one segment per LAYER, in the order the backward finishes them (vc_comm.hip: step_update_impl without a communicator)
+int step_num_layer_segments(const vc_plan* p) { return (int)(p->D.layers.size() + p->G.layers.size()); }
+int step_layer_segment(const vc_plan* p, int k, int64_t* lo0, int64_t* lo1, int64_t* n, int* disc, hipStream_t us) {
+    const int nD = (int)p->D.layers.size(), nG = (int)p->G.layers.size();
+    const bool d = k < nD;
+    const int i = d ? nD - 1 - k : nG - 1 - (k - nD);              // backward order: D.d3 .. D.h1, then G.o1 .. G.h1
+    const NetDesc& net = d ? p->D : p->G;
+    const long lo = net.layers[i].w, hi = (i + 1 < (int)net.layers.size()) ? net.layers[i + 1].w : net.total;   // D's last layer takes the dense head with it
+    *lo0 = vc_flat_offset(p, d ? 2 : 0) + lo; *lo1 = vc_flat_offset(p, d ? 3 : 1) + lo; *n = hi - lo; *disc = d ? 1 : 0;
+    if (d) {
+        VC_HIP(hipStreamWaitEvent(us, p->dl_ready[i], 0)); VC_HIP(hipStreamWaitEvent(us, p->dl_free_d[i], 0)); VC_HIP(hipStreamWaitEvent(us, p->dl_free_g[i], 0));
+    } else {
+        VC_HIP(hipStreamWaitEvent(us, p->gl_ready[i], 0)); VC_HIP(hipStreamWaitEvent(us, p->gl_free[i], 0));
+    }
     return 0;
 }
 extern "C" int vc_step_wait_d_grads(const vc_plan* p, void* other_stream) {
