@@ -39,9 +39,15 @@ int  vc_tune_c1_dgrad_gather(int on);
  * ApplyAdam layer by layer in the order the backward finishes them, behind per-layer events the backward records; 0 = the four-bucket form of
  * the multi-GPU exchange (no per-layer events recorded).  Control for timing and for the round-6 wrong-lane-group finding. */
 int  vc_tune_layer_updates(int on);
+/* fp32 mode, calling thread's following convolutions: 1 (production) = forward and input gradient of the 3-tap stride-1 1-D convolutions
+ * whose width is a multiple of 4 (the residual blocks, module.py:66-83) run as Winograd F(4,3): six channel GEMMs in the transform domain
+ * (csrc/vc_conv_wino.hip); 0 = the direct implicit GEMM for every convolution (the control of the parity tests and of the A/B timing). */
+int  vc_tune_winograd(int on);
+/* Winograd-domain GEMM launches (one per convolution forward / input gradient on the route) the calling thread has issued; reset != 0 clears. */
+long long vc_testing_wino_gemms(int reset);
 /* Bit mask of the switches of this header that are NOT at their production value in the calling thread (0 = a product run; the product
  * header's vc_thread_is_product_run() is `== 0` of this).  bits: 1 igemm, 2 wgrad, 4 conv_bf16 override, 8 conv_bf16_spec, 16 pixel octets,
- * 32 rowskip, 64 wgrad_store, 128 glu, 256 c1 gather, 512 layer updates. */
+ * 32 rowskip, 64 wgrad_store, 128 glu, 256 c1 gather, 512 layer updates, 1024 winograd. */
 int  vc_testing_hooks_active(void);
 /* Which configuration did the calling thread's last conv forward / input-gradient launch (igemm) or filter-gradient launch
  * (wgrad) run with, and where did it come from?  out4 = {tile rows | columns, K groups, split-K, source}; source: 0 cost

@@ -522,3 +522,78 @@ def test_bias_grad_and_adam(built_lib):
         opt.apply(P, {'generator_x': g}, 2e-4)
         got = p_d.cpu().numpy()[:n]
         assert np.abs(got - P['generator_x']).max() < 2e-7, (step, np.abs(got - P['generator_x']).max())
+
+
+# ---- Winograd F(4,3) route (csrc/vc_conv_wino.hip): forward and input gradient of 3-tap stride-1 1-D convolutions in fp32 mode
+WINO_CASES = [
+    # Cin, W, Cout, B
+    (512, 32, 2048, 8),        # residual h1, cycle hop of the batch-8 step: 64 pixels per transform position = the route's threshold
+    (1024, 32, 512, 16),       # residual h2, first hop
+    (64, 8, 64, 32),           # two tiles a row: both are edge tiles
+    (128, 64, 96, 4),          # 36 x 256 geometry's frame count (16 tiles a row), Cout not a multiple of 64
+    (96, 12, 64, 24),          # three tiles a row (W = 12), Cin = 96
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', WINO_CASES)
+def test_winograd_route_against_the_oracle_and_the_direct_kernel(built_lib, case):
+    """module.py:66-83 (conv1d, kernel 3, stride 1, SAME): the Winograd route (production in fp32 mode) against the oracle at the operator
+    tolerance and against the direct implicit GEMM (vc_tune_winograd(0)) at 2e-5 of the tensor's maximum -- the route changes the summation
+    order and adds the rounding of its transforms (2-3e-6 measured against fp64), nothing else; addend / accumulate semantics of the input
+    gradient included.  The launch counter proves which route ran."""
+    from tests import gpu_util as U
+    lib, check = built_lib.lib, built_lib.check
+    O = _oracle()
+    Cin, W, Cout, B = case
+    rng = np.random.default_rng(hash(case) % (2 ** 31))
+    G = 2
+    xs = rng.standard_normal((G, B, W, Cin)).astype(np.float32)
+    ws = (rng.standard_normal((G, 1, 3, Cin, Cout)) / np.sqrt(3 * Cin)).astype(np.float32)
+    bs = rng.uniform(-0.5, 0.5, (G, Cout)).astype(np.float32)
+    ys, dxs, dys = [], [], []
+    for g in range(G):
+        y, cache = O.conv1d_fwd(xs[g], ws[g][0], bs[g], 1)
+        dy = rng.standard_normal(y.shape).astype(np.float32)
+        dx, _, _ = O.conv1d_bwd(dy, ws[g][0], cache)
+        ys.append(y); dxs.append(dx); dys.append(dy)
+    cf = lambda a: np.ascontiguousarray(np.transpose(np.stack(a), (0, 1, 3, 2)))[:, :, :, None, :]      # [G, B, C, 1, W]
+    x_d, w_d, b_d, dy_d = U.dev(cf(list(xs))), U.dev(ws), U.dev(bs), U.dev(cf(dys))
+    add = U.dev(rng.standard_normal(cf(dxs).shape).astype(np.float32)); init = U.dev(rng.standard_normal(cf(dxs).shape).astype(np.float32))
+    out = {}
+    try:
+        for on in (1, 0):
+            check(lib.vc_tune_winograd(on)); lib.vc_testing_wino_gemms(1)
+            y = U.conv_fwd(x_d, w_d, b_d, 1, 3, 1, 1)
+            dx = U.conv_dgrad(dy_d, w_d, 1, W, 1, 3, 1, 1)
+            dx2 = U.conv_dgrad(dy_d, w_d, 1, W, 1, 3, 1, 1, addend=add, init=init)
+            assert lib.vc_testing_wino_gemms(1) == (3 if on else 0)
+            out[on] = (y.cpu().numpy(), dx.cpu().numpy(), dx2.cpu().numpy())
+            assert U.rel_err(out[on][0], cf(ys)) < TOL and U.rel_err(out[on][1], cf(dxs)) < TOL
+            assert U.rel_err(out[on][2], cf(dxs) + add.cpu().numpy() + init.cpu().numpy()) < TOL
+    finally:
+        check(lib.vc_tune_winograd(1))
+    for a, b in zip(out[1], out[0]):
+        e = U.rel_err(a, b)
+        print('winograd vs direct: %.2e' % e)
+        assert e < 2e-5
+
+
+@pytest.mark.gpu
+def test_winograd_route_leaves_other_geometries_alone(built_lib):
+    """stride 2, 5 taps, 2-D, a width that is not a multiple of 4, bf16 mode, fewer than 64 pixels per transform position: the direct kernels"""
+    from tests import gpu_util as U
+    lib, check = built_lib.lib, built_lib.check
+    lib.vc_testing_wino_gemms(1)
+    for Cin, H, W, Cout, kh, kw, sh, sw, B in [(64, 1, 32, 64, 1, 3, 1, 2, 8), (64, 1, 32, 64, 1, 5, 1, 1, 8), (64, 4, 32, 64, 3, 3, 1, 1, 8),
+                                                (64, 1, 30, 64, 1, 3, 1, 1, 16), (64, 1, 32, 64, 1, 3, 1, 1, 4)]:
+        x = torch.randn((2, B, Cin, H, W), device=U.DEV); w = torch.randn((2, kh, kw, Cin, Cout), device=U.DEV) * 0.05; b = torch.zeros((2, Cout), device=U.DEV)
+        U.conv_fwd(x, w, b, kh, kw, sh, sw)
+    assert lib.vc_testing_wino_gemms(1) == 0
+    check(lib.vc_set_math_mode(1))
+    try:
+        x = torch.randn((2, 16, 64, 1, 32), device=U.DEV); w = torch.randn((2, 1, 3, 64, 64), device=U.DEV) * 0.05; b = torch.zeros((2, 64), device=U.DEV)
+        U.conv_fwd(x, w, b, 1, 3, 1, 1)
+    finally:
+        check(lib.vc_set_math_mode(0))
+    assert lib.vc_testing_wino_gemms(1) == 0

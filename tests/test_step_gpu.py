@@ -1144,3 +1144,46 @@ def test_error_behaviour_of_the_c_abi(built_lib):
     check(lib.vc_cyclegan_step_grads(*args(1, ptr(ws), ws.numel())))
     torch.cuda.synchronize()
     assert torch.isfinite(eng.losses).all()
+
+
+@pytest.mark.gpu
+def test_winograd_route_inside_the_train_step(built_lib):
+    """fp32 B = 8 (BASELINE configs[1]): the residual blocks' 12 convolutions per generator run their forward and input gradient in the
+    Winograd domain on filters transformed once per step, the tile transforms inside the instance-norm launches on either side
+    (csrc/vc_conv_wino.hip, vc_net.hip).  Against the direct kernels (vc_tune_winograd(0)) on the same state: losses to 1e-5, every gradient
+    tensor to 1e-4 rel-L2 (what a change of summation order inside 24 convolutions moves); the counter shows the route ran: 2 forward passes +
+    2 backward passes x 12 layers.  (Against the oracle: test_train_step_losses_grads_and_updates[8] runs with the route on.)"""
+    lib, check = built_lib.lib, built_lib.check
+    O, P, A, Bm, eng = _setup(8, seed=16)
+    A_d, B_d = eng._to_dev(A), eng._to_dev(Bm)
+    res = {}
+    try:
+        for on in (1, 0, 1):
+            check(lib.vc_tune_winograd(on)); lib.vc_testing_wino_gemms(1)
+            eng.step_grads(A_d, B_d, 10.0, 5.0); torch.cuda.synchronize()
+            n = lib.vc_testing_wino_gemms(1)
+            assert n == (48 if on else 0), n
+            res.setdefault(on, []).append((eng.losses.cpu().numpy().copy(), eng.tf_gradients()))
+    finally:
+        check(lib.vc_tune_winograd(1))
+    l1, g1 = res[1][0]; l0, g0 = res[0][0]
+    assert np.allclose(l1, l0, rtol=1e-5, atol=1e-6), (l1, l0)
+    names = [n for n in g0 if not _is_noise_bias(n)]
+    worst = sorted(_rel_l2(g1, g0, names).items(), key=lambda t: -t[1])[:3]
+    print('winograd vs direct, worst gradient tensors:', worst)
+    assert worst[0][1] < 1e-4, worst
+    # switching the route off and on again leaves no state behind
+    worst2 = sorted(_rel_l2(res[1][1][1], g1, names).items(), key=lambda t: -t[1])[:1]
+    assert worst2[0][1] < 1e-4, worst2
+    eng.close()
+
+
+@pytest.mark.gpu
+def test_winograd_route_below_its_batch_threshold(built_lib):
+    """B = 2: 16 / 32 pixels per transform position -- every convolution stays on the direct kernels (no filter transforms, no GEMMs)"""
+    lib = built_lib.lib
+    O, P, A, Bm, eng = _setup(2, gap=False)
+    lib.vc_testing_wino_gemms(1)
+    eng.train_step(A, Bm, 10.0, 5.0, 2e-4, 1e-4)
+    assert lib.vc_testing_wino_gemms(1) == 0
+    eng.close()

@@ -11,8 +11,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(CSRC, 'build')
 LIB = os.path.join(CSRC, 'libvcgan_hip.so')
-SOURCES = ['vc_testing.hip', 'vc_conv_igemm.hip', 'vc_conv_bf16.hip', 'vc_conv_wgrad.hip', 'vc_conv_small.hip', 'vc_conv_glu.hip', 'vc_elementwise.hip', 'vc_tables.hip', 'vc_ops.hip', 'vc_net.hip', 'vc_step.hip', 'vc_comm.hip']
-HEADERS = ['vc_internal.h', 'vc_host.h', 'vc_device_util.h', 'vc_tuned_igemm.h', 'vc_tuned_wgrad.h', 'vc_tuned_bf16.h', os.path.join('..', '..', 'include', 'vc_cyclegan.h'),
+SOURCES = ['vc_testing.hip', 'vc_conv_igemm.hip', 'vc_conv_bf16.hip', 'vc_conv_wgrad.hip', 'vc_conv_small.hip', 'vc_conv_glu.hip', 'vc_conv_wino.hip', 'vc_elementwise.hip', 'vc_tables.hip', 'vc_ops.hip', 'vc_net.hip', 'vc_step.hip', 'vc_comm.hip']
+HEADERS = ['vc_internal.h', 'vc_host.h', 'vc_device_util.h', 'vc_wino.h', 'vc_tuned_igemm.h', 'vc_tuned_wgrad.h', 'vc_tuned_bf16.h', os.path.join('..', '..', 'include', 'vc_cyclegan.h'),
            os.path.join('..', '..', 'include', 'vc_cyclegan_testing.h')]
 # -packed-fp32-ops: no v_pk_{mul,add,fma}_f32 in any kernel.  Round 6: inside the bf16 train step, with the generator's filter-gradient GEMMs on
 # their own stream, norm_bwd_v4_kernel now and then gave ONE 16-lane group (lanes 48-63 of one wave) wrong row sums from register contents that

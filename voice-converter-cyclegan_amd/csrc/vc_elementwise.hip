@@ -7,6 +7,7 @@
 //  crop_batch      : preprocess.sample_train_data's crop (preprocess.py:226-233)
 #include "vc_internal.h"
 #include "vc_device_util.h"
+#include "vc_wino.h"
 #include <algorithm>
 #include <cstdlib>
 #include <mutex>
@@ -368,9 +369,24 @@ __global__ __launch_bounds__(256) void norm_fwd_v4_kernel(const NormArgs p) {
     for (int j = 0; j < NV; ++j) {
         const int pos4 = (sub + j * LPR) * 4;
         ok[j] = rowv && pos4 < p.L;
+        o[j] = zero;
+        if constexpr (NV == 1 && !PS) {
+            if (p.win) {       // Winograd route: this row's quad = A^T of its six transform-domain values + the conv bias; the raw value is kept for the backward
+                const int nt = p.L >> 2;
+                const long plane = (long)p.B * NB * p.C * nt;
+                const float* m = p.win + (long)g * p.win_gs + ((long)b * NB * p.C + c) * nt + sub;
+                const float* wb = p.wbias + (long)g * p.wbias_gs;
+                float* yw = p.yw + (long)g * p.y_gs;
+                v[j] = zero; gt[j] = zero;
+                if (ok[j]) {
+                    v[j] = wino_load_output(m, plane, wb[c]); r0.store(yw, pos4, v[j]);
+                    if (NB == 2) { gt[j] = wino_load_output(m + (long)p.C * nt, plane, wb[p.C + c]); r1.store(yw, pos4, gt[j]); }
+                }
+                continue;
+            }
+        }
         v[j] = ok[j] ? r0.load(y, pos4) : zero;
         gt[j] = (NB == 2 && ok[j]) ? r1.load(y, pos4) : zero;
-        o[j] = zero;
     }
     if (MODE == 1) {
 #pragma unroll
@@ -414,6 +430,14 @@ __global__ __launch_bounds__(256) void norm_fwd_v4_kernel(const NormArgs p) {
     }
 #pragma unroll
     for (int j = 0; j < NV; ++j) if (ok[j]) *reinterpret_cast<f32x4*>(out + (sub + j * LPR) * 4) = o[j];
+    if constexpr (NV == 1 && !PS) {
+        if (p.wout) {          // the activation once more in the next layer's Winograd domain: V = B^T (x[4i-1], quad, x[4i+4]), neighbours from the lanes beside
+            const int nt = p.L >> 2;
+            const float left = __shfl_up(o[0][3], 1, LPR), right = __shfl_down(o[0][0], 1, LPR);
+            if (ok[0]) wino_store_input(o[0], sub > 0 ? left : 0.f, sub + 1 < nt ? right : 0.f,
+                                        p.wout + (long)g * p.wout_gs + ((long)b * p.C + c) * nt + sub, (long)p.B * p.C * nt);
+        }
+    }
     if (p.outp) {
         // the block's rows: units unit0 .. unit0 + 256 / LPR - 1 = consecutive channels of ONE (group, sample) (the launcher checks C % (256 / LPR) == 0)
         const int u0 = unit0 < total ? unit0 : 0;
@@ -476,8 +500,30 @@ __global__ __launch_bounds__(256) void norm_bwd_v4_kernel(const NormArgs p) {
         ok[j] = rowv && pos4 < p.L;
         v[j] = ok[j] ? r0.load(y, pos4) : zero;
         gt[j] = (NB == 2 && ok[j]) ? r1.load(y, pos4) : zero;
+        if constexpr (NV == 1 && !PS) {
+            if (p.dwin) {      // Winograd route: the gradient of this activation arrives as the next layer's dV planes: dO = B dV (+ the skip path)
+                const int nt = p.L >> 2;
+                dO[j] = zero;
+                if (ok[j]) {
+                    dO[j] = wino_load_dx(p.dwin + (long)g * p.dwin_gs + ((long)b * p.C + c) * nt + sub, (long)p.B * p.C * nt, sub > 0, sub + 1 < nt);
+                    const long o = ((long)b * p.C + c) * p.L + pos4;
+                    if (p.dadd) dO[j] += *reinterpret_cast<const f32x4*>(p.dadd + (long)g * p.dadd_gs + o);
+                    if (p.dsave) *reinterpret_cast<f32x4*>(p.dsave + (long)g * p.dsave_gs + o) = dO[j];
+                }
+                continue;
+            }
+        }
         dO[j] = ok[j] ? *reinterpret_cast<const f32x4*>(dout + pos4) : zero;
     }
+    // dy once more in this layer's Winograd domain (dM = A dy), for its input-gradient GEMMs: branch br = conv channels [br C, (br + 1) C)
+    auto emit_dm = [&](const f32x4 (&val)[NV], int br) {
+        if constexpr (NV == 1 && !PS) {
+            if (p.dwout && ok[0]) {
+                const int nt = p.L >> 2;
+                wino_store_dy(val[0], p.dwout + (long)g * p.dwout_gs + ((long)b * NB * p.C + br * p.C + c) * nt + sub, (long)p.B * NB * p.C * nt);
+            }
+        }
+    };
     auto bias_sums = [&](const f32x4 (&dv)[NV], int br) {          // conv-bias gradient of one branch (even / odd positions apart when shuffled)
         float se = 0.f, so = 0.f;
 #pragma unroll
@@ -519,6 +565,7 @@ __global__ __launch_bounds__(256) void norm_bwd_v4_kernel(const NormArgs p) {
         }
         if (dbias) bias_sums(d, 0);
         if (sub == 0 && dgam && rowv) { atomicAdd(dgam + c, s2); atomicAdd(dbet + c, s1); }
+        emit_dm(d, 0);
         if (p.outp || p.outq) emit_dy(d, ok, 0);
         return;
     }
@@ -549,6 +596,7 @@ __global__ __launch_bounds__(256) void norm_bwd_v4_kernel(const NormArgs p) {
         atomicAdd(dgam + c, s2v); atomicAdd(dbet + c, s1v);
         atomicAdd(dgam + p.C + c, s2g); atomicAdd(dbet + p.C + c, s1g);
     }
+    emit_dm(dv, 0); emit_dm(dg, 1);
     if (p.outp || p.outq) { emit_dy(dv, ok, 0); emit_dy(dg, ok, 1); }
 }
 
@@ -1079,7 +1127,11 @@ static int norm_dispatch(const NormArgs& a, hipStream_t s) {
         auto al = [](const void* q, long gs) { return ((uintptr_t)q & 15) == 0 && (gs & 3) == 0; };
         bool ok = !det && (a.L & 3) == 0 && al(a.y, a.y_gs);
         if (FWD) ok = ok && al(a.out, a.out_gs) && (MODE != 2 || al(a.res, a.res_gs));
-        else ok = ok && al(a.dy, a.dy_gs) && al(a.dout, a.do_gs);
+        else ok = ok && al(a.dy, a.dy_gs) && (a.dwin || al(a.dout, a.do_gs));
+        if ((a.win || a.wout || a.dwin || a.dwout) && !(MODE != 1 && norm_takes_wino(a, FWD))) {
+            vc_set_error("norm forward / backward: Winograd-domain operands were passed to a launch that does not apply the transforms (ask norm_takes_wino first)");
+            return -1;
+        }
         if (!FWD && !a.dy && !(a.outp || a.outq)) { vc_set_error("norm backward: dy may only be left out when an octet form of it is written"); return -1; }
         if (!FWD && a.outq && !(ok && a.L <= 512 && a.C % 32 == 0 && ((a.ps ? a.L >> 1 : a.L) & 7) == 0 && al(a.outq, a.outq_gs / 4))) {
             vc_set_error("norm backward: pixel octets were requested for a launch that does not produce them (ask norm_bwd_emits_pixel_octets first)");
@@ -1126,6 +1178,16 @@ static int norm_dispatch(const NormArgs& a, hipStream_t s) {
 #undef VC_NORM_CASE
     VC_HIP(hipGetLastError());
     return 0;
+}
+// would launch_norm_fwd / launch_norm_bwd apply the Winograd transforms of NormArgs (win / wout, dwin / dwout) inside this launch?  The 16-byte
+// kernels with one quad per lane: rows of 8 .. 128 positions in multiples of 4, no pixel shuffle, gated-with-norm or residual-tail blocks, not the
+// deterministic backward (it walks the batch inside a lane group)
+bool norm_takes_wino(const NormArgs& a, bool fwd) {
+    auto al = [](const void* q, long gs) { return ((uintptr_t)q & 15) == 0 && (gs & 3) == 0; };
+    bool ok = (a.L & 3) == 0 && a.L >= 8 && a.L <= 128 && !a.ps && al(a.y, a.y_gs);
+    if (fwd) ok = ok && al(a.out, a.out_gs) && (!a.res || al(a.res, a.res_gs));
+    else ok = ok && !a.det && al(a.dy, a.dy_gs) && (a.dwin || al(a.dout, a.do_gs));
+    return ok;
 }
 // would launch_norm_fwd honour NormArgs::outp for this launch?  (rows of up to 512 positions in multiples of 4, 16-byte aligned tensors,
 // channel counts whose blocks of 8 / 16 / 32 rows hold whole octets of one sample)

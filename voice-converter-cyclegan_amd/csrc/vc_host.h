@@ -62,6 +62,11 @@ int conv_dgrad(const float* dy, long dy_gs, const float* w, long w_gs, float* dx
                const float* addend, long add_gs, int accumulate, int G, int B, const Geom& g, int math, hipStream_t s,
                bool prezeroed = false, bool* query = nullptr, const char* const* packed_w = nullptr,
                const char* dy_packed = nullptr, long dy_packed_gs = 0);   // dy_packed: dy already as bf16 channel octets (its producer wrote them; group stride in bytes)
+bool wino_eligible(const Geom& g, int math, int B);                        // fp32: forward / input gradient of this geometry take the Winograd F(4,3) route (vc_ops.hip)
+Geom wino_gemm_geom(const Geom& g);                                   // the 1 x 1 geometry of its six channel GEMMs
+int wino_workspace(hipStream_t s, size_t floats, float** out);        // transform-domain scratch of the launches issued on stream s (grows on demand, reused launch to launch)
+int wino_gemm_fwd(const float* V, const float* U, float* M, int G, int B, const Geom& g, int math, hipStream_t s);
+int wino_gemm_dgrad(const float* dM, const float* U, float* dV, int G, int B, const Geom& g, int math, hipStream_t s);
 bool conv_dgrad_packs_input(const Geom& g, int B, int math);          // the input gradient of this geometry at batch B runs on the 16-bit data path
 // bf16 data path: the layer's stacked pixel-octet dY [all applications' pixel octets][Cout][8] bf16 (group stride in bytes; room for every
 // application of the launch) and which applications' parts their norm backward has already written (bit k = application k): the
@@ -128,6 +133,15 @@ struct vc_plan {
     struct LayerImages { const char* fwd = nullptr; const char* dg[4] = {nullptr, nullptr, nullptr, nullptr}; bool has_dg = false; };
     mutable std::vector<LayerImages> img_g, img_d;
     mutable char* img_block = nullptr;
+    // fp32 mode: the Winograd-domain filters U = G w of the generators' 3-tap layers (vc_conv_wino.hip), both generators as the two groups,
+    // rebuilt from the weights at the head of every train step on the side stream (a step uses each four times: two forward passes, two
+    // input gradients); fwd = dg[0] = the layer's U.
+    mutable std::vector<LayerImages> wino_img;
+    mutable float* wino_block = nullptr;
+    mutable bool wino_active = false;      // the running step rebuilt them (its batch is large enough for the route)
+    static constexpr int kWinoChunks = 3;  // the rebuild goes out as this many launches in layer order, an event behind each: the forward waits for a layer's chunk only
+    hipEvent_t ev_wino[kWinoChunks] = {nullptr, nullptr, nullptr};
+    mutable std::vector<int> wino_chunk;   // per generator layer: which launch carries its filters (-1: none)
 };
 struct SaveMap { std::vector<long> raw, act, st, actp; long total; };
 SaveMap save_map(const NetDesc& n, const std::vector<LayerGeo>& geo, int B);
@@ -163,3 +177,4 @@ int disc_backward(const vc_plan* p, const float* params, long par_gs, const floa
 int backward_prezero(const vc_plan* p, bool gen, float* scratch, long scr_gs, int G, int B, hipStream_t s);   // record_layers (train step): the plan's per-layer events dl_ready / dl_free_d (dparams) or dl_free_g
 // The step's prebuilt filter images describe `params` of the running step: only the step hands them to its network passes
 struct StepImages { explicit StepImages(const vc_plan* p); ~StepImages(); };
+int refresh_wino_filters(const vc_plan* p, const float* params, int B, hipStream_t s, bool* active);   // B: the largest batch of the step's generator passes   // vc_net.hip; *active: the plan's passes will take them

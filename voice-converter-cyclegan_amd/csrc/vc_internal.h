@@ -177,6 +177,14 @@ int launch_gated_conv1d_glu_prepack(const float* w, long w_gs, void* img, long i
 // measurement control: the launch of the gated kernel with its memory operations only (a.wimg = a bf16 image, a.y written)
 int launch_glu_copy_roof(const WsConvArgs& a, int cin, int kw, hipStream_t s);
 
+// Winograd F(4,3) transforms (vc_conv_wino.hip): 1-D, 3 taps, stride 1, W = 4 nt
+struct WinoFilter { const float* w; float* U; long w_gs; int Cin, Cout; };       // U [G][6][Cin][Cout], group stride 6 Cin Cout
+int launch_wino_filters(const std::vector<WinoFilter>& f, int G, hipStream_t s);
+int launch_wino_input(const float* x, long x_gs, float* V, int G, int B, int C, int nt, hipStream_t s);
+int launch_wino_output(const float* M, const float* bias, long b_gs, float* y, long y_gs, int G, int B, int C, int nt, hipStream_t s);
+int launch_wino_dy(const float* dy, long dy_gs, float* dM, int G, int B, int C, int nt, hipStream_t s);
+int launch_wino_dx(const float* dV, float* dx, long dx_gs, const float* addend, long add_gs, int accumulate, int G, int B, int C, int nt, hipStream_t s);
+
 struct NormArgs {
     const float* y; const float* res; const float* gamma; const float* beta;
     const float* dout; const float* stats_in;
@@ -187,7 +195,18 @@ struct NormArgs {
     long y_gs, res_gs, par_gs, out_gs, st_gs, do_gs, dy_gs, dpar_gs, dbias_gs;
     int G, B, C, L, ps;
     int det;                              // backward: reduce dgamma / dbeta / dbias over the batch inside one lane group (fixed order, no atomics)
+    // fp32 mode, Winograd route (vc_conv_wino.hip; transform-domain tensors are six planes [p][b][channel][L / 4], group stride 6 planes):
+    // the transforms next to a norm launch run inside it (launch_norm_* honour these for rows of up to 128 positions without pixel shuffle, not
+    // in deterministic mode: ask norm_takes_wino first).  Forward: the raw conv output ARRIVES as M planes (win; + the conv bias wbias) and is
+    // written to yw (= y, kept for the backward); the activation leaves once more as V planes (wout) for the next layer's GEMMs.  Backward:
+    // dout ARRIVES as dV planes (dwin; + dadd, the skip path) and is written to dsave when somebody else needs it; dy leaves once more as dM
+    // planes (dwout) for this layer's input-gradient GEMMs.
+    const float* win; long win_gs; const float* wbias; long wbias_gs; float* yw;
+    float* wout; long wout_gs;
+    const float* dwin; long dwin_gs; const float* dadd; long dadd_gs; float* dsave; long dsave_gs;
+    float* dwout; long dwout_gs;
 };
+bool norm_takes_wino(const NormArgs& a, bool fwd);   // launch_norm_fwd / launch_norm_bwd would honour the Winograd fields for this launch
 
 // picks tile rows, K groups and split-K for a launch (fills bm/kg/splitk/mtiles/ntiles)
 void igemm_config(IgemmArgs& a, int math);
@@ -270,5 +289,7 @@ struct TestHooks {
     int glu_flags = 0;                                 // vc_tune_glu
     int c1_gather = 0;                                 // vc_tune_c1_dgrad_gather
     int layer_updates = 1;                             // vc_tune_layer_updates
+    int winograd = 1;                                  // vc_tune_winograd
 };
 const TestHooks& vc_hooks();
+void vc_count_wino_gemm();            // vc_testing_wino_gemms: the calling thread issued one more Winograd-domain GEMM launch

@@ -139,6 +139,11 @@ static int plan_create(int num_features, int n_frames, bool inference, vc_plan**
         for (auto& l : *v) {
             if (c1_path(l.g)) continue;
             Table t;
+            if (!inference && v == &p->gg && wino_eligible(l.g, VC_MATH_FP32, 1 << 20)) {      // the 1 x 1 tables of the Winograd route's channel GEMMs
+                const Geom g1 = wino_gemm_geom(l.g);
+                r = r ? r : get_fwd_table(g1, &t, &p->tables);
+                r = r ? r : get_dgrad_table(g1, 0, 0, &t, &p->tables);
+            }
             if (!(wsconv_path(l.g) && inference)) r = r ? r : get_fwd_table(l.g, &t, &p->tables);
             if (inference) continue;
             for (int ph = 0; ph < l.g.sh && !r; ++ph) for (int pw = 0; pw < l.g.sw && !r; ++pw) r = get_dgrad_table(l.g, ph, pw, &t, &p->tables);
@@ -165,6 +170,7 @@ static int plan_create(int num_features, int n_frames, bool inference, vc_plan**
         if (e == hipSuccess) e = hipEventCreateWithFlags(&p->dl_free_d[k], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&p->dl_free_g[k], hipEventDisableTiming);
     }
+    for (int k = 0; k < vc_plan::kWinoChunks && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&p->ev_wino[k], hipEventDisableTiming);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->gstream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->ustream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_gin, hipEventDisableTiming);
@@ -195,6 +201,8 @@ extern "C" void vc_plan_destroy(vc_plan* p) {
     if (p->d_free) (void)hipEventDestroy(p->d_free);
     for (auto* arr : {p->gl_ready, p->gl_free}) for (int k = 0; k < 24; ++k) if (arr[k]) (void)hipEventDestroy(arr[k]);
     for (auto* arr : {p->dl_ready, p->dl_free_d, p->dl_free_g}) for (int k = 0; k < 8; ++k) if (arr[k]) (void)hipEventDestroy(arr[k]);
+    for (hipEvent_t ev : p->ev_wino) if (ev) (void)hipEventDestroy(ev);
+    if (p->wino_block) (void)hipFree(p->wino_block);
     for (auto& g : p->graphs) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); }
     if (p->gstream) (void)hipStreamDestroy(p->gstream);
     if (p->ustream) (void)hipStreamDestroy(p->ustream);
@@ -285,6 +293,7 @@ struct NetCtx {
     bool fuse_glu = false;                 // forward only: gated blocks without instance norm go out as one conv + GLU kernel
     unsigned* q_ready_out = nullptr;       // W_NONE passes report which layers' dY they left as pixel octets (BwdOpts::q_ready_out)
     unsigned* dy_dropped_out = nullptr; bool drop_dy = false;   // BwdOpts::drop_fp32_dy
+    const hipEvent_t* wino_ev = nullptr; const int* wino_chunk = nullptr;   // fp32, inside a train step: `images` holds the Winograd-domain filters; layer i's are valid once wino_ev[wino_chunk[i]] has passed
     bool prezeroed = false;                // the split-K dA buffers of this pass were zeroed ahead of time (backward_prezero)
     int wmode = W_SELF;                    // W_NONE: leave the conv filter gradients to a later application (DeferredApp)
     bool wgrad_store = false;              // this backward's filter gradients are the step's only contribution to dparams' conv kernels
@@ -355,6 +364,20 @@ static int net_forward(NetCtx& c, const float* x, long x_gs, float* y_plain, lon
         }
         if (!zl.empty()) VC_CHECK(launch_zero_list(zl, c.s));
     }
+    // fp32 inside a train step: the 3-tap layers (residual blocks) run in the Winograd domain (vc_conv_wino.hip) on the step's transformed filters;
+    // the transforms ride in the instance-norm launches on either side of the GEMMs (NormArgs::win / wout), stand-alone launches where they cannot
+    auto wino_layer = [&](size_t i) {
+        return c.images && c.math == VC_MATH_FP32 && (*c.images)[i].fwd && wino_eligible((*c.geo)[i].g, c.math, c.B);
+    };
+    float* wV = nullptr; float* wM = nullptr; bool v_ready = false; unsigned wino_waited = 0;
+    {
+        size_t nV = 0, nM = 0;
+        for (size_t i = 0; i < c.n->layers.size(); ++i) if (wino_layer(i)) {
+            const Geom& g = (*c.geo)[i].g;
+            nV = std::max(nV, (size_t)6 * c.G * c.B * g.Cin * (g.W / 4)); nM = std::max(nM, (size_t)6 * c.G * c.B * g.Cout * (g.W / 4));
+        }
+        if (nV) { VC_CHECK(wino_workspace(c.s, nV + nM, &wV)); wM = wV + nV; }
+    }
     const float* in = x; long in_gs = x_gs;
     const float* blk_in = nullptr; long blk_in_gs = 0;
     bool in_packed = false;               // bf16 data path: layer i's input already lies in actp[i - 1] as channel octets (its producer emitted them)
@@ -387,8 +410,15 @@ static int net_forward(NetCtx& c, const float* x, long x_gs, float* y_plain, lon
             fn.gamma = c.params + L.gamma; fn.beta = c.params + L.beta; fn.par_gs = c.par_gs;
             fn.stats = c.save + c.sm.st[i]; fn.st_gs = c.save_gs; fn.act = c.save + c.sm.act[i]; fn.act_gs = c.save_gs;
         }
+        const bool wino = wV && wino_layer(i) && L.mode != M_PLAIN;
+        if (wino) {
+            if (c.wino_ev && !(wino_waited >> c.wino_chunk[i] & 1u)) { VC_HIP(hipStreamWaitEvent(c.s, c.wino_ev[c.wino_chunk[i]], 0)); wino_waited |= 1u << c.wino_chunk[i]; }   // this step's filter transforms (side stream)
+            if (!v_ready) VC_CHECK(launch_wino_input(in, in_gs, wV, c.G, c.B, lg.g.Cin, lg.g.W / 4, c.s));
+            v_ready = false;
+            VC_CHECK(wino_gemm_fwd(wV, (const float*)(*c.images)[i].fwd, wM, c.G, c.B, lg.g, c.math, c.s));
+        } else
         VC_CHECK(conv_fwd(in, in_gs, c.params + L.w, c.par_gs, c.params + L.b, c.par_gs, raw, raw_gs, c.G, c.B, lg.g, c.math, c.s,
-                          /*prezeroed=*/L.mode != M_PLAIN || plain_zeroed, nullptr, c.images ? (*c.images)[i].fwd : nullptr,
+                          /*prezeroed=*/L.mode != M_PLAIN || plain_zeroed, nullptr, (c.images && c.math == VC_MATH_BF16) ? (*c.images)[i].fwd : nullptr,
                           (c.keep_packed && i > 0) ? (char*)(c.save + c.sm.actp[i - 1]) : nullptr, c.save_gs * 4,
                           fn.act ? &fn : nullptr, in_packed));
         in_packed = false;
@@ -403,6 +433,15 @@ static int net_forward(NetCtx& c, const float* x, long x_gs, float* y_plain, lon
             a.stats = c.save + c.sm.st[i]; a.st_gs = c.save_gs;
         }
         if (L.mode == M_IN_RES) { a.res = blk_in; a.res_gs = blk_in_gs; }
+        if (wino) {            // the raw conv output still lies in the transform domain
+            if (L.mode != M_GATED && norm_takes_wino(a, true)) {
+                a.win = wM; a.win_gs = 6L * c.B * lg.g.Cout * (lg.g.W / 4); a.wbias = c.params + L.b; a.wbias_gs = c.par_gs; a.yw = raw;
+            } else VC_CHECK(launch_wino_output(wM, c.params + L.b, c.par_gs, raw, raw_gs, c.G, c.B, lg.g.Cout, lg.g.W / 4, c.s));
+        }
+        if (wV && i + 1 < c.n->layers.size() && wino_layer(i + 1) && L.mode != M_GATED && norm_takes_wino(a, true)) {
+            a.wout = wV; a.wout_gs = 6L * c.B * L.C * (a.L / 4);      // the next layer's GEMMs read this activation as V = B^T x
+            v_ready = true;
+        }
         // the next layer's convolution reads this activation as bf16 channel octets out of actp[i]: let the kernel that produces it write
         // them (round 4: a pack launch per convolution re-read the fp32 tensor)
         if (c.keep_packed && i + 1 < c.n->layers.size() && conv_fwd_packs_input((*c.geo)[i + 1].g, c.B, c.math) && norm_fwd_emits_packed(a)) {
@@ -449,12 +488,34 @@ static int net_backward(NetCtx& c, const float* x, long x_gs, const float* dtop,
     if (!c.prezeroed) VC_CHECK(zero_split_dA(c, scratch, scr_gs));
     const float* dcur = dtop; long dcur_gs = dtop_gs;   // gradient w.r.t. the output activation of layer i
     const float* skip = nullptr; long skip_gs = 0;      // gradient flowing around a residual block (module.py:81)
+    // fp32 inside a train step: input gradients of the 3-tap layers in the Winograd domain (see net_forward): dM = A dy leaves the layer's norm
+    // backward, dV = U^T dM is the six GEMMs, and dO = B dV (+ skip) is rebuilt by the NEXT norm backward on its way in (`pend`)
+    auto wino_layer = [&](int i) {
+        return c.images && c.math == VC_MATH_FP32 && (*c.images)[i].has_dg && wino_eligible((*c.geo)[i].g, c.math, c.B);
+    };
+    auto norm_fusable = [&](int i) {      // layer i's norm backward can apply the transforms (the launcher checks alignment once more)
+        const Layer& Li = c.n->layers[i]; const LayerGeo& li = (*c.geo)[i];
+        const int Ln = li.g.OH * li.g.OW;
+        return (Li.mode == M_GATED_IN || Li.mode == M_IN_RES) && !Li.ps && !vc_det_active() && (Ln & 3) == 0 && Ln >= 8 && Ln <= 128;
+    };
+    float* wdM = nullptr; float* wdV = nullptr;
+    {
+        size_t nV = 0, nM = 0;
+        for (int i = 1; i < nl; ++i) if (wino_layer(i)) {
+            const Geom& g = (*c.geo)[i].g;
+            nV = std::max(nV, (size_t)6 * c.G * c.B * g.Cin * (g.W / 4)); nM = std::max(nM, (size_t)6 * c.G * c.B * g.Cout * (g.W / 4));
+        }
+        if (nV) { VC_CHECK(wino_workspace(c.s, nV + nM, &wdM)); wdV = wdM + nM; }
+    }
+    struct { const float* dV; long dV_gs; const float* add; long add_gs; bool on; } pend{nullptr, 0, nullptr, 0, false};
     for (int i = nl - 1; i >= 0; --i) {
         const Layer& L = c.n->layers[i]; const LayerGeo& lg = (*c.geo)[i];
         const float* in = (i == 0) ? x : c.save + c.sm.act[i - 1];
         const long in_gs = (i == 0) ? x_gs : c.save_gs;
         const float* dyp; long dy_gs;
         const char* dy_packed = nullptr;                 // dy of this layer as bf16 channel octets in the scratch's packed region, if its producer emitted them
+        const bool wino = wdM && i > 0 && wino_layer(i);
+        bool dm_ready = false;
         if (L.mode == M_PLAIN) {
             dyp = dcur; dy_gs = dcur_gs;
             if (c.dparams) {
@@ -473,6 +534,12 @@ static int net_backward(NetCtx& c, const float* x, long x_gs, const float* dtop,
                 if (c.dparams) { a.dgamma = c.dparams + L.gamma; a.dbeta = c.dparams + L.beta; a.dpar_gs = c.dpar_gs; }
             }
             if (c.dparams) { a.dbias = c.dparams + L.b; a.dbias_gs = c.dpar_gs; }
+            if (pend.on) {     // the gradient of this activation lies in the transform domain; the block's skip gradient (= this dO) is kept for the block head
+                a.dwin = pend.dV; a.dwin_gs = pend.dV_gs; a.dadd = pend.add; a.dadd_gs = pend.add_gs;
+                if (L.mode == M_IN_RES) { a.dsave = const_cast<float*>(dcur); a.dsave_gs = dcur_gs; }
+                pend.on = false;
+            }
+            if (wino && norm_fusable(i)) { a.dwout = wdM; a.dwout_gs = 6L * c.B * lg.g.Cout * (lg.g.W / 4); dm_ready = true; }
             // bf16 data path: this layer's input gradient gathers dy as bf16 channel octets -- the kernel that produces dy writes them
             // (round 4: a pack launch per input gradient re-read the fp32 tensor).  i == 0 without dx: nobody reads them.
             if ((i > 0 || dx) && conv_dgrad_packs_input(lg.g, c.B, c.math) && norm_bwd_emits_packed(a)) {
@@ -520,16 +587,23 @@ static int net_backward(NetCtx& c, const float* x, long x_gs, const float* dtop,
         if (c.lay_ready && layer_events_on()) VC_HIP(hipEventRecord(c.lay_ready[i], ws));
         if (i == 0) {
             if (dx) VC_CHECK(conv_dgrad(dyp, dy_gs, c.params + L.w, c.par_gs, dx, dx_gs, nullptr, 0, dx_acc, c.G, c.B, lg.g, c.math, c.s,
-                                        false, nullptr, (c.images && (*c.images)[i].has_dg) ? (*c.images)[i].dg : nullptr, dy_packed, scr_gs * 4));
+                                        false, nullptr, (c.images && c.math == VC_MATH_BF16 && (*c.images)[i].has_dg) ? (*c.images)[i].dg : nullptr, dy_packed, scr_gs * 4));
             for (int k = 0; k < c.n_ev; ++k) if (c.ev_free && c.ev_first[k] == i) VC_HIP(hipEventRecord(c.ev_free[k], c.s));
             if (c.lay_free && layer_events_on()) VC_HIP(hipEventRecord(c.lay_free[i], c.s));
             break;        // falls through to the join below
         }
         // gradient w.r.t. this layer's input = activation of layer i-1; the head of a residual block adds the skip
         const bool block_head = (L.mode == M_GATED_IN && i + 1 < nl && c.n->layers[i + 1].mode == M_IN_RES);
+        if (wino) {
+            const int nt = lg.g.W / 4;
+            if (!dm_ready) VC_CHECK(launch_wino_dy(dyp, dy_gs, wdM, c.G, c.B, lg.g.Cout, nt, c.s));
+            VC_CHECK(wino_gemm_dgrad(wdM, (const float*)(*c.images)[i].dg[0], wdV, c.G, c.B, lg.g, c.math, c.s));
+            if (norm_fusable(i - 1)) { pend.dV = wdV; pend.dV_gs = 6L * c.B * lg.g.Cin * nt; pend.add = block_head ? skip : nullptr; pend.add_gs = block_head ? skip_gs : 0; pend.on = true; }
+            else VC_CHECK(launch_wino_dx(wdV, scratch + dAo[i - 1], scr_gs, block_head ? skip : nullptr, block_head ? skip_gs : 0, 0, c.G, c.B, lg.g.Cin, nt, c.s));
+        } else
         VC_CHECK(conv_dgrad(dyp, dy_gs, c.params + L.w, c.par_gs, scratch + dAo[i - 1], scr_gs,
                             block_head ? skip : nullptr, block_head ? skip_gs : 0, 0, c.G, c.B, lg.g, c.math, c.s, /*prezeroed=*/true,
-                            nullptr, (c.images && (*c.images)[i].has_dg) ? (*c.images)[i].dg : nullptr, dy_packed, scr_gs * 4));
+                            nullptr, (c.images && c.math == VC_MATH_BF16 && (*c.images)[i].has_dg) ? (*c.images)[i].dg : nullptr, dy_packed, scr_gs * 4));
         if (block_head) skip = nullptr;
         for (int k = 0; k < c.n_ev; ++k) if (c.ev_free && c.ev_first[k] == i) VC_HIP(hipEventRecord(c.ev_free[k], c.s));
         if (c.lay_free && layer_events_on()) VC_HIP(hipEventRecord(c.lay_free[i], c.s));
@@ -562,14 +636,60 @@ static thread_local const vc_plan* t_step_images = nullptr;
 StepImages::StepImages(const vc_plan* p) { t_step_images = p; }
 StepImages::~StepImages() { t_step_images = nullptr; }
 static const std::vector<vc_plan::LayerImages>* step_images(const vc_plan* p, bool gen, int G) {
-    if (t_step_images != p || G != 2 || p->math != VC_MATH_BF16) return nullptr;
+    if (t_step_images != p || G != 2) return nullptr;
+    if (p->math == VC_MATH_FP32) return (gen && p->wino_active && !p->wino_img.empty() && vc_hooks().winograd != 0) ? &p->wino_img : nullptr;
+    if (p->math != VC_MATH_BF16) return nullptr;
     const auto& v = gen ? p->img_g : p->img_d;
     return v.empty() ? nullptr : &v;
+}
+// fp32 mode, head of a train step: U = G w for every generator layer on the Winograd route, one launch on stream s (then ev_wino)
+int refresh_wino_filters(const vc_plan* p, const float* params, int B, hipStream_t s, bool* active) {
+    *active = false; p->wino_active = false;
+    if (p->math != VC_MATH_FP32 || vc_hooks().winograd == 0 || p->inference) return 0;
+    std::vector<WinoFilter> jobs; std::vector<size_t> offs; std::vector<vc_plan::LayerImages> img(p->G.layers.size());
+    size_t tot = 0;
+    for (size_t i = 0; i < p->G.layers.size(); ++i) {
+        const Geom& g = p->gg[i].g;
+        if (!wino_eligible(g, p->math, B)) continue;
+        jobs.push_back(WinoFilter{params + p->G.layers[i].w, nullptr, p->G.total, g.Cin, g.Cout}); offs.push_back(tot);
+        img[i].fwd = (const char*)(tot + 1);       // offset + 1 until the block exists (0 = no image)
+        tot += (size_t)2 * 6 * g.Cin * g.Cout;
+    }
+    if (jobs.empty()) return 0;
+    if (!p->wino_block) {
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        if (s && hipStreamIsCapturing(s, &st) == hipSuccess && st != hipStreamCaptureStatusNone) {
+            vc_set_error("Winograd route: run one eager step before capturing (the transformed filters are allocated on first use)");
+            return VC_E_STATE;
+        }
+        VC_HIP(hipMalloc((void**)&p->wino_block, tot * sizeof(float)));
+    }
+    if (p->wino_img.empty()) {
+        for (auto& li : img) if (li.fwd) { li.fwd = (const char*)(p->wino_block + ((size_t)li.fwd - 1)); li.dg[0] = li.fwd; li.has_dg = true; }
+        p->wino_img = img;
+    }
+    for (size_t k = 0; k < jobs.size(); ++k) jobs[k].U = p->wino_block + offs[k];
+    // in layer order, kWinoChunks launches with an event behind each: the first-hop forward reaches its first residual block ~60 us into the step
+    // and waits for that block's filters only (one launch: 0.12 ms ahead of the first Winograd GEMM at batch 8)
+    const size_t per = (jobs.size() + vc_plan::kWinoChunks - 1) / vc_plan::kWinoChunks;
+    if (p->wino_chunk.empty()) {
+        p->wino_chunk.assign(p->G.layers.size(), -1);
+        size_t k = 0;
+        for (size_t i = 0; i < p->G.layers.size(); ++i) if (p->wino_img[i].fwd) p->wino_chunk[i] = (int)(k++ / per);
+    }
+    for (int ck = 0; ck < vc_plan::kWinoChunks; ++ck) {
+        const size_t lo = std::min(jobs.size(), ck * per), hi = std::min(jobs.size(), (ck + 1) * per);
+        if (hi > lo) VC_CHECK(launch_wino_filters(std::vector<WinoFilter>(jobs.begin() + lo, jobs.begin() + hi), 2, s));
+        VC_HIP(hipEventRecord(p->ev_wino[ck], s));
+    }
+    *active = true; p->wino_active = true;
+    return 0;
 }
 int gen_forward(const vc_plan* p, const float* params, long par_gs, const float* x, long x_gs,
                        float* y, long y_gs, float* save, int G, int B, hipStream_t s) {
     NetCtx c = gen_ctx(p, params, par_gs, nullptr, 0, save, G, B, B, s);
-    c.images = step_images(p, true, G); c.keep_packed = c.images != nullptr;
+    c.images = step_images(p, true, G); c.keep_packed = c.images != nullptr && p->math == VC_MATH_BF16;
+    if (c.images && p->math == VC_MATH_FP32) { c.wino_ev = p->ev_wino; c.wino_chunk = p->wino_chunk.data(); }
     c.fuse_glu = p->inference;
     return net_forward(c, x, x_gs, y, y_gs);
 }
@@ -581,7 +701,8 @@ int gen_backward(const vc_plan* p, const float* params, long par_gs, const float
     NetCtx c = gen_ctx(p, params, par_gs, dparams, dpar_gs, save, G, B, Bl, s);
     c.prezeroed = o.prezeroed;
     c.wgrad_store = o.wgrad_store; c.wmode = o.wmode; c.deferred = o.deferred; c.q_ready_out = o.q_ready_out; c.dy_dropped_out = o.dy_dropped_out; c.drop_dy = o.drop_fp32_dy;
-    c.images = step_images(p, true, G); c.keep_packed = c.images != nullptr;
+    c.images = step_images(p, true, G); c.keep_packed = c.images != nullptr && p->math == VC_MATH_BF16;
+    if (c.images && p->math == VC_MATH_FP32) { c.wino_ev = p->ev_wino; c.wino_chunk = p->wino_chunk.data(); }
     if ((p->use_side & 2) && dparams && o.wmode != W_NONE) { c.ws = p->wstream; c.ev_layer = p->ev_layer; c.ev_wjoin = p->ev_wjoin; }
     if (o.record_buckets) { c.ev_first = p->bucket_first; c.ev = p->g_ready; c.ev_free = p->g_free; c.n_ev = vc_plan::kBuckets; c.lay_ready = p->gl_ready; c.lay_free = p->gl_free; }
     return net_backward(c, x, x_gs, dy, dy_gs, dx, dx_gs, dx_acc, scratch, scr_gs);
@@ -595,7 +716,7 @@ int disc_forward(const vc_plan* p, const float* params, long par_gs, const float
                         float* o, long o_gs, float* save, int G, int B, hipStream_t s) {
     VC_ARG(!p->inference, "this plan was created for inference only (vc_plan_create_inference)");
     NetCtx c = disc_ctx(p, params, par_gs, nullptr, 0, save, G, B, B, s);
-    c.images = step_images(p, false, G); c.keep_packed = c.images != nullptr;
+    c.images = step_images(p, false, G); c.keep_packed = c.images != nullptr && p->math == VC_MATH_BF16;
     VC_CHECK(net_forward(c, x, x_gs, nullptr, 0));
     const int last = (int)p->D.layers.size() - 1;
     return launch_head_fwd(save + c.sm.act[last], c.save_gs, params + p->D.head_w, params + p->D.head_b, par_gs,
@@ -609,7 +730,7 @@ int disc_backward(const vc_plan* p, const float* params, long par_gs, const floa
     VC_ARG(!p->inference, "this plan was created for inference only (vc_plan_create_inference)");
     NetCtx c = disc_ctx(p, params, par_gs, dparams, dpar_gs, save, G, B, Bl, s);
     c.wgrad_store = wgrad_store; c.drop_dy = drop_fp32_dy;
-    c.images = step_images(p, false, G); c.keep_packed = c.images != nullptr;
+    c.images = step_images(p, false, G); c.keep_packed = c.images != nullptr && p->math == VC_MATH_BF16;
     c.prezeroed = prezeroed;
     if (record_layers) { if (dparams) { c.lay_ready = p->dl_ready; c.lay_free = p->dl_free_d; } else c.lay_free = p->dl_free_g; }
     if ((p->use_side & 4) && dparams) { c.ws = p->wstream_d; c.ev_layer = p->ev_layer_d; c.ev_wjoin = p->ev_wjoin_d; }

@@ -149,6 +149,60 @@ static void bf16_set_vec4(ConvBf16Args& a) {
              a.y_gs % 4 == 0 && aligned16(a.Y) && (!a.addend || (aligned16(a.addend) && a.add_gs % 4 == 0));
 }
 
+// ------------------------------------------------------------------------------------
+// Winograd F(4,3) route (csrc/vc_conv_wino.hip): forward and input gradient of the 3-tap stride-1 1-D convolutions in fp32 mode
+// ------------------------------------------------------------------------------------
+// B: the batch of the launch -- each of the six GEMMs sees B W / 4 pixels, and below one 64-pixel tile the direct kernel wins (measured at
+// batch 1: 3.4 -> 5.1 ms per step with the route forced on; a threshold of 128 pixels instead of 64 measured the same at batch 8 and 16)
+bool wino_eligible(const Geom& g, int math, int B) {
+    return math == VC_MATH_FP32 && vc_hooks().winograd != 0 && g.kh == 1 && g.kw == 3 && g.sh == 1 && g.sw == 1 && g.H == 1 &&
+           g.W % 4 == 0 && g.W >= 8 && g.Cin % 32 == 0 && g.Cout % 32 == 0 && g.Cin >= 64 && g.Cout >= 64 && (long)B * (g.W / 4) >= 64;
+}
+int wino_workspace(hipStream_t s, size_t floats, float** out) {
+    char* q; VC_CHECK(pack_space(s, floats * sizeof(float), &q));
+    *out = (float*)q;
+    return 0;
+}
+// the six channel GEMMs of one layer: M[p] = U[p] V[p] (forward) / dV[p] = U[p]^T dM[p] (input gradient), p = transform position, as a 1 x 1
+// convolution with 6 G groups.  K is split inside the workgroup only: the launches have 6 x the groups of the direct form to fill the chip with,
+// and split-K across workgroups would cost a memset of the transform-domain destination per launch.
+int wino_gemm_fwd(const float* V, const float* U, float* M, int G, int B, const Geom& g, int math, hipStream_t s) {
+    const int nt = g.W / 4; const Geom g1 = wino_gemm_geom(g);
+    DetScope no_split(1);
+    vc_count_wino_gemm();
+    return conv_fwd(V, (long)B * g.Cin * nt, U, (long)g.Cin * g.Cout, nullptr, 0, M, (long)B * g.Cout * nt, 6 * G, B, g1, math, s);
+}
+int wino_gemm_dgrad(const float* dM, const float* U, float* dV, int G, int B, const Geom& g, int math, hipStream_t s) {
+    const int nt = g.W / 4; const Geom g1 = wino_gemm_geom(g);
+    DetScope no_split(1);
+    vc_count_wino_gemm();
+    return conv_dgrad(dM, (long)B * g.Cout * nt, U, (long)g.Cin * g.Cout, dV, (long)B * g.Cin * nt, nullptr, 0, 0, 6 * G, B, g1, math, s);
+}
+Geom wino_gemm_geom(const Geom& g) { return make_geom(g.Cin, 1, g.W / 4, g.Cout, 1, 1, 1, 1); }
+// U: the layer's transformed filters [G][6][Cin][Cout] when the caller holds them (inside a train step: built once per step), else built here
+static int wino_fwd(const float* x, long x_gs, const float* w, long w_gs, const float* bias, long b_gs, float* y, long y_gs,
+                    int G, int B, const Geom& g, int math, hipStream_t s, const float* U) {
+    const int nt = g.W / 4;
+    const size_t nV = (size_t)6 * G * B * g.Cin * nt, nM = (size_t)6 * G * B * g.Cout * nt, nU = U ? 0 : (size_t)6 * G * g.Cin * g.Cout;
+    char* wsp; VC_CHECK(pack_space(s, (nV + nM + nU) * sizeof(float), &wsp));
+    float* V = (float*)wsp; float* M = V + nV; float* Ub = M + nM;
+    if (!U) { VC_CHECK(launch_wino_filters({WinoFilter{w, Ub, w_gs, g.Cin, g.Cout}}, G, s)); U = Ub; }
+    VC_CHECK(launch_wino_input(x, x_gs, V, G, B, g.Cin, nt, s));
+    VC_CHECK(wino_gemm_fwd(V, U, M, G, B, g, math, s));
+    return launch_wino_output(M, bias, b_gs, y, y_gs, G, B, g.Cout, nt, s);
+}
+static int wino_dgrad(const float* dy, long dy_gs, const float* w, long w_gs, float* dx, long dx_gs, const float* addend, long add_gs,
+                      int accumulate, int G, int B, const Geom& g, int math, hipStream_t s, const float* U) {
+    const int nt = g.W / 4;
+    const size_t nM = (size_t)6 * G * B * g.Cout * nt, nV = (size_t)6 * G * B * g.Cin * nt, nU = U ? 0 : (size_t)6 * G * g.Cin * g.Cout;
+    char* wsp; VC_CHECK(pack_space(s, (nV + nM + nU) * sizeof(float), &wsp));
+    float* dM = (float*)wsp; float* dV = dM + nM; float* Ub = dV + nV;
+    if (!U) { VC_CHECK(launch_wino_filters({WinoFilter{w, Ub, w_gs, g.Cin, g.Cout}}, G, s)); U = Ub; }
+    VC_CHECK(launch_wino_dy(dy, dy_gs, dM, G, B, g.Cout, nt, s));
+    VC_CHECK(wino_gemm_dgrad(dM, U, dV, G, B, g, math, s));
+    return launch_wino_dx(dV, dx, dx_gs, addend, add_gs, accumulate, G, B, g.Cin, nt, s);
+}
+
 // query != nullptr: do not launch, only report whether the launch would use split-K atomics (needs a zeroed y)
 int conv_fwd(const float* x, long x_gs, const float* w, long w_gs, const float* bias, long b_gs,
                     float* y, long y_gs, int G, int B, const Geom& g, int math, hipStream_t s,
@@ -156,6 +210,10 @@ int conv_fwd(const float* x, long x_gs, const float* w, long w_gs, const float* 
     // fuse: the caller would like instance norm + GLU done in the epilogue; fuse->done tells whether this launch did it
     // xp_keep: where the packed bf16 copy of x is left for the layer's filter gradient (16-bit data path; group stride in bytes)
     VC_CHECK(check_conv_geom(g, B));
+    if (wino_eligible(g, math, B)) {      // residual-block convolutions, fp32: six GEMMs in the Winograd domain; every output is stored once
+        if (query) { *query = false; return 0; }
+        return wino_fwd(x, x_gs, w, w_gs, bias, b_gs, y, y_gs, G, B, g, math, s, (const float*)packed_w);
+    }
     if (c1_path(g)) {      // Cin = 1 (D.h1): vector-ALU kernel, plain stores, never needs a zeroed destination
         if (query) { *query = false; return 0; }
         C1Args c = c1_args(g, G, B, math); c.x = x; c.x_gs = x_gs; c.w = w; c.w_gs = w_gs; c.bias = bias; c.b_gs = b_gs; c.y = y; c.y_gs = y_gs;
@@ -232,6 +290,11 @@ int conv_dgrad(const float* dy, long dy_gs, const float* w, long w_gs, float* dx
                       const float* addend, long add_gs, int accumulate, int G, int B, const Geom& g, int math, hipStream_t s,
                       bool prezeroed, bool* query, const char* const* packed_w, const char* dy_packed, long dy_packed_gs) {
     VC_CHECK(check_conv_geom(g, B));
+    if (wino_eligible(g, math, B)) {
+        if (query) { *query = false; return 0; }      // the back transform stores (or accumulates into) every element of dx itself
+        VC_ARG(dy, "conv input gradient (Winograd route): the fp32 dy was left unwritten");
+        return wino_dgrad(dy, dy_gs, w, w_gs, dx, dx_gs, addend, add_gs, accumulate, G, B, g, math, s, packed_w ? (const float*)packed_w[0] : nullptr);
+    }
     if (c1_path(g)) {
         if (query) { *query = false; return 0; }      // zeroes dx itself when it has to
         C1Args c = c1_args(g, G, B, math); c.dy = dy; c.y_gs = dy_gs; c.w = w; c.w_gs = w_gs; c.dx = dx; c.dx_gs = dx_gs;

@@ -186,7 +186,10 @@ static int step_grads_impl(const vc_plan* p, const float* params, float* grads,
     hipStream_t s2 = (p->use_side & 1) ? p->side : s;
     std::vector<PackFilterJob> later_images;
     if (p->math == VC_MATH_BF16) VC_CHECK(refresh_filter_images(p, params, s, &later_images));
-    StepImages scope(p->math == VC_MATH_BF16 ? p : nullptr);
+    bool wino = false;                      // fp32: the generators' 3-tap layers run in the Winograd domain on filters transformed once per step
+    if (p->math == VC_MATH_FP32 && s2 == s) VC_CHECK(refresh_wino_filters(p, params, 2 * B, s, &wino));
+    const bool wino_side = p->math == VC_MATH_FP32 && s2 != s;
+    StepImages scope((p->math == VC_MATH_BF16 || p->math == VC_MATH_FP32) ? p : nullptr);
     // 1. first-hop inputs: g0 = A2B on [A;B], g1 = B2A on [B;A]   (model.py:44,51 / 47,50)
     VC_CHECK(launch_copy_list({{X1, A, ft1}, {X1 + ft1, Bm, ft1}, {X1 + X1g, Bm, ft1}, {X1 + X1g + ft1, A, ft1}}, s));
     // 0. zero the accumulated parts of the flat gradient on the side stream, under the first-hop forward (nothing touches
@@ -196,6 +199,7 @@ static int step_grads_impl(const vc_plan* p, const float* params, float* grads,
     if (s2 != s) { VC_HIP(hipEventRecord(p->ev_fork, s)); VC_HIP(hipStreamWaitEvent(s2, p->ev_fork, 0)); }
     // the filter images nothing reads before the discriminator forward (side stream, in order behind this launch) and the backward
     // passes (behind the join after the discriminator forward)
+    if (wino_side) VC_CHECK(refresh_wino_filters(p, params, 2 * B, s2, &wino));      // first on the side stream: the first-hop forward reaches its residual blocks ~0.1 ms in
     if (!later_images.empty()) VC_CHECK(launch_pack_filter_multi(later_images, 2, s2));
     VC_CHECK(zero_step_grads(p, grads, B, Bbwd, s2));
     // ... and the split-K destinations of the three backward passes whose scratch is theirs alone until they run (step 10 shares SCR with step 8)
@@ -306,7 +310,8 @@ extern "C" int vc_train_step_graph(vc_plan* p, float* params, float* grads, floa
         // the side stream) crashes hipStreamEndCapture; the captured schedule keeps those launches on the side stream
         const int overlap = p->use_side;
         p->use_side &= ~4;
-        if (p->math == VC_MATH_BF16) {
+        if (p->math == VC_MATH_BF16 || p->math == VC_MATH_FP32) {
+            // (fp32: the Winograd route's transformed filters and transform-domain scratch, same rule)
             // the 16-bit data path keeps packed operands in per-stream workspaces and per-plan filter images that are
             // allocated on first use -- not allowed while capturing: run the schedule once, eagerly, on the capture streams
             // (it writes only gradients, losses and the generation outputs, all of which the replay overwrites)

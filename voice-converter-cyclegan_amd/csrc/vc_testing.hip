@@ -34,6 +34,10 @@ extern "C" int vc_tune_wgrad_store(int on) { t_hooks.wgrad_store = on ? 1 : 0; r
 extern "C" int vc_tune_glu(int flags) { t_hooks.glu_flags = flags; return 0; }
 extern "C" int vc_tune_c1_dgrad_gather(int on) { t_hooks.c1_gather = on ? 1 : 0; return 0; }
 extern "C" int vc_tune_layer_updates(int on) { t_hooks.layer_updates = on ? 1 : 0; return 0; }
+extern "C" int vc_tune_winograd(int on) { t_hooks.winograd = on ? 1 : 0; return 0; }
+static thread_local long long t_wino_gemms = 0;
+void vc_count_wino_gemm() { ++t_wino_gemms; }
+extern "C" long long vc_testing_wino_gemms(int reset) { const long long n = t_wino_gemms; if (reset) t_wino_gemms = 0; return n; }
 extern "C" int vc_testing_hooks_active(void);
 extern "C" int vc_thread_is_product_run(void) { return vc_testing_hooks_active() == 0; }
 // bit per switch that is NOT at its production value in the calling thread (0: a product run)
@@ -42,5 +46,5 @@ extern "C" int vc_testing_hooks_active(void) {
     const TestHooks& h = t_hooks;
     return (h.igemm_bm != d.igemm_bm ? 1 : 0) | (h.wgrad_bn != d.wgrad_bn ? 2 : 0) | (h.bf16_bm != d.bf16_bm ? 4 : 0) | (h.bf16_spec != d.bf16_spec ? 8 : 0) |
            (h.pixel_octets != d.pixel_octets ? 16 : 0) | (h.rowskip_wgrad != d.rowskip_wgrad ? 32 : 0) | (h.wgrad_store != d.wgrad_store ? 64 : 0) |
-           (h.glu_flags != d.glu_flags ? 128 : 0) | (h.c1_gather != d.c1_gather ? 256 : 0) | (h.layer_updates != d.layer_updates ? 512 : 0);
+           (h.glu_flags != d.glu_flags ? 128 : 0) | (h.c1_gather != d.c1_gather ? 256 : 0) | (h.layer_updates != d.layer_updates ? 512 : 0) | (h.winograd != d.winograd ? 1024 : 0);
 }
