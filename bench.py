@@ -101,7 +101,7 @@ def cpu_baseline(leg_timeout_s=150):
                 sample='24x128 MCEP, fp32; ' + '; '.join([l[2] for l in legs] + notes) + '; TF1 reference not runnable (no tensorflow)')
 
 
-PMC_FILES = ('r05_pmc_traffic.json', 'r04_pmc_traffic.json', 'r03_pmc_traffic.json')
+PMC_FILES = ('r06_pmc_traffic.json', 'r05_pmc_traffic.json', 'r04_pmc_traffic.json', 'r03_pmc_traffic.json')
 
 
 def _pmc_traffic(B, F, T, world, math, role='igemm'):
@@ -255,9 +255,11 @@ def roofline_leg(eng, lib, A, Bm, hp, math, peak, world, serial, n_prof=3):
         eng.train_step(A, Bm, *hp, sync=False)
     torch.cuda.synchronize()
     CycleGANEngine.profiling(True)
+    lib.vc_testing_wino_saved_flops(0, 1); lib.vc_testing_wino_saved_flops(1, 1)
     for _ in range(n_prof):
         eng.train_step(A, Bm, *hp, sync=False)
     torch.cuda.synchronize()
+    saved = [lib.vc_testing_wino_saved_flops(0, 1), lib.vc_testing_wino_saved_flops(1, 1)]    # fp32: work the Winograd route did not execute
     stats = {}
     knames = ((0, 'igemm_kernel (conv fwd + dgrad, every Cin > 1 layer)'), (1, 'wgrad_kernel'), (2, 'wsconv1d_kernel'))
     if math == 'bf16':       # 16-bit data path (csrc/vc_conv_bf16.hip); launches too small for its tiles stay on igemm / wgrad_kernel
@@ -284,11 +286,24 @@ def roofline_leg(eng, lib, A, Bm, hp, math, peak, world, serial, n_prof=3):
         'condition': 'step chains serialised on one stream (no co-running launches); see --serial',
         'avg_launch_us': 1e3 * ms / max(n, 1), 'algorithmic_gflop_per_step': fl / n_prof / 1e9,
         'kernel_ms_per_step': ms / n_prof}}
+    if saved[0] > 0 or saved[1] > 0:
+        # `achieved` above counts the multiply-adds the MFMA pipe EXECUTED (what the MFMA roof bounds).  The residual blocks' convolutions run as
+        # Winograd F(4,3) (csrc/vc_conv_wino.hip): half the multiplies of the direct form for the same result -- the rate in direct-form FLOPs:
+        out['roofline']['winograd'] = {
+            'what': 'forward + input gradient of the 3-tap stride-1 convolutions as 6 transform-domain GEMMs (1 x 1, 6G groups) on igemm_kernel',
+            'direct_form_gflop_per_step': (fl + saved[0]) / n_prof / 1e9,
+            'direct_equivalent_tflops': (fl + saved[0]) / (ms * 1e-3) / 1e12 if ms > 0 else 0.0,
+            'direct_equivalent_frac': (fl + saved[0]) / (ms * 1e-3) / 1e12 / peak if ms > 0 else 0.0}
     name, ms, n, fl = stats[1]
     ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     out['roofline_wgrad'] = {'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak, 'kernel': name,
                              'launches_per_step': n // n_prof, 'kernel_ms_per_step': ms / n_prof,
                              'traffic': _pmc_traffic(B, F, T, world, math, 'wgrad')[0]}
+    if saved[1] > 0:
+        out['roofline_wgrad']['kernel'] = 'wgrad_kernel + wino_wgrad_kernel (residual blocks: Winograd-domain filter gradient, taps folded in registers)'
+        out['roofline_wgrad']['winograd'] = {'direct_form_gflop_per_step': (fl + saved[1]) / n_prof / 1e9,
+                                             'direct_equivalent_tflops': (fl + saved[1]) / (ms * 1e-3) / 1e12 if ms > 0 else 0.0,
+                                             'direct_equivalent_frac': (fl + saved[1]) / (ms * 1e-3) / 1e12 / peak if ms > 0 else 0.0}
     # FLOPs the step executes: every MFMA launch carries its algorithmic FLOPs; the Cin = 1 layer (D.h1, vector ALU)
     # is added analytically: forward over 2B samples per D, filter gradient over 2B, input gradient over B
     c1 = 2.0 * 9 * 256 * (F * (T // 2)) * 2 * (2 * B + 2 * B + B)      # 9 taps x 256 filters x F x T/2 pixels, 2 discriminators

@@ -44,7 +44,7 @@ extern "C" {
 typedef struct vc_plan vc_plan;   /* opaque: geometry tables + workspace map for one (F, T) */
 
 /* ---- library ------------------------------------------------------------- */
-int         vc_version(void);          /* ABI revision: 115 (bumped whenever an entry point changes or is added) */
+int         vc_version(void);          /* ABI revision: 116 (bumped whenever an entry point changes or is added) */
 int         vc_thread_is_product_run(void);   /* 1 when every test / tuning switch of vc_cyclegan_testing.h is at its production value in the
                                                * calling thread (model.CycleGAN.train and bench.py refuse to run otherwise: a forced tile
                                                * configuration left behind by a test must never be trained or benched with) */

@@ -45,6 +45,9 @@ int  vc_tune_layer_updates(int on);
 int  vc_tune_winograd(int on);
 /* Winograd-domain GEMM launches (one per convolution forward / input gradient on the route) the calling thread has issued; reset != 0 clears. */
 long long vc_testing_wino_gemms(int reset);
+/* Multiply-add work (FLOP) those launches did NOT execute compared with the direct form, since the last reset: kind 0 = forward + input gradient,
+ * 1 = filter gradient.  bench.py prints the kernels' executed FLOP/s (its MFMA roofline) and, beside it, the direct-equivalent rate. */
+double vc_testing_wino_saved_flops(int kind, int reset);
 /* Bit mask of the switches of this header that are NOT at their production value in the calling thread (0 = a product run; the product
  * header's vc_thread_is_product_run() is `== 0` of this).  bits: 1 igemm, 2 wgrad, 4 conv_bf16 override, 8 conv_bf16_spec, 16 pixel octets,
  * 32 rowskip, 64 wgrad_store, 128 glu, 256 c1 gather, 512 layer updates, 1024 winograd. */

@@ -37,7 +37,7 @@ def test_header_symbols_exported_and_bound(built_lib):
         assert hasattr(built_lib.lib, n), 'symbol %s declared in include/*.h is not exported' % n
         assert n in bound, 'symbol %s has no ctypes signature in _lib.SIGNATURES' % n
     assert bound <= set(names), 'python binds symbols the header does not declare: %s' % (bound - set(names))
-    assert built_lib.lib.vc_version() == built_lib.ABI_VERSION == 115
+    assert built_lib.lib.vc_version() == built_lib.ABI_VERSION == 116
 
 
 def test_library_is_stamped_with_the_hash_of_its_sources(built_lib, tmp_path, monkeypatch):

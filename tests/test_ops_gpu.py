@@ -532,6 +532,8 @@ WINO_CASES = [
     (64, 8, 64, 32),           # two tiles a row: both are edge tiles
     (128, 64, 96, 4),          # 36 x 256 geometry's frame count (16 tiles a row), Cout not a multiple of 64
     (96, 12, 64, 24),          # three tiles a row (W = 12), Cin = 96
+    (128, 64, 128, 4),         # filter gradient: two k octets a row (16 tiles)
+    (64, 32, 64, 12),          # filter gradient: 12 iterations per transform position (prefetch depth 4 instead of 8)
 ]
 
 
@@ -551,12 +553,14 @@ def test_winograd_route_against_the_oracle_and_the_direct_kernel(built_lib, case
     xs = rng.standard_normal((G, B, W, Cin)).astype(np.float32)
     ws = (rng.standard_normal((G, 1, 3, Cin, Cout)) / np.sqrt(3 * Cin)).astype(np.float32)
     bs = rng.uniform(-0.5, 0.5, (G, Cout)).astype(np.float32)
-    ys, dxs, dys = [], [], []
+    ys, dxs, dys, dws = [], [], [], []
     for g in range(G):
         y, cache = O.conv1d_fwd(xs[g], ws[g][0], bs[g], 1)
         dy = rng.standard_normal(y.shape).astype(np.float32)
-        dx, _, _ = O.conv1d_bwd(dy, ws[g][0], cache)
-        ys.append(y); dxs.append(dx); dys.append(dy)
+        dx, dw, _ = O.conv1d_bwd(dy, ws[g][0], cache)
+        ys.append(y); dxs.append(dx); dys.append(dy); dws.append(dw[None])
+    # the fused filter-gradient kernel: whole k octets, 64 x 64 channel tiles, iterations in multiples of 4 (else the direct kernel)
+    wg = (W // 4) % 8 == 0 and Cin % 64 == 0 and Cout % 64 == 0 and (B * (W // 32)) % 4 == 0
     cf = lambda a: np.ascontiguousarray(np.transpose(np.stack(a), (0, 1, 3, 2)))[:, :, :, None, :]      # [G, B, C, 1, W]
     x_d, w_d, b_d, dy_d = U.dev(cf(list(xs))), U.dev(ws), U.dev(bs), U.dev(cf(dys))
     add = U.dev(rng.standard_normal(cf(dxs).shape).astype(np.float32)); init = U.dev(rng.standard_normal(cf(dxs).shape).astype(np.float32))
@@ -567,10 +571,13 @@ def test_winograd_route_against_the_oracle_and_the_direct_kernel(built_lib, case
             y = U.conv_fwd(x_d, w_d, b_d, 1, 3, 1, 1)
             dx = U.conv_dgrad(dy_d, w_d, 1, W, 1, 3, 1, 1)
             dx2 = U.conv_dgrad(dy_d, w_d, 1, W, 1, 3, 1, 1, addend=add, init=init)
-            assert lib.vc_testing_wino_gemms(1) == (3 if on else 0)
-            out[on] = (y.cpu().numpy(), dx.cpu().numpy(), dx2.cpu().numpy())
+            dw = U.conv_wgrad(x_d, dy_d, 1, 3, 1, 1)
+            dw2 = U.conv_wgrad(x_d, dy_d, 1, 3, 1, 1, init=dw)              # the operator accumulates: twice the gradient
+            assert lib.vc_testing_wino_gemms(1) == ((3 + (2 if wg else 0)) if on else 0)
+            out[on] = (y.cpu().numpy(), dx.cpu().numpy(), dx2.cpu().numpy(), dw.cpu().numpy(), dw2.cpu().numpy())
             assert U.rel_err(out[on][0], cf(ys)) < TOL and U.rel_err(out[on][1], cf(dxs)) < TOL
             assert U.rel_err(out[on][2], cf(dxs) + add.cpu().numpy() + init.cpu().numpy()) < TOL
+            assert U.rel_err(out[on][3], np.stack(dws)) < TOL and U.rel_err(out[on][4], 2 * np.stack(dws)) < TOL
     finally:
         check(lib.vc_tune_winograd(1))
     for a, b in zip(out[1], out[0]):

@@ -1151,8 +1151,8 @@ def test_winograd_route_inside_the_train_step(built_lib):
     """fp32 B = 8 (BASELINE configs[1]): the residual blocks' 12 convolutions per generator run their forward and input gradient in the
     Winograd domain on filters transformed once per step, the tile transforms inside the instance-norm launches on either side
     (csrc/vc_conv_wino.hip, vc_net.hip).  Against the direct kernels (vc_tune_winograd(0)) on the same state: losses to 1e-5, every gradient
-    tensor to 1e-4 rel-L2 (what a change of summation order inside 24 convolutions moves); the counter shows the route ran: 2 forward passes +
-    2 backward passes x 12 layers.  (Against the oracle: test_train_step_losses_grads_and_updates[8] runs with the route on.)"""
+    tensor to 1e-4 rel-L2 (what a change of summation order inside 24 convolutions moves); the counter shows the route ran: (2 forward passes +
+    2 input-gradient passes + 1 two-application filter-gradient pass) x 12 layers.  (Against the oracle: test_train_step_losses_grads_and_updates[8] runs with the route on.)"""
     lib, check = built_lib.lib, built_lib.check
     O, P, A, Bm, eng = _setup(8, seed=16)
     A_d, B_d = eng._to_dev(A), eng._to_dev(Bm)
@@ -1162,7 +1162,7 @@ def test_winograd_route_inside_the_train_step(built_lib):
             check(lib.vc_tune_winograd(on)); lib.vc_testing_wino_gemms(1)
             eng.step_grads(A_d, B_d, 10.0, 5.0); torch.cuda.synchronize()
             n = lib.vc_testing_wino_gemms(1)
-            assert n == (48 if on else 0), n
+            assert n == (60 if on else 0), n
             res.setdefault(on, []).append((eng.losses.cpu().numpy().copy(), eng.tf_gradients()))
     finally:
         check(lib.vc_tune_winograd(1))

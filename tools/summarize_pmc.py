@@ -30,7 +30,7 @@ def role(k):
     if k.startswith('conv_bf16_kernel'):
         args = k[k.index('<') + 1:].rstrip('>').replace(' ', '').split(',')      # <tile rows, ring stages, ROLE[, SPEC]>
         return 'wgrad' if len(args) > 2 and args[2] == '1' else 'igemm'
-    return 'igemm' if k.startswith('igemm_kernel') else 'wgrad' if k.startswith('wgrad_kernel') else None
+    return 'igemm' if k.startswith('igemm_kernel') else 'wgrad' if (k.startswith('wgrad_kernel') or 'wino_wgrad_kernel' in k) else None
 
 
 summary = {}

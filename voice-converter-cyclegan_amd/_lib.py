@@ -29,7 +29,7 @@ def _expected_build_id():
     return mod, mod.build_id(os.environ.get('VC_EXTRA_FLAGS', '').split())
 
 
-ABI_VERSION = 115
+ABI_VERSION = 116
 lib = C.CDLL(LIB_PATH)
 lib.vc_build_id.restype = C.c_char_p
 BUILD_ID = lib.vc_build_id().decode()
@@ -91,6 +91,7 @@ SIGNATURES = [
     ('vc_tune_layer_updates', i32, [i32]),
     ('vc_tune_winograd', i32, [i32]),
     ('vc_testing_wino_gemms', C.c_longlong, [i32]),
+    ('vc_testing_wino_saved_flops', C.c_double, [i32, i32]),
     ('vc_testing_hooks_active', i32, []),
     ('vc_testing_describe_step', i64, [vp, i32, i32, C.c_char_p, i64]),
     ('vc_testing_poison_internal', i32, [vp, vp, i32]),

@@ -14,6 +14,7 @@
 #include "vc_internal.h"
 #include "vc_device_util.h"
 #include "vc_wino.h"
+#include <algorithm>
 
 namespace {
 
@@ -98,6 +99,95 @@ __global__ __launch_bounds__(256) void wino_filter_kernel(const WinoFilterJobs j
     *reinterpret_cast<f32x4*>(u + 5 * plane) = g2;
 }
 
+// up to four tile transforms in one launch (blockIdx.y = job): the operands of a filter gradient in the Winograd domain -- both applications'
+// inputs (B^T x) and output gradients (A dy)
+struct WinoPrep { WinoArgs a[4]; int kind[4]; int n; };      // kind 0: input transform, 1: dy transform
+__global__ __launch_bounds__(256) void wino_prep_kernel(const WinoPrep pp) {
+    const WinoArgs& p = pp.a[blockIdx.y];
+    int g, i; long r;
+    if (!wino_row(p, g, r, i)) return;
+    const float* x = p.src + (long)g * p.src_gs + r * (4 * p.nt) + 4 * i;
+    const f32x4 c = *reinterpret_cast<const f32x4*>(x);
+    float* d = p.dst + (long)g * p.dst_gs + r * p.nt + i;
+    if (pp.kind[blockIdx.y] == 0) wino_store_input(c, i > 0 ? x[-1] : 0.f, i + 1 < p.nt ? x[4] : 0.f, d, p.plane);
+    else wino_store_dy(c, d, p.plane);
+}
+
+// Filter gradient in the Winograd domain: dU[p] = sum over tiles of V[p] dM[p]^T (six channel GEMMs over a quarter of the pixels each), reduced
+// to the three taps in registers: dw[k] = sum_p G[p][k] dU[p].  One wave = a 32 x 32 (cin x cout) tile of all three taps; no LDS: the operands
+// are [p][b][channel][tile] with 8 k tiles of a row contiguous, so a lane's 16-byte load IS its four k values of four MFMA steps (lanes 0-31
+// take tiles 0-3 of the octet, lanes 32-63 tiles 4-7 -- any k order is right as long as both operands use the same one), and a wave's load is
+// one contiguous 1 KB run.  Loads run VC_WW_AHEAD (8, or 4 when the iteration count is no multiple of 8) iterations ahead of their multiplies.  Fixed summation order (no atomics, no split-K).
+struct WinoWgradArgs {
+    const float* V[2]; const float* dM[2]; long V_gs[2], dM_gs[2]; int B[2]; int napp;
+    float* dW; long dw_gs; int Cin, Cout, nt, store;
+};
+template <int VC_WW_AHEAD>
+__global__ __launch_bounds__(256) void wino_wgrad_kernel(const WinoWgradArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, h = lane >> 5;
+    const int ctiles = a.Cout >> 6;                                  // 64 x 64 per workgroup: waves 2 x 2
+    const int tm = blockIdx.x / ctiles, tn = blockIdx.x - tm * ctiles;
+    const int cin0 = tm * 64 + (wave >> 1) * 32, cout0 = tn * 64 + (wave & 1) * 32;
+    const int g = blockIdx.y;
+    const int oct = a.nt >> 3;                                       // k octets (8 tiles) per row
+    f32x16 acc[3], T;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; acc[2][r] = 0.f; T[r] = 0.f; }
+    // fold the finished transform position p into the taps: acc[k] += G[p][k] T
+    auto fold = [&](int p) {
+        float g0, g1, g2;
+        switch (p) {
+            case 0: g0 = 0.25f; g1 = 0.f; g2 = 0.f; break;
+            case 1: g0 = -1.f / 6.f; g1 = -1.f / 6.f; g2 = -1.f / 6.f; break;
+            case 2: g0 = -1.f / 6.f; g1 = 1.f / 6.f; g2 = -1.f / 6.f; break;
+            case 3: g0 = 1.f / 24.f; g1 = 1.f / 12.f; g2 = 1.f / 6.f; break;
+            case 4: g0 = 1.f / 24.f; g1 = -1.f / 12.f; g2 = 1.f / 6.f; break;
+            default: g0 = 0.f; g1 = 0.f; g2 = 1.f; break;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[0][r] += g0 * T[r]; acc[1][r] += g1 * T[r]; acc[2][r] += g2 * T[r]; T[r] = 0.f; }
+    };
+    for (int app = 0; app < a.napp; ++app) {
+        // one application: iterations = (p, sample, octet) with p slowest -- the operands' own memory order, so both pointers walk by constant
+        // steps straight through the six transform positions; B oct is a multiple of VC_WW_AHEAD (the launcher checks)
+        const int per_p = a.B[app] * oct;
+        const float* pa = a.V[app] + (long)g * a.V_gs[app] + (long)(cin0 + l31) * a.nt + h * 4;
+        const float* pb = a.dM[app] + (long)g * a.dM_gs[app] + (long)(cout0 + l31) * a.nt + h * 4;
+        const long ja = (long)a.Cin * a.nt - 8 * (oct - 1), jb = (long)a.Cout * a.nt - 8 * (oct - 1);   // step from a row's last octet to the next sample's first
+        int o = 0;
+        auto advance = [&]() { if (++o == oct) { o = 0; pa += ja; pb += jb; } else { pa += 8; pb += 8; } };
+        f32x4 av[VC_WW_AHEAD], bv[VC_WW_AHEAD];
+#pragma unroll
+        for (int d = 0; d < VC_WW_AHEAD; ++d) { av[d] = *reinterpret_cast<const f32x4*>(pa); bv[d] = *reinterpret_cast<const f32x4*>(pb); advance(); }
+        for (int p = 0; p < 6; ++p) {
+            const int nc = p < 5 ? per_p : per_p - VC_WW_AHEAD;       // (the last VC_WW_AHEAD iterations of the application have nothing to fetch: below)
+            for (int c = 0; c < nc; c += VC_WW_AHEAD) {
+#pragma unroll
+                for (int d = 0; d < VC_WW_AHEAD; ++d) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) T = __builtin_amdgcn_mfma_f32_32x32x2f32(av[d][e], bv[d][e], T, 0, 0, 0);
+                    av[d] = *reinterpret_cast<const f32x4*>(pa); bv[d] = *reinterpret_cast<const f32x4*>(pb); advance();
+                }
+            }
+            if (p < 5) fold(p);
+        }
+#pragma unroll
+        for (int d = 0; d < VC_WW_AHEAD; ++d)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) T = __builtin_amdgcn_mfma_f32_32x32x2f32(av[d][e], bv[d][e], T, 0, 0, 0);
+        fold(5);
+    }
+    float* dw = a.dW + (long)g * a.dw_gs;
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int cin = cin0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            float* q = dw + ((long)k * a.Cin + cin) * a.Cout + cout0 + l31;
+            *q = a.store ? acc[k][r] : *q + acc[k][r];
+        }
+}
+
 int launch_wino(void (*k)(WinoArgs), WinoArgs a, hipStream_t s) {
     a.rows = a.G * a.B * a.C;
     a.plane = (long)a.B * a.C * a.nt;
@@ -145,5 +235,38 @@ int launch_wino_filters(const std::vector<WinoFilter>& f, int G, hipStream_t s) 
         wino_filter_kernel<<<dim3(blk, (unsigned)G), 256, 0, s>>>(jj);
         VC_HIP(hipGetLastError());
     }
+    return 0;
+}
+
+// the four operands of a Winograd-domain filter gradient in one launch: napp applications' x -> V and dy -> dM (all [G][6][B][C][nt])
+int launch_wino_prep(const WinoPrepJob* jobs, int n, int G, int nt, hipStream_t s) {
+    WinoPrep pp{}; pp.n = n; long maxthreads = 0;
+    for (int k = 0; k < n; ++k) {
+        WinoArgs& a = pp.a[k]; a = WinoArgs{};
+        a.src = jobs[k].src; a.src_gs = jobs[k].src_gs; a.dst = jobs[k].dst; a.dst_gs = 6L * jobs[k].B * jobs[k].C * nt;
+        a.G = G; a.B = jobs[k].B; a.C = jobs[k].C; a.nt = nt; a.rows = G * jobs[k].B * jobs[k].C; a.plane = (long)jobs[k].B * jobs[k].C * nt;
+        pp.kind[k] = jobs[k].kind;
+        maxthreads = std::max(maxthreads, (long)a.rows * nt);
+    }
+    if (maxthreads <= 0) return 0;
+    wino_prep_kernel<<<dim3((unsigned)((maxthreads + 255) / 256), (unsigned)n), 256, 0, s>>>(pp);
+    VC_HIP(hipGetLastError());
+    return 0;
+}
+// dW [G][3][Cin][Cout] (+)= the filter gradient of napp applications from their transform-domain operands
+int launch_wino_wgrad(const float* const* V, const float* const* dM, const int* B, int napp, float* dW, long dw_gs, int store,
+                      int G, int Cin, int Cout, int nt, hipStream_t s, double flops) {
+    WinoWgradArgs a{};
+    for (int k = 0; k < napp; ++k) { a.V[k] = V[k]; a.dM[k] = dM[k]; a.B[k] = B[k]; a.V_gs[k] = 6L * B[k] * Cin * nt; a.dM_gs[k] = 6L * B[k] * Cout * nt; }
+    a.napp = napp; a.dW = dW; a.dw_gs = dw_gs; a.Cin = Cin; a.Cout = Cout; a.nt = nt; a.store = store;
+    ProfScope prof(1, flops, s);
+    bool by8 = true;
+    for (int k = 0; k < napp; ++k) {
+        if ((B[k] * (nt / 8)) % 4 != 0) { vc_set_error("winograd filter gradient: samples x k octets must be a multiple of 4"); return -1; }
+        by8 = by8 && (B[k] * (nt / 8)) % 8 == 0;
+    }
+    const dim3 grid((unsigned)((Cin / 64) * (Cout / 64)), (unsigned)G);
+    if (by8) wino_wgrad_kernel<8><<<grid, 256, 0, s>>>(a); else wino_wgrad_kernel<4><<<grid, 256, 0, s>>>(a);
+    VC_HIP(hipGetLastError());
     return 0;
 }

@@ -183,6 +183,10 @@ int launch_wino_filters(const std::vector<WinoFilter>& f, int G, hipStream_t s);
 int launch_wino_input(const float* x, long x_gs, float* V, int G, int B, int C, int nt, hipStream_t s);
 int launch_wino_output(const float* M, const float* bias, long b_gs, float* y, long y_gs, int G, int B, int C, int nt, hipStream_t s);
 int launch_wino_dy(const float* dy, long dy_gs, float* dM, int G, int B, int C, int nt, hipStream_t s);
+struct WinoPrepJob { const float* src; long src_gs; float* dst; int B, C, kind; };   // kind 0: x -> V = B^T x, 1: dy -> dM = A dy
+int launch_wino_prep(const WinoPrepJob* jobs, int n, int G, int nt, hipStream_t s);
+int launch_wino_wgrad(const float* const* V, const float* const* dM, const int* B, int napp, float* dW, long dw_gs, int store,
+                      int G, int Cin, int Cout, int nt, hipStream_t s, double flops);
 int launch_wino_dx(const float* dV, float* dx, long dx_gs, const float* addend, long add_gs, int accumulate, int G, int B, int C, int nt, hipStream_t s);
 
 struct NormArgs {
@@ -292,4 +296,4 @@ struct TestHooks {
     int winograd = 1;                                  // vc_tune_winograd
 };
 const TestHooks& vc_hooks();
-void vc_count_wino_gemm();            // vc_testing_wino_gemms: the calling thread issued one more Winograd-domain GEMM launch
+void vc_count_wino_gemm(int kind, double saved_flops);   // vc_testing_wino_gemms / _saved_flops: one more Winograd-domain launch of the calling thread (kind 0 fwd / dgrad, 1 wgrad)

@@ -158,6 +158,13 @@ bool wino_eligible(const Geom& g, int math, int B) {
     return math == VC_MATH_FP32 && vc_hooks().winograd != 0 && g.kh == 1 && g.kw == 3 && g.sh == 1 && g.sw == 1 && g.H == 1 &&
            g.W % 4 == 0 && g.W >= 8 && g.Cin % 32 == 0 && g.Cout % 32 == 0 && g.Cin >= 64 && g.Cout >= 64 && (long)B * (g.W / 4) >= 64;
 }
+// the filter gradient of the same layers: the fused Winograd-domain kernel (vc_conv_wino.hip: wino_wgrad_kernel) wants whole k octets
+// (W / 4 a multiple of 8) and 64 x 64 channel tiles; Bmax = the largest application of the launch
+static bool wino_wgrad_eligible(const Geom& g, int math, const WgradApp* apps, int napps) {
+    int Bmax = 0;
+    for (int k = 0; k < napps; ++k) { Bmax = std::max(Bmax, apps[k].B); if ((apps[k].B * (g.W / 32)) % 4 != 0) return false; }   // the kernel's prefetch depth
+    return wino_eligible(g, math, Bmax) && (g.W / 4) % 8 == 0 && g.Cin % 64 == 0 && g.Cout % 64 == 0;
+}
 int wino_workspace(hipStream_t s, size_t floats, float** out) {
     char* q; VC_CHECK(pack_space(s, floats * sizeof(float), &q));
     *out = (float*)q;
@@ -169,13 +176,13 @@ int wino_workspace(hipStream_t s, size_t floats, float** out) {
 int wino_gemm_fwd(const float* V, const float* U, float* M, int G, int B, const Geom& g, int math, hipStream_t s) {
     const int nt = g.W / 4; const Geom g1 = wino_gemm_geom(g);
     DetScope no_split(1);
-    vc_count_wino_gemm();
+    vc_count_wino_gemm(0, 2.0 * G * B * g.W * (double)g.Cout * g.Cin * (3.0 - 1.5));      // direct: 3 taps x W pixels; here: 6 positions x W / 4
     return conv_fwd(V, (long)B * g.Cin * nt, U, (long)g.Cin * g.Cout, nullptr, 0, M, (long)B * g.Cout * nt, 6 * G, B, g1, math, s);
 }
 int wino_gemm_dgrad(const float* dM, const float* U, float* dV, int G, int B, const Geom& g, int math, hipStream_t s) {
     const int nt = g.W / 4; const Geom g1 = wino_gemm_geom(g);
     DetScope no_split(1);
-    vc_count_wino_gemm();
+    vc_count_wino_gemm(0, 2.0 * G * B * g.W * (double)g.Cout * g.Cin * (3.0 - 1.5));
     return conv_dgrad(dM, (long)B * g.Cout * nt, U, (long)g.Cin * g.Cout, dV, (long)B * g.Cin * nt, nullptr, 0, 0, 6 * G, B, g1, math, s);
 }
 Geom wino_gemm_geom(const Geom& g) { return make_geom(g.Cin, 1, g.W / 4, g.Cout, 1, 1, 1, 1); }
@@ -454,6 +461,30 @@ int conv_wgrad(const WgradApp* apps, int napps, float* dw, long dw_gs, int G, co
         return 0;
     }
     VC_ARG(napps >= 1 && napps <= 2, "conv filter gradient: 1 or 2 applications per launch");
+    if (wino_wgrad_eligible(g, math, apps, napps)) {
+        // residual-block convolutions, fp32: both applications' operands go to the transform domain in one launch (V = B^T x, dM = A dy), the fused
+        // kernel multiplies per transform position and folds the six results into the three taps in registers; a tile has ONE writer
+        if (query) { *query = !store; return 0; }
+        const int nt = g.W / 4;
+        size_t nV[2] = {0, 0}, nM[2] = {0, 0}, tot = 0;
+        for (int k = 0; k < napps; ++k) {
+            VC_CHECK(check_conv_geom(g, apps[k].B));
+            VC_ARG(apps[k].dy && apps[k].x, "conv filter gradient (Winograd route): an application's fp32 operands are missing");
+            nV[k] = (size_t)6 * G * apps[k].B * g.Cin * nt; nM[k] = (size_t)6 * G * apps[k].B * g.Cout * nt; tot += nV[k] + nM[k];
+        }
+        float* wsp; VC_CHECK(wino_workspace(s, tot, &wsp));
+        WinoPrepJob jobs[4]; const float* V[2]; const float* dM[2]; int Bs[2]; int nj = 0; double flops = 0;
+        for (int k = 0; k < napps; ++k) {
+            float* v = wsp; wsp += nV[k]; float* m = wsp; wsp += nM[k];
+            jobs[nj++] = WinoPrepJob{apps[k].x, apps[k].x_gs, v, apps[k].B, g.Cin, 0};
+            jobs[nj++] = WinoPrepJob{apps[k].dy, apps[k].dy_gs, m, apps[k].B, g.Cout, 1};
+            V[k] = v; dM[k] = m; Bs[k] = apps[k].B;
+            flops += 2.0 * 6 * G * apps[k].B * nt * (double)g.Cin * g.Cout;
+        }
+        VC_CHECK(launch_wino_prep(jobs, nj, G, nt, s));
+        vc_count_wino_gemm(1, flops);      // the direct form multiplies twice as much
+        return launch_wino_wgrad(V, dM, Bs, napps, dw, dw_gs, store ? 1 : 0, G, g.Cin, g.Cout, nt, s, flops);
+    }
     Table t; VC_CHECK(get_fwd_table(g, &t));
     {
         long ptot = 0; for (int k = 0; k < napps; ++k) ptot += (long)apps[k].B * g.OH * g.OW;

@@ -19,7 +19,7 @@ extern "C" const char* vc_last_error(void) { return g_err; }
 // arity without a bump -- ADVICE r4).  _lib.py asserts the version it was written against.
 // 111: vc_tune_conv_bf16_spec (testing header; round 5: the wave-specialised bf16 convolutions and their 256-thread control)
 // 112: vc_tune_bf16_pixel_octets (testing header: dy as pixel octets from the norm backward, and the pack-launch control)
-extern "C" int vc_version(void) { return 115; }
+extern "C" int vc_version(void) { return 116; }
 #ifndef VC_BUILD_ID
 #define VC_BUILD_ID "unstamped"
 #endif

@@ -36,7 +36,11 @@ extern "C" int vc_tune_c1_dgrad_gather(int on) { t_hooks.c1_gather = on ? 1 : 0;
 extern "C" int vc_tune_layer_updates(int on) { t_hooks.layer_updates = on ? 1 : 0; return 0; }
 extern "C" int vc_tune_winograd(int on) { t_hooks.winograd = on ? 1 : 0; return 0; }
 static thread_local long long t_wino_gemms = 0;
-void vc_count_wino_gemm() { ++t_wino_gemms; }
+static thread_local double t_wino_saved[2] = {0.0, 0.0};
+void vc_count_wino_gemm(int kind, double saved_flops) { ++t_wino_gemms; t_wino_saved[kind ? 1 : 0] += saved_flops; }
+// multiply-add work the Winograd route did NOT execute (direct form minus transform-domain GEMMs) since the last reset: kind 0 forward + input
+// gradient launches, 1 filter gradients.  bench.py reports the kernels' executed FLOP/s (the MFMA roofline) and, beside it, the direct-equivalent rate.
+extern "C" double vc_testing_wino_saved_flops(int kind, int reset) { const double v = t_wino_saved[kind ? 1 : 0]; if (reset) t_wino_saved[kind ? 1 : 0] = 0.0; return v; }
 extern "C" long long vc_testing_wino_gemms(int reset) { const long long n = t_wino_gemms; if (reset) t_wino_gemms = 0; return n; }
 extern "C" int vc_testing_hooks_active(void);
 extern "C" int vc_thread_is_product_run(void) { return vc_testing_hooks_active() == 0; }
