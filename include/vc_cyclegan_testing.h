@@ -35,9 +35,12 @@ int  vc_tune_bf16_pixel_octets(int on);
  * mode (fixed summation order) without the rest of that mode, 0 = the atomic scatter (production).  The scatter's summation order is the one
  * run-to-run noise source of a split-K-free step that PROPAGATES: it feeds the generators' output gradients. */
 int  vc_tune_c1_dgrad_gather(int on);
-/* Single-GPU parameter update (vc_step_exchange_and_update without a communicator) for the calling thread's following steps: 1 (production) =
- * ApplyAdam layer by layer in the order the backward finishes them, behind per-layer events the backward records; 0 = the four-bucket form of
- * the multi-GPU exchange (no per-layer events recorded).  Control for timing and for the round-6 wrong-lane-group finding. */
+/* Single-GPU parameter update (vc_step_exchange_and_update without a communicator) for the calling thread's following steps: 0 (production) =
+ * the five-segment form of the multi-GPU exchange; 1 = ApplyAdam layer by layer in the order the backward finishes them, behind per-layer events
+ * the backward records (44 launches and ~150 event operations more per step).  Measured both ways, round 6: in a fresh process 2.75 against
+ * 2.80 ms at batch 1 and 7.02 against 7.07 ms at batch 8, but 3.34 against 3.01 ms at batch 1 once the host is the slower side (the same
+ * process after a batch-8 run, which is where bench.py times configs[0]) and 6.72 against 6.67 ms at batch 8 with the Winograd route on -- so
+ * it is a switch, not the default.  Also the timing control of the round-6 wrong-lane-group finding. */
 int  vc_tune_layer_updates(int on);
 /* fp32 mode, calling thread's following convolutions: 1 (production) = forward and input gradient of the 3-tap stride-1 1-D convolutions
  * whose width is a multiple of 4 (the residual blocks, module.py:66-83) run as Winograd F(4,3): six channel GEMMs in the transform domain

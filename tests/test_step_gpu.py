@@ -997,9 +997,13 @@ def _no_summation_order_noise(lib, check, eng, mode):
     eng.set_math(mode)
     check(lib.vc_tune_conv_bf16_override(128, 4, 1)); check(lib.vc_tune_igemm_override(64, 1, 1)); check(lib.vc_tune_wgrad_override(64, 1, 1))
     check(lib.vc_tune_c1_dgrad_gather(1))
+    # the per-layer update events (off in production) are the launch timing under which round 6's wrong 16-lane groups showed in every second
+    # step of the packed-fp32 build (profiles/r06_wrong_lane_group.txt): the bitwise tests below keep running under it
+    check(lib.vc_tune_layer_updates(1))
     try:
         yield
     finally:
+        check(lib.vc_tune_layer_updates(0))
         check(lib.vc_tune_c1_dgrad_gather(0)); check(lib.vc_tune_bf16_pixel_octets(1))
         check(lib.vc_tune_conv_bf16_override(0, 0, 0)); check(lib.vc_tune_igemm_override(0, 0, 0)); check(lib.vc_tune_wgrad_override(0, 0, 0))
         eng.set_math('fp32')

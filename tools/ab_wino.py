@@ -1,4 +1,5 @@
-"""A/B of the Winograd route (vc_tune_winograd) on the fp32 train step: ms per step, interleaved.  python tools/ab_wino.py [batch ...]"""
+"""A/B of one switch on the fp32 train step: ms per step, interleaved.  HOOK=vc_tune_winograd (default) | vc_tune_layer_updates.
+python tools/ab_wino.py [batch ...]"""
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -6,6 +7,7 @@ import __graft_entry__ as ge; ge.build()
 import vcgan_pkg  # noqa
 from voice_converter_cyclegan_amd import engine as E
 from voice_converter_cyclegan_amd._lib import lib, check
+HOOK = getattr(lib, os.environ.get('HOOK', 'vc_tune_winograd'))
 for B in [int(a) for a in sys.argv[1:]] or [8]:
     eng = E.CycleGANEngine(24, seed=0)
     rng = np.random.default_rng(0)
@@ -18,9 +20,11 @@ for B in [int(a) for a in sys.argv[1:]] or [8]:
     res = {0: [], 1: []}
     for rep in range(3):
         for w in (1, 0):
-            check(lib.vc_tune_winograd(w))
-            run(5); torch.cuda.synchronize(); t0 = time.perf_counter(); run(30); torch.cuda.synchronize()
-            res[w].append((time.perf_counter() - t0) / 30 * 1e3)
-    check(lib.vc_tune_winograd(1))
-    print('overlap %s ' % os.environ.get('OVERLAP', 'default') + 'fp32 B=%d: winograd on %s ms   off %s ms' % (B, ' '.join('%.3f' % x for x in res[1]), ' '.join('%.3f' % x for x in res[0])), flush=True)
+            check(HOOK(w))
+            n = 30 if B > 2 else 100
+            run(n // 2); torch.cuda.synchronize(); t0 = time.perf_counter(); run(n); torch.cuda.synchronize()
+            res[w].append((time.perf_counter() - t0) / n * 1e3)
+    check(HOOK(1))
+    print('overlap %s fp32 B=%d: %s on %s ms   off %s ms' % (os.environ.get('OVERLAP', 'default'), B, os.environ.get('HOOK', 'vc_tune_winograd'),
+                                                             ' '.join('%.3f' % x for x in res[1]), ' '.join('%.3f' % x for x in res[0])), flush=True)
     eng.close()

@@ -117,9 +117,8 @@ struct vc_plan {
     // the main stream, the filter gradients on the wgrad stream): after both, the caller may update them in place
     hipEvent_t g_free[kBuckets] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t d_free = nullptr;                          // last read of the discriminator weights (generator_loss path)
-    // the same two moments PER LAYER (single-GPU update: vc_step_exchange_and_update without a communicator runs ApplyAdam layer by layer
-    // in backward order, each layer as soon as its gradient is final and its weights are no longer read -- at batch 1 the four-bucket
-    // form left 0.3 ms of a 2.9 ms step waiting for the update after the backward had ended, profiles/r06_timeline_b1.txt).
+    // the same two moments PER LAYER (vc_tune_layer_updates(1): the single-GPU update runs ApplyAdam layer by layer in backward order, each
+    // layer as soon as its gradient is final and its weights are no longer read; off by default, see include/vc_cyclegan_testing.h).
     // Discriminator weights have two readers: the discriminator_loss backward (side stream) and the generator_loss backward (main).
     hipEvent_t gl_ready[24] = {}, gl_free[24] = {}, dl_ready[8] = {}, dl_free_d[8] = {}, dl_free_g[8] = {};
     // captured train steps (vc_train_step_graph): one executable graph per (batch, schedule, buffer set)

@@ -292,7 +292,7 @@ struct TestHooks {
     int wgrad_store = 0;                               // vc_tune_wgrad_store
     int glu_flags = 0;                                 // vc_tune_glu
     int c1_gather = 0;                                 // vc_tune_c1_dgrad_gather
-    int layer_updates = 1;                             // vc_tune_layer_updates
+    int layer_updates = 0;                             // vc_tune_layer_updates
     int winograd = 1;                                  // vc_tune_winograd
 };
 const TestHooks& vc_hooks();
