@@ -534,24 +534,30 @@ WINO_CASES = [
     (96, 12, 64, 24),          # three tiles a row (W = 12), Cin = 96
     (128, 64, 128, 4),         # filter gradient: two k octets a row (16 tiles)
     (64, 32, 64, 12),          # filter gradient: 12 iterations per transform position (prefetch depth 4 instead of 8)
+    # F(4,5): the up-sampling blocks' 5-tap convolutions (module.py:115-133), eight transform positions
+    (512, 32, 2048, 8, 5),     # up-sample 1 at the B = 8 step's cycle hop
+    (512, 64, 1024, 4, 5),     # up-sample 2 (64 frames: two k octets a row)
+    (64, 8, 96, 32, 5),        # two tiles a row: every tile touches both edges' padding
+    (96, 12, 64, 24, 5),       # three tiles a row
 ]
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('case', WINO_CASES)
 def test_winograd_route_against_the_oracle_and_the_direct_kernel(built_lib, case):
-    """module.py:66-83 (conv1d, kernel 3, stride 1, SAME): the Winograd route (production in fp32 mode) against the oracle at the operator
+    """module.py:66-83 / 115-133 (conv1d, kernel 3 or 5, stride 1, SAME): the Winograd route (production in fp32 mode) against the oracle at the operator
     tolerance and against the direct implicit GEMM (vc_tune_winograd(0)) at 2e-5 of the tensor's maximum -- the route changes the summation
     order and adds the rounding of its transforms (2-3e-6 measured against fp64), nothing else; addend / accumulate semantics of the input
     gradient included.  The launch counter proves which route ran."""
     from tests import gpu_util as U
     lib, check = built_lib.lib, built_lib.check
     O = _oracle()
-    Cin, W, Cout, B = case
+    Cin, W, Cout, B = case[:4]
+    K = case[4] if len(case) > 4 else 3
     rng = np.random.default_rng(hash(case) % (2 ** 31))
     G = 2
     xs = rng.standard_normal((G, B, W, Cin)).astype(np.float32)
-    ws = (rng.standard_normal((G, 1, 3, Cin, Cout)) / np.sqrt(3 * Cin)).astype(np.float32)
+    ws = (rng.standard_normal((G, 1, K, Cin, Cout)) / np.sqrt(K * Cin)).astype(np.float32)
     bs = rng.uniform(-0.5, 0.5, (G, Cout)).astype(np.float32)
     ys, dxs, dys, dws = [], [], [], []
     for g in range(G):
@@ -568,11 +574,11 @@ def test_winograd_route_against_the_oracle_and_the_direct_kernel(built_lib, case
     try:
         for on in (1, 0):
             check(lib.vc_tune_winograd(on)); lib.vc_testing_wino_gemms(1)
-            y = U.conv_fwd(x_d, w_d, b_d, 1, 3, 1, 1)
-            dx = U.conv_dgrad(dy_d, w_d, 1, W, 1, 3, 1, 1)
-            dx2 = U.conv_dgrad(dy_d, w_d, 1, W, 1, 3, 1, 1, addend=add, init=init)
-            dw = U.conv_wgrad(x_d, dy_d, 1, 3, 1, 1)
-            dw2 = U.conv_wgrad(x_d, dy_d, 1, 3, 1, 1, init=dw)              # the operator accumulates: twice the gradient
+            y = U.conv_fwd(x_d, w_d, b_d, 1, K, 1, 1)
+            dx = U.conv_dgrad(dy_d, w_d, 1, W, 1, K, 1, 1)
+            dx2 = U.conv_dgrad(dy_d, w_d, 1, W, 1, K, 1, 1, addend=add, init=init)
+            dw = U.conv_wgrad(x_d, dy_d, 1, K, 1, 1)
+            dw2 = U.conv_wgrad(x_d, dy_d, 1, K, 1, 1, init=dw)              # the operator accumulates: twice the gradient
             assert lib.vc_testing_wino_gemms(1) == ((3 + (2 if wg else 0)) if on else 0)
             out[on] = (y.cpu().numpy(), dx.cpu().numpy(), dx2.cpu().numpy(), dw.cpu().numpy(), dw2.cpu().numpy())
             assert U.rel_err(out[on][0], cf(ys)) < TOL and U.rel_err(out[on][1], cf(dxs)) < TOL
@@ -588,11 +594,11 @@ def test_winograd_route_against_the_oracle_and_the_direct_kernel(built_lib, case
 
 @pytest.mark.gpu
 def test_winograd_route_leaves_other_geometries_alone(built_lib):
-    """stride 2, 5 taps, 2-D, a width that is not a multiple of 4, bf16 mode, fewer than 64 pixels per transform position: the direct kernels"""
+    """stride 2, 7 taps, 2-D, a width that is not a multiple of 4, bf16 mode, fewer than 64 pixels per transform position: the direct kernels"""
     from tests import gpu_util as U
     lib, check = built_lib.lib, built_lib.check
     lib.vc_testing_wino_gemms(1)
-    for Cin, H, W, Cout, kh, kw, sh, sw, B in [(64, 1, 32, 64, 1, 3, 1, 2, 8), (64, 1, 32, 64, 1, 5, 1, 1, 8), (64, 4, 32, 64, 3, 3, 1, 1, 8),
+    for Cin, H, W, Cout, kh, kw, sh, sw, B in [(64, 1, 32, 64, 1, 3, 1, 2, 8), (64, 1, 32, 64, 1, 7, 1, 1, 8), (64, 4, 32, 64, 3, 3, 1, 1, 8),
                                                 (64, 1, 30, 64, 1, 3, 1, 1, 16), (64, 1, 32, 64, 1, 3, 1, 1, 4)]:
         x = torch.randn((2, B, Cin, H, W), device=U.DEV); w = torch.randn((2, kh, kw, Cin, Cout), device=U.DEV) * 0.05; b = torch.zeros((2, Cout), device=U.DEV)
         U.conv_fwd(x, w, b, kh, kw, sh, sw)

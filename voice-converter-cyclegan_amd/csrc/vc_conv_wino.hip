@@ -16,14 +16,13 @@
 #include "vc_wino.h"
 #include <algorithm>
 
-namespace {
-
 struct WinoArgs {
     const float* src; float* dst; const float* bias; const float* addend;
     long src_gs, dst_gs, bias_gs, add_gs;      // group strides (floats); for the transformed side: stride of one g (6 planes inside)
     long plane;                                // floats of one transform plane: B * C * nt
     int G, B, C, nt, accumulate;
     int rows;                                  // G * B * C
+    int taps;                                  // 3: F(4,3), six planes; 5: F(4,5), eight planes
 };
 
 // a thread = one tile of one (g, b, c) row; consecutive threads = consecutive tiles, then consecutive channels
@@ -42,7 +41,11 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const WinoArgs p) {
     if (!wino_row(p, g, r, i)) return;
     const float* x = p.src + (long)g * p.src_gs + r * (4 * p.nt) + 4 * i;
     const f32x4 c = *reinterpret_cast<const f32x4*>(x);
-    wino_store_input(c, i > 0 ? x[-1] : 0.f, i + 1 < p.nt ? x[4] : 0.f, p.dst + (long)g * p.dst_gs + r * p.nt + i, p.plane);
+    float* v = p.dst + (long)g * p.dst_gs + r * p.nt + i;
+    if (p.taps == 5) {
+        const float d[8] = {i > 0 ? x[-2] : 0.f, i > 0 ? x[-1] : 0.f, c[0], c[1], c[2], c[3], i + 1 < p.nt ? x[4] : 0.f, i + 1 < p.nt ? x[5] : 0.f};
+        wino5_store_input(d, v, p.plane);
+    } else wino_store_input(c, i > 0 ? x[-1] : 0.f, i + 1 < p.nt ? x[4] : 0.f, v, p.plane);
 }
 
 // y[4i .. 4i+3] = A^T M + bias
@@ -51,7 +54,8 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const WinoArgs p) {
     if (!wino_row(p, g, r, i)) return;
     const int c = (int)(r % p.C);
     const float b = p.bias ? p.bias[(long)g * p.bias_gs + c] : 0.f;
-    *reinterpret_cast<f32x4*>(p.dst + (long)g * p.dst_gs + r * (4 * p.nt) + 4 * i) = wino_load_output(p.src + (long)g * p.src_gs + r * p.nt + i, p.plane, b);
+    const float* m = p.src + (long)g * p.src_gs + r * p.nt + i;
+    *reinterpret_cast<f32x4*>(p.dst + (long)g * p.dst_gs + r * (4 * p.nt) + 4 * i) = p.taps == 5 ? wino5_load_output(m, p.plane, b) : wino_load_output(m, p.plane, b);
 }
 
 // dM[p] = A dy[4i .. 4i+3]
@@ -59,14 +63,16 @@ __global__ __launch_bounds__(256) void wino_dy_kernel(const WinoArgs p) {
     int g, i; long r;
     if (!wino_row(p, g, r, i)) return;
     const f32x4 d = *reinterpret_cast<const f32x4*>(p.src + (long)g * p.src_gs + r * (4 * p.nt) + 4 * i);
-    wino_store_dy(d, p.dst + (long)g * p.dst_gs + r * p.nt + i, p.plane);
+    float* m = p.dst + (long)g * p.dst_gs + r * p.nt + i;
+    if (p.taps == 5) wino5_store_dy(d, m, p.plane); else wino_store_dy(d, m, p.plane);
 }
 
 // dx[4i .. 4i+3] (+)= B dV (+ addend: the skip path of a residual block head)
 __global__ __launch_bounds__(256) void wino_dx_kernel(const WinoArgs p) {
     int g, i; long r;
     if (!wino_row(p, g, r, i)) return;
-    f32x4 dx = wino_load_dx(p.src + (long)g * p.src_gs + r * p.nt + i, p.plane, i > 0, i + 1 < p.nt);
+    const float* v = p.src + (long)g * p.src_gs + r * p.nt + i;
+    f32x4 dx = p.taps == 5 ? wino5_load_dx(v, p.plane, i > 0, i + 1 < p.nt) : wino_load_dx(v, p.plane, i > 0, i + 1 < p.nt);
     const long o = r * (4 * p.nt) + 4 * i;
     if (p.addend) dx += *reinterpret_cast<const f32x4*>(p.addend + (long)g * p.add_gs + o);
     float* dst = p.dst + (long)g * p.dst_gs + o;
@@ -75,7 +81,7 @@ __global__ __launch_bounds__(256) void wino_dx_kernel(const WinoArgs p) {
 }
 
 // U[p][cin][cout] = G w[tap][cin][cout]; a thread = 4 consecutive output channels of one input channel
-struct WinoFilterJob { const float* w; float* U; long w_gs, U_gs; int n4; };      // n4 = Cin * Cout / 4
+struct WinoFilterJob { const float* w; float* U; long w_gs, U_gs; int n4, taps; };      // n4 = Cin * Cout / 4
 #define VC_WINO_JOBS 16
 struct WinoFilterJobs { WinoFilterJob j[VC_WINO_JOBS]; int n, G; unsigned blk0[VC_WINO_JOBS + 1]; };
 __global__ __launch_bounds__(256) void wino_filter_kernel(const WinoFilterJobs jj) {
@@ -87,6 +93,20 @@ __global__ __launch_bounds__(256) void wino_filter_kernel(const WinoFilterJobs j
     const int g = blockIdx.y;
     const long plane = (long)j.n4 * 4;
     const float* w = j.w + (long)g * j.w_gs + (long)t * 4;
+    if (j.taps == 5) {        // U[p] = sum_k G5[p][k] w[k]
+        f32x4 wk[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) wk[k] = *reinterpret_cast<const f32x4*>(w + k * plane);
+        float* u5 = j.U + (long)g * j.U_gs + (long)t * 4;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 5; ++k) if (kG5[p][k] != 0.f) a += wk[k] * kG5[p][k];
+            *reinterpret_cast<f32x4*>(u5 + p * plane) = a;
+        }
+        return;
+    }
     const f32x4 g0 = *reinterpret_cast<const f32x4*>(w), g1 = *reinterpret_cast<const f32x4*>(w + plane), g2 = *reinterpret_cast<const f32x4*>(w + 2 * plane);
     float* u = j.U + (long)g * j.U_gs + (long)t * 4;
     const f32x4 s = (g0 + g2) * (-1.f / 6.f), q = g1 * (1.f / 6.f);
@@ -109,7 +129,12 @@ __global__ __launch_bounds__(256) void wino_prep_kernel(const WinoPrep pp) {
     const float* x = p.src + (long)g * p.src_gs + r * (4 * p.nt) + 4 * i;
     const f32x4 c = *reinterpret_cast<const f32x4*>(x);
     float* d = p.dst + (long)g * p.dst_gs + r * p.nt + i;
-    if (pp.kind[blockIdx.y] == 0) wino_store_input(c, i > 0 ? x[-1] : 0.f, i + 1 < p.nt ? x[4] : 0.f, d, p.plane);
+    if (p.taps == 5) {
+        if (pp.kind[blockIdx.y] == 0) {
+            const float dd[8] = {i > 0 ? x[-2] : 0.f, i > 0 ? x[-1] : 0.f, c[0], c[1], c[2], c[3], i + 1 < p.nt ? x[4] : 0.f, i + 1 < p.nt ? x[5] : 0.f};
+            wino5_store_input(dd, d, p.plane);
+        } else wino5_store_dy(c, d, p.plane);
+    } else if (pp.kind[blockIdx.y] == 0) wino_store_input(c, i > 0 ? x[-1] : 0.f, i + 1 < p.nt ? x[4] : 0.f, d, p.plane);
     else wino_store_dy(c, d, p.plane);
 }
 
@@ -122,30 +147,37 @@ struct WinoWgradArgs {
     const float* V[2]; const float* dM[2]; long V_gs[2], dM_gs[2]; int B[2]; int napp;
     float* dW; long dw_gs; int Cin, Cout, nt, store;
 };
-template <int VC_WW_AHEAD>
+__device__ const float kG3dev[6][3] = {{0.25f, 0.f, 0.f}, {-1.f / 6.f, -1.f / 6.f, -1.f / 6.f}, {-1.f / 6.f, 1.f / 6.f, -1.f / 6.f},
+                                        {1.f / 24.f, 1.f / 12.f, 1.f / 6.f}, {1.f / 24.f, -1.f / 12.f, 1.f / 6.f}, {0.f, 0.f, 1.f}};
+__device__ const float kG5dev[8][5] = {{1.f, 0.f, 0.f, 0.f, 0.f}, {1.f, 1.f, 1.f, 1.f, 1.f}, {1.f, -1.f, 1.f, -1.f, 1.f}, {1.f, 2.f, 4.f, 8.f, 16.f}, {1.f, -2.f, 4.f, -8.f, 16.f},
+                                        {1.f, 0.5f, 0.25f, 0.125f, 0.0625f}, {1.f, -0.5f, 0.25f, -0.125f, 0.0625f}, {0.f, 0.f, 0.f, 0.f, 1.f}};
+template <int VC_WW_AHEAD, int TAPS>
 __global__ __launch_bounds__(256) void wino_wgrad_kernel(const WinoWgradArgs a) {
+    constexpr int NP = TAPS + 3;                                     // transform positions
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, h = lane >> 5;
     const int ctiles = a.Cout >> 6;                                  // 64 x 64 per workgroup: waves 2 x 2
     const int tm = blockIdx.x / ctiles, tn = blockIdx.x - tm * ctiles;
     const int cin0 = tm * 64 + (wave >> 1) * 32, cout0 = tn * 64 + (wave & 1) * 32;
     const int g = blockIdx.y;
     const int oct = a.nt >> 3;                                       // k octets (8 tiles) per row
-    f32x16 acc[3], T;
+    f32x16 acc[TAPS], T;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; acc[2][r] = 0.f; T[r] = 0.f; }
+    for (int r = 0; r < 16; ++r) {
+        T[r] = 0.f;
+#pragma unroll
+        for (int k = 0; k < TAPS; ++k) acc[k][r] = 0.f;
+    }
     // fold the finished transform position p into the taps: acc[k] += G[p][k] T
     auto fold = [&](int p) {
-        float g0, g1, g2;
-        switch (p) {
-            case 0: g0 = 0.25f; g1 = 0.f; g2 = 0.f; break;
-            case 1: g0 = -1.f / 6.f; g1 = -1.f / 6.f; g2 = -1.f / 6.f; break;
-            case 2: g0 = -1.f / 6.f; g1 = 1.f / 6.f; g2 = -1.f / 6.f; break;
-            case 3: g0 = 1.f / 24.f; g1 = 1.f / 12.f; g2 = 1.f / 6.f; break;
-            case 4: g0 = 1.f / 24.f; g1 = -1.f / 12.f; g2 = 1.f / 6.f; break;
-            default: g0 = 0.f; g1 = 0.f; g2 = 1.f; break;
-        }
+        float gk[TAPS];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { acc[0][r] += g0 * T[r]; acc[1][r] += g1 * T[r]; acc[2][r] += g2 * T[r]; T[r] = 0.f; }
+        for (int k = 0; k < TAPS; ++k) gk[k] = TAPS == 3 ? kG3dev[p][k] : kG5dev[p][k];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+#pragma unroll
+            for (int k = 0; k < TAPS; ++k) acc[k][r] += gk[k] * T[r];
+            T[r] = 0.f;
+        }
     };
     for (int app = 0; app < a.napp; ++app) {
         // one application: iterations = (p, sample, octet) with p slowest -- the operands' own memory order, so both pointers walk by constant
@@ -159,8 +191,8 @@ __global__ __launch_bounds__(256) void wino_wgrad_kernel(const WinoWgradArgs a) 
         f32x4 av[VC_WW_AHEAD], bv[VC_WW_AHEAD];
 #pragma unroll
         for (int d = 0; d < VC_WW_AHEAD; ++d) { av[d] = *reinterpret_cast<const f32x4*>(pa); bv[d] = *reinterpret_cast<const f32x4*>(pb); advance(); }
-        for (int p = 0; p < 6; ++p) {
-            const int nc = p < 5 ? per_p : per_p - VC_WW_AHEAD;       // (the last VC_WW_AHEAD iterations of the application have nothing to fetch: below)
+        for (int p = 0; p < NP; ++p) {
+            const int nc = p < NP - 1 ? per_p : per_p - VC_WW_AHEAD;       // (the last VC_WW_AHEAD iterations of the application have nothing to fetch: below)
             for (int c = 0; c < nc; c += VC_WW_AHEAD) {
 #pragma unroll
                 for (int d = 0; d < VC_WW_AHEAD; ++d) {
@@ -169,17 +201,17 @@ __global__ __launch_bounds__(256) void wino_wgrad_kernel(const WinoWgradArgs a) 
                     av[d] = *reinterpret_cast<const f32x4*>(pa); bv[d] = *reinterpret_cast<const f32x4*>(pb); advance();
                 }
             }
-            if (p < 5) fold(p);
+            if (p < NP - 1) fold(p);
         }
 #pragma unroll
         for (int d = 0; d < VC_WW_AHEAD; ++d)
 #pragma unroll
             for (int e = 0; e < 4; ++e) T = __builtin_amdgcn_mfma_f32_32x32x2f32(av[d][e], bv[d][e], T, 0, 0, 0);
-        fold(5);
+        fold(NP - 1);
     }
     float* dw = a.dW + (long)g * a.dw_gs;
 #pragma unroll
-    for (int k = 0; k < 3; ++k)
+    for (int k = 0; k < TAPS; ++k)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int cin = cin0 + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -188,7 +220,7 @@ __global__ __launch_bounds__(256) void wino_wgrad_kernel(const WinoWgradArgs a) 
         }
 }
 
-int launch_wino(void (*k)(WinoArgs), WinoArgs a, hipStream_t s) {
+static int launch_wino(void (*k)(WinoArgs), WinoArgs a, hipStream_t s) {
     a.rows = a.G * a.B * a.C;
     a.plane = (long)a.B * a.C * a.nt;
     const long threads = (long)a.rows * a.nt;
@@ -198,37 +230,36 @@ int launch_wino(void (*k)(WinoArgs), WinoArgs a, hipStream_t s) {
     return 0;
 }
 
-}  // namespace
 
 // x [G][B][C][4 nt] -> V [G][6][B][C][nt]
-int launch_wino_input(const float* x, long x_gs, float* V, int G, int B, int C, int nt, hipStream_t s) {
-    WinoArgs a{}; a.src = x; a.src_gs = x_gs; a.dst = V; a.dst_gs = 6L * B * C * nt; a.G = G; a.B = B; a.C = C; a.nt = nt;
+int launch_wino_input(const float* x, long x_gs, float* V, int G, int B, int C, int nt, hipStream_t s, int taps) {
+    WinoArgs a{}; a.taps = taps; a.src = x; a.src_gs = x_gs; a.dst = V; a.dst_gs = (long)(taps + 3) * B * C * nt; a.G = G; a.B = B; a.C = C; a.nt = nt;
     return launch_wino(wino_input_kernel, a, s);
 }
 // M [G][6][B][C][nt] -> y [G][B][C][4 nt] (+ bias)
-int launch_wino_output(const float* M, const float* bias, long b_gs, float* y, long y_gs, int G, int B, int C, int nt, hipStream_t s) {
-    WinoArgs a{}; a.src = M; a.src_gs = 6L * B * C * nt; a.dst = y; a.dst_gs = y_gs; a.bias = bias; a.bias_gs = b_gs; a.G = G; a.B = B; a.C = C; a.nt = nt;
+int launch_wino_output(const float* M, const float* bias, long b_gs, float* y, long y_gs, int G, int B, int C, int nt, hipStream_t s, int taps) {
+    WinoArgs a{}; a.taps = taps; a.src = M; a.src_gs = (long)(taps + 3) * B * C * nt; a.dst = y; a.dst_gs = y_gs; a.bias = bias; a.bias_gs = b_gs; a.G = G; a.B = B; a.C = C; a.nt = nt;
     return launch_wino(wino_output_kernel, a, s);
 }
 // dy [G][B][C][4 nt] -> dM [G][6][B][C][nt]
-int launch_wino_dy(const float* dy, long dy_gs, float* dM, int G, int B, int C, int nt, hipStream_t s) {
-    WinoArgs a{}; a.src = dy; a.src_gs = dy_gs; a.dst = dM; a.dst_gs = 6L * B * C * nt; a.G = G; a.B = B; a.C = C; a.nt = nt;
+int launch_wino_dy(const float* dy, long dy_gs, float* dM, int G, int B, int C, int nt, hipStream_t s, int taps) {
+    WinoArgs a{}; a.taps = taps; a.src = dy; a.src_gs = dy_gs; a.dst = dM; a.dst_gs = (long)(taps + 3) * B * C * nt; a.G = G; a.B = B; a.C = C; a.nt = nt;
     return launch_wino(wino_dy_kernel, a, s);
 }
 // dV [G][6][B][C][nt] -> dx [G][B][C][4 nt] = (accumulate ? dx : 0) + addend + B dV
-int launch_wino_dx(const float* dV, float* dx, long dx_gs, const float* addend, long add_gs, int accumulate, int G, int B, int C, int nt, hipStream_t s) {
-    WinoArgs a{}; a.src = dV; a.src_gs = 6L * B * C * nt; a.dst = dx; a.dst_gs = dx_gs; a.addend = addend; a.add_gs = add_gs; a.accumulate = accumulate;
+int launch_wino_dx(const float* dV, float* dx, long dx_gs, const float* addend, long add_gs, int accumulate, int G, int B, int C, int nt, hipStream_t s, int taps) {
+    WinoArgs a{}; a.taps = taps; a.src = dV; a.src_gs = (long)(taps + 3) * B * C * nt; a.dst = dx; a.dst_gs = dx_gs; a.addend = addend; a.add_gs = add_gs; a.accumulate = accumulate;
     a.G = G; a.B = B; a.C = C; a.nt = nt;
     return launch_wino(wino_dx_kernel, a, s);
 }
-// filters w [G][3][Cin][Cout] -> U [G][6][Cin][Cout], several layers per launch
+// filters w [G][taps][Cin][Cout] -> U [G][taps + 3][Cin][Cout], several layers per launch
 int launch_wino_filters(const std::vector<WinoFilter>& f, int G, hipStream_t s) {
     for (size_t k0 = 0; k0 < f.size(); k0 += VC_WINO_JOBS) {
         WinoFilterJobs jj{}; jj.G = G; unsigned blk = 0;
         for (size_t k = k0; k < f.size() && k < k0 + VC_WINO_JOBS; ++k) {
             const long n = (long)f[k].Cin * f[k].Cout;
             if (n % 4 != 0 || n / 4 >= (1L << 30)) { vc_set_error("winograd filter transform: Cin * Cout must be a multiple of 4"); return -1; }
-            WinoFilterJob& j = jj.j[jj.n]; j.w = f[k].w; j.U = f[k].U; j.w_gs = f[k].w_gs; j.U_gs = 6 * n; j.n4 = (int)(n / 4);
+            WinoFilterJob& j = jj.j[jj.n]; j.w = f[k].w; j.U = f[k].U; j.w_gs = f[k].w_gs; j.U_gs = (long)(f[k].taps + 3) * n; j.n4 = (int)(n / 4); j.taps = f[k].taps;
             jj.blk0[jj.n++] = blk; blk += (unsigned)((j.n4 + 255) / 256);
         }
         jj.blk0[jj.n] = blk;
@@ -239,11 +270,11 @@ int launch_wino_filters(const std::vector<WinoFilter>& f, int G, hipStream_t s) 
 }
 
 // the four operands of a Winograd-domain filter gradient in one launch: napp applications' x -> V and dy -> dM (all [G][6][B][C][nt])
-int launch_wino_prep(const WinoPrepJob* jobs, int n, int G, int nt, hipStream_t s) {
+int launch_wino_prep(const WinoPrepJob* jobs, int n, int G, int nt, hipStream_t s, int taps) {
     WinoPrep pp{}; pp.n = n; long maxthreads = 0;
     for (int k = 0; k < n; ++k) {
         WinoArgs& a = pp.a[k]; a = WinoArgs{};
-        a.src = jobs[k].src; a.src_gs = jobs[k].src_gs; a.dst = jobs[k].dst; a.dst_gs = 6L * jobs[k].B * jobs[k].C * nt;
+        a.taps = taps; a.src = jobs[k].src; a.src_gs = jobs[k].src_gs; a.dst = jobs[k].dst; a.dst_gs = (long)(taps + 3) * jobs[k].B * jobs[k].C * nt;
         a.G = G; a.B = jobs[k].B; a.C = jobs[k].C; a.nt = nt; a.rows = G * jobs[k].B * jobs[k].C; a.plane = (long)jobs[k].B * jobs[k].C * nt;
         pp.kind[k] = jobs[k].kind;
         maxthreads = std::max(maxthreads, (long)a.rows * nt);
@@ -255,9 +286,9 @@ int launch_wino_prep(const WinoPrepJob* jobs, int n, int G, int nt, hipStream_t 
 }
 // dW [G][3][Cin][Cout] (+)= the filter gradient of napp applications from their transform-domain operands
 int launch_wino_wgrad(const float* const* V, const float* const* dM, const int* B, int napp, float* dW, long dw_gs, int store,
-                      int G, int Cin, int Cout, int nt, hipStream_t s, double flops) {
+                      int G, int Cin, int Cout, int nt, hipStream_t s, double flops, int taps) {
     WinoWgradArgs a{};
-    for (int k = 0; k < napp; ++k) { a.V[k] = V[k]; a.dM[k] = dM[k]; a.B[k] = B[k]; a.V_gs[k] = 6L * B[k] * Cin * nt; a.dM_gs[k] = 6L * B[k] * Cout * nt; }
+    for (int k = 0; k < napp; ++k) { a.V[k] = V[k]; a.dM[k] = dM[k]; a.B[k] = B[k]; a.V_gs[k] = (long)(taps + 3) * B[k] * Cin * nt; a.dM_gs[k] = (long)(taps + 3) * B[k] * Cout * nt; }
     a.napp = napp; a.dW = dW; a.dw_gs = dw_gs; a.Cin = Cin; a.Cout = Cout; a.nt = nt; a.store = store;
     ProfScope prof(1, flops, s);
     bool by8 = true;
@@ -266,7 +297,8 @@ int launch_wino_wgrad(const float* const* V, const float* const* dM, const int* 
         by8 = by8 && (B[k] * (nt / 8)) % 8 == 0;
     }
     const dim3 grid((unsigned)((Cin / 64) * (Cout / 64)), (unsigned)G);
-    if (by8) wino_wgrad_kernel<8><<<grid, 256, 0, s>>>(a); else wino_wgrad_kernel<4><<<grid, 256, 0, s>>>(a);
+    if (taps == 5) { if (by8) wino_wgrad_kernel<8, 5><<<grid, 256, 0, s>>>(a); else wino_wgrad_kernel<4, 5><<<grid, 256, 0, s>>>(a); }
+    else if (by8) wino_wgrad_kernel<8, 3><<<grid, 256, 0, s>>>(a); else wino_wgrad_kernel<4, 3><<<grid, 256, 0, s>>>(a);
     VC_HIP(hipGetLastError());
     return 0;
 }

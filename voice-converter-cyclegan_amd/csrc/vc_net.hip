@@ -345,6 +345,7 @@ void describe_scratch(std::string& out, const char* tag, const std::vector<Layer
 
 bool layer_events_on() { return vc_hooks().layer_updates != 0; }
 static int net_forward(NetCtx& c, const float* x, long x_gs, float* y_plain, long y_plain_gs) {
+    unsigned wino_waited_mask = 0;
     // one launch zeroes every raw conv output of this pass whose convolution will reduce over split-K with atomics
     bool plain_zeroed = true;
     {
@@ -366,10 +367,15 @@ static int net_forward(NetCtx& c, const float* x, long x_gs, float* y_plain, lon
     }
     // fp32 inside a train step: the 3-tap layers (residual blocks) run in the Winograd domain (vc_conv_wino.hip) on the step's transformed filters;
     // the transforms ride in the instance-norm launches on either side of the GEMMs (NormArgs::win / wout), stand-alone launches where they cannot
-    auto wino_layer = [&](size_t i) {
+    auto wino_cached = [&](size_t i) {       // the step holds this layer's transformed filters and the launch is large enough for the route
         return c.images && c.math == VC_MATH_FP32 && (*c.images)[i].fwd && wino_eligible((*c.geo)[i].g, c.math, c.B);
     };
-    float* wV = nullptr; float* wM = nullptr; bool v_ready = false; unsigned wino_waited = 0;
+    auto wino_layer = [&](size_t i) { return wino_cached(i) && (*c.geo)[i].g.kw == 3; };     // ... and its transforms can ride in the norm launches
+    auto wino_wait = [&](size_t i) -> int {    // this step's filter transforms (side stream), chunk by chunk
+        if (c.wino_ev && !(wino_waited_mask >> c.wino_chunk[i] & 1u)) { VC_HIP(hipStreamWaitEvent(c.s, c.wino_ev[c.wino_chunk[i]], 0)); wino_waited_mask |= 1u << c.wino_chunk[i]; }
+        return 0;
+    };
+    float* wV = nullptr; float* wM = nullptr; bool v_ready = false;
     {
         size_t nV = 0, nM = 0;
         for (size_t i = 0; i < c.n->layers.size(); ++i) if (wino_layer(i)) {
@@ -412,15 +418,18 @@ static int net_forward(NetCtx& c, const float* x, long x_gs, float* y_plain, lon
         }
         const bool wino = wV && wino_layer(i) && L.mode != M_PLAIN;
         if (wino) {
-            if (c.wino_ev && !(wino_waited >> c.wino_chunk[i] & 1u)) { VC_HIP(hipStreamWaitEvent(c.s, c.wino_ev[c.wino_chunk[i]], 0)); wino_waited |= 1u << c.wino_chunk[i]; }   // this step's filter transforms (side stream)
+            VC_CHECK(wino_wait(i));
             if (!v_ready) VC_CHECK(launch_wino_input(in, in_gs, wV, c.G, c.B, lg.g.Cin, lg.g.W / 4, c.s));
             v_ready = false;
             VC_CHECK(wino_gemm_fwd(wV, (const float*)(*c.images)[i].fwd, wM, c.G, c.B, lg.g, c.math, c.s));
-        } else
+        } else {
+        const bool wino_u = wino_cached(i);      // 5-tap layers (pixel-shuffled up-sampling blocks): the route with stand-alone transforms, on the step's filters
+        if (wino_u) VC_CHECK(wino_wait(i));
         VC_CHECK(conv_fwd(in, in_gs, c.params + L.w, c.par_gs, c.params + L.b, c.par_gs, raw, raw_gs, c.G, c.B, lg.g, c.math, c.s,
-                          /*prezeroed=*/L.mode != M_PLAIN || plain_zeroed, nullptr, (c.images && c.math == VC_MATH_BF16) ? (*c.images)[i].fwd : nullptr,
+                          /*prezeroed=*/L.mode != M_PLAIN || plain_zeroed, nullptr, (c.images && (c.math == VC_MATH_BF16 || wino_u)) ? (*c.images)[i].fwd : nullptr,
                           (c.keep_packed && i > 0) ? (char*)(c.save + c.sm.actp[i - 1]) : nullptr, c.save_gs * 4,
                           fn.act ? &fn : nullptr, in_packed));
+        }
         in_packed = false;
         if (L.mode == M_PLAIN) break;
         if (fn.done) { in = fn.act; in_gs = c.save_gs; continue; }
@@ -490,9 +499,10 @@ static int net_backward(NetCtx& c, const float* x, long x_gs, const float* dtop,
     const float* skip = nullptr; long skip_gs = 0;      // gradient flowing around a residual block (module.py:81)
     // fp32 inside a train step: input gradients of the 3-tap layers in the Winograd domain (see net_forward): dM = A dy leaves the layer's norm
     // backward, dV = U^T dM is the six GEMMs, and dO = B dV (+ skip) is rebuilt by the NEXT norm backward on its way in (`pend`)
-    auto wino_layer = [&](int i) {
+    auto wino_cached = [&](int i) {
         return c.images && c.math == VC_MATH_FP32 && (*c.images)[i].has_dg && wino_eligible((*c.geo)[i].g, c.math, c.B);
     };
+    auto wino_layer = [&](int i) { return wino_cached(i) && (*c.geo)[i].g.kw == 3; };
     auto norm_fusable = [&](int i) {      // layer i's norm backward can apply the transforms (the launcher checks alignment once more)
         const Layer& Li = c.n->layers[i]; const LayerGeo& li = (*c.geo)[i];
         const int Ln = li.g.OH * li.g.OW;
@@ -603,7 +613,7 @@ static int net_backward(NetCtx& c, const float* x, long x_gs, const float* dtop,
         } else
         VC_CHECK(conv_dgrad(dyp, dy_gs, c.params + L.w, c.par_gs, scratch + dAo[i - 1], scr_gs,
                             block_head ? skip : nullptr, block_head ? skip_gs : 0, 0, c.G, c.B, lg.g, c.math, c.s, /*prezeroed=*/true,
-                            nullptr, (c.images && c.math == VC_MATH_BF16 && (*c.images)[i].has_dg) ? (*c.images)[i].dg : nullptr, dy_packed, scr_gs * 4));
+                            nullptr, (c.images && (c.math == VC_MATH_BF16 || wino_cached(i)) && (*c.images)[i].has_dg) ? (*c.images)[i].dg : nullptr, dy_packed, scr_gs * 4));
         if (block_head) skip = nullptr;
         for (int k = 0; k < c.n_ev; ++k) if (c.ev_free && c.ev_first[k] == i) VC_HIP(hipEventRecord(c.ev_free[k], c.s));
         if (c.lay_free && layer_events_on()) VC_HIP(hipEventRecord(c.lay_free[i], c.s));
@@ -646,16 +656,21 @@ static const std::vector<vc_plan::LayerImages>* step_images(const vc_plan* p, bo
 int refresh_wino_filters(const vc_plan* p, const float* params, int B, hipStream_t s, bool* active) {
     *active = false; p->wino_active = false;
     if (p->math != VC_MATH_FP32 || vc_hooks().winograd == 0 || p->inference) return 0;
-    std::vector<WinoFilter> jobs; std::vector<size_t> offs; std::vector<vc_plan::LayerImages> img(p->G.layers.size());
-    size_t tot = 0;
+    // The block's layout covers every layer the route can EVER take in this plan (geometry only); a step transforms the layers its own batch
+    // takes it for (B = the largest batch of its passes: a layer eligible in a smaller pass is eligible here).  Round 6, found by the
+    // deterministic-mode test: a layout built from the first step's batch was too small for a later, larger one.
+    std::vector<size_t> offs(p->G.layers.size(), 0); std::vector<vc_plan::LayerImages> img(p->G.layers.size());
+    size_t tot = 0; int nlay = 0;
     for (size_t i = 0; i < p->G.layers.size(); ++i) {
         const Geom& g = p->gg[i].g;
-        if (!wino_eligible(g, p->math, B)) continue;
-        jobs.push_back(WinoFilter{params + p->G.layers[i].w, nullptr, p->G.total, g.Cin, g.Cout}); offs.push_back(tot);
-        img[i].fwd = (const char*)(tot + 1);       // offset + 1 until the block exists (0 = no image)
-        tot += (size_t)2 * 6 * g.Cin * g.Cout;
+        if (!wino_eligible(g, p->math, 1 << 20)) continue;
+        offs[i] = tot; img[i].fwd = (const char*)(tot + 1);       // offset + 1 until the block exists (0 = no image)
+        tot += (size_t)2 * (g.kw + 3) * g.Cin * g.Cout; ++nlay;
     }
-    if (jobs.empty()) return 0;
+    if (!nlay) return 0;
+    bool any = false;
+    for (size_t i = 0; i < p->G.layers.size(); ++i) any = any || (img[i].fwd && wino_eligible(p->gg[i].g, p->math, B));
+    if (!any) return 0;
     if (!p->wino_block) {
         hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
         if (s && hipStreamIsCapturing(s, &st) == hipSuccess && st != hipStreamCaptureStatusNone) {
@@ -667,19 +682,21 @@ int refresh_wino_filters(const vc_plan* p, const float* params, int B, hipStream
     if (p->wino_img.empty()) {
         for (auto& li : img) if (li.fwd) { li.fwd = (const char*)(p->wino_block + ((size_t)li.fwd - 1)); li.dg[0] = li.fwd; li.has_dg = true; }
         p->wino_img = img;
-    }
-    for (size_t k = 0; k < jobs.size(); ++k) jobs[k].U = p->wino_block + offs[k];
-    // in layer order, kWinoChunks launches with an event behind each: the first-hop forward reaches its first residual block ~60 us into the step
-    // and waits for that block's filters only (one launch: 0.12 ms ahead of the first Winograd GEMM at batch 8)
-    const size_t per = (jobs.size() + vc_plan::kWinoChunks - 1) / vc_plan::kWinoChunks;
-    if (p->wino_chunk.empty()) {
+        // in layer order, kWinoChunks launches with an event behind each: the first-hop forward reaches its first residual block ~70 us into the
+        // step and waits for that block's filters only (one launch: 0.12 ms ahead of the first Winograd GEMM at batch 8)
+        const int per = (nlay + vc_plan::kWinoChunks - 1) / vc_plan::kWinoChunks;
         p->wino_chunk.assign(p->G.layers.size(), -1);
-        size_t k = 0;
-        for (size_t i = 0; i < p->G.layers.size(); ++i) if (p->wino_img[i].fwd) p->wino_chunk[i] = (int)(k++ / per);
+        int k = 0;
+        for (size_t i = 0; i < p->G.layers.size(); ++i) if (p->wino_img[i].fwd) p->wino_chunk[i] = k++ / per;
     }
     for (int ck = 0; ck < vc_plan::kWinoChunks; ++ck) {
-        const size_t lo = std::min(jobs.size(), ck * per), hi = std::min(jobs.size(), (ck + 1) * per);
-        if (hi > lo) VC_CHECK(launch_wino_filters(std::vector<WinoFilter>(jobs.begin() + lo, jobs.begin() + hi), 2, s));
+        std::vector<WinoFilter> jobs;
+        for (size_t i = 0; i < p->G.layers.size(); ++i) {
+            const Geom& g = p->gg[i].g;
+            if (p->wino_chunk[i] == ck && wino_eligible(g, p->math, B))
+                jobs.push_back(WinoFilter{params + p->G.layers[i].w, p->wino_block + offs[i], p->G.total, g.Cin, g.Cout, g.kw});
+        }
+        if (!jobs.empty()) VC_CHECK(launch_wino_filters(jobs, 2, s));
         VC_HIP(hipEventRecord(p->ev_wino[ck], s));
     }
     *active = true; p->wino_active = true;

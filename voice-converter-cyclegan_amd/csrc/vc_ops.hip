@@ -155,7 +155,7 @@ static void bf16_set_vec4(ConvBf16Args& a) {
 // B: the batch of the launch -- each of the six GEMMs sees B W / 4 pixels, and below one 64-pixel tile the direct kernel wins (measured at
 // batch 1: 3.4 -> 5.1 ms per step with the route forced on; a threshold of 128 pixels instead of 64 measured the same at batch 8 and 16)
 bool wino_eligible(const Geom& g, int math, int B) {
-    return math == VC_MATH_FP32 && vc_hooks().winograd != 0 && g.kh == 1 && g.kw == 3 && g.sh == 1 && g.sw == 1 && g.H == 1 &&
+    return math == VC_MATH_FP32 && vc_hooks().winograd != 0 && g.kh == 1 && (g.kw == 3 || g.kw == 5) && g.sh == 1 && g.sw == 1 && g.H == 1 &&
            g.W % 4 == 0 && g.W >= 8 && g.Cin % 32 == 0 && g.Cout % 32 == 0 && g.Cin >= 64 && g.Cout >= 64 && (long)B * (g.W / 4) >= 64;
 }
 // the filter gradient of the same layers: the fused Winograd-domain kernel (vc_conv_wino.hip: wino_wgrad_kernel) wants whole k octets
@@ -174,40 +174,40 @@ int wino_workspace(hipStream_t s, size_t floats, float** out) {
 // convolution with 6 G groups.  K is split inside the workgroup only: the launches have 6 x the groups of the direct form to fill the chip with,
 // and split-K across workgroups would cost a memset of the transform-domain destination per launch.
 int wino_gemm_fwd(const float* V, const float* U, float* M, int G, int B, const Geom& g, int math, hipStream_t s) {
-    const int nt = g.W / 4; const Geom g1 = wino_gemm_geom(g);
+    const int nt = g.W / 4, P = g.kw + 3; const Geom g1 = wino_gemm_geom(g);
     DetScope no_split(1);
-    vc_count_wino_gemm(0, 2.0 * G * B * g.W * (double)g.Cout * g.Cin * (3.0 - 1.5));      // direct: 3 taps x W pixels; here: 6 positions x W / 4
-    return conv_fwd(V, (long)B * g.Cin * nt, U, (long)g.Cin * g.Cout, nullptr, 0, M, (long)B * g.Cout * nt, 6 * G, B, g1, math, s);
+    vc_count_wino_gemm(0, 2.0 * G * B * g.W * (double)g.Cout * g.Cin * (g.kw - 0.25 * P));      // direct: kw taps x W pixels; here: kw + 3 positions x W / 4
+    return conv_fwd(V, (long)B * g.Cin * nt, U, (long)g.Cin * g.Cout, nullptr, 0, M, (long)B * g.Cout * nt, P * G, B, g1, math, s);
 }
 int wino_gemm_dgrad(const float* dM, const float* U, float* dV, int G, int B, const Geom& g, int math, hipStream_t s) {
-    const int nt = g.W / 4; const Geom g1 = wino_gemm_geom(g);
+    const int nt = g.W / 4, P = g.kw + 3; const Geom g1 = wino_gemm_geom(g);
     DetScope no_split(1);
-    vc_count_wino_gemm(0, 2.0 * G * B * g.W * (double)g.Cout * g.Cin * (3.0 - 1.5));
-    return conv_dgrad(dM, (long)B * g.Cout * nt, U, (long)g.Cin * g.Cout, dV, (long)B * g.Cin * nt, nullptr, 0, 0, 6 * G, B, g1, math, s);
+    vc_count_wino_gemm(0, 2.0 * G * B * g.W * (double)g.Cout * g.Cin * (g.kw - 0.25 * P));
+    return conv_dgrad(dM, (long)B * g.Cout * nt, U, (long)g.Cin * g.Cout, dV, (long)B * g.Cin * nt, nullptr, 0, 0, P * G, B, g1, math, s);
 }
 Geom wino_gemm_geom(const Geom& g) { return make_geom(g.Cin, 1, g.W / 4, g.Cout, 1, 1, 1, 1); }
 // U: the layer's transformed filters [G][6][Cin][Cout] when the caller holds them (inside a train step: built once per step), else built here
 static int wino_fwd(const float* x, long x_gs, const float* w, long w_gs, const float* bias, long b_gs, float* y, long y_gs,
                     int G, int B, const Geom& g, int math, hipStream_t s, const float* U) {
-    const int nt = g.W / 4;
-    const size_t nV = (size_t)6 * G * B * g.Cin * nt, nM = (size_t)6 * G * B * g.Cout * nt, nU = U ? 0 : (size_t)6 * G * g.Cin * g.Cout;
+    const int nt = g.W / 4, P = g.kw + 3;
+    const size_t nV = (size_t)P * G * B * g.Cin * nt, nM = (size_t)P * G * B * g.Cout * nt, nU = U ? 0 : (size_t)P * G * g.Cin * g.Cout;
     char* wsp; VC_CHECK(pack_space(s, (nV + nM + nU) * sizeof(float), &wsp));
     float* V = (float*)wsp; float* M = V + nV; float* Ub = M + nM;
-    if (!U) { VC_CHECK(launch_wino_filters({WinoFilter{w, Ub, w_gs, g.Cin, g.Cout}}, G, s)); U = Ub; }
-    VC_CHECK(launch_wino_input(x, x_gs, V, G, B, g.Cin, nt, s));
+    if (!U) { VC_CHECK(launch_wino_filters({WinoFilter{w, Ub, w_gs, g.Cin, g.Cout, g.kw}}, G, s)); U = Ub; }
+    VC_CHECK(launch_wino_input(x, x_gs, V, G, B, g.Cin, nt, s, g.kw));
     VC_CHECK(wino_gemm_fwd(V, U, M, G, B, g, math, s));
-    return launch_wino_output(M, bias, b_gs, y, y_gs, G, B, g.Cout, nt, s);
+    return launch_wino_output(M, bias, b_gs, y, y_gs, G, B, g.Cout, nt, s, g.kw);
 }
 static int wino_dgrad(const float* dy, long dy_gs, const float* w, long w_gs, float* dx, long dx_gs, const float* addend, long add_gs,
                       int accumulate, int G, int B, const Geom& g, int math, hipStream_t s, const float* U) {
-    const int nt = g.W / 4;
-    const size_t nM = (size_t)6 * G * B * g.Cout * nt, nV = (size_t)6 * G * B * g.Cin * nt, nU = U ? 0 : (size_t)6 * G * g.Cin * g.Cout;
+    const int nt = g.W / 4, P = g.kw + 3;
+    const size_t nM = (size_t)P * G * B * g.Cout * nt, nV = (size_t)P * G * B * g.Cin * nt, nU = U ? 0 : (size_t)P * G * g.Cin * g.Cout;
     char* wsp; VC_CHECK(pack_space(s, (nV + nM + nU) * sizeof(float), &wsp));
     float* dM = (float*)wsp; float* dV = dM + nM; float* Ub = dV + nV;
-    if (!U) { VC_CHECK(launch_wino_filters({WinoFilter{w, Ub, w_gs, g.Cin, g.Cout}}, G, s)); U = Ub; }
-    VC_CHECK(launch_wino_dy(dy, dy_gs, dM, G, B, g.Cout, nt, s));
+    if (!U) { VC_CHECK(launch_wino_filters({WinoFilter{w, Ub, w_gs, g.Cin, g.Cout, g.kw}}, G, s)); U = Ub; }
+    VC_CHECK(launch_wino_dy(dy, dy_gs, dM, G, B, g.Cout, nt, s, g.kw));
     VC_CHECK(wino_gemm_dgrad(dM, U, dV, G, B, g, math, s));
-    return launch_wino_dx(dV, dx, dx_gs, addend, add_gs, accumulate, G, B, g.Cin, nt, s);
+    return launch_wino_dx(dV, dx, dx_gs, addend, add_gs, accumulate, G, B, g.Cin, nt, s, g.kw);
 }
 
 // query != nullptr: do not launch, only report whether the launch would use split-K atomics (needs a zeroed y)
@@ -470,7 +470,7 @@ int conv_wgrad(const WgradApp* apps, int napps, float* dw, long dw_gs, int G, co
         for (int k = 0; k < napps; ++k) {
             VC_CHECK(check_conv_geom(g, apps[k].B));
             VC_ARG(apps[k].dy && apps[k].x, "conv filter gradient (Winograd route): an application's fp32 operands are missing");
-            nV[k] = (size_t)6 * G * apps[k].B * g.Cin * nt; nM[k] = (size_t)6 * G * apps[k].B * g.Cout * nt; tot += nV[k] + nM[k];
+            nV[k] = (size_t)(g.kw + 3) * G * apps[k].B * g.Cin * nt; nM[k] = (size_t)(g.kw + 3) * G * apps[k].B * g.Cout * nt; tot += nV[k] + nM[k];
         }
         float* wsp; VC_CHECK(wino_workspace(s, tot, &wsp));
         WinoPrepJob jobs[4]; const float* V[2]; const float* dM[2]; int Bs[2]; int nj = 0; double flops = 0;
@@ -479,11 +479,11 @@ int conv_wgrad(const WgradApp* apps, int napps, float* dw, long dw_gs, int G, co
             jobs[nj++] = WinoPrepJob{apps[k].x, apps[k].x_gs, v, apps[k].B, g.Cin, 0};
             jobs[nj++] = WinoPrepJob{apps[k].dy, apps[k].dy_gs, m, apps[k].B, g.Cout, 1};
             V[k] = v; dM[k] = m; Bs[k] = apps[k].B;
-            flops += 2.0 * 6 * G * apps[k].B * nt * (double)g.Cin * g.Cout;
+            flops += 2.0 * (g.kw + 3) * G * apps[k].B * nt * (double)g.Cin * g.Cout;
         }
-        VC_CHECK(launch_wino_prep(jobs, nj, G, nt, s));
-        vc_count_wino_gemm(1, flops);      // the direct form multiplies twice as much
-        return launch_wino_wgrad(V, dM, Bs, napps, dw, dw_gs, store ? 1 : 0, G, g.Cin, g.Cout, nt, s, flops);
+        VC_CHECK(launch_wino_prep(jobs, nj, G, nt, s, g.kw));
+        vc_count_wino_gemm(1, flops * (4.0 * g.kw / (g.kw + 3) - 1.0));      // the direct form multiplies kw x W against (kw + 3) x W / 4
+        return launch_wino_wgrad(V, dM, Bs, napps, dw, dw_gs, store ? 1 : 0, G, g.Cin, g.Cout, nt, s, flops, g.kw);
     }
     Table t; VC_CHECK(get_fwd_table(g, &t));
     {
