@@ -610,3 +610,46 @@ def test_winograd_route_leaves_other_geometries_alone(built_lib):
     finally:
         check(lib.vc_set_math_mode(0))
     assert lib.vc_testing_wino_gemms(1) == 0
+
+
+# ---- F(3,6) along H (csrc/vc_conv_wino.hip: winoh_kernel): the discriminator's last block, kernel 6 x 3, strides 1 x 2 (module.py:208)
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', [(512, 6, 16, 2048, 8), (512, 9, 32, 2048, 3), (64, 6, 16, 128, 16), (64, 12, 8, 96, 4)])
+def test_winograd_along_h_for_the_discriminators_last_block(built_lib, case):
+    """forward and input gradient (+ addend / accumulate) against the oracle (1e-4) and against the direct kernel (2e-5); 6 rows (24 MCEPs),
+    9 rows (36 MCEPs: three tiles), 12 rows; the launch counter proves which route ran"""
+    from tests import gpu_util as U
+    lib, check = built_lib.lib, built_lib.check
+    O = _oracle()
+    Cin, H, W, Cout, B = case
+    rng = np.random.default_rng(hash(case) % (2 ** 31))
+    G = 2
+    xs = rng.standard_normal((G, B, H, W, Cin)).astype(np.float32)
+    ws = (rng.standard_normal((G, 6, 3, Cin, Cout)) / np.sqrt(18 * Cin)).astype(np.float32)
+    bs = rng.uniform(-0.5, 0.5, (G, Cout)).astype(np.float32)
+    ys, dxs, dys = [], [], []
+    for g in range(G):
+        y, cache = O.conv2d_fwd(xs[g], ws[g], bs[g], (1, 2))
+        dy = rng.standard_normal(y.shape).astype(np.float32)
+        dx, _, _ = O.conv2d_bwd(dy, ws[g], cache)
+        ys.append(y); dxs.append(dx); dys.append(dy)
+    cf = lambda a: np.ascontiguousarray(np.transpose(np.stack(a), (0, 1, 4, 2, 3)))
+    x_d, w_d, b_d, dy_d = U.dev(cf(list(xs))), U.dev(ws), U.dev(bs), U.dev(cf(dys))
+    add = U.dev(rng.standard_normal(cf(dxs).shape).astype(np.float32)); init = U.dev(rng.standard_normal(cf(dxs).shape).astype(np.float32))
+    out = {}
+    try:
+        for on in (1, 0):
+            check(lib.vc_tune_winograd(on)); lib.vc_testing_wino_gemms(1)
+            y = U.conv_fwd(x_d, w_d, b_d, 6, 3, 1, 2)
+            dx = U.conv_dgrad(dy_d, w_d, H, W, 6, 3, 1, 2)
+            dx2 = U.conv_dgrad(dy_d, w_d, H, W, 6, 3, 1, 2, addend=add, init=init)
+            assert lib.vc_testing_wino_gemms(1) == (3 if on else 0)
+            out[on] = (y.cpu().numpy(), dx.cpu().numpy(), dx2.cpu().numpy())
+            assert U.rel_err(out[on][0], cf(ys)) < TOL and U.rel_err(out[on][1], cf(dxs)) < TOL
+            assert U.rel_err(out[on][2], cf(dxs) + add.cpu().numpy() + init.cpu().numpy()) < TOL
+    finally:
+        check(lib.vc_tune_winograd(1))
+    for a, b in zip(out[1], out[0]):
+        e = U.rel_err(a, b)
+        print('winograd along H vs direct: %.2e' % e)
+        assert e < 2e-5

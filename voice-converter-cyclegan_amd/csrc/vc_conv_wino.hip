@@ -93,6 +93,20 @@ __global__ __launch_bounds__(256) void wino_filter_kernel(const WinoFilterJobs j
     const int g = blockIdx.y;
     const long plane = (long)j.n4 * 4;
     const float* w = j.w + (long)g * j.w_gs + (long)t * 4;
+    if (j.taps == 6) {        // F(3,6) along H: a plane = one row tap's [kw][Cin][Cout]; U[p] = sum_dh G6[p][dh] w[dh]
+        f32x4 wk[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) wk[k] = *reinterpret_cast<const f32x4*>(w + k * plane);
+        float* u6 = j.U + (long)g * j.U_gs + (long)t * 4;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 6; ++k) if (kG6[p][k] != 0.f) a += wk[k] * kG6[p][k];
+            *reinterpret_cast<f32x4*>(u6 + p * plane) = a;
+        }
+        return;
+    }
     if (j.taps == 5) {        // U[p] = sum_k G5[p][k] w[k]
         f32x4 wk[5];
 #pragma unroll
@@ -220,6 +234,91 @@ __global__ __launch_bounds__(256) void wino_wgrad_kernel(const WinoWgradArgs a) 
         }
 }
 
+// ---- F(3,6) along H (vc_wino.h).  x [g][b][C][H][W], H = 3 nt; transform-domain tensors [g][p][b][C][nt][W] (eight planes).
+// A thread = 4 consecutive columns of one tile of one (g, b, c) image.
+struct WinoHArgs {
+    const float* src; float* dst; const float* bias; const float* addend;
+    long src_gs, dst_gs, bias_gs, add_gs, plane;      // plane = B * C * nt * W floats
+    int G, B, C, nt, W, accumulate, mode;             // mode 0: x -> V, 1: M -> y (+ bias), 2: dy -> dM, 3: dV -> dx
+    long items;                                       // mode 0..2: G * B * C * nt * W / 4; mode 3: G * B * C * H * W / 4
+};
+__global__ __launch_bounds__(256) void winoh_kernel(const WinoHArgs p) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= p.items) return;
+    const int W4 = p.W >> 2, H = 3 * p.nt;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    if (p.mode == 3) {          // dx row r = sum over the tiles that read it: q = r - 3 t + 2 in 0 .. 7
+        const int wq = (int)(t % W4); long u = t / W4;
+        const int r = (int)(u % H); u /= H;                    // u = (g, b, c) image
+        const long per_g = (long)p.B * p.C; const int g = (int)(u / per_g); const long img = u - g * per_g;
+        const float* v = p.src + (long)g * p.src_gs + img * p.nt * p.W + 4 * wq;
+        f32x4 a = zero;
+        for (int tt = 0; tt < p.nt; ++tt) {
+            const int q = r - 3 * tt + 2;
+            if (q < 0 || q > 7) continue;
+#pragma unroll
+            for (int pp = 0; pp < 8; ++pp) {
+                float c = 0.f;
+#pragma unroll
+                for (int qq = 0; qq < 8; ++qq) if (qq == q) c = kBT5[pp][qq];
+                if (c != 0.f) a += *reinterpret_cast<const f32x4*>(v + pp * p.plane + (long)tt * p.W) * c;
+            }
+        }
+        const long o = (img * H + r) * p.W + 4 * wq;
+        if (p.addend) a += *reinterpret_cast<const f32x4*>(p.addend + (long)g * p.add_gs + o);
+        float* d = p.dst + (long)g * p.dst_gs + o;
+        if (p.accumulate) a += *reinterpret_cast<const f32x4*>(d);
+        *reinterpret_cast<f32x4*>(d) = a;
+        return;
+    }
+    const int wq = (int)(t % W4); long u = t / W4;
+    const int tt = (int)(u % p.nt); u /= p.nt;
+    const long per_g = (long)p.B * p.C; const int g = (int)(u / per_g); const long img = u - g * per_g;
+    const long tile = (img * p.nt + tt) * p.W + 4 * wq;          // offset inside one transform plane
+    if (p.mode == 0) {          // V[p] = B^T x[3t-2 .. 3t+5]
+        const float* x = p.src + (long)g * p.src_gs + img * H * p.W + 4 * wq;
+        f32x4 d[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { const int r = 3 * tt - 2 + q; d[q] = (r >= 0 && r < H) ? *reinterpret_cast<const f32x4*>(x + (long)r * p.W) : zero; }
+        float* v = p.dst + (long)g * p.dst_gs + tile;
+#pragma unroll
+        for (int pp = 0; pp < 8; ++pp) {
+            f32x4 a = zero;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) if (kBT5[pp][q] != 0.f) a += d[q] * kBT5[pp][q];
+            *reinterpret_cast<f32x4*>(v + pp * p.plane) = a;
+        }
+    } else if (p.mode == 1) {   // y[3t + m] = A^T M + bias
+        const float* m = p.src + (long)g * p.src_gs + tile;
+        f32x4 mm[8];
+#pragma unroll
+        for (int pp = 0; pp < 8; ++pp) mm[pp] = *reinterpret_cast<const f32x4*>(m + pp * p.plane);
+        const int c = (int)(img % p.C);
+        const float b = p.bias ? p.bias[(long)g * p.bias_gs + c] : 0.f;
+        float* y = p.dst + (long)g * p.dst_gs + img * H * p.W + 4 * wq;
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+            f32x4 a = {b, b, b, b};
+#pragma unroll
+            for (int pp = 0; pp < 8; ++pp) if (kAT6[e][pp] != 0.f) a += mm[pp] * kAT6[e][pp];
+            *reinterpret_cast<f32x4*>(y + (long)(3 * tt + e) * p.W) = a;
+        }
+    } else {                    // dM[p] = A dy[3t .. 3t+2]
+        const float* y = p.src + (long)g * p.src_gs + img * H * p.W + 4 * wq;
+        f32x4 d[3];
+#pragma unroll
+        for (int e = 0; e < 3; ++e) d[e] = *reinterpret_cast<const f32x4*>(y + (long)(3 * tt + e) * p.W);
+        float* m = p.dst + (long)g * p.dst_gs + tile;
+#pragma unroll
+        for (int pp = 0; pp < 8; ++pp) {
+            f32x4 a = zero;
+#pragma unroll
+            for (int e = 0; e < 3; ++e) if (kAT6[e][pp] != 0.f) a += d[e] * kAT6[e][pp];
+            *reinterpret_cast<f32x4*>(m + pp * p.plane) = a;
+        }
+    }
+}
+
 static int launch_wino(void (*k)(WinoArgs), WinoArgs a, hipStream_t s) {
     a.rows = a.G * a.B * a.C;
     a.plane = (long)a.B * a.C * a.nt;
@@ -259,7 +358,7 @@ int launch_wino_filters(const std::vector<WinoFilter>& f, int G, hipStream_t s) 
         for (size_t k = k0; k < f.size() && k < k0 + VC_WINO_JOBS; ++k) {
             const long n = (long)f[k].Cin * f[k].Cout;
             if (n % 4 != 0 || n / 4 >= (1L << 30)) { vc_set_error("winograd filter transform: Cin * Cout must be a multiple of 4"); return -1; }
-            WinoFilterJob& j = jj.j[jj.n]; j.w = f[k].w; j.U = f[k].U; j.w_gs = f[k].w_gs; j.U_gs = (long)(f[k].taps + 3) * n; j.n4 = (int)(n / 4); j.taps = f[k].taps;
+            WinoFilterJob& j = jj.j[jj.n]; j.w = f[k].w; j.U = f[k].U; j.w_gs = f[k].w_gs; j.U_gs = (long)(f[k].taps == 6 ? 8 : f[k].taps + 3) * n; j.n4 = (int)(n / 4); j.taps = f[k].taps;
             jj.blk0[jj.n++] = blk; blk += (unsigned)((j.n4 + 255) / 256);
         }
         jj.blk0[jj.n] = blk;
@@ -299,6 +398,21 @@ int launch_wino_wgrad(const float* const* V, const float* const* dM, const int* 
     const dim3 grid((unsigned)((Cin / 64) * (Cout / 64)), (unsigned)G);
     if (taps == 5) { if (by8) wino_wgrad_kernel<8, 5><<<grid, 256, 0, s>>>(a); else wino_wgrad_kernel<4, 5><<<grid, 256, 0, s>>>(a); }
     else if (by8) wino_wgrad_kernel<8, 3><<<grid, 256, 0, s>>>(a); else wino_wgrad_kernel<4, 3><<<grid, 256, 0, s>>>(a);
+    VC_HIP(hipGetLastError());
+    return 0;
+}
+
+// F(3,6) along H: mode 0 x [G][B][C][3 nt][W] -> V [G][8][B][C][nt][W]; 1 M -> y (+ bias); 2 dy -> dM; 3 dV -> dx = (accumulate ? dx : 0) + addend + B dV
+int launch_winoh(int mode, const float* src, long src_gs, float* dst, long dst_gs, const float* bias, long b_gs, const float* addend, long add_gs,
+                 int accumulate, int G, int B, int C, int nt, int W, hipStream_t s) {
+    WinoHArgs a{}; a.mode = mode; a.src = src; a.dst = dst; a.bias = bias; a.bias_gs = b_gs; a.addend = addend; a.add_gs = add_gs; a.accumulate = accumulate;
+    a.G = G; a.B = B; a.C = C; a.nt = nt; a.W = W; a.plane = (long)B * C * nt * W;
+    const long planes_gs = 8 * a.plane;
+    a.src_gs = (mode == 1 || mode == 3) ? planes_gs : src_gs;
+    a.dst_gs = (mode == 0 || mode == 2) ? planes_gs : dst_gs;
+    a.items = (long)G * B * C * (mode == 3 ? 3 * nt : nt) * (W / 4);
+    if (a.items <= 0) return 0;
+    winoh_kernel<<<dim3((unsigned)((a.items + 255) / 256)), 256, 0, s>>>(a);
     VC_HIP(hipGetLastError());
     return 0;
 }

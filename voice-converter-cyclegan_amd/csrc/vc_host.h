@@ -63,6 +63,8 @@ int conv_dgrad(const float* dy, long dy_gs, const float* w, long w_gs, float* dx
                bool prezeroed = false, bool* query = nullptr, const char* const* packed_w = nullptr,
                const char* dy_packed = nullptr, long dy_packed_gs = 0);   // dy_packed: dy already as bf16 channel octets (its producer wrote them; group stride in bytes)
 bool wino_eligible(const Geom& g, int math, int B);                        // fp32: forward / input gradient of this geometry take the Winograd F(4,3) route (vc_ops.hip)
+bool winoh_eligible(const Geom& g, int math, int B);                       // ... or the F(3,6)-along-H route (D.d3)
+bool wino_route(const Geom& g, int math, int B);                           // either
 Geom wino_gemm_geom(const Geom& g);                                   // the 1 x 1 geometry of its six channel GEMMs
 int wino_workspace(hipStream_t s, size_t floats, float** out);        // transform-domain scratch of the launches issued on stream s (grows on demand, reused launch to launch)
 int wino_gemm_fwd(const float* V, const float* U, float* M, int G, int B, const Geom& g, int math, hipStream_t s);
@@ -135,12 +137,13 @@ struct vc_plan {
     // fp32 mode: the Winograd-domain filters U = G w of the generators' 3-tap layers (vc_conv_wino.hip), both generators as the two groups,
     // rebuilt from the weights at the head of every train step on the side stream (a step uses each four times: two forward passes, two
     // input gradients); fwd = dg[0] = the layer's U.
-    mutable std::vector<LayerImages> wino_img;
+    mutable std::vector<LayerImages> wino_img, wino_img_d;     // generators' layers; discriminators' (D.d3: F(3,6) along H)
     mutable float* wino_block = nullptr;
     mutable bool wino_active = false;      // the running step rebuilt them (its batch is large enough for the route)
+    mutable hipStream_t wino_stream = nullptr;   // ... on this stream (a pass on the same stream needs no event wait)
     static constexpr int kWinoChunks = 3;  // the rebuild goes out as this many launches in layer order, an event behind each: the forward waits for a layer's chunk only
     hipEvent_t ev_wino[kWinoChunks] = {nullptr, nullptr, nullptr};
-    mutable std::vector<int> wino_chunk;   // per generator layer: which launch carries its filters (-1: none)
+    mutable std::vector<int> wino_chunk, wino_chunk_d;   // per generator / discriminator layer: which launch carries its filters (-1: none)
 };
 struct SaveMap { std::vector<long> raw, act, st, actp; long total; };
 SaveMap save_map(const NetDesc& n, const std::vector<LayerGeo>& geo, int B);

@@ -178,11 +178,13 @@ int launch_gated_conv1d_glu_prepack(const float* w, long w_gs, void* img, long i
 int launch_glu_copy_roof(const WsConvArgs& a, int cin, int kw, hipStream_t s);
 
 // Winograd F(4,3) / F(4,5) transforms (vc_conv_wino.hip): 1-D, 3 or 5 taps, stride 1, W = 4 nt; taps + 3 transform positions
-struct WinoFilter { const float* w; float* U; long w_gs; int Cin, Cout, taps; }; // U [G][taps + 3][Cin][Cout], group stride (taps + 3) Cin Cout
+struct WinoFilter { const float* w; float* U; long w_gs; int Cin, Cout, taps; }; // U [G][taps + 3][Cin][Cout], group stride (taps + 3) Cin Cout (taps 6: F(3,6) along H, 8 planes, Cin = kw x the layer's)
 int launch_wino_filters(const std::vector<WinoFilter>& f, int G, hipStream_t s);
 int launch_wino_input(const float* x, long x_gs, float* V, int G, int B, int C, int nt, hipStream_t s, int taps = 3);
 int launch_wino_output(const float* M, const float* bias, long b_gs, float* y, long y_gs, int G, int B, int C, int nt, hipStream_t s, int taps = 3);
 int launch_wino_dy(const float* dy, long dy_gs, float* dM, int G, int B, int C, int nt, hipStream_t s, int taps = 3);
+int launch_winoh(int mode, const float* src, long src_gs, float* dst, long dst_gs, const float* bias, long b_gs, const float* addend, long add_gs,
+                 int accumulate, int G, int B, int C, int nt, int W, hipStream_t s);      // F(3,6) along H (D.d3): see vc_conv_wino.hip
 struct WinoPrepJob { const float* src; long src_gs; float* dst; int B, C, kind; };   // kind 0: x -> V = B^T x, 1: dy -> dM = A dy
 int launch_wino_prep(const WinoPrepJob* jobs, int n, int G, int nt, hipStream_t s, int taps = 3);
 int launch_wino_wgrad(const float* const* V, const float* const* dM, const int* B, int napp, float* dW, long dw_gs, int store,

@@ -139,6 +139,11 @@ static int plan_create(int num_features, int n_frames, bool inference, vc_plan**
         for (auto& l : *v) {
             if (c1_path(l.g)) continue;
             Table t;
+            if (!inference && winoh_eligible(l.g, VC_MATH_FP32, 1 << 20)) {      // D.d3: the (1 x kw, stride 1 x sw) tables of the F(3,6)-along-H planes
+                const Geom g1 = make_geom(l.g.Cin, l.g.H / 3, l.g.W, l.g.Cout, 1, l.g.kw, 1, l.g.sw);
+                r = r ? r : get_fwd_table(g1, &t, &p->tables);
+                for (int pw = 0; pw < g1.sw && !r; ++pw) r = get_dgrad_table(g1, 0, pw, &t, &p->tables);
+            }
             if (!inference && v == &p->gg && wino_eligible(l.g, VC_MATH_FP32, 1 << 20)) {      // the 1 x 1 tables of the Winograd route's channel GEMMs
                 const Geom g1 = wino_gemm_geom(l.g);
                 r = r ? r : get_fwd_table(g1, &t, &p->tables);
@@ -368,9 +373,9 @@ static int net_forward(NetCtx& c, const float* x, long x_gs, float* y_plain, lon
     // fp32 inside a train step: the 3-tap layers (residual blocks) run in the Winograd domain (vc_conv_wino.hip) on the step's transformed filters;
     // the transforms ride in the instance-norm launches on either side of the GEMMs (NormArgs::win / wout), stand-alone launches where they cannot
     auto wino_cached = [&](size_t i) {       // the step holds this layer's transformed filters and the launch is large enough for the route
-        return c.images && c.math == VC_MATH_FP32 && (*c.images)[i].fwd && wino_eligible((*c.geo)[i].g, c.math, c.B);
+        return c.images && c.math == VC_MATH_FP32 && (*c.images)[i].fwd && wino_route((*c.geo)[i].g, c.math, c.B);
     };
-    auto wino_layer = [&](size_t i) { return wino_cached(i) && (*c.geo)[i].g.kw == 3; };     // ... and its transforms can ride in the norm launches
+    auto wino_layer = [&](size_t i) { return wino_cached(i) && (*c.geo)[i].g.kh == 1 && (*c.geo)[i].g.kw == 3; };     // ... and its transforms can ride in the norm launches
     auto wino_wait = [&](size_t i) -> int {    // this step's filter transforms (side stream), chunk by chunk
         if (c.wino_ev && !(wino_waited_mask >> c.wino_chunk[i] & 1u)) { VC_HIP(hipStreamWaitEvent(c.s, c.wino_ev[c.wino_chunk[i]], 0)); wino_waited_mask |= 1u << c.wino_chunk[i]; }
         return 0;
@@ -500,9 +505,9 @@ static int net_backward(NetCtx& c, const float* x, long x_gs, const float* dtop,
     // fp32 inside a train step: input gradients of the 3-tap layers in the Winograd domain (see net_forward): dM = A dy leaves the layer's norm
     // backward, dV = U^T dM is the six GEMMs, and dO = B dV (+ skip) is rebuilt by the NEXT norm backward on its way in (`pend`)
     auto wino_cached = [&](int i) {
-        return c.images && c.math == VC_MATH_FP32 && (*c.images)[i].has_dg && wino_eligible((*c.geo)[i].g, c.math, c.B);
+        return c.images && c.math == VC_MATH_FP32 && (*c.images)[i].has_dg && wino_route((*c.geo)[i].g, c.math, c.B);
     };
-    auto wino_layer = [&](int i) { return wino_cached(i) && (*c.geo)[i].g.kw == 3; };
+    auto wino_layer = [&](int i) { return wino_cached(i) && (*c.geo)[i].g.kh == 1 && (*c.geo)[i].g.kw == 3; };
     auto norm_fusable = [&](int i) {      // layer i's norm backward can apply the transforms (the launcher checks alignment once more)
         const Layer& Li = c.n->layers[i]; const LayerGeo& li = (*c.geo)[i];
         const int Ln = li.g.OH * li.g.OW;
@@ -647,7 +652,10 @@ StepImages::StepImages(const vc_plan* p) { t_step_images = p; }
 StepImages::~StepImages() { t_step_images = nullptr; }
 static const std::vector<vc_plan::LayerImages>* step_images(const vc_plan* p, bool gen, int G) {
     if (t_step_images != p || G != 2) return nullptr;
-    if (p->math == VC_MATH_FP32) return (gen && p->wino_active && !p->wino_img.empty() && vc_hooks().winograd != 0) ? &p->wino_img : nullptr;
+    if (p->math == VC_MATH_FP32) {
+        const auto& v = gen ? p->wino_img : p->wino_img_d;
+        return (p->wino_active && !v.empty() && vc_hooks().winograd != 0) ? &v : nullptr;
+    }
     if (p->math != VC_MATH_BF16) return nullptr;
     const auto& v = gen ? p->img_g : p->img_d;
     return v.empty() ? nullptr : &v;
@@ -659,17 +667,26 @@ int refresh_wino_filters(const vc_plan* p, const float* params, int B, hipStream
     // The block's layout covers every layer the route can EVER take in this plan (geometry only); a step transforms the layers its own batch
     // takes it for (B = the largest batch of its passes: a layer eligible in a smaller pass is eligible here).  Round 6, found by the
     // deterministic-mode test: a layout built from the first step's batch was too small for a later, larger one.
-    std::vector<size_t> offs(p->G.layers.size(), 0); std::vector<vc_plan::LayerImages> img(p->G.layers.size());
-    size_t tot = 0; int nlay = 0;
-    for (size_t i = 0; i < p->G.layers.size(); ++i) {
-        const Geom& g = p->gg[i].g;
-        if (!wino_eligible(g, p->math, 1 << 20)) continue;
-        offs[i] = tot; img[i].fwd = (const char*)(tot + 1);       // offset + 1 until the block exists (0 = no image)
-        tot += (size_t)2 * (g.kw + 3) * g.Cin * g.Cout; ++nlay;
+    const long PG = p->G.total, PD = p->D.total;
+    struct Lay { int net, i; size_t off; WinoFilter f; };
+    std::vector<Lay> lays; size_t tot = 0;
+    for (int net = 0; net < 2; ++net) {
+        const NetDesc& n = net ? p->D : p->G; const auto& geo = net ? p->dg : p->gg;
+        const float* base = net ? params + 2 * PG : params; const long gs = net ? PD : PG;
+        for (size_t i = 0; i < n.layers.size(); ++i) {
+            const Geom& g = geo[i].g;
+            const bool w1 = wino_eligible(g, p->math, 1 << 20), wh = !w1 && winoh_eligible(g, p->math, 1 << 20);
+            if (!w1 && !wh) continue;
+            const int planes = wh ? 8 : g.kw + 3;
+            const long inner = wh ? (long)g.kw * g.Cin * g.Cout : (long)g.Cin * g.Cout;
+            lays.push_back(Lay{net, (int)i, tot, WinoFilter{base + n.layers[i].w, nullptr, gs, wh ? g.kw * g.Cin : g.Cin, g.Cout, wh ? 6 : g.kw}});
+            tot += (size_t)2 * planes * inner;
+        }
     }
-    if (!nlay) return 0;
+    if (lays.empty()) return 0;
+    auto takes = [&](const Lay& l) { return wino_route((l.net ? p->dg : p->gg)[l.i].g, p->math, B); };
     bool any = false;
-    for (size_t i = 0; i < p->G.layers.size(); ++i) any = any || (img[i].fwd && wino_eligible(p->gg[i].g, p->math, B));
+    for (const Lay& l : lays) any = any || takes(l);
     if (!any) return 0;
     if (!p->wino_block) {
         hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
@@ -680,33 +697,33 @@ int refresh_wino_filters(const vc_plan* p, const float* params, int B, hipStream
         VC_HIP(hipMalloc((void**)&p->wino_block, tot * sizeof(float)));
     }
     if (p->wino_img.empty()) {
-        for (auto& li : img) if (li.fwd) { li.fwd = (const char*)(p->wino_block + ((size_t)li.fwd - 1)); li.dg[0] = li.fwd; li.has_dg = true; }
-        p->wino_img = img;
-        // in layer order, kWinoChunks launches with an event behind each: the first-hop forward reaches its first residual block ~70 us into the
-        // step and waits for that block's filters only (one launch: 0.12 ms ahead of the first Winograd GEMM at batch 8)
-        const int per = (nlay + vc_plan::kWinoChunks - 1) / vc_plan::kWinoChunks;
-        p->wino_chunk.assign(p->G.layers.size(), -1);
+        // in layer order (generators, then discriminators), kWinoChunks launches with an event behind each: the first-hop forward reaches its
+        // first residual block ~70 us into the step and waits for that block's filters only (one launch: 0.12 ms ahead of the first GEMM)
+        p->wino_img.assign(p->G.layers.size(), vc_plan::LayerImages{}); p->wino_img_d.assign(p->D.layers.size(), vc_plan::LayerImages{});
+        p->wino_chunk.assign(p->G.layers.size(), -1); p->wino_chunk_d.assign(p->D.layers.size(), -1);
+        const int per = ((int)lays.size() + vc_plan::kWinoChunks - 1) / vc_plan::kWinoChunks;
         int k = 0;
-        for (size_t i = 0; i < p->G.layers.size(); ++i) if (p->wino_img[i].fwd) p->wino_chunk[i] = k++ / per;
+        for (const Lay& l : lays) {
+            vc_plan::LayerImages& li = (l.net ? p->wino_img_d : p->wino_img)[l.i];
+            li.fwd = (const char*)(p->wino_block + l.off); li.dg[0] = li.fwd; li.has_dg = true;
+            (l.net ? p->wino_chunk_d : p->wino_chunk)[l.i] = k++ / per;
+        }
     }
     for (int ck = 0; ck < vc_plan::kWinoChunks; ++ck) {
         std::vector<WinoFilter> jobs;
-        for (size_t i = 0; i < p->G.layers.size(); ++i) {
-            const Geom& g = p->gg[i].g;
-            if (p->wino_chunk[i] == ck && wino_eligible(g, p->math, B))
-                jobs.push_back(WinoFilter{params + p->G.layers[i].w, p->wino_block + offs[i], p->G.total, g.Cin, g.Cout, g.kw});
-        }
+        for (const Lay& l : lays)
+            if ((l.net ? p->wino_chunk_d : p->wino_chunk)[l.i] == ck && takes(l)) { WinoFilter f = l.f; f.U = p->wino_block + l.off; jobs.push_back(f); }
         if (!jobs.empty()) VC_CHECK(launch_wino_filters(jobs, 2, s));
         VC_HIP(hipEventRecord(p->ev_wino[ck], s));
     }
-    *active = true; p->wino_active = true;
+    *active = true; p->wino_active = true; p->wino_stream = s;
     return 0;
 }
 int gen_forward(const vc_plan* p, const float* params, long par_gs, const float* x, long x_gs,
                        float* y, long y_gs, float* save, int G, int B, hipStream_t s) {
     NetCtx c = gen_ctx(p, params, par_gs, nullptr, 0, save, G, B, B, s);
     c.images = step_images(p, true, G); c.keep_packed = c.images != nullptr && p->math == VC_MATH_BF16;
-    if (c.images && p->math == VC_MATH_FP32) { c.wino_ev = p->ev_wino; c.wino_chunk = p->wino_chunk.data(); }
+    if (c.images && p->math == VC_MATH_FP32 && s != p->wino_stream) { c.wino_ev = p->ev_wino; c.wino_chunk = p->wino_chunk.data(); }
     c.fuse_glu = p->inference;
     return net_forward(c, x, x_gs, y, y_gs);
 }
@@ -719,7 +736,7 @@ int gen_backward(const vc_plan* p, const float* params, long par_gs, const float
     c.prezeroed = o.prezeroed;
     c.wgrad_store = o.wgrad_store; c.wmode = o.wmode; c.deferred = o.deferred; c.q_ready_out = o.q_ready_out; c.dy_dropped_out = o.dy_dropped_out; c.drop_dy = o.drop_fp32_dy;
     c.images = step_images(p, true, G); c.keep_packed = c.images != nullptr && p->math == VC_MATH_BF16;
-    if (c.images && p->math == VC_MATH_FP32) { c.wino_ev = p->ev_wino; c.wino_chunk = p->wino_chunk.data(); }
+    if (c.images && p->math == VC_MATH_FP32 && s != p->wino_stream) { c.wino_ev = p->ev_wino; c.wino_chunk = p->wino_chunk.data(); }
     if ((p->use_side & 2) && dparams && o.wmode != W_NONE) { c.ws = p->wstream; c.ev_layer = p->ev_layer; c.ev_wjoin = p->ev_wjoin; }
     if (o.record_buckets) { c.ev_first = p->bucket_first; c.ev = p->g_ready; c.ev_free = p->g_free; c.n_ev = vc_plan::kBuckets; c.lay_ready = p->gl_ready; c.lay_free = p->gl_free; }
     return net_backward(c, x, x_gs, dy, dy_gs, dx, dx_gs, dx_acc, scratch, scr_gs);
@@ -734,6 +751,9 @@ int disc_forward(const vc_plan* p, const float* params, long par_gs, const float
     VC_ARG(!p->inference, "this plan was created for inference only (vc_plan_create_inference)");
     NetCtx c = disc_ctx(p, params, par_gs, nullptr, 0, save, G, B, B, s);
     c.images = step_images(p, false, G); c.keep_packed = c.images != nullptr && p->math == VC_MATH_BF16;
+    // (same stream as the rebuild: ordered already -- and under hipGraph capture a wait on an event the waiting stream itself recorded crashed
+    // hipStreamEndCapture on ROCm 7.2, found by the graph test when D.d3 joined the route)
+    if (c.images && p->math == VC_MATH_FP32 && s != p->wino_stream) { c.wino_ev = p->ev_wino; c.wino_chunk = p->wino_chunk_d.data(); }
     VC_CHECK(net_forward(c, x, x_gs, nullptr, 0));
     const int last = (int)p->D.layers.size() - 1;
     return launch_head_fwd(save + c.sm.act[last], c.save_gs, params + p->D.head_w, params + p->D.head_b, par_gs,
@@ -748,6 +768,9 @@ int disc_backward(const vc_plan* p, const float* params, long par_gs, const floa
     NetCtx c = disc_ctx(p, params, par_gs, dparams, dpar_gs, save, G, B, Bl, s);
     c.wgrad_store = wgrad_store; c.drop_dy = drop_fp32_dy;
     c.images = step_images(p, false, G); c.keep_packed = c.images != nullptr && p->math == VC_MATH_BF16;
+    // (same stream as the rebuild: ordered already -- and under hipGraph capture a wait on an event the waiting stream itself recorded crashed
+    // hipStreamEndCapture on ROCm 7.2, found by the graph test when D.d3 joined the route)
+    if (c.images && p->math == VC_MATH_FP32 && s != p->wino_stream) { c.wino_ev = p->ev_wino; c.wino_chunk = p->wino_chunk_d.data(); }
     c.prezeroed = prezeroed;
     if (record_layers) { if (dparams) { c.lay_ready = p->dl_ready; c.lay_free = p->dl_free_d; } else c.lay_free = p->dl_free_g; }
     if ((p->use_side & 4) && dparams) { c.ws = p->wstream_d; c.ev_layer = p->ev_layer_d; c.ev_wjoin = p->ev_wjoin_d; }

@@ -165,6 +165,52 @@ static bool wino_wgrad_eligible(const Geom& g, int math, const WgradApp* apps, i
     for (int k = 0; k < napps; ++k) { Bmax = std::max(Bmax, apps[k].B); if ((apps[k].B * (g.W / 32)) % 4 != 0) return false; }   // the kernel's prefetch depth
     return wino_eligible(g, math, Bmax) && (g.W / 4) % 8 == 0 && g.Cin % 64 == 0 && g.Cout % 64 == 0;
 }
+// (row, row tap) pairs of a 6-tap SAME convolution along H that do not fall into the padding: what the direct kernel multiplies per column tap
+static double winoh_valid_pairs(const Geom& g) {
+    int n = 0;
+    for (int i = 0; i < g.OH; ++i) for (int d = 0; d < g.kh; ++d) { const int r = i + d - g.pt; n += (r >= 0 && r < g.H) ? 1 : 0; }
+    return (double)n;
+}
+// F(3,6) along H for the discriminator's last block (kernel 6 x kw, stride 1 along H; csrc/vc_conv_wino.hip: winoh_kernel): forward and input
+// gradient as eight (1 x kw, stride 1 x sw) convolutions of transformed row planes.  B: each plane's GEMM sees B (H / 3) OW pixels.
+bool winoh_eligible(const Geom& g, int math, int B) {
+    return math == VC_MATH_FP32 && vc_hooks().winograd != 0 && g.kh == 6 && g.sh == 1 && g.H % 3 == 0 && g.H >= 6 && g.OH == g.H && g.pt == 2 &&
+           g.W % 4 == 0 && g.OW % 4 == 0 && g.Cin % 32 == 0 && g.Cout % 32 == 0 && g.Cin >= 64 && g.Cout >= 64 && (long)B * (g.H / 3) * g.OW >= 64;
+}
+bool wino_route(const Geom& g, int math, int B) { return wino_eligible(g, math, B) || winoh_eligible(g, math, B); }
+static Geom winoh_gemm_geom(const Geom& g) { return make_geom(g.Cin, g.H / 3, g.W, g.Cout, 1, g.kw, 1, g.sw); }
+static int winoh_fwd(const float* x, long x_gs, const float* w, long w_gs, const float* bias, long b_gs, float* y, long y_gs,
+                     int G, int B, const Geom& g, int math, hipStream_t s, const float* U) {
+    const int nt = g.H / 3; const Geom g1 = winoh_gemm_geom(g);
+    const long inner = (long)g.kw * g.Cin * g.Cout;
+    const size_t nV = (size_t)8 * G * B * g.Cin * nt * g.W, nM = (size_t)8 * G * B * g.Cout * nt * g.OW, nU = U ? 0 : (size_t)8 * G * inner;
+    char* wsp; VC_CHECK(pack_space(s, (nV + nM + nU) * sizeof(float), &wsp));
+    float* V = (float*)wsp; float* M = V + nV; float* Ub = M + nM;
+    if (!U) { VC_CHECK(launch_wino_filters({WinoFilter{w, Ub, w_gs, g.kw * g.Cin, g.Cout, 6}}, G, s)); U = Ub; }
+    VC_CHECK(launch_winoh(0, x, x_gs, V, 0, nullptr, 0, nullptr, 0, 0, G, B, g.Cin, nt, g.W, s));
+    {
+        DetScope no_split(1);
+        vc_count_wino_gemm(0, 2.0 * G * B * g.OW * (double)g.Cout * g.Cin * g.kw * (winoh_valid_pairs(g) - 8.0 * nt));
+        VC_CHECK(conv_fwd(V, (long)B * g.Cin * nt * g.W, U, inner, nullptr, 0, M, (long)B * g.Cout * nt * g.OW, 8 * G, B, g1, math, s));
+    }
+    return launch_winoh(1, M, 0, y, y_gs, bias, b_gs, nullptr, 0, 0, G, B, g.Cout, nt, g.OW, s);
+}
+static int winoh_dgrad(const float* dy, long dy_gs, const float* w, long w_gs, float* dx, long dx_gs, const float* addend, long add_gs,
+                       int accumulate, int G, int B, const Geom& g, int math, hipStream_t s, const float* U) {
+    const int nt = g.H / 3; const Geom g1 = winoh_gemm_geom(g);
+    const long inner = (long)g.kw * g.Cin * g.Cout;
+    const size_t nM = (size_t)8 * G * B * g.Cout * nt * g.OW, nV = (size_t)8 * G * B * g.Cin * nt * g.W, nU = U ? 0 : (size_t)8 * G * inner;
+    char* wsp; VC_CHECK(pack_space(s, (nV + nM + nU) * sizeof(float), &wsp));
+    float* dM = (float*)wsp; float* dV = dM + nM; float* Ub = dV + nV;
+    if (!U) { VC_CHECK(launch_wino_filters({WinoFilter{w, Ub, w_gs, g.kw * g.Cin, g.Cout, 6}}, G, s)); U = Ub; }
+    VC_CHECK(launch_winoh(2, dy, dy_gs, dM, 0, nullptr, 0, nullptr, 0, 0, G, B, g.Cout, nt, g.OW, s));
+    {
+        DetScope no_split(1);
+        vc_count_wino_gemm(0, 2.0 * G * B * g.OW * (double)g.Cout * g.Cin * g.kw * (winoh_valid_pairs(g) - 8.0 * nt));
+        VC_CHECK(conv_dgrad(dM, (long)B * g.Cout * nt * g.OW, U, inner, dV, (long)B * g.Cin * nt * g.W, nullptr, 0, 0, 8 * G, B, g1, math, s));
+    }
+    return launch_winoh(3, dV, 0, dx, dx_gs, nullptr, 0, addend, add_gs, accumulate, G, B, g.Cin, nt, g.W, s);
+}
 int wino_workspace(hipStream_t s, size_t floats, float** out) {
     char* q; VC_CHECK(pack_space(s, floats * sizeof(float), &q));
     *out = (float*)q;
@@ -220,6 +266,10 @@ int conv_fwd(const float* x, long x_gs, const float* w, long w_gs, const float* 
     if (wino_eligible(g, math, B)) {      // residual-block convolutions, fp32: six GEMMs in the Winograd domain; every output is stored once
         if (query) { *query = false; return 0; }
         return wino_fwd(x, x_gs, w, w_gs, bias, b_gs, y, y_gs, G, B, g, math, s, (const float*)packed_w);
+    }
+    if (winoh_eligible(g, math, B)) {     // D.d3, fp32: F(3,6) along H
+        if (query) { *query = false; return 0; }
+        return winoh_fwd(x, x_gs, w, w_gs, bias, b_gs, y, y_gs, G, B, g, math, s, (const float*)packed_w);
     }
     if (c1_path(g)) {      // Cin = 1 (D.h1): vector-ALU kernel, plain stores, never needs a zeroed destination
         if (query) { *query = false; return 0; }
@@ -301,6 +351,11 @@ int conv_dgrad(const float* dy, long dy_gs, const float* w, long w_gs, float* dx
         if (query) { *query = false; return 0; }      // the back transform stores (or accumulates into) every element of dx itself
         VC_ARG(dy, "conv input gradient (Winograd route): the fp32 dy was left unwritten");
         return wino_dgrad(dy, dy_gs, w, w_gs, dx, dx_gs, addend, add_gs, accumulate, G, B, g, math, s, packed_w ? (const float*)packed_w[0] : nullptr);
+    }
+    if (winoh_eligible(g, math, B)) {
+        if (query) { *query = false; return 0; }
+        VC_ARG(dy, "conv input gradient (Winograd route): the fp32 dy was left unwritten");
+        return winoh_dgrad(dy, dy_gs, w, w_gs, dx, dx_gs, addend, add_gs, accumulate, G, B, g, math, s, packed_w ? (const float*)packed_w[0] : nullptr);
     }
     if (c1_path(g)) {
         if (query) { *query = false; return 0; }      // zeroes dx itself when it has to
