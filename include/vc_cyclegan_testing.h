@@ -42,9 +42,12 @@ int  vc_tune_c1_dgrad_gather(int on);
  * process after a batch-8 run, which is where bench.py times configs[0]) and 6.72 against 6.67 ms at batch 8 with the Winograd route on -- so
  * it is a switch, not the default.  Also the timing control of the round-6 wrong-lane-group finding. */
 int  vc_tune_layer_updates(int on);
-/* fp32 mode, calling thread's following convolutions: 1 (production) = forward and input gradient of the 3-tap stride-1 1-D convolutions
- * whose width is a multiple of 4 (the residual blocks, module.py:66-83) run as Winograd F(4,3): six channel GEMMs in the transform domain
- * (csrc/vc_conv_wino.hip); 0 = the direct implicit GEMM for every convolution (the control of the parity tests and of the A/B timing). */
+/* fp32 mode, calling thread's following convolutions.  1 (production): inside a train step, forward and input gradient of the stride-1 1-D
+ * convolutions with 3 or 5 taps whose width is a multiple of 4 (residual and up-sampling blocks, module.py:66-133: Winograd F(4,3) / F(4,5)) and of
+ * the discriminators' 6 x 3 block (module.py:208: F(3,6) along H) run as GEMMs in the transform domain on filters transformed once per step, and
+ * the 1-D layers' filter gradients in the fused transform-domain kernel (csrc/vc_conv_wino.hip); calls without cached filters (operator / network
+ * level, inference) stay on the direct kernels.  2: those calls take the route too, transforming the filters per call (the parity tests).
+ * 0: the direct implicit GEMM everywhere (control of the parity tests and of the A/B timing). */
 int  vc_tune_winograd(int on);
 /* Winograd-domain GEMM launches (one per convolution forward / input gradient on the route) the calling thread has issued; reset != 0 clears. */
 long long vc_testing_wino_gemms(int reset);

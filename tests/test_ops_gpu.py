@@ -546,7 +546,7 @@ WINO_CASES = [
 @pytest.mark.parametrize('case', WINO_CASES)
 def test_winograd_route_against_the_oracle_and_the_direct_kernel(built_lib, case):
     """module.py:66-83 / 115-133 (conv1d, kernel 3 or 5, stride 1, SAME): the Winograd route (production in fp32 mode) against the oracle at the operator
-    tolerance and against the direct implicit GEMM (vc_tune_winograd(0)) at 2e-5 of the tensor's maximum -- the route changes the summation
+    tolerance (forced for operator-level calls: vc_tune_winograd(2)) and against the direct implicit GEMM (vc_tune_winograd(0)) at 2e-5 of the tensor's maximum -- the route changes the summation
     order and adds the rounding of its transforms (2-3e-6 measured against fp64), nothing else; addend / accumulate semantics of the input
     gradient included.  The launch counter proves which route ran."""
     from tests import gpu_util as U
@@ -572,21 +572,21 @@ def test_winograd_route_against_the_oracle_and_the_direct_kernel(built_lib, case
     add = U.dev(rng.standard_normal(cf(dxs).shape).astype(np.float32)); init = U.dev(rng.standard_normal(cf(dxs).shape).astype(np.float32))
     out = {}
     try:
-        for on in (1, 0):
+        for on in (2, 0):
             check(lib.vc_tune_winograd(on)); lib.vc_testing_wino_gemms(1)
             y = U.conv_fwd(x_d, w_d, b_d, 1, K, 1, 1)
             dx = U.conv_dgrad(dy_d, w_d, 1, W, 1, K, 1, 1)
             dx2 = U.conv_dgrad(dy_d, w_d, 1, W, 1, K, 1, 1, addend=add, init=init)
             dw = U.conv_wgrad(x_d, dy_d, 1, K, 1, 1)
             dw2 = U.conv_wgrad(x_d, dy_d, 1, K, 1, 1, init=dw)              # the operator accumulates: twice the gradient
-            assert lib.vc_testing_wino_gemms(1) == ((3 + (2 if wg else 0)) if on else 0)
+            assert lib.vc_testing_wino_gemms(1) == ((3 + (2 if wg else 0)) if on else 0)      # forward, two input gradients, two filter gradients
             out[on] = (y.cpu().numpy(), dx.cpu().numpy(), dx2.cpu().numpy(), dw.cpu().numpy(), dw2.cpu().numpy())
             assert U.rel_err(out[on][0], cf(ys)) < TOL and U.rel_err(out[on][1], cf(dxs)) < TOL
             assert U.rel_err(out[on][2], cf(dxs) + add.cpu().numpy() + init.cpu().numpy()) < TOL
             assert U.rel_err(out[on][3], np.stack(dws)) < TOL and U.rel_err(out[on][4], 2 * np.stack(dws)) < TOL
     finally:
         check(lib.vc_tune_winograd(1))
-    for a, b in zip(out[1], out[0]):
+    for a, b in zip(out[2], out[0]):
         e = U.rel_err(a, b)
         print('winograd vs direct: %.2e' % e)
         assert e < 2e-5
@@ -597,6 +597,7 @@ def test_winograd_route_leaves_other_geometries_alone(built_lib):
     """stride 2, 7 taps, 2-D, a width that is not a multiple of 4, bf16 mode, fewer than 64 pixels per transform position: the direct kernels"""
     from tests import gpu_util as U
     lib, check = built_lib.lib, built_lib.check
+    check(lib.vc_tune_winograd(2))
     lib.vc_testing_wino_gemms(1)
     for Cin, H, W, Cout, kh, kw, sh, sw, B in [(64, 1, 32, 64, 1, 3, 1, 2, 8), (64, 1, 32, 64, 1, 7, 1, 1, 8), (64, 4, 32, 64, 3, 3, 1, 1, 8),
                                                 (64, 1, 30, 64, 1, 3, 1, 1, 16), (64, 1, 32, 64, 1, 3, 1, 1, 4)]:
@@ -608,7 +609,11 @@ def test_winograd_route_leaves_other_geometries_alone(built_lib):
         x = torch.randn((2, 16, 64, 1, 32), device=U.DEV); w = torch.randn((2, 1, 3, 64, 64), device=U.DEV) * 0.05; b = torch.zeros((2, 64), device=U.DEV)
         U.conv_fwd(x, w, b, 1, 3, 1, 1)
     finally:
-        check(lib.vc_set_math_mode(0))
+        check(lib.vc_set_math_mode(0)); check(lib.vc_tune_winograd(1))
+    assert lib.vc_testing_wino_gemms(1) == 0
+    # production mode: an operator-level call carries no transformed filters and stays on the direct kernel (its filter gradient needs none)
+    x = torch.randn((2, 16, 64, 1, 32), device=U.DEV); w = torch.randn((2, 1, 3, 64, 64), device=U.DEV) * 0.05; b = torch.zeros((2, 64), device=U.DEV)
+    U.conv_fwd(x, w, b, 1, 3, 1, 1)
     assert lib.vc_testing_wino_gemms(1) == 0
 
 
@@ -638,7 +643,7 @@ def test_winograd_along_h_for_the_discriminators_last_block(built_lib, case):
     add = U.dev(rng.standard_normal(cf(dxs).shape).astype(np.float32)); init = U.dev(rng.standard_normal(cf(dxs).shape).astype(np.float32))
     out = {}
     try:
-        for on in (1, 0):
+        for on in (2, 0):
             check(lib.vc_tune_winograd(on)); lib.vc_testing_wino_gemms(1)
             y = U.conv_fwd(x_d, w_d, b_d, 6, 3, 1, 2)
             dx = U.conv_dgrad(dy_d, w_d, H, W, 6, 3, 1, 2)
@@ -649,7 +654,7 @@ def test_winograd_along_h_for_the_discriminators_last_block(built_lib, case):
             assert U.rel_err(out[on][2], cf(dxs) + add.cpu().numpy() + init.cpu().numpy()) < TOL
     finally:
         check(lib.vc_tune_winograd(1))
-    for a, b in zip(out[1], out[0]):
+    for a, b in zip(out[2], out[0]):
         e = U.rel_err(a, b)
         print('winograd along H vs direct: %.2e' % e)
         assert e < 2e-5

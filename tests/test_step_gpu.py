@@ -546,18 +546,30 @@ def test_config5_geometry_36x256(built_lib):
         assert diff.max() <= 2.02 * 2e-4 and (float((diff > 0.05 * 2e-4).mean()) < 1e-3 or int((diff > 0.05 * 2e-4).sum()) <= 2), n
 
 
-@pytest.mark.parametrize('mode', ['fp32', 'bf16'])
-def test_long_utterance_inference(built_lib, mode):
+@pytest.mark.parametrize('mode,T', [('fp32', 2200), ('bf16', 2200), ('fp32', 2208)])
+def test_long_utterance_inference(built_lib, mode, T):
     """CycleGAN.test on a whole utterance (convert.py:33-59: coded_sp of a few thousand frames padded to a multiple of 4):
     T = 2200 > 2048, so every layer runs its multi-tile loops and the h1 GLU / instance norms their streaming row kernels
-    (rows of 2200, 1100, 550 frames)."""
+    (rows of 2200, 1100, 550 frames).  T = 2208 (fp32): a multiple of 16, so the residual and up-sampling blocks' convolutions take the
+    Winograd route when forced (552 / 1104 frames = whole tiles; filters transformed per call, stand-alone tile transforms);
+    unforced, inference stays on the direct kernels."""
     from tests import gpu_util as U
-    O, P, A, Bm, eng = _setup(1, 2200, gap=False)
+    O, P, A, Bm, eng = _setup(1, T, gap=False)
+    lib = built_lib.lib
     with _math(mode, O, eng):
         for direction, scope, x in (('A2B', 'generator_A2B', A), ('B2A', 'generator_B2A', Bm)):
             ref, _ = O.generator_fwd(P, scope, x)
+            lib.vc_testing_wino_gemms(1)
             e = U.rel_err(eng.generate(x, direction), ref)
-            assert e < (TOL if mode == 'fp32' else BF16_TOL), '%s T=2200 %s rel err %g' % (direction, mode, e)
+            assert lib.vc_testing_wino_gemms(1) == 0          # inference carries no transformed filters: direct kernels (measured faster there)
+            assert e < (TOL if mode == 'fp32' else BF16_TOL), '%s T=%d %s rel err %g' % (direction, T, mode, e)
+            if mode == 'fp32' and T % 16 == 0:                # the same pass forced onto the route (filters transformed per call)
+                built_lib.check(lib.vc_tune_winograd(2))
+                try:
+                    e = U.rel_err(eng.generate(x, direction), ref)
+                finally:
+                    built_lib.check(lib.vc_tune_winograd(1))
+                assert lib.vc_testing_wino_gemms(1) == 14 and e < TOL, (direction, e)
 
 
 def _check_step_golden(mode, B, F, T, fname, lam=(10.0, 5.0)):

@@ -60,9 +60,10 @@ def test_every_benched_table_row_against_the_oracle(built_lib, F, T, B):
         OH, OW = -(-H // sh), -(-W // sw)
         pick = sorted(rng.choice(Bs, size=min(2, Bs), replace=False).tolist())
         # fp32 production sends the residual blocks' launches (3 taps, stride 1) down the Winograd route from 64 pixels per transform position
-        # on (csrc/vc_conv_wino.hip): those run HERE as production runs them (parity against the oracle; their GEMMs are 1 x 1 launches the
-        # cost model configures, no measured row) AND once more on the direct kernel, whose measured row the control path still uses
-        routes = (1, 0) if (kh == 1 and kw == 3 and sh == 1 and sw == 1) else (1,)
+        # on (csrc/vc_conv_wino.hip): those run HERE as production runs them (parity against the oracle; their GEMMs are launches the
+        # cost model configures, no measured row; vc_tune_winograd(2): without a step's cached filters) AND once more on the direct kernel,
+        # whose measured row operator-level calls, inference and the control path use
+        routes = (2, 0) if ((kh == 1 and kw in (3, 5) and sh == 1 and sw == 1) or (kh == 6 and sh == 1)) else (1,)
         if op == 'fwd':
             for route in routes:
                 check(lib.vc_tune_winograd(route)); lib.vc_testing_wino_gemms(1)

@@ -10,6 +10,8 @@ T = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 math = sys.argv[3] if len(sys.argv) > 3 else 'fp32'
 eng = CycleGANEngine(24, seed=1); eng.set_math(math)
+if os.environ.get('WINO') is not None:
+    check(lib.vc_tune_winograd(int(os.environ['WINO'])))      # A/B of the fp32 Winograd route (default: on)
 p = eng.plan(T)
 x = torch.randn((B, 24, T), device='cuda'); y = torch.empty_like(x)
 save = torch.empty(lib.vc_generator_save_floats(p, B), device='cuda')

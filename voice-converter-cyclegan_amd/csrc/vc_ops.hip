@@ -263,11 +263,16 @@ int conv_fwd(const float* x, long x_gs, const float* w, long w_gs, const float* 
     // fuse: the caller would like instance norm + GLU done in the epilogue; fuse->done tells whether this launch did it
     // xp_keep: where the packed bf16 copy of x is left for the layer's filter gradient (16-bit data path; group stride in bytes)
     VC_CHECK(check_conv_geom(g, B));
-    if (wino_eligible(g, math, B)) {      // residual-block convolutions, fp32: six GEMMs in the Winograd domain; every output is stored once
+    // Winograd routes, fp32: taken on the caller's transformed filters (inside a train step: built once per step, used four times).  A call
+    // without them (operator / network level, inference) would transform the filters itself -- measured slower than the direct kernels for a
+    // forward-only pass (B = 8 x 128 frames 0.56 vs 0.46 ms, one 2048-frame utterance 0.68 vs 0.60) -- and takes the route only when a test
+    // forces it (vc_tune_winograd(2)).
+    const bool wino_ok = packed_w != nullptr || vc_hooks().winograd == 2;
+    if (wino_ok && wino_eligible(g, math, B)) {      // residual / up-sampling convolutions: taps + 3 GEMMs in the transform domain; every output is stored once
         if (query) { *query = false; return 0; }
         return wino_fwd(x, x_gs, w, w_gs, bias, b_gs, y, y_gs, G, B, g, math, s, (const float*)packed_w);
     }
-    if (winoh_eligible(g, math, B)) {     // D.d3, fp32: F(3,6) along H
+    if (wino_ok && winoh_eligible(g, math, B)) {     // D.d3: F(3,6) along H
         if (query) { *query = false; return 0; }
         return winoh_fwd(x, x_gs, w, w_gs, bias, b_gs, y, y_gs, G, B, g, math, s, (const float*)packed_w);
     }
@@ -347,12 +352,13 @@ int conv_dgrad(const float* dy, long dy_gs, const float* w, long w_gs, float* dx
                       const float* addend, long add_gs, int accumulate, int G, int B, const Geom& g, int math, hipStream_t s,
                       bool prezeroed, bool* query, const char* const* packed_w, const char* dy_packed, long dy_packed_gs) {
     VC_CHECK(check_conv_geom(g, B));
-    if (wino_eligible(g, math, B)) {
+    const bool wino_ok = packed_w != nullptr || vc_hooks().winograd == 2;      // see conv_fwd
+    if (wino_ok && wino_eligible(g, math, B)) {
         if (query) { *query = false; return 0; }      // the back transform stores (or accumulates into) every element of dx itself
         VC_ARG(dy, "conv input gradient (Winograd route): the fp32 dy was left unwritten");
         return wino_dgrad(dy, dy_gs, w, w_gs, dx, dx_gs, addend, add_gs, accumulate, G, B, g, math, s, packed_w ? (const float*)packed_w[0] : nullptr);
     }
-    if (winoh_eligible(g, math, B)) {
+    if (wino_ok && winoh_eligible(g, math, B)) {
         if (query) { *query = false; return 0; }
         VC_ARG(dy, "conv input gradient (Winograd route): the fp32 dy was left unwritten");
         return winoh_dgrad(dy, dy_gs, w, w_gs, dx, dx_gs, addend, add_gs, accumulate, G, B, g, math, s, packed_w ? (const float*)packed_w[0] : nullptr);

@@ -34,7 +34,7 @@ extern "C" int vc_tune_wgrad_store(int on) { t_hooks.wgrad_store = on ? 1 : 0; r
 extern "C" int vc_tune_glu(int flags) { t_hooks.glu_flags = flags; return 0; }
 extern "C" int vc_tune_c1_dgrad_gather(int on) { t_hooks.c1_gather = on ? 1 : 0; return 0; }
 extern "C" int vc_tune_layer_updates(int on) { t_hooks.layer_updates = on ? 1 : 0; return 0; }
-extern "C" int vc_tune_winograd(int on) { t_hooks.winograd = on ? 1 : 0; return 0; }
+extern "C" int vc_tune_winograd(int on) { t_hooks.winograd = on < 0 ? 0 : on > 2 ? 2 : on; return 0; }
 static thread_local long long t_wino_gemms = 0;
 static thread_local double t_wino_saved[2] = {0.0, 0.0};
 void vc_count_wino_gemm(int kind, double saved_flops) { ++t_wino_gemms; t_wino_saved[kind ? 1 : 0] += saved_flops; }
