@@ -287,10 +287,11 @@ def roofline_leg(eng, lib, A, Bm, hp, math, peak, world, serial, n_prof=3):
         'avg_launch_us': 1e3 * ms / max(n, 1), 'algorithmic_gflop_per_step': fl / n_prof / 1e9,
         'kernel_ms_per_step': ms / n_prof}}
     if saved[0] > 0 or saved[1] > 0:
-        # `achieved` above counts the multiply-adds the MFMA pipe EXECUTED (what the MFMA roof bounds).  The residual blocks' convolutions run as
-        # Winograd F(4,3) (csrc/vc_conv_wino.hip): half the multiplies of the direct form for the same result -- the rate in direct-form FLOPs:
+        # `achieved` above counts the multiply-adds the MFMA pipe EXECUTED (what the MFMA roof bounds).  The residual / up-sampling blocks' and D.d3's
+        # convolutions run in a Winograd transform domain (csrc/vc_conv_wino.hip: F(4,3), F(4,5), F(3,6) along H): 0.4-0.67 of the direct form's
+        # multiplies for the same result -- the same time priced in direct-form FLOPs:
         out['roofline']['winograd'] = {
-            'what': 'forward + input gradient of the 3-tap stride-1 convolutions as 6 transform-domain GEMMs (1 x 1, 6G groups) on igemm_kernel',
+            'what': 'forward + input gradient of the residual blocks (F(4,3)), up-sampling blocks (F(4,5)) and D.d3 (F(3,6) along H) as transform-domain GEMMs (grouped launches of igemm_kernel); direct form = what the round-5 kernels executed for the same layers',
             'direct_form_gflop_per_step': (fl + saved[0]) / n_prof / 1e9,
             'direct_equivalent_tflops': (fl + saved[0]) / (ms * 1e-3) / 1e12 if ms > 0 else 0.0,
             'direct_equivalent_frac': (fl + saved[0]) / (ms * 1e-3) / 1e12 / peak if ms > 0 else 0.0}
@@ -300,7 +301,7 @@ def roofline_leg(eng, lib, A, Bm, hp, math, peak, world, serial, n_prof=3):
                              'launches_per_step': n // n_prof, 'kernel_ms_per_step': ms / n_prof,
                              'traffic': _pmc_traffic(B, F, T, world, math, 'wgrad')[0]}
     if saved[1] > 0:
-        out['roofline_wgrad']['kernel'] = 'wgrad_kernel + wino_wgrad_kernel (residual blocks: Winograd-domain filter gradient, taps folded in registers)'
+        out['roofline_wgrad']['kernel'] = 'wgrad_kernel + wino_wgrad_kernel (residual and up-sampling blocks: Winograd-domain filter gradient, taps folded in registers)'
         out['roofline_wgrad']['winograd'] = {'direct_form_gflop_per_step': (fl + saved[1]) / n_prof / 1e9,
                                              'direct_equivalent_tflops': (fl + saved[1]) / (ms * 1e-3) / 1e12 if ms > 0 else 0.0,
                                              'direct_equivalent_frac': (fl + saved[1]) / (ms * 1e-3) / 1e12 / peak if ms > 0 else 0.0}

@@ -1,16 +1,18 @@
-// vc_conv_wino.hip -- Winograd F(4,3) transforms around the residual blocks' convolutions (reference module.py:66-83: conv1d, 3 taps,
-// stride 1, SAME padding; 68 % of a generator's multiply-adds).  Four output frames of a row come from six transformed inputs:
+// vc_conv_wino.hip -- Toom-Cook / Winograd transforms around the convolutions that have stride 1 and >= 3 taps along an axis (fp32 mode):
+//   F(4,3)  the generators' residual blocks   (reference module.py:66-83:   conv1d, 3 taps)          6 multiplies per output quad instead of 12
+//   F(4,5)  their up-sampling blocks          (module.py:115-133:           conv1d, 5 taps)          8 instead of 20
+//   F(3,6)  the discriminators' last block    (module.py:208: 6 x 3 kernel, strides 1 x 2) ALONG H   8 row planes per 3 output rows, each a 1 x 3 stride-2 conv
 //
-//     y[4i .. 4i+3] = A^T [ (G w) . (B^T x[4i-1 .. 4i+4]) ]       (Lavin & Gray 2016, interpolation points 0, +-1, +-2, inf)
+//     y[4i .. 4i+3] = A^T [ (G w) . (B^T x[4i-1 .. 4i+4]) ]       (Lavin & Gray 2016; points 0, +-1, +-2, (+-1/2,) inf; matrices in vc_wino.h)
 //
-// so the convolution becomes SIX independent channel GEMMs (one per transform position p) over a quarter of the pixels each: 6 multiplies
-// per output quad and channel pair instead of 12.  The GEMMs are 1 x 1 convolutions with 6 G groups on the implicit-GEMM kernel
-// (vc_conv_igemm.hip) -- exact fp32 products, fp32 accumulation; the transforms are exact in binary floating point up to the rounding of
-// their few additions (measured against the fp64 direct convolution at the residual blocks' sizes: 2-3e-6 of the output's maximum, the
-// direct fp32 kernel 0.7-1.2e-6; the operator tests hold both to 1e-4).  The input gradient is the adjoint of the same three steps
-// (dx = B [ U^T (A dy) ]), on the same transformed filters U = G w; the filter gradient stays on the direct kernel.
+// The convolution becomes taps + 3 (8) independent channel GEMMs over a quarter (third) of the pixels each, launched as ONE grouped launch on the
+// implicit-GEMM kernel (vc_conv_igemm.hip) -- exact fp32 products, fp32 accumulation; the transforms add the rounding of a few additions (against
+// the fp64 direct convolution at the layers' sizes: 1.2-3e-6 of the output's maximum, the direct fp32 kernel 0.2-1.2e-6; the operator tests hold
+// both to 1e-4).  The input gradient is the adjoint of the same three steps (dx = B [ U^T (A dy) ]) on the same transformed filters U = G w; the
+// 1-D layers' filter gradient is wino_wgrad_kernel below (dU[p] per position, folded into the taps in registers); D.d3's stays direct.
 //
-// Layouts (H = 1, W = 4 nt):  x [g][b][C][W];  V = B^T x [g][p][b][C][nt];  U [g][p][Cin][Cout];  M = U V [g][p][b][Cout][nt].
+// Layouts (1-D, W = 4 nt):  x [g][b][C][W];  V = B^T x [g][p][b][C][nt];  U [g][p][Cin][Cout];  M = U V [g][p][b][Cout][nt].
+// Along H (D.d3, H = 3 nt): x [g][b][C][H][W];  V [g][p][b][C][nt][W];  U [g][p][kw][Cin][Cout];  M [g][p][b][Cout][nt][OW].
 #include "vc_internal.h"
 #include "vc_device_util.h"
 #include "vc_wino.h"
