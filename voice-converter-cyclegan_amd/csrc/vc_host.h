@@ -66,6 +66,7 @@ bool wino_eligible(const Geom& g, int math, int B);                        // fp
 bool winoh_eligible(const Geom& g, int math, int B);                       // ... or the F(3,6)-along-H route (D.d3)
 bool wino_route(const Geom& g, int math, int B);                           // either
 Geom wino_gemm_geom(const Geom& g);                                   // the 1 x 1 geometry of its six channel GEMMs
+size_t wino_scratch_floats(const Geom& g, int G, int B);               // what one routed forward / input-gradient call takes from that block
 int wino_workspace(hipStream_t s, size_t floats, float** out);        // transform-domain scratch of the launches issued on stream s (grows on demand, reused launch to launch)
 int wino_gemm_fwd(const float* V, const float* U, float* M, int G, int B, const Geom& g, int math, hipStream_t s);
 int wino_gemm_dgrad(const float* dM, const float* U, float* dV, int G, int B, const Geom& g, int math, hipStream_t s);

@@ -383,11 +383,14 @@ static int net_forward(NetCtx& c, const float* x, long x_gs, float* y_plain, lon
     float* wV = nullptr; float* wM = nullptr; bool v_ready = false;
     {
         size_t nV = 0, nM = 0;
-        for (size_t i = 0; i < c.n->layers.size(); ++i) if (wino_layer(i)) {
+        size_t other = 0;      // the routed layers whose transforms stay stand-alone take their scratch inside conv_fwd, from the same per-stream block:
+                               // ask for the pass's largest need NOW, so that no later request can move the block under wV / wM
+        for (size_t i = 0; i < c.n->layers.size(); ++i) {
             const Geom& g = (*c.geo)[i].g;
-            nV = std::max(nV, (size_t)6 * c.G * c.B * g.Cin * (g.W / 4)); nM = std::max(nM, (size_t)6 * c.G * c.B * g.Cout * (g.W / 4));
+            if (wino_layer(i)) { nV = std::max(nV, (size_t)6 * c.G * c.B * g.Cin * (g.W / 4)); nM = std::max(nM, (size_t)6 * c.G * c.B * g.Cout * (g.W / 4)); }
+            else if (wino_cached(i)) other = std::max(other, wino_scratch_floats(g, c.G, c.B));
         }
-        if (nV) { VC_CHECK(wino_workspace(c.s, nV + nM, &wV)); wM = wV + nV; }
+        if (nV || other) { VC_CHECK(wino_workspace(c.s, std::max(nV + nM, other), &wV)); wM = wV + nV; if (!nV) wV = wM = nullptr; }
     }
     const float* in = x; long in_gs = x_gs;
     const float* blk_in = nullptr; long blk_in_gs = 0;
@@ -516,11 +519,13 @@ static int net_backward(NetCtx& c, const float* x, long x_gs, const float* dtop,
     float* wdM = nullptr; float* wdV = nullptr;
     {
         size_t nV = 0, nM = 0;
-        for (int i = 1; i < nl; ++i) if (wino_layer(i)) {
+        size_t other = 0;      // (see net_forward: the pass's largest scratch need is requested up front)
+        for (int i = 0; i < nl; ++i) {
             const Geom& g = (*c.geo)[i].g;
-            nV = std::max(nV, (size_t)6 * c.G * c.B * g.Cin * (g.W / 4)); nM = std::max(nM, (size_t)6 * c.G * c.B * g.Cout * (g.W / 4));
+            if (i > 0 && wino_layer(i)) { nV = std::max(nV, (size_t)6 * c.G * c.B * g.Cin * (g.W / 4)); nM = std::max(nM, (size_t)6 * c.G * c.B * g.Cout * (g.W / 4)); }
+            else if (wino_cached(i) && (i > 0 || dx)) other = std::max(other, wino_scratch_floats(g, c.G, c.B));
         }
-        if (nV) { VC_CHECK(wino_workspace(c.s, nV + nM, &wdM)); wdV = wdM + nM; }
+        if (nV || other) { VC_CHECK(wino_workspace(c.s, std::max(nV + nM, other), &wdM)); wdV = wdM + nM; if (!nV) wdM = wdV = nullptr; }
     }
     struct { const float* dV; long dV_gs; const float* add; long add_gs; bool on; } pend{nullptr, 0, nullptr, 0, false};
     for (int i = nl - 1; i >= 0; --i) {

@@ -211,6 +211,11 @@ static int winoh_dgrad(const float* dy, long dy_gs, const float* w, long w_gs, f
     }
     return launch_winoh(3, dV, 0, dx, dx_gs, nullptr, 0, addend, add_gs, accumulate, G, B, g.Cin, nt, g.W, s);
 }
+// transform-domain scratch (floats) one forward / input-gradient call of a routed layer takes from its stream's block when the caller supplies the filters
+size_t wino_scratch_floats(const Geom& g, int G, int B) {
+    if (g.kh == 6) { const int nt = g.H / 3; return (size_t)8 * G * B * ((size_t)g.Cin * nt * g.W + (size_t)g.Cout * nt * g.OW); }
+    return (size_t)(g.kw + 3) * G * B * ((size_t)g.Cin + g.Cout) * (g.W / 4);
+}
 int wino_workspace(hipStream_t s, size_t floats, float** out) {
     char* q; VC_CHECK(pack_space(s, floats * sizeof(float), &q));
     *out = (float*)q;
