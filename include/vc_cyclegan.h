@@ -60,6 +60,11 @@ uint32_t vc_crc32c(const void* data, uint64_t n, uint32_t crc);
  *   1 bf16   operands rounded to bf16 (round-to-nearest-even) on the way into v_mfma_f32_32x32x16_bf16, fp32 accumulate;
  *            tensors in HBM, instance-norm statistics, losses and Adam state stay fp32 (BASELINE config 3)
  *   2 bf16x3 operands split hi+lo into two bf16, three MFMAs (hi*hi + hi*lo + lo*hi): ~2^-16 relative per product
+ *   3 f16    operands rounded to IEEE half (round-to-nearest-even, 10-bit mantissa) into v_mfma_f32_32x32x16_f16, fp32 accumulate: the
+ *            bf16 kernel's rate at an eighth of its operand error (3e-4 of the output's maximum against fp32 arithmetic, where bf16
+ *            gives 2.5e-3).  THREAD mode only and ONE operator only: vc_gated_conv1d_glu_fwd / _prepack / _fwd_packed (z-scored frames
+ *            and glorot filters lie well inside half's range).  Every other operator, vc_plan_create and vc_plan_set_math_mode
+ *            return VC_E_ARG in / for this mode -- nothing computes in a different arithmetic than the one asked for.
  * The mode is a property of a PLAN (vc_plan_set_math_mode): every launch made through a plan uses the plan's mode,
  * so two plans in one process never interfere.  vc_set_math_mode sets the calling THREAD's default: the mode of the
  * operator-level calls below (which carry no plan) and the initial mode of plans that thread creates.
@@ -124,7 +129,7 @@ int vc_conv2d_wgrad(const float* x, int64_t x_gs, const float* dy, int64_t dy_gs
  * with the value filters in [0, Cout2/2) and the gate filters in [Cout2/2, Cout2), bias likewise.  Neither raw convolution
  * is written: HBM sees the frames once and the activation once (the north-star kernel; inference plans use it, the train
  * step keeps value and gate for the backward).  Built for Cin = 24, k = 15 (24 MCEPs), Cout2 % 64 == 0, T % 4 == 0.
- * Math mode of the calling thread: fp32 (exact) or bf16 (operands rounded once: the filters when a workgroup builds its
+ * Math mode of the calling thread: fp32 (exact; also taken in mode 2), f16 (mode 3) or bf16 (operands rounded once: the filters when a workgroup builds its
  * register-resident fragments straight from w, the frames when they are staged).  ONE launch, no workspace.  Tensors of
  * one group must stay below 2 GiB (32-bit buffer offsets). */
 int vc_gated_conv1d_glu_fwd(const float* x, int64_t x_gs, const float* w, int64_t w_gs,
@@ -132,7 +137,7 @@ int vc_gated_conv1d_glu_fwd(const float* x, int64_t x_gs, const float* w, int64_
                             int G, int B, int Cin, int T, int Cout2, int k, void* stream);
 /* The same block with the filters pre-packed (weights that do not change between calls: CycleGAN.test / convert.py, model.py:128-137,
  * or once per weight update).  vc_gated_conv1d_glu_prepack writes, per group, the MFMA fragment image of w for the calling
- * thread's math mode (bf16: rounded once, 16-bit; fp32: exact) -- vc_gated_conv1d_glu_image_bytes(Cin, k, Cout2) bytes, 16-byte
+ * thread's math mode (bf16 / f16: rounded once, 16-bit; fp32: exact) -- vc_gated_conv1d_glu_image_bytes(Cin, k, Cout2) bytes, 16-byte
  * aligned, group stride in bytes; -1: geometry not built.  vc_gated_conv1d_glu_fwd_packed is vc_gated_conv1d_glu_fwd reading
  * that image instead of w: a workgroup fetches its filter fragments with 16-byte coalesced loads straight into registers.
  * The image must have been built in the math mode of the call. */

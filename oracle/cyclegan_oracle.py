@@ -59,15 +59,18 @@ def sigmoid(x):
 # (model.py:35-42); this switch restates what the bf16 mode of the HIP path
 # defines: BOTH operands of every conv contraction (forward, input gradient,
 # filter gradient) are rounded to bfloat16, round-to-nearest-even, products and
-# sums stay in the working dtype.  None (default) = no rounding.
+# sums stay in the working dtype.  None (default) = no rounding.  'f16' restates
+# math mode 3 of the HIP path (IEEE half operands, one operator: the gated
+# conv1d + GLU forward of module.py:161-163): numpy's float16 cast is
+# round-to-nearest-even with gradual underflow, as v_cvt_pk_f16_f32 is.
 # ----------------------------------------------------------------------------
 OPERAND_ROUNDING = None
 
 
 def set_operand_rounding(kind):
     global OPERAND_ROUNDING
-    if kind not in (None, 'bf16'):
-        raise ValueError('operand rounding must be None or "bf16"')
+    if kind not in (None, 'bf16', 'f16'):
+        raise ValueError('operand rounding must be None, "bf16" or "f16"')
     OPERAND_ROUNDING = kind
 
 
@@ -79,6 +82,8 @@ def round_bf16(x):
 
 
 def _rop(x):
+    if OPERAND_ROUNDING == 'f16':
+        return np.asarray(x, dtype=np.float32).astype(np.float16).astype(x.dtype)
     return round_bf16(x) if OPERAND_ROUNDING == 'bf16' else x
 
 

@@ -58,7 +58,7 @@ def test_no_scratch_and_register_budget(asm):
         v = re.search(r'\.vgpr_count:\s+(\d+)', blk)
         if n and s and 'gated_conv1d_glu_kernel' in n.group(1):
             seen[n.group(1)] = (int(s.group(1)), int(v.group(1)) if v else 0)
-    assert len(seen) == 8, seen
+    assert len(seen) == 12, seen          # fp32, bf16 and IEEE-half operands x (GLU only | + raw outputs) x (filters converted in place | pre-packed)
     assert all(v[0] == 0 for v in seen.values()), 'scratch in use: %s' % seen
     # two waves per SIMD: the unified register file gives each 256 registers (VGPR + AGPR)
     assert all(0 < v[1] <= 256 for v in seen.values()), seen
@@ -66,9 +66,11 @@ def test_no_scratch_and_register_budget(asm):
 
 
 @pytest.mark.parametrize('pre', [False, True])
-@pytest.mark.parametrize('bf16,raw', [(True, False), (True, True), (False, False), (False, True)])
-def test_trip_issues_the_counted_operations(asm, bf16, raw, pre):
-    tag = 'ILi24ELi15ELb%dELb%dELb%dEE' % (int(bf16), int(raw), int(pre))
+@pytest.mark.parametrize('bf16,raw,half', [(True, False, False), (True, True, False), (False, False, False), (False, True, False),
+                                           (True, False, True), (True, True, True)])
+def test_trip_issues_the_counted_operations(asm, bf16, raw, pre, half):
+    """half: the 16-bit form with IEEE-half operands (math mode 3) -- the bf16 kernel with another conversion and another MFMA, same schedule"""
+    tag = 'ILi24ELi15ELb%dELb%dELb%dELb%dEE' % (int(bf16), int(raw), int(pre), int(half))
     body = [b for n, b in _kernels(asm) if tag in n]
     assert len(body) == 1
     body = body[0]
@@ -134,6 +136,8 @@ def test_trip_issues_the_counted_operations(asm, bf16, raw, pre):
                     assert not (regs & mine), 'trip %d touches its own loads before the next trip\'s wait: %s' % (k, x)
     # the K axis is split 12 / 11 steps (bf16: two MFMAs per step) or 23 / 22 (fp32: eight per step) between the two bodies
     assert mfmas == ({24, 22} if bf16 else {184, 176}), mfmas
+    mf = {x.split()[0] for x in _instrs(body) if x.startswith('v_mfma')}
+    assert mf == ({'v_mfma_f32_32x32x16_f16'} if half else {'v_mfma_f32_32x32x16_bf16'} if bf16 else {'v_mfma_f32_32x32x2_f32'}), mf
 
 
 def _vregs(x):
@@ -149,7 +153,7 @@ def test_nothing_is_in_flight_at_the_loop_entry_and_nothing_touches_frames_in_fl
     trip's wait -- a copy of a register whose load has not landed is a copy of garbage: 0.1 - 0.4 % of the launches of the un-packed
     bf16 kernel at B >= 512 computed their second tile from it (tools/stress_glu.py; tests/test_ops_gpu.py::
     test_gated_conv1d_glu_is_bitwise_repeatable).  The prologue now retires BOTH tiles' loads with one wait before the loop.
-    Checked here, for all 8 instantiations and both bodies: every group of 8 inline-asm frame loads is followed -- in program text --
+    Checked here, for all 12 instantiations and both bodies: every group of 8 inline-asm frame loads is followed -- in program text --
     by the inline-asm wait that retires it with no instruction in between that reads or writes one of its destination registers;
     and each body's first two groups (the prologue's) reach their wait BEFORE the first loop header behind them."""
     n_kernels = 0
@@ -171,4 +175,4 @@ def test_nothing_is_in_flight_at_the_loop_entry_and_nothing_touches_frames_in_fl
             if gi % 4 < 2:                                   # the prologue's two groups of this body
                 nxt = [lh for lh in loops if lh > g[0]]
                 assert nxt and j < nxt[0], '%s: the prologue\'s loads (line %d) are still in flight at the loop entry (wait at %d, loop at %s)' % (name[-30:], g[0], j, nxt[:1])
-    assert n_kernels == 8
+    assert n_kernels == 12

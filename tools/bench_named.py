@@ -1,4 +1,4 @@
-"""The north-star kernel (vc_gated_conv1d_glu_fwd / _fwd_packed) at several sizes, fp32 and bf16.  Run on the GPU box.
+"""The north-star kernel (vc_gated_conv1d_glu_fwd / _fwd_packed) at several sizes, fp32, bf16 and f16 (math mode 3).  Run on the GPU box.
 
 Per (math, shape) three launches are timed with the same protocol (>= 50 ms of the same call first: sustained clocks):
   plain   vc_gated_conv1d_glu_fwd         filters in TF layout, converted by every workgroup
@@ -69,22 +69,22 @@ for math in args.maths.split(','):
         y = torch.empty((1, B, 128, T), device=dev)
         s = vp(torch.cuda.current_stream().cuda_stream)
         lib.vc_tune_glu(args.flags)
-        check(lib.vc_set_math_mode({'fp32': 0, 'bf16': 1}[math]))
+        check(lib.vc_set_math_mode({'fp32': 0, 'bf16': 1, 'f16': 3}[math]))
         nb_img = lib.vc_gated_conv1d_glu_image_bytes(24, 15, 256)
         img = torch.empty((nb_img,), dtype=torch.uint8, device=dev)
         check(lib.vc_gated_conv1d_glu_prepack(ptr(w), 0, ptr(img), 0, 1, 24, 15, 256, s))
         check(lib.vc_set_math_mode(1))
         img16 = torch.empty((lib.vc_gated_conv1d_glu_image_bytes(24, 15, 256),), dtype=torch.uint8, device=dev)
         check(lib.vc_gated_conv1d_glu_prepack(ptr(w), 0, ptr(img16), 0, 1, 24, 15, 256, s))
-        check(lib.vc_set_math_mode({'fp32': 0, 'bf16': 1}[math]))
+        check(lib.vc_set_math_mode({'fp32': 0, 'bf16': 1, 'f16': 3}[math]))
         calls = [('plain ', lambda: check(lib.vc_gated_conv1d_glu_fwd(ptr(x), 0, ptr(w), 0, ptr(b), 0, ptr(y), 0, 1, B, 24, T, 256, 15, s))),
                  ('packed', lambda: check(lib.vc_gated_conv1d_glu_fwd_packed(ptr(x), 0, ptr(img), 0, ptr(b), 0, ptr(y), 0, 1, B, 24, T, 256, 15, s)))]
-        if math == 'bf16':
+        if math in ('bf16', 'f16'):
             calls.append(('roof  ', lambda: check(lib.vc_prof_glu_copy_roof(ptr(x), ptr(img16), ptr(y), B, T, 256, s))))
         algo = B * (24 * T + 128 * T) * 4 + (15 * 24 * 256 + 256) * 4
         flops = 2.0 * B * T * 256 * 15 * 24
         for name, call in calls:
             ev, b2b = timed(call, B)
-            print('r5%s %-4s %s B=%-4d T=%-4d  ev %8.2f us (HBM %5.3f, %7.1f TFLOP/s)   b2b %8.2f us (HBM %5.3f, %7.1f TFLOP/s)' % (
+            print('r6%s %-4s %s B=%-4d T=%-4d  ev %8.2f us (HBM %5.3f, %7.1f TFLOP/s)   b2b %8.2f us (HBM %5.3f, %7.1f TFLOP/s)' % (
                 '' if args.data == 'rand' else '[' + args.data + ']', math, name, B, T, ev * 1e6, algo / ev / 8e12, flops / ev / 1e12, b2b * 1e6, algo / b2b / 8e12, flops / b2b / 1e12), flush=True)
         check(lib.vc_set_math_mode(0))

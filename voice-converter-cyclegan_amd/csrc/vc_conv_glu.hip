@@ -47,6 +47,23 @@
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 #define VC_OOB_ST 0x80000000u      // store offset beyond every buffer this kernel accepts (< 2 GiB); adding an immediate cannot wrap
 
+// element e of a fragment from an fp32 value.  IEEE half goes pair-wise through a vector conversion: gfx950 has v_cvt_pk_f16_f32 (two RNE
+// conversions + the pack in one instruction), which the compiler takes for <2 x float> -> <2 x half> but not always for two scalar casts
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2_ __attribute__((ext_vector_type(2)));
+template <typename T, int R, typename F, typename X> __device__ __forceinline__ void glu_cvt(F& f, X&& src) {      // f[e] = (T)src(e), e < R
+    if constexpr (std::is_same<T, _Float16>::value) {
+#pragma unroll
+        for (int e = 0; e < R; e += 2) {
+            const f16x2 h = __builtin_convertvector(f32x2_{src(e), src(e + 1)}, f16x2);
+            f[e] = h[0]; f[e + 1] = h[1];
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < R; ++e) f[e] = (T)src(e);
+    }
+}
+
 // geometry of the fragment image, shared by the kernel, the pre-pack kernel and the host
 template <int CIN, int KW, bool BF16> struct GluGeo {
     static constexpr int R = BF16 ? 8 : 4;                 // k values per lane and K step (one 16-byte fragment)
@@ -58,7 +75,7 @@ template <int CIN, int KW, bool BF16> struct GluGeo {
 };
 
 // image[g][slab][U = 2u + vg][lane] (16 bytes): lane (channel l31 of the slab, half h) holds W[k = R (2u + h) + e][channel], e < R
-template <int CIN, int KW, bool BF16>
+template <int CIN, int KW, bool BF16, bool HALF = false>      // HALF (with BF16): the 16-bit form is IEEE half instead of bfloat16
 __global__ __launch_bounds__(256) void glu_prepack_kernel(const float* __restrict__ w, long w_gs, char* __restrict__ img, long img_gs, int Cout) {
     typedef GluGeo<CIN, KW, BF16> GG;
     const int C = Cout >> 1, slabs = C / 32, g = blockIdx.y;
@@ -75,7 +92,12 @@ __global__ __launch_bounds__(256) void glu_prepack_kernel(const float* __restric
         v[e] = k < GG::K ? wg_[(long)k * Cout + ch] : 0.f;
     }
     char* dst = img + (long)g * img_gs + (long)i * 16;
-    if constexpr (BF16) {
+    if constexpr (BF16 && HALF) {
+        f16x8 f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = (_Float16)v[e];
+        *reinterpret_cast<f16x8*>(dst) = f;
+    } else if constexpr (BF16) {
         bf16x8 f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) f[e] = (__bf16)v[e];
@@ -99,11 +121,12 @@ template <int CIN, int KW, bool BF16, bool PRE> struct GluLds {
 // the kernel's body for the waves of K set S (a wave-uniform branch at the kernel's entry picks one: the set's K steps, which half of
 // the accumulators it hands over and which half it finishes are compile-time constants, and no register is live across a join
 // of the two).  Both bodies execute the same sequence of workgroup barriers.
-template <int CIN, int KW, bool BF16, bool RAW, bool PRE, int S>
+template <int CIN, int KW, bool BF16, bool RAW, bool PRE, bool HALF, int S>
 __device__ __forceinline__ void gated_conv1d_glu_body(const WsConvArgs& a, char* lds) {
     typedef GluGeo<CIN, KW, BF16> GG;
-    typedef typename std::conditional<BF16, __bf16, float>::type T;
-    typedef typename std::conditional<BF16, bf16x8, f32x4>::type frag_t;
+    static_assert(BF16 || !HALF, "HALF selects the element type of the 16-bit form");
+    typedef typename std::conditional<BF16, typename std::conditional<HALF, _Float16, __bf16>::type, float>::type T;
+    typedef typename std::conditional<BF16, typename std::conditional<HALF, f16x8, bf16x8>::type, f32x4>::type frag_t;
     constexpr int R = GG::R, RPT = GG::RPT, NU = GG::NU, K = GG::K;
     static_assert(CIN % R == 0 && (BF16 || RPT % 2 == 0), "runs of R channels inside one tap; fp32: both lane halves in the same tap");
     constexpr int TP = 128, PADL = (KW - 1) / 2;
@@ -201,8 +224,7 @@ __device__ __forceinline__ void gated_conv1d_glu_body(const WsConvArgs& a, char*
     auto stage_task = [&](const float (&x)[NXL], auto JC, T* slot) {
         constexpr int j = decltype(JC)::value;
         frag_t f;
-#pragma unroll
-        for (int e = 0; e < R; ++e) f[e] = (T)x[j * R + e];
+        glu_cvt<T, R>(f, [&](int e) { return x[j * R + e]; });
         *reinterpret_cast<frag_t*>(reinterpret_cast<char*>(slot) + ldsb[j]) = f;
     };
     auto stage_all = [&](const float (&x)[NXL], T* slot) {
@@ -280,8 +302,7 @@ __device__ __forceinline__ void gated_conv1d_glu_body(const WsConvArgs& a, char*
             const int U = w8 + 8 * it;
             if (U < 2 * NU) {
                 frag_t f;
-#pragma unroll
-                for (int e = 0; e < R; ++e) f[e] = (T)v[it][e];
+                glu_cvt<T, R>(f, [&](int e) { return v[it][e]; });
                 Wf[U * 64 + lane] = f;
             }
         }
@@ -427,7 +448,10 @@ __device__ __forceinline__ void gated_conv1d_glu_body(const WsConvArgs& a, char*
             auto mm = [&](auto JC, auto HC) {                // HC: 0 = the value MFMA(s) of step j, 1 = the gate MFMA(s)
                 constexpr int j = decltype(JC)::value, half = decltype(HC)::value;
                 const frag_t x_ = fx[j % RS];
-                if constexpr (BF16) {
+                if constexpr (BF16 && HALF) {
+                    if constexpr (half == 0) accv = __builtin_amdgcn_mfma_f32_32x32x16_f16(wv[j], x_, j == 0 ? (S ? zero16 : bvv) : accv, 0, 0, 0);
+                    else accg = __builtin_amdgcn_mfma_f32_32x32x16_f16(wgt[j], x_, j == 0 ? (S ? zero16 : bgv) : accg, 0, 0, 0);
+                } else if constexpr (BF16) {
                     if constexpr (half == 0) accv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv[j], x_, j == 0 ? (S ? zero16 : bvv) : accv, 0, 0, 0);
                     else accg = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wgt[j], x_, j == 0 ? (S ? zero16 : bgv) : accg, 0, 0, 0);
                 } else if constexpr (half == 0) {
@@ -496,12 +520,12 @@ __device__ __forceinline__ void gated_conv1d_glu_body(const WsConvArgs& a, char*
     }
 }
 
-template <int CIN, int KW, bool BF16, bool RAW, bool PRE>
+template <int CIN, int KW, bool BF16, bool RAW, bool PRE, bool HALF>
 __global__ __launch_bounds__(512, 1) void gated_conv1d_glu_kernel(const WsConvArgs a) {
     touch_kernarg(a);
     __shared__ __attribute__((aligned(16))) char lds[GluLds<CIN, KW, BF16, PRE>::BYTES];
-    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 8) == 0) gated_conv1d_glu_body<CIN, KW, BF16, RAW, PRE, 0>(a, lds);
-    else gated_conv1d_glu_body<CIN, KW, BF16, RAW, PRE, 1>(a, lds);
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 8) == 0) gated_conv1d_glu_body<CIN, KW, BF16, RAW, PRE, HALF, 0>(a, lds);
+    else gated_conv1d_glu_body<CIN, KW, BF16, RAW, PRE, HALF, 1>(a, lds);
 }
 
 // same grid, same frame and fragment-image reads, same output stores, no arithmetic: what the memory system alone allows a launch of
@@ -576,15 +600,16 @@ __global__ __launch_bounds__(512, 1) void glu_copy_roof_kernel(const WsConvArgs 
 long gated_conv1d_glu_image_bytes(int cin, int kw, int cout, int math) {
     if (cin != 24 || kw != 15 || (cout & 63)) return -1;
     const long slabs = cout / 64;
-    return slabs * (math == VC_MATH_BF16 ? GluGeo<24, 15, true>::SLAB_BYTES : GluGeo<24, 15, false>::SLAB_BYTES);
+    return slabs * (math == VC_MATH_BF16 || math == VC_MATH_F16 ? GluGeo<24, 15, true>::SLAB_BYTES : GluGeo<24, 15, false>::SLAB_BYTES);
 }
 
 int launch_gated_conv1d_glu_prepack(const float* w, long w_gs, void* img, long img_gs_bytes, int G, int cin, int kw, int cout, int math, hipStream_t s) {
     if (gated_conv1d_glu_image_bytes(cin, kw, cout, math) < 0) return -2;
     const int slabs = cout / 64;
-    if (math == VC_MATH_BF16) {
+    if (math == VC_MATH_BF16 || math == VC_MATH_F16) {
         const int n = slabs * 2 * GluGeo<24, 15, true>::NU * 64;
-        glu_prepack_kernel<24, 15, true><<<dim3((n + 255) / 256, G), dim3(256), 0, s>>>(w, w_gs, (char*)img, img_gs_bytes, cout);
+        if (math == VC_MATH_F16) glu_prepack_kernel<24, 15, true, true><<<dim3((n + 255) / 256, G), dim3(256), 0, s>>>(w, w_gs, (char*)img, img_gs_bytes, cout);
+        else glu_prepack_kernel<24, 15, true><<<dim3((n + 255) / 256, G), dim3(256), 0, s>>>(w, w_gs, (char*)img, img_gs_bytes, cout);
     } else {
         const int n = slabs * 2 * GluGeo<24, 15, false>::NU * 64;
         glu_prepack_kernel<24, 15, false><<<dim3((n + 255) / 256, G), dim3(256), 0, s>>>(w, w_gs, (char*)img, img_gs_bytes, cout);
@@ -611,10 +636,10 @@ int launch_gated_conv1d_glu(const WsConvArgs& a_, int cin, int kw, int math, hip
     if (!glu_grid(a_, cin, kw, &grid)) return -2;
     WsConvArgs a = a_; a.flags = glu_tune_flags();
     ProfScope ps(2, flops, s);
-#define VC_GLU2(BF, RW) { if (a.wimg) gated_conv1d_glu_kernel<24, 15, BF, RW, true><<<grid, dim3(512), 0, s>>>(a); \
-                          else gated_conv1d_glu_kernel<24, 15, BF, RW, false><<<grid, dim3(512), 0, s>>>(a); }
-#define VC_GLU(BF) { if (a.raw) VC_GLU2(BF, true) else VC_GLU2(BF, false) }
-    if (math == VC_MATH_BF16) VC_GLU(true) else VC_GLU(false)
+#define VC_GLU2(BF, RW, HF) { if (a.wimg) gated_conv1d_glu_kernel<24, 15, BF, RW, true, HF><<<grid, dim3(512), 0, s>>>(a); \
+                              else gated_conv1d_glu_kernel<24, 15, BF, RW, false, HF><<<grid, dim3(512), 0, s>>>(a); }
+#define VC_GLU(BF, HF) { if (a.raw) VC_GLU2(BF, true, HF) else VC_GLU2(BF, false, HF) }
+    if (math == VC_MATH_F16) VC_GLU(true, true) else if (math == VC_MATH_BF16) VC_GLU(true, false) else VC_GLU(false, false)
 #undef VC_GLU
 #undef VC_GLU2
     VC_HIP(hipGetLastError());

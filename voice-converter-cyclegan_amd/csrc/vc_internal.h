@@ -10,13 +10,18 @@
 //   0  fp32   v_mfma_f32_32x32x2_f32, exact fp32 products (default; the parity configuration)
 //   1  bf16   operands rounded to bf16 (RNE) on their way into v_mfma_f32_32x32x16_bf16, fp32 accumulate
 //   2  bf16x3 every operand split x = hi + lo (two bf16), products hi*hi + hi*lo + lo*hi: ~2^-16 relative per product
+//   3  f16    operands rounded to IEEE half (RNE, 10-bit mantissa) into v_mfma_f32_32x32x16_f16, fp32 accumulate: the bf16 kernel's rate at
+//             an eighth of its operand error.  Thread mode only, and built for ONE operator: the gated conv1d + GLU forward
+//             (vc_conv_glu.hip; z-scored frames and glorot filters sit well inside half's range).  Every other entry point refuses it.
 #define VC_MATH_FP32 0
 #define VC_MATH_BF16 1
 #define VC_MATH_BF16X3 2
+#define VC_MATH_F16 3
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 // 8 k-values of one operand row -> one bf16 MFMA fragment (and the residual fragment for the split mode)
 template <int MATH> __device__ __forceinline__ void to_frag(const float (&v)[8], bf16x8& hi, bf16x8& lo) {

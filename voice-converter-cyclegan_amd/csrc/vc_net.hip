@@ -126,6 +126,7 @@ static int plan_create(int num_features, int n_frames, bool inference, vc_plan**
     VC_ARG(out, "vc_plan_create: out is NULL");
     VC_ARG(num_features > 0 && num_features % 4 == 0, "vc_plan_create: num_features must be a positive multiple of 4");
     VC_ARG(n_frames > 0 && n_frames % 4 == 0, "vc_plan_create: n_frames must be a positive multiple of 4 (preprocess.py:146-156)");
+    VC_ARG(vc_thread_math() != VC_MATH_F16, "vc_plan_create: the calling thread's math mode 3 (f16 operands) is built for the gated conv1d + GLU forward only; a plan takes 0, 1 or 2");
     vc_plan* p = new vc_plan();
     p->F = num_features; p->T = n_frames; p->inference = inference; p->math = vc_thread_math(); p->det = vc_thread_det();
     p->G = make_generator(num_features); p->D = make_discriminator();

@@ -629,12 +629,16 @@ int conv_wgrad(const WgradApp* apps, int napps, float* dw, long dw_gs, int G, co
     return launch_wgrad(a, math, s, flops);
 }
 
+// mode 3 (IEEE-half operands) exists for the gated conv1d + GLU forward only: every other operator refuses it instead of computing in another arithmetic
+#define VC_NO_F16(name) VC_ARG(vc_thread_math() != VC_MATH_F16, name ": math mode 3 (f16 operands) is built for vc_gated_conv1d_glu_fwd / _prepack / _fwd_packed only")
+static int glu_math() { const int m = vc_thread_math(); return m == VC_MATH_BF16 || m == VC_MATH_F16 ? m : VC_MATH_FP32; }   // bf16x3: the exact fp32 kernel
 extern "C" int vc_conv2d_fwd(const float* x, int64_t x_gs, const float* w, int64_t w_gs,
                              const float* bias, int64_t b_gs, float* y, int64_t y_gs,
                              int G, int B, int Cin, int H, int W, int Cout,
                              int kh, int kw, int sh, int sw, void* stream) {
     VC_ARG(x && w && y && G > 0 && B > 0 && Cin > 0 && H > 0 && W > 0 && Cout > 0, "vc_conv2d_fwd: bad args");
     VC_ARG(Cout % 4 == 0, "vc_conv2d_fwd: Cout must be a multiple of 4");
+    VC_NO_F16("vc_conv2d_fwd");
     return conv_fwd(x, x_gs, w, w_gs, bias, b_gs, y, y_gs, G, B, make_geom(Cin, H, W, Cout, kh, kw, sh, sw), vc_thread_math(), (hipStream_t)stream);
 }
 extern "C" int vc_conv2d_dgrad(const float* dy, int64_t dy_gs, const float* w, int64_t w_gs,
@@ -642,6 +646,7 @@ extern "C" int vc_conv2d_dgrad(const float* dy, int64_t dy_gs, const float* w, i
                                int G, int B, int Cin, int H, int W, int Cout,
                                int kh, int kw, int sh, int sw, void* stream) {
     VC_ARG(dy && w && dx && G > 0 && B > 0, "vc_conv2d_dgrad: bad args");
+    VC_NO_F16("vc_conv2d_dgrad");
     return conv_dgrad(dy, dy_gs, w, w_gs, dx, dx_gs, addend, add_gs, accumulate, G, B,
                       make_geom(Cin, H, W, Cout, kh, kw, sh, sw), vc_thread_math(), (hipStream_t)stream);
 }
@@ -650,6 +655,7 @@ extern "C" int vc_conv2d_wgrad(const float* x, int64_t x_gs, const float* dy, in
                                float* dw, int64_t dw_gs, int G, int B, int Cin, int H, int W, int Cout,
                                int kh, int kw, int sh, int sw, void* stream) {
     VC_ARG(x && dy && dw && G > 0 && B > 0, "vc_conv2d_wgrad: bad args");
+    VC_NO_F16("vc_conv2d_wgrad");
     const WgradApp app{x, x_gs, dy, dy_gs, B};
     return conv_wgrad(&app, 1, dw, dw_gs, G, make_geom(Cin, H, W, Cout, kh, kw, sh, sw), vc_thread_math(), (hipStream_t)stream, /*store=*/vc_hooks().wgrad_store != 0);
 }
@@ -660,19 +666,19 @@ extern "C" int vc_gated_conv1d_glu_fwd(const float* x, int64_t x_gs, const float
     VC_ARG(aligned16(out) && out_gs % 4 == 0, "vc_gated_conv1d_glu_fwd: out must be 16-byte aligned");
     WsConvArgs c{}; c.x = x; c.w = w; c.bias = bias; c.y = out; c.x_gs = x_gs; c.w_gs = w_gs; c.b_gs = b_gs; c.y_gs = out_gs;
     c.B = B; c.T = T; c.Cout = Cout2; c.G = G;
-    const int r = launch_gated_conv1d_glu(c, Cin, k, vc_thread_math(), (hipStream_t)stream, 2.0 * G * B * T * (double)Cout2 * k * Cin);
+    const int r = launch_gated_conv1d_glu(c, Cin, k, glu_math(), (hipStream_t)stream, 2.0 * G * B * T * (double)Cout2 * k * Cin);
     VC_ARG(r != -2, "vc_gated_conv1d_glu_fwd: built for Cin = 24, k = 15, Cout2 %% 64 == 0, T %% 4 == 0, tensors < 2 GiB (the generator's h1 block)");
     return r;
 }
 int glu_tune_flags() { return vc_hooks().glu_flags; }
 extern "C" int64_t vc_gated_conv1d_glu_image_bytes(int Cin, int k, int Cout2) {
-    return gated_conv1d_glu_image_bytes(Cin, k, Cout2, vc_thread_math() == VC_MATH_BF16 ? VC_MATH_BF16 : VC_MATH_FP32);
+    return gated_conv1d_glu_image_bytes(Cin, k, Cout2, glu_math());
 }
 extern "C" int vc_gated_conv1d_glu_prepack(const float* w, int64_t w_gs, void* image, int64_t image_gs_bytes,
                                            int G, int Cin, int k, int Cout2, void* stream) {
     VC_ARG(w && image && G > 0, "vc_gated_conv1d_glu_prepack: bad args");
     VC_ARG(aligned16(image) && image_gs_bytes % 16 == 0, "vc_gated_conv1d_glu_prepack: image must be 16-byte aligned");
-    const int math = vc_thread_math() == VC_MATH_BF16 ? VC_MATH_BF16 : VC_MATH_FP32;
+    const int math = glu_math();
     const int r = launch_gated_conv1d_glu_prepack(w, w_gs, image, image_gs_bytes, G, Cin, k, Cout2, math, (hipStream_t)stream);
     VC_ARG(r != -2, "vc_gated_conv1d_glu_prepack: built for Cin = 24, k = 15, Cout2 %% 64 == 0");
     return r;
@@ -684,7 +690,7 @@ extern "C" int vc_gated_conv1d_glu_fwd_packed(const float* x, int64_t x_gs, cons
     VC_ARG(aligned16(image) && image_gs_bytes % 16 == 0, "vc_gated_conv1d_glu_fwd_packed: image must be 16-byte aligned");
     WsConvArgs c{}; c.x = x; c.wimg = image; c.wimg_gs = image_gs_bytes; c.bias = bias; c.y = out; c.x_gs = x_gs; c.b_gs = b_gs; c.y_gs = out_gs;
     c.B = B; c.T = T; c.Cout = Cout2; c.G = G;
-    const int math = vc_thread_math() == VC_MATH_BF16 ? VC_MATH_BF16 : VC_MATH_FP32;
+    const int math = glu_math();
     const int r = launch_gated_conv1d_glu(c, Cin, k, math, (hipStream_t)stream, 2.0 * G * B * T * (double)Cout2 * k * Cin);
     VC_ARG(r != -2, "vc_gated_conv1d_glu_fwd_packed: built for Cin = 24, k = 15, Cout2 %% 64 == 0, T %% 4 == 0, tensors < 2 GiB (the generator's h1 block)");
     return r;

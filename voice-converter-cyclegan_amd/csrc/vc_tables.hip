@@ -243,7 +243,7 @@ void release_tables(std::vector<TabKey>& keys) {
 // arithmetic of the MFMA kernels for calls that carry no plan (operator level): per calling thread
 static thread_local int t_math = VC_MATH_FP32;
 extern "C" int vc_set_math_mode(int mode) {
-    if (mode < VC_MATH_FP32 || mode > VC_MATH_BF16X3) { vc_set_error("vc_set_math_mode: mode %d (0 fp32, 1 bf16, 2 bf16x3)", mode); return VC_E_ARG; }
+    if (mode < VC_MATH_FP32 || mode > VC_MATH_F16) { vc_set_error("vc_set_math_mode: mode %d (0 fp32, 1 bf16, 2 bf16x3, 3 f16: gated conv1d + GLU forward only)", mode); return VC_E_ARG; }
     t_math = mode;
     return 0;
 }
