@@ -285,11 +285,19 @@ def roofline_leg(eng, lib, A, Bm, hp, math, peak, world, serial, n_prof=3):
         stats[kind] = (name, ms.value, n.value, fl.value)
     CycleGANEngine.profiling(False)
     eng.set_overlap(not serial)
+    # `achieved` / `frac` price a launch's time in ALGORITHMIC FLOPs -- SURVEY 8d's per-unit figure (the direct-form convolution count,
+    # 91.41 GFLOP per sample and step) x the units the launches process -- as the bench contract defines the roofline entry.  Where a layer
+    # runs in a Winograd transform domain (fp32: residual and up-sampling blocks, D.d3) the MFMA pipe EXECUTES fewer multiply-adds than that
+    # for the same result: `executed` reports those (what the MFMA roof physically bounds); without such layers (bf16, batch 1) the two agree.
     name, ms, n, fl = stats[0]
-    ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    exe = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    ach = (fl + saved[0]) / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     tr, tr_n, tr_file = _pmc_traffic(B, F, T, world, math, 'igemm')
     out = {'roofline': {
         'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak,
+        'flops': 'algorithmic = direct-form convolution FLOPs of these launches (SURVEY 8d), %.1f GFLOP per step' % ((fl + saved[0]) / n_prof / 1e9),
+        'executed': {'achieved': exe, 'frac': exe / peak, 'gflop_per_step': fl / n_prof / 1e9,
+                     'what': 'multiply-adds the MFMA pipe executed in the same time (Winograd-domain layers execute 0.4-0.67 of the direct form)'},
         # HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
         # (FETCH_SIZE doubled per MI355X_MICROARCH.md, Infinity-Cache hits included), over THIS entry's launches
         'traffic': tr,
@@ -298,20 +306,21 @@ def roofline_leg(eng, lib, A, Bm, hp, math, peak, world, serial, n_prof=3):
                         % ('%g' % tr_n if tr_n else '?', tr_file),
         'kernel': name, 'launches_per_step': n // n_prof,
         'condition': 'step chains serialised on one stream (no co-running launches); see --serial',
-        'avg_launch_us': 1e3 * ms / max(n, 1), 'algorithmic_gflop_per_step': fl / n_prof / 1e9,
+        'avg_launch_us': 1e3 * ms / max(n, 1), 'algorithmic_gflop_per_step': (fl + saved[0]) / n_prof / 1e9,
         'kernel_ms_per_step': ms / n_prof}}
     if saved[0] > 0 or saved[1] > 0:
-        # `achieved` above counts the multiply-adds the MFMA pipe EXECUTED (what the MFMA roof bounds).  The residual / up-sampling blocks' and D.d3's
-        # convolutions run in a Winograd transform domain (csrc/vc_conv_wino.hip: F(4,3), F(4,5), F(3,6) along H): 0.4-0.67 of the direct form's
-        # multiplies for the same result -- the same time priced in direct-form FLOPs:
+        # The residual / up-sampling blocks' and D.d3's convolutions run in a Winograd transform domain (csrc/vc_conv_wino.hip: F(4,3), F(4,5),
+        # F(3,6) along H): 0.4-0.67 of the direct form's multiplies for the same result
         out['roofline']['winograd'] = {
             'what': 'forward + input gradient of the residual blocks (F(4,3)), up-sampling blocks (F(4,5)) and D.d3 (F(3,6) along H) as transform-domain GEMMs (grouped launches of igemm_kernel); direct form = what the round-5 kernels executed for the same layers',
             'direct_form_gflop_per_step': (fl + saved[0]) / n_prof / 1e9,
             'direct_equivalent_tflops': (fl + saved[0]) / (ms * 1e-3) / 1e12 if ms > 0 else 0.0,
             'direct_equivalent_frac': (fl + saved[0]) / (ms * 1e-3) / 1e12 / peak if ms > 0 else 0.0}
     name, ms, n, fl = stats[1]
-    ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    exe = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    ach = (fl + saved[1]) / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     out['roofline_wgrad'] = {'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak, 'kernel': name,
+                             'executed': {'achieved': exe, 'frac': exe / peak, 'gflop_per_step': fl / n_prof / 1e9},
                              'launches_per_step': n // n_prof, 'kernel_ms_per_step': ms / n_prof,
                              'traffic': _pmc_traffic(B, F, T, world, math, 'wgrad')[0]}
     if saved[1] > 0:
@@ -388,6 +397,44 @@ def workload_text(math, B, F, T, global_batch):
     idx = 4 if (F, T) == (36, 256) else 3 if global_batch else 2 if math != 'fp32' else 0 if B == 1 else 1
     return ('BASELINE configs[%d]: full CycleGAN-VC train step (2G+2D fwd/bwd + losses + TF-Adam), %s, batch %d per GPU, '
             '%dx%d MCEP, random-init weights' % (idx, MATH_TEXT[math], B, F, T))
+
+
+def inference_report(lib, dev):
+    """the conversion path (CycleGAN.test, model.py:128-137; convert.py:46 feeds one whole utterance [1, 24, T] per call): generator
+    forward through an inference plan, weights and frames resident in HBM, HIP events around `reps` calls on the call's stream.  T = 2208
+    frames = 11 s of speech at convert.py's 5 ms frame period (a multiple of 4 as preprocess.py pads it); B = 8 the same as a batch."""
+    import torch
+    from voice_converter_cyclegan_amd.engine import CycleGANEngine
+    from voice_converter_cyclegan_amd._lib import ptr, check, vp
+    out = []
+    for math in ('fp32', 'bf16'):
+        eng = CycleGANEngine(num_features=24, device=dev, seed=42, data_parallel=False)
+        eng.set_math(math)
+        for B, T in ((1, 2208), (8, 2208)):
+            p = eng._infer_plans.get(T)
+            x = torch.randn((B, 24, T), device=dev); y = torch.empty_like(x)
+            save = torch.empty(lib.vc_generator_save_floats(p, B), device=dev)
+            s = vp(torch.cuda.current_stream().cuda_stream)
+            run = lambda: check(lib.vc_generator_forward(p, ptr(eng.params), 0, ptr(x), 0, ptr(y), 0, ptr(save), 1, B, s))
+            for _ in range(5):
+                run()
+            torch.cuda.synchronize()
+            reps = 30
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                run()
+            e1.record(); torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / reps
+            assert bool(torch.isfinite(y).all())
+            gf = 2.656 * B * T / 128        # GFLOP per generator application (SURVEY 8d), linear in T
+            out.append({'workload': 'generator forward (vc_generator_forward, inference plan), %s, B=%d, 24x%d' % (math, B, T), 'dtype': {'fp32': 'f32'}.get(math, math),
+                        'ms': ms, 'frames_per_s': B * T / ms * 1e3, 'TFLOPs': gf / ms,
+                        'x_real_time': B * T * 5.0 / ms})        # convert.py: frame_period = 5.0 ms
+        eng.close()
+        del eng
+        torch.cuda.empty_cache()
+    return out
 
 
 def extra_config(lib, dev, math, B, F, T, steps, warmup, note, constant_operands=False):
@@ -627,6 +674,10 @@ def main():
             out.update(r)
             out['config']['executed_gflop_per_step'] = world * executed / 1e9
             out['step_flop_frac_of_fp32_peak'] = executed / (out['ms_per_step'] * 1e-3) / (FP32_MFMA_PEAK_TFLOPS * 1e12)
+            if out['config'].get('reference_graph_gflop_per_step'):
+                # SURVEY 8d's whole-step ceiling: 91.41 GFLOP per sample (direct form) at the fp32 peak = 220 k frames/s per GPU at 24 x 128
+                out['step_algorithmic_frac_of_fp32_peak'] = (out['config']['reference_graph_gflop_per_step'] * 1e9 / world / (out['ms_per_step'] * 1e-3)
+                                                             / (FP32_MFMA_PEAK_TFLOPS * 1e12))
 
     # ---- the kernel the north_star names: gated-conv1d forward (G.h1: 24 -> 2x128, k=15) at B=256 (and B=4096: the asymptote)
     if rank == 0 and not args.no_roofline:
@@ -649,6 +700,7 @@ def main():
             extra_config(lib, dev, 'fp32', 256, 24, 128, 3, 1, 'configs[3] on ONE GPU: global batch 256, the N = 1 end of the strong-scaling curve (`--gpus 1 --global-batch 256`; golden-backed: tests/golden/golden_f32_b256.npz)'),
             extra_config(lib, dev, 'fp32', 64, 36, 256, 5, 2, 'configs[4]: the per-GPU share (64) of global batch 512 at 36x256, measured on one GPU without the exchange'),
         ]}
+        out['extra']['inference'] = inference_report(lib, dev)
         # diagnostic, not a result: the headline configuration's launches on constant operands (data-dependent power management)
         out['extra']['dp_overlap'] = dp
         out['extra']['constant_operands_diagnostic'] = extra_config(
