@@ -90,7 +90,7 @@ int  vc_tune_glu(int flags);
  * frames (eight tiles in flight) and writes its output rows with the same dword stores -- and no arithmetic.  Recorded under profiling kind 2. */
 int  vc_prof_glu_copy_roof(const float* x, const void* image_bf16, float* out, int B, int T, int Cout2, void* stream);
 
-/* Stale-read probes (tools/stale_read_probe.py, tests): vc_testing_describe_step writes "name offset floats" lines for every buffer of the
+/* Stale-read probes (tests; profiles/r06_stale_read_probe.txt): vc_testing_describe_step writes "name offset floats" lines for every buffer of the
  * train step inside the caller's workspace (the backward scratch areas as each of the four backward passes lays them out) into buf and
  * returns the bytes needed; vc_testing_poison_internal fills the plan-internal buffers (packed-operand workspaces of the plan's streams
  * and of `stream`, the bf16 filter images) with `byte` (0xff = NaN in fp32 and bf16) after a device-wide synchronisation. */

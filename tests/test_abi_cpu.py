@@ -192,16 +192,3 @@ def test_product_path_never_imports_oracle():
         if f.endswith('.py'):
             src = open(os.path.join(pkg, f)).read()
             assert 'oracle' not in src, f
-
-
-def test_experiment_patch_still_applies():
-    """tools/igemm_timeline.patch (in-kernel phase stamps for csrc/vc_conv_igemm.hip) must track the kernel"""
-    import os
-    import shutil
-    import subprocess
-    import pytest
-    if shutil.which('git') is None:
-        pytest.skip('git not available')
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run(['git', 'apply', '--check', os.path.join('tools', 'igemm_timeline.patch')], cwd=root, capture_output=True, text=True)
-    assert r.returncode == 0, r.stderr

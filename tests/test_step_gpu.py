@@ -1038,7 +1038,7 @@ def test_bf16_dy_in_octet_forms_equals_the_pack_launches(built_lib, lam):
     Round 5 recorded an 'open finding' here (generator_B2A 2e-3 apart at lambda_identity == 0); round 6 found it is neither schedule- nor
     octet-related: D.h1's input gradient scatters with atomics, its 1-ulp summation-order noise in d generation_A/B flips the bf16 rounding
     of an element now and then (about one step in ten at B = 8), and every layer below re-rounds to bf16, so the flip grows layer by layer
-    to the bf16 noise floor (1.7e-3 at h1, 7e-9 at o1; tools/stale_read_probe3.py, profiles/r06_stale_read_probe.txt).  Round 5's version of
+    to the bf16 noise floor (1.7e-3 at h1, 7e-9 at o1; profiles/r06_stale_read_probe.txt; the probe scripts are in the git history).  Round 5's version of
     this test left the scatter in and passed or failed by chance."""
     from tests import gpu_util as U
     from voice_converter_cyclegan_amd._lib import lib, check

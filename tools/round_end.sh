@@ -20,5 +20,4 @@ cd $GRAFT_REPO_ROOT
 (timeout 300 python tools/bench_named.py > $D/named.log 2>&1)
 (timeout 200 python tools/bench_named.py --batches 256,4096 --maths bf16 --data zero > $D/named_zero.log 2>&1)
 for b in 1 8; do for g in "" "--graph"; do timeout 200 python bench.py --batch $b $g --no-cpu-baseline --no-extra --no-roofline --steps 40 --warmup 20 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('B=$b $g', round(d['ms_per_step'],3), d['config']['launch'])"; done; done > $D/graph_control.txt 2>&1
-timeout 500 bash tools/run_glu_probe.sh > $D/glu_probe.log 2>&1
 tail -3 $D/t_all.log; cut -c1-400 $D/bench.json; cat $D/named.log | grep -v amdgpu; tail -5 $D/prof_bf16.log; tail -4 $D/bench_gpus2.err

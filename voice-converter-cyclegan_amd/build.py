@@ -16,7 +16,7 @@ HEADERS = ['vc_internal.h', 'vc_host.h', 'vc_device_util.h', 'vc_wino.h', 'vc_tu
            os.path.join('..', '..', 'include', 'vc_cyclegan_testing.h')]
 # -packed-fp32-ops: no v_pk_{mul,add,fma}_f32 in any kernel.  Round 6: inside the bf16 train step, with the generator's filter-gradient GEMMs on
 # their own stream, norm_bwd_v4_kernel now and then gave ONE 16-lane group (lanes 48-63 of one wave) wrong row sums from register contents that
-# were bitwise the same as in a good launch (tools/octet_probe4.py: values as loaded identical, s1 / s2 different); 31 of 80 trials with the
+# were bitwise the same as in a good launch (round-6 probe, in the git history: values as loaded identical, s1 / s2 different); 31 of 80 trials with the
 # packed instructions, 0 of 240 without them in this translation unit or anywhere, at the same ms per step in every benched configuration
 # (profiles/r06_wrong_lane_group.txt).  The cause is not established beyond that correlation; the instructions buy nothing here (every kernel
 # that uses them is bound by memory or by MFMA), so the whole library is built without them.

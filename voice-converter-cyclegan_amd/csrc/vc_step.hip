@@ -37,7 +37,7 @@ static StepMap step_map(const vc_plan* p, int B) {
     return m;
 }
 // testing: where every buffer of the step lies inside the caller's workspace ("name offset floats" per line; the scratch areas as
-// each pass lays them out), and a poison for the plan-internal buffers -- tools/stale_read_probe.py names a stale read with them
+// each pass lays them out), and a poison for the plan-internal buffers -- the round-6 stale-read probe named its buffers with them (profiles/r06_stale_read_probe.txt; tests/test_step_gpu.py poisons between steps)
 void describe_save(std::string& out, const char* tag, const NetDesc& n, const std::vector<LayerGeo>& geo, int B, long base, long gs, int G);
 void describe_scratch(std::string& out, const char* tag, const std::vector<LayerGeo>& geo, int B, int math, long base, long gs, int G);
 extern "C" long long vc_testing_describe_step(const vc_plan* p, int B, int Bbwd, char* buf, long long cap) {
