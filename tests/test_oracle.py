@@ -243,3 +243,25 @@ def test_bf16_operand_rounding_is_round_to_nearest_even():
     assert 1e-4 < np.abs(y - y32).max() / np.abs(y32).max() < 3e-2
     with pytest.raises(ValueError):
         O.set_operand_rounding('fp8')
+
+
+def test_f16_operand_rounding_is_ieee_half_round_to_nearest_even():
+    """oracle operand rounding 'f16' (math mode 3 of the HIP path: the gated conv1d + GLU forward of module.py:161-163 with IEEE-half operands) against
+    torch's float32 -> float16 cast: ties to even, gradual underflow, overflow to inf -- what v_cvt_pk_f16_f32 does in the default rounding mode."""
+    import torch
+    from oracle import cyclegan_oracle as O
+    x = np.random.default_rng(1).standard_normal(200000).astype(np.float32) * np.float32(3.7)
+    x[:8] = [0.0, -0.0, 1.0 + 2.0 ** -11, 1.0 + 3 * 2.0 ** -11, 1e-8, 3e-5, 65519.0, 70000.0]      # ties, subnormals, the last finite value, overflow
+    want = torch.from_numpy(x).to(torch.float16).to(torch.float32).numpy()
+    O.set_operand_rounding('f16')
+    try:
+        got = O._rop(x)
+        assert got.dtype == np.float32 and np.array_equal(got, want)
+        assert got[2] == 1.0 and got[3] == np.float32(1.0 + 2.0 ** -9) and np.isinf(got[7]) and got[6] == 65504.0
+        assert O._rop(x.astype(np.float64)).dtype == np.float64
+        y, _ = O.conv1d_fwd(x[8:8 + 2 * 16 * 8].reshape(2, 16, 8), x[1000:1000 + 3 * 8 * 4].reshape(3, 8, 4), np.zeros(4, np.float32), 1)
+    finally:
+        O.set_operand_rounding(None)
+    y32, _ = O.conv1d_fwd(x[8:8 + 2 * 16 * 8].reshape(2, 16, 8), x[1000:1000 + 3 * 8 * 4].reshape(3, 8, 4), np.zeros(4, np.float32), 1)
+    e = np.abs(y - y32).max() / np.abs(y32).max()
+    assert 1e-5 < e < 2e-3, e                # an eighth of bf16's operand error
