@@ -140,7 +140,9 @@ int vc_gated_conv1d_glu_fwd(const float* x, int64_t x_gs, const float* w, int64_
  * thread's math mode (bf16 / f16: rounded once, 16-bit; fp32: exact) -- vc_gated_conv1d_glu_image_bytes(Cin, k, Cout2) bytes, 16-byte
  * aligned, group stride in bytes; -1: geometry not built.  vc_gated_conv1d_glu_fwd_packed is vc_gated_conv1d_glu_fwd reading
  * that image instead of w: a workgroup fetches its filter fragments with 16-byte coalesced loads straight into registers.
- * The image must have been built in the math mode of the call. */
+ * The image must have been built in the math mode of the call: the bf16 and the f16 image of the same filters differ only in how their 16-bit
+ * fields are read, so the library remembers which mode packed the image at an address (its last 64 prepack calls, host side) and returns
+ * VC_E_ARG for a packed call in another mode; an image it has never seen is taken on trust. */
 int64_t vc_gated_conv1d_glu_image_bytes(int Cin, int k, int Cout2);
 int vc_gated_conv1d_glu_prepack(const float* w, int64_t w_gs, void* image, int64_t image_gs_bytes,
                                 int G, int Cin, int k, int Cout2, void* stream);

@@ -341,6 +341,27 @@ def test_f16_mode_is_one_operator_only(built_lib):
     finally:
         check(lib.vc_set_math_mode(0))
     assert lib.vc_set_math_mode(4) != 0
+    # a bf16 and an f16 fragment image have the same size and layout: the library remembers which mode packed an image and refuses the other
+    from voice_converter_cyclegan_amd._lib import ptr
+    G, B, T = 1, 2, 128
+    xg = torch.randn((G, B, 24, T), device=U.DEV); wg = torch.randn((G, 15, 24, 256), device=U.DEV) * 0.05; bg = torch.zeros((G, 256), device=U.DEV)
+    out = torch.empty((G, B, 128, T), device=U.DEV)
+    try:
+        check(lib.vc_set_math_mode(1))
+        nb = lib.vc_gated_conv1d_glu_image_bytes(24, 15, 256)
+        img = torch.zeros((G, nb), dtype=torch.uint8, device=U.DEV)
+        check(lib.vc_gated_conv1d_glu_prepack(ptr(wg), wg[0].numel(), ptr(img), nb, G, 24, 15, 256, U.stream()))
+        call = lambda: lib.vc_gated_conv1d_glu_fwd_packed(ptr(xg), xg[0].numel(), ptr(img), nb, ptr(bg), 256, ptr(out), out[0].numel(), G, B, 24, T, 256, 15, U.stream())
+        assert call() == 0
+        check(lib.vc_set_math_mode(3))
+        assert lib.vc_gated_conv1d_glu_image_bytes(24, 15, 256) == nb
+        assert call() != 0 and b'built' in lib.vc_last_error() and b'mode 1' in lib.vc_last_error()
+        check(lib.vc_gated_conv1d_glu_prepack(ptr(wg), wg[0].numel(), ptr(img), nb, G, 24, 15, 256, U.stream()))     # re-packed in the new mode: accepted
+        assert call() == 0
+        check(lib.vc_set_math_mode(1))
+        assert call() != 0
+    finally:
+        check(lib.vc_set_math_mode(0))
 
 
 @pytest.mark.parametrize('mode', [1, 3])

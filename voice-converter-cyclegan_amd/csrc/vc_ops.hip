@@ -671,6 +671,24 @@ extern "C" int vc_gated_conv1d_glu_fwd(const float* x, int64_t x_gs, const float
     return r;
 }
 int glu_tune_flags() { return vc_hooks().glu_flags; }
+// The bf16 and the IEEE-half fragment image of the same filters have the same size and layout and differ only in how 16 bits are read: a
+// call in the other mode would multiply garbage silently.  The library remembers which mode built the image at an address (the last
+// VC_IMG_LOG prepack calls; host side, no device traffic) and refuses a packed call whose image it knows to be of another mode.  An image it
+// has never seen (copied, or built by another process) passes: the contract in the header stays "built in the mode of the call".
+#define VC_IMG_LOG 64
+static std::mutex g_img_mu;
+static struct { const void* p; int math; } g_img_log[VC_IMG_LOG];
+static int g_img_next = 0;
+static void glu_image_note(const void* img, int math) {
+    std::lock_guard<std::mutex> l(g_img_mu);
+    for (auto& e : g_img_log) if (e.p == img) { e.math = math; return; }
+    g_img_log[g_img_next] = {img, math}; g_img_next = (g_img_next + 1) % VC_IMG_LOG;
+}
+static int glu_image_mode(const void* img) {       // -1: unknown
+    std::lock_guard<std::mutex> l(g_img_mu);
+    for (const auto& e : g_img_log) if (e.p == img && img) return e.math;
+    return -1;
+}
 extern "C" int64_t vc_gated_conv1d_glu_image_bytes(int Cin, int k, int Cout2) {
     return gated_conv1d_glu_image_bytes(Cin, k, Cout2, glu_math());
 }
@@ -681,6 +699,7 @@ extern "C" int vc_gated_conv1d_glu_prepack(const float* w, int64_t w_gs, void* i
     const int math = glu_math();
     const int r = launch_gated_conv1d_glu_prepack(w, w_gs, image, image_gs_bytes, G, Cin, k, Cout2, math, (hipStream_t)stream);
     VC_ARG(r != -2, "vc_gated_conv1d_glu_prepack: built for Cin = 24, k = 15, Cout2 %% 64 == 0");
+    if (r == 0) glu_image_note(image, math);
     return r;
 }
 extern "C" int vc_gated_conv1d_glu_fwd_packed(const float* x, int64_t x_gs, const void* image, int64_t image_gs_bytes,
@@ -691,6 +710,11 @@ extern "C" int vc_gated_conv1d_glu_fwd_packed(const float* x, int64_t x_gs, cons
     WsConvArgs c{}; c.x = x; c.wimg = image; c.wimg_gs = image_gs_bytes; c.bias = bias; c.y = out; c.x_gs = x_gs; c.b_gs = b_gs; c.y_gs = out_gs;
     c.B = B; c.T = T; c.Cout = Cout2; c.G = G;
     const int math = glu_math();
+    {
+        const int built = glu_image_mode(image);
+        VC_ARG(built < 0 || built == math, "vc_gated_conv1d_glu_fwd_packed: this image was built by vc_gated_conv1d_glu_prepack in math mode %d, the calling thread's mode is %d "
+                                           "(a fragment image is read in the arithmetic it was packed for)", built, math);
+    }
     const int r = launch_gated_conv1d_glu(c, Cin, k, math, (hipStream_t)stream, 2.0 * G * B * T * (double)Cout2 * k * Cin);
     VC_ARG(r != -2, "vc_gated_conv1d_glu_fwd_packed: built for Cin = 24, k = 15, Cout2 %% 64 == 0, T %% 4 == 0, tensors < 2 GiB (the generator's h1 block)");
     return r;
