@@ -613,7 +613,11 @@ def _check_step_golden(mode, B, F, T, fname, lam=(10.0, 5.0)):
     delta = 3.0 * float(np.sqrt((dfw ** 2).mean()))
     smooth = lam[0] == 0.0 and lam[1] == 0.0                              # no L1 term in the objective: nothing can flip
     f = 0.0 if smooth else float(np.interp(delta, z['l1_cdf_x'], z['l1_cdf_y']))   # fraction of L1 elements within delta of a tie
-    flip = 2.0 * np.sqrt(f)
+    # ... and never less than ONE flipped element when any element is within reach: a single flipped sign moves its own L1 term's seed (B F T
+    # elements of +-1) by 2 / sqrt(B F T) relative.  (Round 6: at 36x256 B = 8, f = 1.56e-6 of 4 x 73 728 elements is 0.46 EXPECTED flips = an
+    # allowance of 2.5e-3, and in one run of four the default mode's atomics order did flip one element -- 7.4e-3 of that term's seed: a beta
+    # gradient's projection missed its 3-sigma bound by 10 %.  Whether a near-tie element flips is the run's summation order, not a defect.)
+    flip = 0.0 if f == 0.0 else 2.0 * np.sqrt(max(f, 1.0 / (B * F * T)))
     print('%s B=%d %dx%d: forward diff rms %.3g; L1 elements within 3 rms of a tie: %.3g -> sign-flip allowance %.3g' % (mode, B, F, T, delta / 3, f, flip))
     assert f < 1e-2
     G = eng.tf_gradients()
